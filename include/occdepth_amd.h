@@ -1,0 +1,205 @@
+/*
+ * occdepth_amd.h -- C-ABI of libocc_hip.so, the MI355X (gfx950) kernel library
+ * under the `occdepth.models` nn.Module surface.
+ *
+ * The reference (megvii-research/OccDepth) has NO FFI layer of its own: its hot
+ * path is a graph of stock ATen ops called from Python.
+ * Each entry point below therefore names the reference *Python* call site whose
+ * ATen-op sequence it replaces; `occdepth_amd/hip.py` is the ctypes binding.
+ *
+ * Conventions
+ *  - plain pointers + ints only; all pointers are DEVICE pointers (fp32 unless
+ *    noted) owned by the caller; nothing is retained after the call returns.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every
+ *    launch is asynchronous on that stream; no call synchronises the device.
+ *  - return value: 0 (OCCD_OK) or a negative OCCD_E* code; occd_strerror()
+ *    gives text.  The Python layer converts non-zero into RuntimeError.
+ *  - voxel tensors are channels-last: row r = ((b*X + x)*Y + y)*Z + z holds the
+ *    C channels of one voxel, `cs` floats apart (cs >= C, multiple of 4), at
+ *    channel offset `coff` inside the row (so a tensor can be a channel slice
+ *    of a wider concat buffer).  Channel pads must hold zeros.
+ */
+#ifndef OCCDEPTH_AMD_H
+#define OCCDEPTH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCCD_OK 0
+#define OCCD_EINVAL (-1)   /* bad argument / unsupported geometry          */
+#define OCCD_ELAUNCH (-2)  /* hip launch / runtime error                   */
+#define OCCD_ENOMEM (-3)   /* tile does not fit LDS                        */
+
+#define OCCD_MAX_VIEWS 4
+#define OCCD_MAX_SCALES 4
+
+#define OCCD_ACT_NONE 0
+#define OCCD_ACT_RELU 1
+#define OCCD_ACT_SIGMOID 2
+#define OCCD_ACT_RELU_PRE 3 /* act_out only: relu(conv + bias) + res1 + res2 */
+
+/* ABI version; bumped whenever a struct below changes. */
+int occd_abi_version(void);
+const char* occd_strerror(int code);
+
+/* ------------------------------------------------------------------------ *
+ * K2: implicit-GEMM 3-D convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32),
+ * fused epilogue:  out = act_out( conv(act_in(in)) + bias + res1 + res2 ).
+ *
+ * Replaces, in eval mode with BatchNorm folded into (w, bias):
+ *   nn.Conv3d + BatchNorm3d + ReLU + residual adds   occdepth/models/DDR.py:111-139
+ *   ASPP / segmentation-head conv chains             occdepth/models/modules.py:40-46,158-175
+ *   AvgPool3d + 1x1x1 conv side branches             occdepth/models/DDR.py:95-109 (as k=stride convs)
+ *   nn.ConvTranspose3d(k3,s2,p1,op1)+BN+ReLU         occdepth/models/modules.py:278-296
+ *     (run as 8 sub-pixel phases through the o_stride/o_off output scatter)
+ *   1x1x1 relation logits, sigmoid + torch.bmm       occdepth/models/CRP3D.py:68-82
+ *
+ * `wpk` is the packed weight image produced by occd_pack_weights():
+ *   wpk[tap][kt][nt][lane][q],  lane = kk*32 + j,  value =
+ *   W[cout = nt*32 + j][cin = kt*8 + kk*4 + q][tap], tap = (kx*KY + ky)*KZ + kz,
+ *   zero padded to Cin8 = ceil8(Cin) and 32*NT = ceil32(Cout).
+ * ------------------------------------------------------------------------ */
+typedef struct occd_conv3d_args {
+    const float* in;    /* (B, X, Y, Z, in_cs)                               */
+    const float* wpk;   /* packed weights, see above                         */
+    const float* bias;  /* (32*NT) floats or NULL                            */
+    const float* res1;  /* optional residual, laid out like `out`            */
+    const float* res2;  /* optional second residual                          */
+    float* out;         /* (B, OX, OY, OZ, out_cs)                           */
+    int32_t batch;
+    int32_t X, Y, Z;            /* input spatial dims                        */
+    int32_t cin;                /* logical input channels (weights K extent) */
+    int32_t in_cs, in_coff;
+    int32_t cout;               /* logical output channels                   */
+    int32_t out_cs, out_coff;
+    int32_t res1_cs, res1_coff;
+    int32_t res2_cs, res2_coff;
+    int32_t kx, ky, kz;         /* kernel extent                             */
+    int32_t sx, sy, sz;         /* stride                                    */
+    int32_t dx, dy, dz;         /* dilation                                  */
+    int32_t px, py, pz;         /* leading zero padding                      */
+    int32_t Xo, Yo, Zo;         /* number of output positions computed       */
+    int32_t OX, OY, OZ;         /* spatial dims of the out/res buffers       */
+    int32_t o_stride_x, o_stride_y, o_stride_z; /* output voxel = o*stride+off */
+    int32_t o_off_x, o_off_y, o_off_z;
+    int32_t act_in;             /* OCCD_ACT_* applied to `in` on load        */
+    int32_t act_out;            /* OCCD_ACT_NONE, OCCD_ACT_RELU (after the residual
+                                   adds) or OCCD_ACT_RELU_PRE (before them)  */
+    int32_t cout_store;         /* channels written per voxel (>= cout,
+                                   multiple of 4, <= 32*NT); pads get 0+bias */
+    int32_t tile_hint;          /* 0 = auto; else forces a kernel variant    */
+} occd_conv3d_args;
+
+int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream);
+
+/* Pack PyTorch-layout conv weights (Cout, Cin, KX, KY, KZ) [transposed=0] or
+ * conv-transpose weights (Cin, Cout, KX, KY, KZ) [transposed=1] into `wpk`,
+ * multiplying output channel c by scale[c] when scale != NULL (BN fold).
+ * For a dynamic GEMM B operand (CRP bmm) pass w as (K=Cin, N=Cout) row-major
+ * with layout=2.  Returns the number of floats written, or <0.              */
+int64_t occd_packed_weight_floats(int32_t cout, int32_t cin, int32_t taps);
+int occd_pack_weights(const float* w, const float* scale, float* wpk,
+                      int32_t cout, int32_t cin, int32_t kx, int32_t ky, int32_t kz,
+                      int32_t layout, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * K1a: FLoSP-Depth frustum sample.  For every voxel of the (A,B,C) grid and
+ * every camera: voxel centre -> camera -> image (u, v, LID depth bin) -> ida ->
+ * normalise by (W_img-1, H_img-1, D-1) -> trilinear grid_sample(align_corners=
+ * False, zeros) of the (D, h, w) depth-probability frustum, plus the same sample
+ * of an all-ones volume; mean over cameras where the ones-sample is > 0.
+ * Replaces occdepth/models/flosp_depth/flosp_depth.py:561-602,
+ * f2v/frustum_grid_generator.py:70-152, f2v/sampler.py:59-64.
+ * ------------------------------------------------------------------------ */
+typedef struct occd_flosp_args {
+    const float* depth;     /* (B, n_cams, D, h, w) softmaxed depth bins      */
+    const float* trans;     /* (B, n_cams, 4, 4)  lidar_to_cam @ grid_to_lidar */
+    const float* proj;      /* (B, n_cams, 3, 4)  cam_to_img                   */
+    const float* ida;       /* (B, n_cams, 4, 4)                               */
+    const float* grids;     /* infer_mode: (n_cams, B, A, B, C, 3) precomputed
+                               normalised grids, else NULL                    */
+    float* out;             /* (B, A*B*C) */
+    int32_t batch, n_cams;
+    int32_t D, h, w;
+    int32_t A, Bdim, C;     /* voxel grid dims (voxel_num)                    */
+    float img_w, img_h;     /* final_dim (W, H) used by the normalisation     */
+    float depth_min, depth_max;
+    int32_t mean_mode;      /* 1 = "mean" aggregation, 0 = "sum"              */
+} occd_flosp_args;
+
+int occd_flosp_sample_fwd(const occd_flosp_args* a, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * K1b: Stereo-SFA multi-scale lift.  Per voxel: for each 2-D scale gather the
+ * projected pixel's C-vector from every view (mean over in-FOV pattern points),
+ * fuse the views with the cosine-similarity weights, sum the scales, multiply by
+ * depth_scale[voxel] * scale_const when depth_scale != NULL, write a
+ * channels-last voxel row.
+ * Replaces occdepth/models/SFA.py:12-106 called B x n_scales times from
+ * occdepth/models/OccDepth.py:266-298, and the `x3ds * x3ds_depth * 100` of :339.
+ * ------------------------------------------------------------------------ */
+typedef struct occd_lift_args {
+    /* feat[s][v]: (B, H_s*W_s, C) channels-last feature rows of view v, scale s */
+    const float* feat[OCCD_MAX_SCALES][OCCD_MAX_VIEWS];
+    int32_t feat_h[OCCD_MAX_SCALES], feat_w[OCCD_MAX_SCALES];
+    int32_t feat_cs[OCCD_MAX_SCALES];     /* row stride (floats) of feat[s][*] */
+    int32_t scale_div[OCCD_MAX_SCALES];   /* scale_2d: pixel // scale_div      */
+    int32_t n_scales, n_views, batch;
+    int32_t C;                            /* feature channels (multiple of 4)  */
+    const int64_t* pix;                   /* (B, V, N, P, 2) int64 (x, y)      */
+    const uint8_t* fov;                   /* (B, V, N, P) bool                 */
+    int32_t N, P;
+    const float* depth_scale;             /* (B, N) or NULL                    */
+    float scale_const;                    /* 100.0 in the reference            */
+    int32_t dimA, dimB, dimC;             /* n -> (a, b, c), n = (a*dimB+b)*dimC+c */
+    int64_t row_a, row_b, row_c;          /* out row = a*row_a + b*row_b + c*row_c  */
+    float* out;                           /* (B, rows, out_cs)                 */
+    int64_t out_rows;                     /* rows per batch item               */
+    int32_t out_cs;                       /* pads [C, out_cs) are zero-filled  */
+} occd_lift_args;
+
+int occd_lift_fwd(const occd_lift_args* a, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Layout / small fused helpers around the two big kernels.
+ * ------------------------------------------------------------------------ */
+/* (B, C, S) channel-first -> (B, S, cs) channels-last rows, zero pad [C, cs).
+ * Feeds K1 from the torch 2-D decoder output (occdepth/models/unet2d.py:148-163)
+ * and K2 from externally supplied (B,C,X,Y,Z) tensors.                        */
+int occd_nchw_to_nhwc(const float* in, float* out, int32_t batch, int32_t C,
+                      int64_t S, int32_t cs, void* stream);
+/* inverse: (B, S, cs)[.., coff:coff+C] -> (B, C, S) */
+int occd_nhwc_to_nchw(const float* in, float* out, int32_t batch, int32_t C,
+                      int64_t S, int32_t cs, int32_t coff, void* stream);
+/* softmax over n channels at [src_coff, src_coff+n) of each row, written to
+ * [dst_coff, dst_coff+n) of the same-shaped dst rows, followed by dst_pad
+ * zeros (cascade head: occdepth/models/modules.py:168-171 softmax + torch.cat). */
+int occd_softmax_channels(const float* src, float* dst, int64_t rows,
+                          int32_t src_cs, int32_t src_coff, int32_t dst_cs,
+                          int32_t dst_coff, int32_t n, int32_t dst_pad, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * In-library kernel timing (HIP events on the launch stream) used by bench.py
+ * for `roofline.achieved`.  occd_prof_enable(1) starts recording one event pair
+ * per launch; occd_prof_report() synchronises the recorded events and returns,
+ * per kernel tag, launches / total ms / total algorithmic flops / bytes.
+ * ------------------------------------------------------------------------ */
+typedef struct occd_prof_row {
+    char tag[48];
+    int64_t launches;
+    double ms;
+    double flops;
+    double bytes;
+} occd_prof_row;
+
+int occd_prof_enable(int32_t on);
+int occd_prof_set_tag(const char* tag);   /* tag attached to subsequent launches */
+int occd_prof_report(occd_prof_row* rows, int32_t max_rows); /* returns #rows; resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCCDEPTH_AMD_H */

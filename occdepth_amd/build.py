@@ -1,0 +1,64 @@
+"""Build libocc_hip.so (gfx950 only) in-tree with hipcc.
+
+    python -m occdepth_amd.build [--force]
+
+The shared object lands next to this file so it travels with the source tree
+(it is git-ignored, not gpurun-ignored).  No torch headers are involved: the
+library exposes the C ABI of include/occdepth_amd.h only.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["conv3d_igemm.hip", "lift.hip", "prof.cpp"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "occdepth_amd.h")]
+LIB = os.path.join(HERE, "libocc_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libocc_hip.so cannot be built")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(bdir, os.path.splitext(s)[0] + ".o")
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+               "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), cmd))
+        objs.append(o)
+    for p, cmd in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,39 @@
+// Shared host-side helpers for libocc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/occdepth_amd.h"
+
+namespace occd {
+
+// Launch-time profiling (HIP events on the launch stream); see prof.cpp.
+struct ProfScope {
+    ProfScope(const char* kind, hipStream_t s, double flops, double bytes);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? OCCD_OK : OCCD_ELAUNCH;
+}
+
+// q = n / d for n*d < 2^32 via one mul-hi; d == 1 is encoded as magic 0.
+struct FastDiv {
+    uint32_t magic;
+    uint32_t d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.magic = d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d);
+    return f;
+}
+
+}  // namespace occd
+
+__device__ __forceinline__ uint32_t occd_fastdiv(uint32_t n, occd::FastDiv f) {
+    // branch-free: magic == 0 encodes d == 1
+    return __umulhi(n, f.magic) + (f.magic == 0u ? n : 0u);
+}

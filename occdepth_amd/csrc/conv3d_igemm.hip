@@ -1,0 +1,411 @@
+// K2 -- implicit-GEMM 3-D convolution on the CDNA4 fp32 matrix pipe.
+//
+//   out[vox][co] = act_out( sum_{tap,ci} act_in(in[vox*stride - pad + tap*dil][ci]) * W[co][ci][tap]
+//                           + bias[co] + res1[vox][co] + res2[vox][co] )
+//
+// GEMM view: M = output voxels, N = Cout, K = taps * Cin.  One wavefront owns
+// MT x NT tiles of 32(M) x 32(N) and issues v_mfma_f32_32x32x2_f32 (exact fp32,
+// 64 FLOP/clk/SIMD).  A workgroup (WM x WN waves) walks K as
+//   for kx: for cin-chunk(CK): stage the input slab [YIN][ZIN][CK] of plane
+//   x_in = xo*SX - PX + kx*DX into LDS (zero filled outside the volume, act_in
+//   applied once per element), then for (ky,kz,kt): A fragments are one
+//   ds_read_b128 per lane from the slab (row = voxel, 4 consecutive channels),
+//   B fragments one global_load_dwordx4 from the pre-packed L2-resident weights.
+// A and B for step s+1 are fetched before the MFMAs of step s (register double
+// buffer).  LDS rows are CK+4 floats so 16 consecutive voxel rows hit 16
+// different 16-byte bank slots (conflict-free ds_read_b128).
+// Output scatter (o_stride/o_off) lets a ConvTranspose3d(k3,s2) run as 8
+// sub-pixel phase convolutions writing interleaved voxels.
+//
+// Reference semantics replaced: occdepth/models/DDR.py:111-139,
+// occdepth/models/modules.py:40-46,158-175,278-296, occdepth/models/CRP3D.py:54-97.
+#include "common.h"
+
+using occd::FastDiv;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct ConvP {
+    const float* in;
+    const float* wpk;
+    const float* bias;
+    const float* res1;
+    const float* res2;
+    float* out;
+    int X, Y, Z, cin8, in_cs, in_coff;
+    int KTtot, NTtot;
+    int out_cs, out_coff, res1_cs, res1_coff, res2_cs, res2_coff;
+    int KX, KY, KZ, SX, SY, SZ, DX, DY, DZ, PX, PY, PZ;
+    int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz, oox, ooy, ooz;
+    int act_in, act_out, cout_store;
+    int TY, TZ, YIN, ZIN, ytiles, ztiles, nwg;
+    FastDiv div_zin, div_tz, div_ztiles, div_ytiles;
+};
+
+__device__ __forceinline__ f32x4 apply_act(f32x4 v, int act) {
+    if (act == OCCD_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (act == OCCD_ACT_SIGMOID) {
+        v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
+        v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+    }
+    return v;
+}
+
+template <int MT, int NT, int WM, int WN, int CK>
+__global__ void __launch_bounds__(WM* WN * 64) conv3d_igemm_kernel(const ConvP p) {
+    constexpr int NTH = WM * WN * 64;
+    constexpr int RS4 = CK / 4 + 1;  // LDS row stride in float4: odd number of 16-B slots
+    constexpr int C4 = CK / 4;
+    extern __shared__ __attribute__((aligned(16))) f32x4 slab4[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int li = lane & 31;
+    const int kk = lane >> 5;
+
+    // XCD-aware bijective remap: the dispatcher round-robins workgroups over
+    // the 8 XCDs; give each XCD a contiguous run of tiles so the kx halo
+    // (the same input planes are used by 3 neighbouring xo) hits its own L2.
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t t1 = occd_fastdiv(bid, p.div_ztiles);
+    const int zt = bid - t1 * p.ztiles;
+    const uint32_t t2 = occd_fastdiv(t1, p.div_ytiles);
+    const int yt = t1 - t2 * p.ytiles;
+    const int xo = t2;
+    const int b = blockIdx.y;
+    const int nt0 = (blockIdx.z * WN + wn) * NT;
+
+    // LDS float4 index of this lane's A row for each M tile.
+    int rowbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const uint32_t m = (wm * MT + mt) * 32 + li;
+        uint32_t yl = occd_fastdiv(m, p.div_tz);
+        uint32_t zl = m - yl * p.TZ;
+        const bool in_tile = yl < (uint32_t)p.TY;
+        yl = in_tile ? yl : 0u;
+        zl = in_tile ? zl : 0u;
+        rowbase[mt] = (int)((yl * p.SY) * p.ZIN + zl * p.SZ) * RS4 + kk;
+    }
+    // float offset of each owned N tile inside one (tap, kt) weight record;
+    // N tiles past the layer's last one alias it (their results are never stored).
+    int wofs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wofs[nt] = min(nt0 + nt, p.NTtot - 1) * 256;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int y_in0 = yt * p.TY * p.SY - p.PY;
+    const int z_in0 = zt * p.TZ * p.SZ - p.PZ;
+    const size_t w_step = (size_t)p.NTtot * 256;  // floats per (tap, kt)
+    const float* const wlane = p.wpk + lane * 4;
+    const int rows = p.YIN * p.ZIN;
+    const int F = rows * C4;
+
+#define OCCD_MFMA_BLOCK()                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] =                               \
+            __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0)
+
+    for (int kx = 0; kx < p.KX; ++kx) {
+        const int xi = xo * p.SX - p.PX + kx * p.DX;
+        if (xi < 0 || xi >= p.X) continue;  // workgroup-uniform
+        const float* const in_plane =
+            p.in + ((size_t)(b * p.X + xi) * p.Y) * p.Z * p.in_cs + p.in_coff;
+        for (int c0 = 0; c0 < p.cin8; c0 += CK) {
+            const int ck = min(CK, p.cin8 - c0);
+            const int ktn = ck >> 3;
+            const int S = p.KY * p.KZ * ktn;
+            const float* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.KTtot + (c0 >> 3)) * w_step;
+
+            // first B fragments fly while the slab is staged
+            f32x4 b_cur[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b_cur[nt] = *(const f32x4*)(wp + wofs[nt]);
+
+            __syncthreads();  // previous slab fully consumed
+            for (int f0 = 0; f0 < F; f0 += NTH * 4) {
+                f32x4 v[4];
+                int dst[4];
+                bool okv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * NTH + tid;
+                    const int fc = min(f, F - 1);
+                    const uint32_t row = (uint32_t)fc / C4;
+                    const int c4 = fc - (int)row * C4;
+                    const uint32_t yi = occd_fastdiv(row, p.div_zin);
+                    const int zi = (int)row - (int)yi * p.ZIN;
+                    const int y = y_in0 + (int)yi, z = z_in0 + zi;
+                    okv[u] = f < F && c4 * 4 < ck && (unsigned)y < (unsigned)p.Y && (unsigned)z < (unsigned)p.Z;
+                    const int yc = min(max(y, 0), p.Y - 1), zc = min(max(z, 0), p.Z - 1);
+                    const int cc = min(c4 * 4, ck - 4);
+                    v[u] = *(const f32x4*)(in_plane + ((size_t)yc * p.Z + zc) * p.in_cs + c0 + cc);
+                    dst[u] = f < F ? (int)row * RS4 + c4 : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 a = apply_act(v[u], p.act_in);
+                    if (dst[u] >= 0) slab4[dst[u]] = okv[u] ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            __syncthreads();
+
+            int ky = 0, kz = 0, ktl = 0;
+            int lds_off = 0;  // float4 units
+            f32x4 a_cur[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = slab4[rowbase[mt]];
+
+            for (int s = 0; s < S - 1; ++s) {
+                // advance (ky, kz, kt): scalar bookkeeping only
+                ++ktl;
+                lds_off += 2;
+                wp += w_step;
+                if (ktl == ktn) {
+                    ktl = 0;
+                    wp += (size_t)(p.KTtot - ktn) * w_step;
+                    if (++kz == p.KZ) { kz = 0; ++ky; }
+                    lds_off = (ky * p.DY * p.ZIN + kz * p.DZ) * RS4;
+                }
+                f32x4 a_nxt[MT], b_nxt[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = slab4[rowbase[mt] + lds_off];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = *(const f32x4*)(wp + wofs[nt]);
+                OCCD_MFMA_BLOCK();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+            }
+            OCCD_MFMA_BLOCK();
+        }
+    }
+#undef OCCD_MFMA_BLOCK
+
+    // ---------------- epilogue: bias + residuals + activation, channels-last store
+    float bias_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = (nt0 + nt) * 32 + li;
+        bias_v[nt] = (p.bias != nullptr && c < p.cout_store) ? p.bias[c] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const uint32_t yl = occd_fastdiv(m, p.div_tz);
+            const uint32_t zl = m - yl * p.TZ;
+            const int yo = yt * p.TY + (int)yl, zo = zt * p.TZ + (int)zl;
+            const bool ok = yl < (uint32_t)p.TY && yo < p.Yo && zo < p.Zo;
+            const size_t vox = ((size_t)(b * p.OX + xo * p.osx + p.oox) * p.OY + (yo * p.osy + p.ooy)) * p.OZ +
+                               (zo * p.osz + p.ooz);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = (nt0 + nt) * 32 + li;
+                if (ok && c < p.cout_store) {
+                    float v = acc[mt][nt][r] + bias_v[nt];
+                    if (p.act_out == OCCD_ACT_RELU_PRE) v = fmaxf(v, 0.f);
+                    if (p.res1 != nullptr) v += p.res1[vox * p.res1_cs + p.res1_coff + c];
+                    if (p.res2 != nullptr) v += p.res2[vox * p.res2_cs + p.res2_coff + c];
+                    if (p.act_out == OCCD_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.out[vox * p.out_cs + p.out_coff + c] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- weight packing
+__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                    float* __restrict__ wpk, int cout, int cin, int taps, int KT, int NT,
+                                    int layout, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = i & 3;
+    const int lane = (i >> 2) & 63;
+    long t = i >> 8;
+    const int nt = t % NT; t /= NT;
+    const int kt = t % KT; t /= KT;
+    const int tap = (int)t;
+    const int co = nt * 32 + (lane & 31);
+    const int ci = kt * 8 + (lane >> 5) * 4 + q;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+        if (layout == 0) v = w[((size_t)co * cin + ci) * taps + tap];
+        else if (layout == 1) v = w[((size_t)ci * cout + co) * taps + tap];
+        else v = w[(size_t)ci * cout + co];
+        if (scale != nullptr) v *= scale[co];
+    }
+    wpk[i] = v;
+}
+
+struct Variant {
+    int MT, NT, WM, WN, CK;
+    void (*kern)(const ConvP);
+};
+
+#define OCCD_VARIANT(MT, NT, WM, WN, CK) \
+    Variant { MT, NT, WM, WN, CK, conv3d_igemm_kernel<MT, NT, WM, WN, CK> }
+
+const Variant kVariants[] = {
+    OCCD_VARIANT(2, 1, 4, 1, 32),  // 0: M256 x N32   (head, bottleneck mids)
+    OCCD_VARIANT(2, 2, 4, 1, 32),  // 1: M256 x N64
+    OCCD_VARIANT(2, 2, 2, 2, 32),  // 2: M128 x N128
+    OCCD_VARIANT(1, 2, 2, 2, 32),  // 3: M64  x N128
+    OCCD_VARIANT(1, 1, 4, 1, 32),  // 4: M128 x N32
+    OCCD_VARIANT(1, 1, 2, 2, 32),  // 5: M64  x N64
+    OCCD_VARIANT(1, 1, 1, 4, 32),  // 6: M32  x N128
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr size_t kMaxLds = 160 * 1024;
+bool g_attr_set[kNumVariants] = {};
+
+struct Tiling {
+    int TY, TZ, YIN, ZIN, ytiles, ztiles, ngroups;
+    size_t lds;
+    long nwg;
+};
+
+bool plan(const occd_conv3d_args* a, const Variant& v, int NTtot, Tiling* t) {
+    const int mwg = v.MT * v.WM * 32;
+    if (a->Zo <= mwg) {
+        t->TZ = a->Zo;
+        t->TY = mwg / a->Zo;
+        if (t->TY > a->Yo) t->TY = a->Yo;
+    } else {
+        t->TZ = mwg;
+        t->TY = 1;
+    }
+    t->YIN = (t->TY - 1) * a->sy + (a->ky - 1) * a->dy + 1;
+    t->ZIN = (t->TZ - 1) * a->sz + (a->kz - 1) * a->dz + 1;
+    t->ytiles = (a->Yo + t->TY - 1) / t->TY;
+    t->ztiles = (a->Zo + t->TZ - 1) / t->TZ;
+    t->lds = (size_t)t->YIN * t->ZIN * (v.CK + 4) * sizeof(float);
+    const int nwg_n = v.NT * v.WN;
+    t->ngroups = (NTtot + nwg_n - 1) / nwg_n;
+    t->nwg = (long)a->Xo * t->ytiles * t->ztiles;
+    return t->lds <= kMaxLds && t->YIN * t->ZIN < 65536 && t->nwg < (1L << 24);
+}
+
+}  // namespace
+
+extern "C" int64_t occd_packed_weight_floats(int32_t cout, int32_t cin, int32_t taps) {
+    if (cout <= 0 || cin <= 0 || taps <= 0) return OCCD_EINVAL;
+    const int64_t KT = (cin + 7) / 8, NT = (cout + 31) / 32;
+    return (int64_t)taps * KT * NT * 256;
+}
+
+extern "C" int occd_pack_weights(const float* w, const float* scale, float* wpk, int32_t cout, int32_t cin,
+                                 int32_t kx, int32_t ky, int32_t kz, int32_t layout, void* stream) {
+    if (!w || !wpk || layout < 0 || layout > 2) return OCCD_EINVAL;
+    const int taps = kx * ky * kz;
+    const int64_t total = occd_packed_weight_floats(cout, cin, taps);
+    if (total <= 0 || (layout == 2 && taps != 1)) return OCCD_EINVAL;
+    const int KT = (cin + 7) / 8, NT = (cout + 31) / 32;
+    const int th = 256;
+    const long blocks = (total + th - 1) / th;
+    occd::ProfScope prof("pack_weights", (hipStream_t)stream, 0.0, (double)total * 8);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
+                       wpk, cout, cin, taps, KT, NT, layout, (long)total);
+    return occd::check_launch();
+}
+
+extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
+    if (!a || !a->in || !a->wpk || !a->out) return OCCD_EINVAL;
+    if (a->batch <= 0 || a->X <= 0 || a->Y <= 0 || a->Z <= 0 || a->cin <= 0 || a->cout <= 0) return OCCD_EINVAL;
+    if (a->kx <= 0 || a->ky <= 0 || a->kz <= 0 || a->sx <= 0 || a->sy <= 0 || a->sz <= 0) return OCCD_EINVAL;
+    if (a->Xo <= 0 || a->Yo <= 0 || a->Zo <= 0) return OCCD_EINVAL;
+    const int cin8 = (a->cin + 7) & ~7;
+    const int NTtot = (a->cout + 31) / 32;
+    // every staged float4 must be 16-byte aligned and inside the row
+    if ((a->in_cs & 3) || (a->in_coff & 3) || a->in_coff + cin8 > a->in_cs) return OCCD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->in) & 15) || (reinterpret_cast<uintptr_t>(a->wpk) & 15)) return OCCD_EINVAL;
+    if (a->cout_store < a->cout || a->cout_store > NTtot * 32 || a->out_coff + a->cout_store > a->out_cs)
+        return OCCD_EINVAL;
+    if (a->res1 && a->res1_coff + a->cout_store > a->res1_cs) return OCCD_EINVAL;
+    if (a->res2 && a->res2_coff + a->cout_store > a->res2_cs) return OCCD_EINVAL;
+    if ((a->Xo - 1) * a->o_stride_x + a->o_off_x >= a->OX || (a->Yo - 1) * a->o_stride_y + a->o_off_y >= a->OY ||
+        (a->Zo - 1) * a->o_stride_z + a->o_off_z >= a->OZ)
+        return OCCD_EINVAL;
+    if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
+        return OCCD_EINVAL;
+
+    // ---- variant choice: widest N tile the layer fills, then the largest M
+    // tile that fits LDS and still yields >= 2 workgroups per CU.
+    int order[kNumVariants];
+    int n = 0;
+    if (a->tile_hint > 0 && a->tile_hint <= kNumVariants) {
+        order[n++] = a->tile_hint - 1;
+    } else if (NTtot == 1) {
+        order[n++] = 0; order[n++] = 4; order[n++] = 5; order[n++] = 6;
+    } else if (NTtot == 2) {
+        order[n++] = 1; order[n++] = 5; order[n++] = 6;
+    } else {
+        order[n++] = 2; order[n++] = 3; order[n++] = 6;
+    }
+    int pick = -1;
+    Tiling til{};
+    for (int i = 0; i < n; ++i) {
+        Tiling t{};
+        if (!plan(a, kVariants[order[i]], NTtot, &t)) continue;
+        pick = order[i];
+        til = t;
+        if (t.nwg * t.ngroups * a->batch >= 512) break;  // else keep refining to the finest fit
+    }
+    if (pick < 0) return OCCD_ENOMEM;
+    const Variant& v = kVariants[pick];
+
+    ConvP p;
+    p.in = a->in; p.wpk = a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
+    p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.cin8 = cin8; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
+    p.KTtot = cin8 / 8; p.NTtot = NTtot;
+    p.out_cs = a->out_cs; p.out_coff = a->out_coff;
+    p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
+    p.KX = a->kx; p.KY = a->ky; p.KZ = a->kz; p.SX = a->sx; p.SY = a->sy; p.SZ = a->sz;
+    p.DX = a->dx; p.DY = a->dy; p.DZ = a->dz; p.PX = a->px; p.PY = a->py; p.PZ = a->pz;
+    p.Xo = a->Xo; p.Yo = a->Yo; p.Zo = a->Zo; p.OX = a->OX; p.OY = a->OY; p.OZ = a->OZ;
+    p.osx = a->o_stride_x; p.osy = a->o_stride_y; p.osz = a->o_stride_z;
+    p.oox = a->o_off_x; p.ooy = a->o_off_y; p.ooz = a->o_off_z;
+    p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
+    p.TY = til.TY; p.TZ = til.TZ; p.YIN = til.YIN; p.ZIN = til.ZIN;
+    p.ytiles = til.ytiles; p.ztiles = til.ztiles; p.nwg = (int)til.nwg;
+    p.div_zin = occd::make_fastdiv(til.ZIN); p.div_tz = occd::make_fastdiv(til.TZ);
+    p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
+
+    if (til.lds > 64 * 1024 && !g_attr_set[pick]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kMaxLds) != hipSuccess)
+            return OCCD_ELAUNCH;
+        g_attr_set[pick] = true;
+    }
+    const double taps = (double)a->kx * a->ky * a->kz;
+    const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
+    const double flops = 2.0 * pos * taps * a->cin * a->cout;
+    const double bytes = 4.0 * ((double)a->batch * a->X * a->Y * a->Z * a->cin +
+                                pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) +
+                                taps * a->cin * a->cout);
+    occd::ProfScope prof("conv3d_igemm", (hipStream_t)stream, flops, bytes);
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
+                       dim3(v.WM * v.WN * 64), til.lds, (hipStream_t)stream, p);
+    return occd::check_launch();
+}

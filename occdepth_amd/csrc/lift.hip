@@ -1,0 +1,381 @@
+// K1 -- 2D->3D lift (Stereo-SFA gather + FLoSP-Depth frustum sample).
+//
+// Both kernels are HBM-bandwidth work: per voxel a handful of index loads, V x S
+// gathers of one contiguous C-float pixel row from channels-last feature maps,
+// a wavefront-level (DPP) reduction for the cosine similarity, and one
+// contiguous C-float voxel row written channels-last for the 3-D stack.
+//
+//   lift_kernel<LPV>: LPV lanes cooperate on one voxel, each lane owns one
+//   float4 of channels, so a pixel row is read as one coalesced LPV*16-byte
+//   segment and the 64-wide wave covers 64/LPV voxels per instruction.
+//
+// Reference semantics: occdepth/models/SFA.py:12-106, occdepth/models/OccDepth.py:266-298,339;
+// occdepth/models/flosp_depth/flosp_depth.py:561-602, f2v/frustum_grid_generator.py:70-152,
+// f2v/utils/{transform_utils.py:5-26,depth_utils.py:24-26,grid_utils.py:4-19}, f2v/sampler.py:59-64.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- sum over the LPV lanes of a voxel group; result in every lane ---------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(moved);
+}
+template <int LPV>
+__device__ __forceinline__ float group_sum(float v) {
+    v = dpp_add<0xB1>(v);                       // quad_perm [1,0,3,2]   (xor 1)
+    v = dpp_add<0x4E>(v);                       // quad_perm [2,3,0,1]   (xor 2)
+    if (LPV >= 8) v = dpp_add<0x141>(v);        // row_half_mirror       (i -> 7-i)
+    if (LPV >= 16) v = dpp_add<0x140>(v);       // row_mirror            (i -> 15-i)
+    if (LPV >= 32) v += __shfl_xor(v, 16, 64);
+    if (LPV >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct LiftP {
+    occd_lift_args a;
+};
+
+template <int LPV>
+__global__ void __launch_bounds__(256) lift_kernel(const LiftP pp) {
+    const occd_lift_args& a = pp.a;
+    const int tid = threadIdx.x;
+    const int sub = tid % LPV;
+    const long n = ((long)blockIdx.x * 256 + tid) / LPV;
+    const int b = blockIdx.y;
+    const bool vox_ok = n < a.N;
+    const long nn = vox_ok ? n : (long)a.N - 1;
+    const int c = sub * 4;
+    const bool ch_ok = c < a.C;
+    const int V = a.n_views, P = a.P;
+
+    // projected pixels / FOV flags of this voxel: identical address for the LPV
+    // lanes of a group (one broadcast transaction).
+    const int64_t* pix = a.pix + (((size_t)b * V) * a.N) * P * 2;
+    const uint8_t* fov = a.fov + (((size_t)b * V) * a.N) * P;
+
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.n_scales; ++s) {
+        const int div = a.scale_div[s];
+        const int w = a.feat_w[s];
+        const int cs = a.feat_cs[s];
+        const size_t bstride = (size_t)a.feat_h[s] * w * cs;
+        f32x4 f[OCCD_MAX_VIEWS];
+        float m[OCCD_MAX_VIEWS];
+#pragma unroll
+        for (int v = 0; v < OCCD_MAX_VIEWS; ++v) {
+            f[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m[v] = 0.f;
+            if (v < V) {
+                const float* fm = a.feat[s][v] + (size_t)b * bstride + c;
+                int cnt = 0;
+                for (int q = 0; q < P; ++q) {
+                    const size_t pi = ((size_t)v * a.N + nn) * P + q;
+                    if (fov[pi]) {
+                        const long px = pix[pi * 2], py = pix[pi * 2 + 1];
+                        const long idx = (py / div) * w + (px / div);
+                        ++cnt;
+                        if (ch_ok) {
+                            const f32x4 g = *(const f32x4*)(fm + (size_t)idx * cs);
+                            f[v] += g;
+                        }
+                    }
+                }
+                if (cnt > 0) {
+                    const float fc = (float)cnt;
+                    f[v].x /= fc; f[v].y /= fc; f[v].z /= fc; f[v].w /= fc;
+                    m[v] = 1.f;
+                }
+            }
+        }
+        f32x4 o;
+        if (V == 1) {
+            o = f[0];
+        } else {
+            o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < OCCD_MAX_VIEWS; ++i) {
+#pragma unroll
+                for (int j = i + 1; j < OCCD_MAX_VIEWS; ++j) {
+                    if (j < V) {
+                        // torch.cosine_similarity: normalise each vector by max(||.||, eps) first
+                        float ni = f[i].x * f[i].x + f[i].y * f[i].y + f[i].z * f[i].z + f[i].w * f[i].w;
+                        float nj = f[j].x * f[j].x + f[j].y * f[j].y + f[j].z * f[j].z + f[j].w * f[j].w;
+                        ni = fmaxf(sqrtf(group_sum<LPV>(ni)), 1e-8f);
+                        nj = fmaxf(sqrtf(group_sum<LPV>(nj)), 1e-8f);
+                        const f32x4 xi = f[i] / ni, xj = f[j] / nj;
+                        float d = xi.x * xj.x + xi.y * xj.y + xi.z * xj.z + xi.w * xj.w;
+                        d = group_sum<LPV>(d) * (m[i] * m[j]);
+                        const float wi = d + (m[i] > m[j] ? 1.f : 0.f);
+                        const float wj = d + (m[j] > m[i] ? 1.f : 0.f);
+                        o += wi * f[i] + wj * f[j];
+                    }
+                }
+            }
+            const float den = (float)(V * (V - 1));
+            o.x /= den; o.y /= den; o.z /= den; o.w /= den;
+        }
+        if (s == 0) total = o; else total += o;
+    }
+    if (a.depth_scale != nullptr) {
+        const float dsc = a.depth_scale[(size_t)b * a.N + nn];
+        total = total * dsc * a.scale_const;
+    }
+    if (vox_ok && c < a.out_cs) {
+        const long bc = a.dimB * (long)a.dimC;
+        const long ia = n / bc;
+        const long rem = n - ia * bc;
+        const long ib = rem / a.dimC, ic = rem - ib * a.dimC;
+        const long row = ia * a.row_a + ib * a.row_b + ic * a.row_c;
+        float* o = a.out + ((size_t)b * a.out_rows + row) * a.out_cs + c;
+        *(f32x4*)o = ch_ok ? total : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ------------------------------------------------------------ frustum sample
+struct FlospP {
+    occd_flosp_args a;
+    float bin_size;
+};
+
+__device__ __forceinline__ float from_homog_scale(float w) {
+    // kornia.convert_points_from_homogeneous (0.5.0): eps = 1e-8
+    return fabsf(w) > 1e-8f ? 1.f / (w + 1e-8f) : 1.f;
+}
+
+__global__ void __launch_bounds__(256) flosp_sample_kernel(const FlospP pp) {
+    const occd_flosp_args& a = pp.a;
+    const long nvox = (long)a.A * a.Bdim * a.C;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= nvox) return;
+    const long bc = (long)a.Bdim * a.C;
+    const int ia = (int)(n / bc);
+    const long rem = n - (long)ia * bc;
+    const int ib = (int)(rem / a.C), ic = (int)(rem - (long)ib * a.C);
+    const float gx = (float)ia + 0.5f, gy = (float)ib + 0.5f, gz = (float)ic + 0.5f;
+
+    float feat_sum = 0.f, mask_sum = 0.f;
+    for (int cam = 0; cam < a.n_cams; ++cam) {
+        float nx, ny, nz;
+        if (a.grids != nullptr) {
+            const float* g = a.grids + ((((size_t)cam * a.batch + b) * nvox) + n) * 3;
+            nx = g[0]; ny = g[1]; nz = g[2];
+        } else {
+            const float* T = a.trans + ((size_t)b * a.n_cams + cam) * 16;
+            const float* K = a.proj + ((size_t)b * a.n_cams + cam) * 12;
+            const float* I = a.ida + ((size_t)b * a.n_cams + cam) * 16;
+            // voxel centre -> camera frame
+            float cx = gx * T[0] + gy * T[1] + gz * T[2] + T[3];
+            float cy = gx * T[4] + gy * T[5] + gz * T[6] + T[7];
+            float cz = gx * T[8] + gy * T[9] + gz * T[10] + T[11];
+            const float cw = gx * T[12] + gy * T[13] + gz * T[14] + T[15];
+            const float sc = from_homog_scale(cw);
+            cx *= sc; cy *= sc; cz *= sc;
+            // camera -> image plane, depth
+            const float u0 = K[0] * cx + K[1] * cy + K[2] * cz + K[3];
+            const float v0 = K[4] * cx + K[5] * cy + K[6] * cz + K[7];
+            const float w0 = K[8] * cx + K[9] * cy + K[10] * cz + K[11];
+            const float sp = from_homog_scale(w0);
+            const float u = u0 * sp, v = v0 * sp;
+            const float dep = w0 - K[11];
+            // LID depth bin
+            const float bin = -0.5f + 0.5f * sqrtf(1.f + 8.f * (dep - a.depth_min) / pp.bin_size);
+            // image-data-augmentation matrix
+            float fx = u * I[0] + v * I[1] + bin * I[2] + I[3];
+            float fy = u * I[4] + v * I[5] + bin * I[6] + I[7];
+            float fz = u * I[8] + v * I[9] + bin * I[10] + I[11];
+            const float fw = u * I[12] + v * I[13] + bin * I[14] + I[15];
+            const float si = from_homog_scale(fw);
+            fx *= si; fy *= si; fz *= si;
+            // normalise with the FULL image size (reference quirk) and D
+            nx = fx / (a.img_w - 1.f) * 2.f + -1.f;
+            ny = fy / (a.img_h - 1.f) * 2.f + -1.f;
+            nz = fz / ((float)a.D - 1.f) * 2.f + -1.f;
+            if (!isfinite(nx)) nx = -2.f;
+            if (!isfinite(ny)) ny = -2.f;
+            if (!isfinite(nz)) nz = -2.f;
+        }
+        // F.grid_sample 5-D, bilinear, zeros padding, align_corners=False
+        const float ix = ((nx + 1.f) * (float)a.w - 1.f) / 2.f;
+        const float iy = ((ny + 1.f) * (float)a.h - 1.f) / 2.f;
+        const float iz = ((nz + 1.f) * (float)a.D - 1.f) / 2.f;
+        const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+        const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
+        const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
+        // float -> int is saturating on the device; far-away coordinates stay out of bounds
+        const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+        const float* vol = a.depth + ((size_t)b * a.n_cams + cam) * a.D * a.h * a.w;
+        float acc = 0.f, msk = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+            const float wgt = (dx ? wx1 : wx0) * (dy ? wy1 : wy0) * (dz ? wz1 : wz0);
+            if ((unsigned)x < (unsigned)a.w && (unsigned)y < (unsigned)a.h && (unsigned)z < (unsigned)a.D) {
+                acc += vol[((size_t)z * a.h + y) * a.w + x] * wgt;
+                msk += wgt;
+            }
+        }
+        feat_sum += acc;
+        mask_sum += msk;
+    }
+    float r = feat_sum;
+    if (a.n_cams > 1 && a.mean_mode && mask_sum > 0.f) r = feat_sum / mask_sum;
+    a.out[(size_t)b * nvox + n] = r;
+}
+
+// ------------------------------------------------------------ layout helpers
+// (B, C, S) -> (B, S, cs): 64 positions x 32 channels per workgroup through LDS
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, long S, int cs) {
+    __shared__ float tile[32][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const long s0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int b = blockIdx.z;
+    const float* ib = in + (size_t)b * C * S;
+    float* ob = out + (size_t)b * S * cs;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + ty * 8 + k;
+        const long s = s0 + tx;
+        tile[ty * 8 + k][tx] = (c < C && s < S) ? ib[(size_t)c * S + s] : 0.f;
+    }
+    __syncthreads();
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long s = s0 + sl + k * 8;
+        const int c = c0 + cl;
+        if (s < S && c < cs) ob[(size_t)s * cs + c] = tile[cl][sl + k * 8];
+    }
+}
+
+// (B, S, cs)[coff : coff + C] -> (B, C, S)
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, long S, int cs, int coff) {
+    __shared__ float tile[64][33];
+    const long s0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int b = blockIdx.z;
+    const float* ib = in + (size_t)b * S * cs + coff;
+    float* ob = out + (size_t)b * C * S;
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long s = s0 + sl + k * 8;
+        const int c = c0 + cl;
+        tile[sl + k * 8][cl] = (s < S && c < C) ? ib[(size_t)s * cs + c] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + ty * 8 + k;
+        const long s = s0 + tx;
+        if (c < C && s < S) ob[(size_t)c * S + s] = tile[tx][ty * 8 + k];
+    }
+}
+
+__global__ void __launch_bounds__(256) softmax_channels_kernel(const float* __restrict__ src,
+                                                               float* __restrict__ dst, long rows, int src_cs,
+                                                               int src_coff, int dst_cs, int dst_coff, int n, int dst_pad) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* s = src + (size_t)r * src_cs + src_coff;
+    float* d = dst + (size_t)r * dst_cs + dst_coff;
+    float mx = s[0];
+    for (int i = 1; i < n; ++i) mx = fmaxf(mx, s[i]);
+    float sum = 0.f;
+    for (int i = 0; i < n; ++i) sum += expf(s[i] - mx);
+    for (int i = 0; i < n; ++i) d[i] = expf(s[i] - mx) / sum;
+    for (int i = 0; i < dst_pad; ++i) d[n + i] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int occd_lift_fwd(const occd_lift_args* a, void* stream) {
+    if (!a || !a->pix || !a->fov || !a->out) return OCCD_EINVAL;
+    if (a->n_scales < 1 || a->n_scales > OCCD_MAX_SCALES || a->n_views < 1 || a->n_views > OCCD_MAX_VIEWS)
+        return OCCD_EINVAL;
+    if (a->C <= 0 || (a->C & 3) || a->C > 256 || (a->out_cs & 3) || a->out_cs < a->C || a->out_cs > 256)
+        return OCCD_EINVAL;
+    if (a->N <= 0 || a->P <= 0 || a->batch <= 0) return OCCD_EINVAL;
+    if ((long)a->dimA * a->dimB * a->dimC != (long)a->N) return OCCD_EINVAL;
+    for (int s = 0; s < a->n_scales; ++s) {
+        if (a->scale_div[s] <= 0 || (a->feat_cs[s] & 3) || a->feat_cs[s] < a->C) return OCCD_EINVAL;
+        for (int v = 0; v < a->n_views; ++v)
+            if (!a->feat[s][v] || (reinterpret_cast<uintptr_t>(a->feat[s][v]) & 15)) return OCCD_EINVAL;
+    }
+    LiftP p;
+    p.a = *a;
+    const int need = a->out_cs / 4;  // lanes that must exist per voxel
+    const int lpv = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+    const long threads = (long)a->N * lpv;
+    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)a->batch);
+    // algorithmic bytes: output rows + one gathered pixel row per view/scale + indices
+    const double bytes = (double)a->batch * a->N *
+                         (4.0 * a->C * (1 + (double)a->n_views * a->n_scales) + (double)a->n_views * a->P * 17 +
+                          (a->depth_scale ? 4 : 0));
+    occd::ProfScope prof("sfa_lift", (hipStream_t)stream, 0.0, bytes);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lpv) {
+        case 8: hipLaunchKernelGGL(lift_kernel<8>, grid, dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL(lift_kernel<16>, grid, dim3(256), 0, st, p); break;
+        case 32: hipLaunchKernelGGL(lift_kernel<32>, grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(lift_kernel<64>, grid, dim3(256), 0, st, p); break;
+    }
+    return occd::check_launch();
+}
+
+extern "C" int occd_flosp_sample_fwd(const occd_flosp_args* a, void* stream) {
+    if (!a || !a->depth || !a->out) return OCCD_EINVAL;
+    if (!a->grids && (!a->trans || !a->proj || !a->ida)) return OCCD_EINVAL;
+    if (a->batch <= 0 || a->n_cams <= 0 || a->D <= 1 || a->h <= 0 || a->w <= 0) return OCCD_EINVAL;
+    if (a->A <= 0 || a->Bdim <= 0 || a->C <= 0) return OCCD_EINVAL;
+    FlospP p;
+    p.a = *a;
+    // python: bin_size = 2 * (depth_max - depth_min) / (num_bins * (1 + num_bins)) in double,
+    // then used as an fp32 scalar operand
+    p.bin_size = (float)(2.0 * ((double)a->depth_max - (double)a->depth_min) / ((double)a->D * (1.0 + a->D)));
+    const long nvox = (long)a->A * a->Bdim * a->C;
+    const double bytes = (double)a->batch * (nvox * (4.0 + 12.0 * (a->grids ? a->n_cams : 0)) +
+                                             4.0 * a->n_cams * a->D * a->h * a->w);
+    occd::ProfScope prof("flosp_sample", (hipStream_t)stream, 0.0, bytes);
+    hipLaunchKernelGGL(flosp_sample_kernel, dim3((unsigned)((nvox + 255) / 256), (unsigned)a->batch), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    return occd::check_launch();
+}
+
+extern "C" int occd_nchw_to_nhwc(const float* in, float* out, int32_t batch, int32_t C, int64_t S, int32_t cs,
+                                 void* stream) {
+    if (!in || !out || batch <= 0 || C <= 0 || S <= 0 || cs < C) return OCCD_EINVAL;
+    occd::ProfScope prof("nchw_to_nhwc", (hipStream_t)stream, 0.0, 4.0 * batch * S * (C + cs));
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((cs + 31) / 32), (unsigned)batch),
+                       dim3(256), 0, (hipStream_t)stream, in, out, C, (long)S, cs);
+    return occd::check_launch();
+}
+
+extern "C" int occd_nhwc_to_nchw(const float* in, float* out, int32_t batch, int32_t C, int64_t S, int32_t cs,
+                                 int32_t coff, void* stream) {
+    if (!in || !out || batch <= 0 || C <= 0 || S <= 0 || coff < 0 || coff + C > cs) return OCCD_EINVAL;
+    occd::ProfScope prof("nhwc_to_nchw", (hipStream_t)stream, 0.0, 8.0 * batch * S * C);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((S + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)batch),
+                       dim3(256), 0, (hipStream_t)stream, in, out, C, (long)S, cs, coff);
+    return occd::check_launch();
+}
+
+extern "C" int occd_softmax_channels(const float* src, float* dst, int64_t rows, int32_t src_cs, int32_t src_coff,
+                                     int32_t dst_cs, int32_t dst_coff, int32_t n, int32_t dst_pad, void* stream) {
+    if (!src || !dst || rows <= 0 || n <= 0 || n > 64 || dst_pad < 0 || src_coff + n > src_cs ||
+        dst_coff + n + dst_pad > dst_cs)
+        return OCCD_EINVAL;
+    occd::ProfScope prof("softmax_channels", (hipStream_t)stream, 0.0, 8.0 * rows * n);
+    hipLaunchKernelGGL(softmax_channels_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, (long)rows, src_cs, src_coff, dst_cs, dst_coff, n, dst_pad);
+    return occd::check_launch();
+}

@@ -1,0 +1,181 @@
+"""Eval-mode execution plans: nn.Conv3d / ConvTranspose3d / AvgPool3d+Conv3d (+ BatchNorm3d)
+folded into one packed-weight launch of the HIP implicit-GEMM kernel (K2).
+
+A plan owns no parameters: it references the live nn modules, folds BatchNorm running
+statistics into (weight scale, bias) and packs on first use; the packed image is rebuilt
+whenever a source tensor is replaced or modified in place (load_state_dict, optimizer step),
+detected through (data_ptr, _version).
+"""
+import torch
+
+from . import hip
+from .hip import ACT_NONE, ACT_RELU, ACT_RELU_PRE, ACT_SIGMOID, Vox  # noqa: F401 (re-exported)
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+def _stamp(*mods):
+    key = []
+    for m in mods:
+        if m is None:
+            continue
+        for t in list(m.parameters(recurse=False)) + list(m.buffers(recurse=False)):
+            key.append((t.data_ptr(), t._version, t.device))
+    return tuple(key)
+
+
+def _bn_affine(bn, cout, device):
+    """BatchNorm (eval) as y = x * scale + shift."""
+    if bn is None:
+        return None, torch.zeros(cout, device=device)
+    inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+    g = bn.weight.float() if bn.weight is not None else torch.ones_like(inv)
+    b = bn.bias.float() if bn.bias is not None else torch.zeros_like(inv)
+    scale = g * inv
+    return scale, b - bn.running_mean.float() * scale
+
+
+def _pad_bias(bias, cout):
+    out = torch.zeros(hip.round_up(cout, 32), device=bias.device, dtype=torch.float32)
+    out[:cout] = bias
+    return out
+
+
+class ConvPlan:
+    """conv (+ optional conv bias) + optional BatchNorm3d as one K2 launch."""
+
+    def __init__(self, conv, bn=None, pool=None):
+        self.conv, self.bn = conv, bn
+        self.pool = _triple(pool) if pool is not None else None  # AvgPool3d(k=stride=pool) in front of a 1x1x1 conv
+        self._key = None
+        self._wpk = self._bias = None
+
+    @property
+    def cout(self):
+        return self.conv.out_channels
+
+    def _prepare(self):
+        key = _stamp(self.conv, self.bn)
+        if key == self._key:
+            return
+        w = self.conv.weight.detach().float()
+        dev = w.device
+        cout = self.cout
+        scale, shift = _bn_affine(self.bn, cout, dev)
+        if self.conv.bias is not None:
+            cb = self.conv.bias.detach().float()
+            shift = shift + (cb * scale if scale is not None else cb)
+        if self.pool is not None:
+            # mean over the pooling window then 1x1x1 conv == conv with k = stride = window, w / |window|
+            kx, ky, kz = self.pool
+            w = (w / float(kx * ky * kz)).expand(-1, -1, kx, ky, kz).contiguous()
+        self._wpk = hip.pack_weights(w, scale)
+        self._bias = _pad_bias(shift, cout)
+        self._key = key
+
+    def geometry(self):
+        if self.pool is not None:
+            return self.pool, self.pool, (1, 1, 1), (0, 0, 0)
+        c = self.conv
+        return _triple(c.kernel_size), _triple(c.stride), _triple(c.dilation), _triple(c.padding)
+
+    def out_dims(self, dims):
+        k, s, d, p = self.geometry()
+        return tuple((n + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for n, kk, ss, dd, pp in zip(dims, k, s, d, p))
+
+    def __call__(self, x, out=None, res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE):
+        self._prepare()
+        k, s, d, p = self.geometry()
+        if out is None:
+            out = Vox.empty(x.batch, self.out_dims(x.dims), self.cout, x.buf.device)
+        return hip.conv3d(x, self._wpk, self._bias, self.cout, k, out, stride=s, dilation=d, padding=p,
+                          res1=res1, res2=res2, act_in=act_in, act_out=act_out)
+
+
+class ConvTransposePlan:
+    """ConvTranspose3d(k=3, s=2, p=1, output_padding=1) (+BN) as 8 sub-pixel phase convolutions,
+    or ConvTranspose3d(k=3, s=1, p=1) (+BN) as one flipped convolution."""
+
+    def __init__(self, convt, bn=None):
+        self.convt, self.bn = convt, bn
+        ks, st = _triple(convt.kernel_size), _triple(convt.stride)
+        pd, op = _triple(convt.padding), _triple(convt.output_padding)
+        if ks != (3, 3, 3) or pd != (1, 1, 1) or _triple(convt.dilation) != (1, 1, 1):
+            raise NotImplementedError("only the k3/p1 transposed convolutions of OccDepth are planned")
+        if st == (2, 2, 2) and op == (1, 1, 1):
+            self.up = 2
+        elif st == (1, 1, 1) and op == (0, 0, 0):
+            self.up = 1
+        else:
+            raise NotImplementedError(f"ConvTranspose3d stride {st} output_padding {op}")
+        self._key = None
+        self._phases = None
+        self._bias = None
+
+    @property
+    def cout(self):
+        return self.convt.out_channels
+
+    def _prepare(self):
+        key = _stamp(self.convt, self.bn)
+        if key == self._key:
+            return
+        wt = self.convt.weight.detach().float()  # (Cin, Cout, 3, 3, 3)
+        dev = wt.device
+        scale, shift = _bn_affine(self.bn, self.cout, dev)
+        if self.convt.bias is not None:
+            cb = self.convt.bias.detach().float()
+            shift = shift + (cb * scale if scale is not None else cb)
+        w = wt.permute(1, 0, 2, 3, 4)  # (Cout, Cin, k, k, k), k indexes the scatter offset o = s*i - 1 + k
+        phases = []
+        if self.up == 1:
+            phases.append(((0, 0, 0), (3, 3, 3), (1, 1, 1), hip.pack_weights(w.flip(2, 3, 4).contiguous(), scale)))
+        else:
+            # even outputs (o = 2j) see only k=1 at i=j; odd outputs (o = 2j+1) see k=2 at i=j and k=0 at i=j+1
+            taps = ([1], [2, 0])
+            for px in (0, 1):
+                for py in (0, 1):
+                    for pz in (0, 1):
+                        sub = w[:, :, taps[px]][:, :, :, taps[py]][:, :, :, :, taps[pz]].contiguous()
+                        phases.append(((px, py, pz), tuple(sub.shape[2:]), (0, 0, 0), hip.pack_weights(sub, scale)))
+        self._phases = phases
+        self._bias = _pad_bias(shift, self.cout)
+        self._key = key
+
+    def out_dims(self, dims):
+        return tuple(n * self.up for n in dims)
+
+    def __call__(self, x, out=None, res1=None, act_out=ACT_NONE):
+        self._prepare()
+        if out is None:
+            out = Vox.empty(x.batch, self.out_dims(x.dims), self.cout, x.buf.device)
+        for off, kern, pad, wpk in self._phases:
+            hip.conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
+                       out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
+        return out
+
+
+def gemm_rows(a, b_rows, out, act_in=ACT_NONE):
+    """out[row, :] = act_in(a[row, :K]) @ b_rows[:K, :N] for channels-last Vox a/out (CRP bmm).
+
+    b_rows is a dense (K, N) row-major device matrix (packed on the fly with occd_pack_weights layout 2)."""
+    K, N = b_rows.shape
+    wpk = hip.pack_weights(b_rows, layout=2)
+    return hip.conv3d(a, wpk, None, N, (1, 1, 1), out, act_in=act_in, cin=K)
+
+
+def as_vox(x):
+    """(B, C, X, Y, Z) tensor -> Vox; zero-copy when it already is a full channels-last buffer of ours."""
+    if isinstance(x, Vox):
+        return x
+    if x.dim() != 5:
+        raise RuntimeError("expected a (B, C, X, Y, Z) tensor")
+    if not x.is_cuda:
+        raise RuntimeError("the HIP path needs GPU tensors (there is no CPU fallback)")
+    x = x.float()
+    cl = x.permute(0, 2, 3, 4, 1)
+    if cl.is_contiguous() and x.shape[1] % 8 == 0:
+        return Vox(cl, x.shape[1])
+    return Vox.from_ncdhw(x)

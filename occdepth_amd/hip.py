@@ -1,0 +1,373 @@
+"""ctypes binding of libocc_hip.so (include/occdepth_amd.h).
+
+torch is used here only as the owner of device memory and of the HIP stream:
+every function takes torch CUDA(=HIP) tensors, passes raw pointers + sizes
+through the C ABI and launches on torch's current stream.  There is NO fallback:
+a missing / unloadable library or a CPU tensor raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
+
+MAX_VIEWS = 4
+MAX_SCALES = 4
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
+ABI_VERSION = 1
+
+_c_float_p = POINTER(c_float)
+
+
+class Conv3dArgs(Structure):
+    _fields_ = [
+        ("inp", c_void_p), ("wpk", c_void_p), ("bias", c_void_p), ("res1", c_void_p), ("res2", c_void_p),
+        ("out", c_void_p),
+        ("batch", c_int32),
+        ("X", c_int32), ("Y", c_int32), ("Z", c_int32),
+        ("cin", c_int32), ("in_cs", c_int32), ("in_coff", c_int32),
+        ("cout", c_int32), ("out_cs", c_int32), ("out_coff", c_int32),
+        ("res1_cs", c_int32), ("res1_coff", c_int32), ("res2_cs", c_int32), ("res2_coff", c_int32),
+        ("kx", c_int32), ("ky", c_int32), ("kz", c_int32),
+        ("sx", c_int32), ("sy", c_int32), ("sz", c_int32),
+        ("dx", c_int32), ("dy", c_int32), ("dz", c_int32),
+        ("px", c_int32), ("py", c_int32), ("pz", c_int32),
+        ("Xo", c_int32), ("Yo", c_int32), ("Zo", c_int32),
+        ("OX", c_int32), ("OY", c_int32), ("OZ", c_int32),
+        ("o_stride_x", c_int32), ("o_stride_y", c_int32), ("o_stride_z", c_int32),
+        ("o_off_x", c_int32), ("o_off_y", c_int32), ("o_off_z", c_int32),
+        ("act_in", c_int32), ("act_out", c_int32), ("cout_store", c_int32), ("tile_hint", c_int32),
+    ]
+
+
+class FlospArgs(Structure):
+    _fields_ = [
+        ("depth", c_void_p), ("trans", c_void_p), ("proj", c_void_p), ("ida", c_void_p), ("grids", c_void_p),
+        ("out", c_void_p),
+        ("batch", c_int32), ("n_cams", c_int32),
+        ("D", c_int32), ("h", c_int32), ("w", c_int32),
+        ("A", c_int32), ("Bdim", c_int32), ("C", c_int32),
+        ("img_w", c_float), ("img_h", c_float), ("depth_min", c_float), ("depth_max", c_float),
+        ("mean_mode", c_int32),
+    ]
+
+
+class LiftArgs(Structure):
+    _fields_ = [
+        ("feat", (c_void_p * MAX_VIEWS) * MAX_SCALES),
+        ("feat_h", c_int32 * MAX_SCALES), ("feat_w", c_int32 * MAX_SCALES),
+        ("feat_cs", c_int32 * MAX_SCALES), ("scale_div", c_int32 * MAX_SCALES),
+        ("n_scales", c_int32), ("n_views", c_int32), ("batch", c_int32), ("C", c_int32),
+        ("pix", c_void_p), ("fov", c_void_p),
+        ("N", c_int32), ("P", c_int32),
+        ("depth_scale", c_void_p), ("scale_const", c_float),
+        ("dimA", c_int32), ("dimB", c_int32), ("dimC", c_int32),
+        ("row_a", c_int64), ("row_b", c_int64), ("row_c", c_int64),
+        ("out", c_void_p), ("out_rows", c_int64), ("out_cs", c_int32),
+    ]
+
+
+class ProfRow(Structure):
+    _fields_ = [("tag", c_char * 48), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
+                ("bytes", c_double)]
+
+
+EXPORTS = {
+    "occd_abi_version": (c_int32, []),
+    "occd_strerror": (c_char_p, [c_int32]),
+    "occd_conv3d_fwd": (c_int32, [POINTER(Conv3dArgs), c_void_p]),
+    "occd_packed_weight_floats": (c_int64, [c_int32, c_int32, c_int32]),
+    "occd_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
+    "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
+    "occd_lift_fwd": (c_int32, [POINTER(LiftArgs), c_void_p]),
+    "occd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p]),
+    "occd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p]),
+    "occd_softmax_channels": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                        c_int32, c_void_p]),
+    "occd_prof_enable": (c_int32, [c_int32]),
+    "occd_prof_set_tag": (c_int32, [c_char_p]),
+    "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libocc_hip.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m occdepth_amd.build` "
+            "(the MI355X HIP kernels are the only implementation of this path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.occd_abi_version() != ABI_VERSION:
+        raise RuntimeError("libocc_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def _check(code, what):
+    if code != 0:
+        msg = load().occd_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def _ptr(t, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (the HIP kernels have no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return _ptr(t, name)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------- voxel tensors
+class Vox:
+    """Channels-last voxel tensor view: buf is (B, X, Y, Z, cs) float32; the
+    logical tensor is buf[..., coff:coff+C].  Pads in [C, round8(C)) must be zero."""
+
+    __slots__ = ("buf", "C", "coff")
+
+    def __init__(self, buf, C, coff=0):
+        assert buf.dim() == 5 and buf.dtype == torch.float32
+        self.buf, self.C, self.coff = buf, int(C), int(coff)
+
+    @property
+    def cs(self):
+        return self.buf.shape[4]
+
+    @property
+    def dims(self):
+        return tuple(self.buf.shape[1:4])
+
+    @property
+    def batch(self):
+        return self.buf.shape[0]
+
+    def ncdhw(self):
+        """Logical (B, C, X, Y, Z) view (channels_last_3d strides, no copy)."""
+        return self.buf[..., self.coff:self.coff + self.C].permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def empty(batch, dims, C, device, cs=None):
+        cs = cs if cs is not None else round_up(C, 8)
+        return Vox(torch.empty((batch,) + tuple(dims) + (cs,), device=device, dtype=torch.float32), C)
+
+    @staticmethod
+    def from_ncdhw(x):
+        """(B, C, X, Y, Z) float32 -> channels-last Vox with zeroed channel pad (HIP transpose)."""
+        B, C = x.shape[0], x.shape[1]
+        dims = tuple(x.shape[2:])
+        v = Vox.empty(B, dims, C, x.device)
+        xc = x.contiguous()
+        S = dims[0] * dims[1] * dims[2]
+        _check(load().occd_nchw_to_nhwc(_f32(xc, "x"), _f32(v.buf, "out"), B, C, S, v.cs, _stream()),
+               "occd_nchw_to_nhwc")
+        return v
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- K2
+def packed_weight_floats(cout, cin, taps):
+    n = load().occd_packed_weight_floats(cout, cin, taps)
+    if n <= 0:
+        raise RuntimeError("occd_packed_weight_floats: bad shape")
+    return n
+
+
+def pack_weights(w, scale=None, layout=0):
+    """w: (Cout, Cin, kx, ky, kz) [layout 0] / (K, N) row-major GEMM B operand [layout 2]."""
+    if layout == 2:
+        cin, cout = w.shape
+        k = (1, 1, 1)
+    else:
+        cout, cin = w.shape[0], w.shape[1]
+        k = tuple(w.shape[2:])
+    w = w.contiguous()
+    out = torch.empty(packed_weight_floats(cout, cin, k[0] * k[1] * k[2]), device=w.device, dtype=torch.float32)
+    sc = scale.contiguous() if scale is not None else None
+    _check(load().occd_pack_weights(_f32(w, "w"), _f32(sc, "scale") if sc is not None else None,
+                                    _f32(out, "wpk"), cout, cin, k[0], k[1], k[2], layout, _stream()),
+           "occd_pack_weights")
+    return out
+
+
+def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0),
+           res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1),
+           o_off=(0, 0, 0), cin=None, tile_hint=0):
+    """out = act_out(conv(act_in(x)) + bias + res1 + res2) on Vox tensors (see include/occdepth_amd.h)."""
+    a = Conv3dArgs()
+    a.inp, a.wpk = _f32(x.buf, "x"), _f32(wpk, "wpk")
+    a.bias = _f32(bias, "bias") if bias is not None else None
+    a.res1 = _f32(res1.buf, "res1") if res1 is not None else None
+    a.res2 = _f32(res2.buf, "res2") if res2 is not None else None
+    a.out = _f32(out.buf, "out")
+    a.batch = x.batch
+    a.X, a.Y, a.Z = x.dims
+    a.cin = x.C if cin is None else cin
+    a.in_cs, a.in_coff = x.cs, x.coff
+    a.cout, a.out_cs, a.out_coff = cout, out.cs, out.coff
+    if res1 is not None:
+        a.res1_cs, a.res1_coff = res1.cs, res1.coff
+    if res2 is not None:
+        a.res2_cs, a.res2_coff = res2.cs, res2.coff
+    a.kx, a.ky, a.kz = kernel
+    a.sx, a.sy, a.sz = stride
+    a.dx, a.dy, a.dz = dilation
+    a.px, a.py, a.pz = padding
+    a.OX, a.OY, a.OZ = out.dims
+    if out_pos is None:
+        out_pos = tuple((n + 2 * p - d * (k - 1) - 1) // s + 1
+                        for n, p, d, k, s in zip(x.dims, padding, dilation, kernel, stride))
+    a.Xo, a.Yo, a.Zo = out_pos
+    a.o_stride_x, a.o_stride_y, a.o_stride_z = o_stride
+    a.o_off_x, a.o_off_y, a.o_off_z = o_off
+    a.act_in, a.act_out = act_in, act_out
+    a.cout_store = min(round_up(cout, 8), out.cs - out.coff, round_up(cout, 32))
+    a.tile_hint = tile_hint
+    _check(load().occd_conv3d_fwd(ctypes.byref(a), _stream()), "occd_conv3d_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- K1
+def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, mean_mode=True, grids=None):
+    """depth (B, V, D, h, w) -> (B, A*B*C) sampled voxel volume (see occd_flosp_sample_fwd)."""
+    B, V, D, h, w = depth.shape
+    A, Bd, C = (int(v) for v in voxel_num)
+    out = torch.empty((B, A * Bd * C), device=depth.device, dtype=torch.float32)
+    a = FlospArgs()
+    a.depth = _f32(depth, "depth")
+    if grids is None:
+        a.trans, a.proj, a.ida = _f32(trans, "trans"), _f32(proj, "proj"), _f32(ida, "ida")
+    else:
+        a.grids = _f32(grids, "grids")
+    a.out = _f32(out, "out")
+    a.batch, a.n_cams, a.D, a.h, a.w = B, V, D, h, w
+    a.A, a.Bdim, a.C = A, Bd, C
+    a.img_h, a.img_w = float(final_dim[0]), float(final_dim[1])
+    a.depth_min, a.depth_max = float(d_min), float(d_max)
+    a.mean_mode = 1 if mean_mode else 0
+    _check(load().occd_flosp_sample_fwd(ctypes.byref(a), _stream()), "occd_flosp_sample_fwd")
+    return out
+
+
+def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0):
+    """feats[s][v]: (B, H_s, W_s, cs) channels-last maps; pix (B, V, N, P, 2) int64; fov (B, V, N, P) bool.
+
+    Writes out.buf rows (channels-last voxel grid); n -> (a,b,c) over n_dims, row = a*ra + b*rb + c*rc."""
+    a = LiftArgs()
+    S, V = len(feats), len(feats[0])
+    B = feats[0][0].shape[0]
+    for s in range(S):
+        for v in range(V):
+            a.feat[s][v] = _f32(feats[s][v], "feat")
+        a.feat_h[s], a.feat_w[s] = feats[s][0].shape[1], feats[s][0].shape[2]
+        a.feat_cs[s] = feats[s][0].shape[3]
+        a.scale_div[s] = int(scale_divs[s])
+    a.n_scales, a.n_views, a.batch = S, V, B
+    a.C = out.C
+    if pix.dtype != torch.int64:
+        raise RuntimeError("projected_pix must be int64")
+    a.pix = _ptr(pix, "projected_pix")
+    fov8 = fov.view(torch.uint8) if fov.dtype == torch.bool else fov
+    if fov8.dtype != torch.uint8:
+        raise RuntimeError("fov_mask must be bool/uint8")
+    a.fov = _ptr(fov8, "fov_mask")
+    a.N, a.P = pix.shape[2], pix.shape[3]
+    if depth_scale is not None:
+        a.depth_scale = _f32(depth_scale, "depth_scale")
+    a.scale_const = float(scale_const)
+    a.dimA, a.dimB, a.dimC = n_dims
+    a.row_a, a.row_b, a.row_c = row_strides
+    a.out = _f32(out.buf, "out")
+    a.out_rows = out.dims[0] * out.dims[1] * out.dims[2]
+    a.out_cs = out.cs
+    if out.coff != 0:
+        raise RuntimeError("lift output must start at channel 0")
+    _check(load().occd_lift_fwd(ctypes.byref(a), _stream()), "occd_lift_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- helpers
+def nchw_to_nhwc(x, cs=None):
+    """(B, C, *spatial) -> (B, *spatial, cs) channels-last copy with zero pad."""
+    B, C = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    S = 1
+    for d in sp:
+        S *= d
+    cs = cs if cs is not None else round_up(C, 4)
+    out = torch.empty((B,) + sp + (cs,), device=x.device, dtype=torch.float32)
+    xc = x.contiguous()
+    _check(load().occd_nchw_to_nhwc(_f32(xc, "x"), _f32(out, "out"), B, C, S, cs, _stream()), "occd_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(vox):
+    """Vox -> dense (B, C, X, Y, Z) tensor (a real copy; Vox.ncdhw() is the zero-copy view)."""
+    B = vox.batch
+    X, Y, Z = vox.dims
+    out = torch.empty((B, vox.C, X, Y, Z), device=vox.buf.device, dtype=torch.float32)
+    _check(load().occd_nhwc_to_nchw(_f32(vox.buf, "in"), _f32(out, "out"), B, vox.C, X * Y * Z, vox.cs, vox.coff,
+                                    _stream()), "occd_nhwc_to_nchw")
+    return out
+
+
+def softmax_channels(src, dst, n, dst_pad=0):
+    """softmax over src's n logical channels -> dst's n logical channels (+ dst_pad zeros) on the same grid."""
+    rows = src.batch * src.dims[0] * src.dims[1] * src.dims[2]
+    _check(load().occd_softmax_channels(_f32(src.buf, "src"), _f32(dst.buf, "dst"), rows, src.cs, src.coff, dst.cs,
+                                        dst.coff, n, dst_pad, _stream()), "occd_softmax_channels")
+    return dst
+
+
+class profile:
+    """Context manager: HIP-event timing of every kernel launched inside (see occd_prof_*)."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def __enter__(self):
+        load().occd_prof_report(None, 0)  # drop stale records
+        load().occd_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        lib.occd_prof_enable(0)
+        buf = (ProfRow * 512)()
+        n = lib.occd_prof_report(buf, 512)
+        if n < 0:
+            raise RuntimeError("occd_prof_report failed")
+        for i in range(min(n, 512)):
+            r = buf[i]
+            self.rows[r.tag.decode()] = dict(launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes)
+        return False
+
+
+def set_tag(tag):
+    load().occd_prof_set_tag(tag.encode() if tag else None)

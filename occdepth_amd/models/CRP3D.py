@@ -1,0 +1,99 @@
+"""3-D Context Relation Prior (mirror of occdepth/models/CRP3D.py:9-97).
+
+Eval-mode dataflow on the HIP kernels (N = voxels at this level, M = mega voxels = N/8):
+  x_agg   = ASPP(x)                                              6 x K2 (3x3x3, dilated)
+  mega    = mega_context(x_agg)          (M rows x 2C)           K2, stride 2
+  logit_r = context_prior_logits[r](x_agg)   (N rows x M)        K2 1x1x1  -> P_logits[:, r]
+  ctx_r   = sigmoid(logit_r) @ mega          (N rows x 2C)       K2 as GEMM: sigmoid fused on the
+                                                                 A-operand load, `mega` packed as B
+  x       = resize([x | ctx_0 .. ctx_{R-1}])                     ctx_r written straight into its
+                                                                 channel slice of the concat rows
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows
+from .modules import ASPP, Process
+
+
+class CPMegaVoxels(nn.Module):
+    def __init__(self, feature, size, n_relations=4, bn_momentum=0.0003):
+        super().__init__()
+        self.size = tuple(int(s) for s in size)
+        self.n_relations = n_relations
+        print("n_relations", self.n_relations)
+        self.flatten_size = self.size[0] * self.size[1] * self.size[2]
+        self.feature = feature
+        self.context_feature = feature * 2
+        self.flatten_context_size = (self.size[0] // 2) * (self.size[1] // 2) * (self.size[2] // 2)
+        padding = tuple((s + 1) % 2 for s in self.size)
+
+        self.mega_context = nn.Sequential(
+            nn.Conv3d(feature, self.context_feature, stride=2, padding=padding, kernel_size=3))
+        self.context_prior_logits = nn.ModuleList([
+            nn.Sequential(nn.Conv3d(self.feature, self.flatten_context_size, padding=0, kernel_size=1))
+            for _ in range(n_relations)])
+        self.aspp = ASPP(feature, [1, 2, 3])
+        self.resize = nn.Sequential(
+            nn.Conv3d(self.context_feature * self.n_relations + feature, feature, kernel_size=1, padding=0,
+                      bias=False),
+            Process(feature, nn.BatchNorm3d, bn_momentum, dilations=[1]))
+        self._plans = None
+
+    def forward_vox(self, x):
+        """x: Vox (B, X, Y, Z, C) -> {"x": Vox, "P_logits": (B, R, M, N) tensor view}."""
+        if self._plans is None:
+            self._plans = {
+                "mega": ConvPlan(self.mega_context[0]),
+                "logits": [ConvPlan(seq[0]) for seq in self.context_prior_logits],
+                "resize": ConvPlan(self.resize[0]),
+            }
+        pl = self._plans
+        B, dims, dev = x.batch, x.dims, x.buf.device
+        C, C2, R = self.feature, self.context_feature, self.n_relations
+        M, N = self.flatten_context_size, self.flatten_size
+        if dims != self.size:
+            raise RuntimeError(f"CPMegaVoxels built for {self.size}, got {dims}")
+        if C % 8 or C2 % 8:
+            raise NotImplementedError("CRP concat rows need feature % 8 == 0")
+
+        cat = torch.empty((B,) + dims + (C + R * C2,), device=dev, dtype=torch.float32)
+        cat[..., :C] = x.buf[..., x.coff:x.coff + C]           # torch.cat's first operand
+        x_agg = self.aspp.forward_vox(x)
+        mega = pl["mega"](x_agg)                                # (B, X/2, Y/2, Z/2, 2C): rows = mega voxels
+        m_cs = hip.round_up(M, 8)
+        logits = torch.empty((R * B,) + dims + (m_cs,), device=dev, dtype=torch.float32)
+        for r in range(R):
+            lg = Vox(logits[r * B:(r + 1) * B], M)
+            pl["logits"][r](x_agg, out=lg)
+            for b in range(B):
+                rows_b = mega.buf[b].reshape(M, mega.cs)[:, :C2]
+                if not rows_b.is_contiguous():
+                    rows_b = rows_b.contiguous()
+                gemm_rows(Vox(lg.buf[b:b + 1], M), rows_b, Vox(cat[b:b + 1], C2, C + r * C2),
+                          act_in=ACT_SIGMOID)
+        y = pl["resize"](Vox(cat, C + R * C2))
+        y = self.resize[1].forward_vox(y)
+        p_logits = logits.view(R, B, N, m_cs)[..., :M].permute(1, 0, 3, 2)
+        return {"P_logits": p_logits, "x": y}
+
+    def _forward_autograd(self, inp):
+        bs = inp.shape[0]
+        x_agg = self.aspp(inp)
+        mega = self.mega_context(x_agg).reshape(bs, self.context_feature, -1).transpose(1, 2)  # (bs, M, 2C)
+        logits, ctx = [], []
+        for head in self.context_prior_logits:
+            lg = head(x_agg).reshape(bs, self.flatten_context_size, self.flatten_size)
+            logits.append(lg.unsqueeze(1))
+            ctx.append(torch.bmm(torch.sigmoid(lg.transpose(1, 2)), mega))                        # (bs, N, 2C)
+        ctx = torch.cat(ctx, dim=2).transpose(1, 2).reshape(bs, -1, *self.size)
+        x = self.resize(torch.cat([inp, ctx], dim=1))
+        return {"P_logits": torch.cat(logits, dim=1), "x": x}
+
+    def forward(self, input):
+        if self.training:
+            return self._forward_autograd(input)
+        ret = self.forward_vox(as_vox(input))
+        ret["x"] = ret["x"].ncdhw()
+        return ret

@@ -1,0 +1,106 @@
+"""DDR-style factorised 3-D residual bottleneck (mirror of occdepth/models/DDR.py:35-139).
+
+Parameter layout is the reference's (conv1..conv5, bn1..bn5, downsample, downsample2/3/4, the
+last three always constructed even when stride == 1 so state_dicts interchange).  Eval-mode
+forward is five K2 launches with BatchNorm folded and every ReLU / residual add fused:
+
+    o1 = relu(c1(x))                 o2 = c2(o1)
+    o3 = c3(relu(o2)) + p2(o2)       o4 = c4(relu(o3)) + p3(p2(o2)) + p4(o3)
+    y  = relu(c5(relu(o4)) + skip(x))
+
+where p2/p3/p4 are the AvgPool+1x1x1+BN side branches (identity when stride == 1), run as
+k = stride = window convolutions.
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..fused import ACT_RELU, ConvPlan, as_vox
+
+
+def _axis(value, axis, other):
+    t = [other] * 3
+    t[axis] = value
+    return tuple(t)
+
+
+class Bottleneck3D(nn.Module):
+    def __init__(self, inplanes, planes, norm_layer, stride=1, dilation=[1, 1, 1], expansion=4,
+                 downsample=None, fist_dilation=1, multi_grid=1, bn_momentum=0.0003):
+        super().__init__()
+        self.expansion = expansion
+        self.stride = stride
+        self.dilation = dilation
+        self.conv1 = nn.Conv3d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = norm_layer(planes, momentum=bn_momentum)
+        # conv2 / conv3 / conv4 filter along Z / Y / X respectively (tensor dims are X, Y, Z)
+        for idx, axis in ((2, 2), (3, 1), (4, 0)):
+            d = dilation[idx - 2]
+            setattr(self, f"conv{idx}", nn.Conv3d(
+                planes, planes, kernel_size=_axis(3, axis, 1), stride=_axis(stride, axis, 1),
+                dilation=_axis(d, axis, 1), padding=_axis(d, axis, 0), bias=False))
+            setattr(self, f"bn{idx}", norm_layer(planes, momentum=bn_momentum))
+        self.conv5 = nn.Conv3d(planes, planes * expansion, kernel_size=1, bias=False)
+        self.bn5 = norm_layer(planes * expansion, momentum=bn_momentum)
+        self.relu = nn.ReLU(inplace=False)
+        self.relu_inplace = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+        def side(window):
+            return nn.Sequential(nn.AvgPool3d(kernel_size=window, stride=window),
+                                 nn.Conv3d(planes, planes, kernel_size=1, stride=1, bias=False),
+                                 norm_layer(planes, momentum=bn_momentum))
+
+        self.downsample2 = side((1, stride, 1))
+        self.downsample3 = side((stride, 1, 1))
+        self.downsample4 = side((stride, 1, 1))
+        self._plans = None
+
+    # ------------------------------------------------------------------ HIP (eval)
+    def _build_plans(self):
+        p = {i: ConvPlan(getattr(self, f"conv{i}"), getattr(self, f"bn{i}")) for i in range(1, 6)}
+        if self.stride != 1:
+            for i in (2, 3, 4):
+                seq = getattr(self, f"downsample{i}")
+                p[f"p{i}"] = ConvPlan(seq[1], seq[2], pool=seq[0].kernel_size)
+        if self.downsample is not None:
+            pool = self.downsample[0]
+            p["skip"] = ConvPlan(self.downsample[1], self.downsample[2], pool=pool.kernel_size)
+        return p
+
+    def forward_vox(self, x):
+        if self._plans is None:
+            self._plans = self._build_plans()
+        p = self._plans
+        strided = self.stride != 1
+        o1 = p[1](x, act_out=ACT_RELU)
+        o2 = p[2](o1)
+        o2s = p["p2"](o2) if strided else o2
+        o3 = p[3](o2, res1=o2s, act_in=ACT_RELU)
+        o2ss = p["p3"](o2s) if strided else o2s
+        o3s = p["p4"](o3) if strided else o3
+        o4 = p[4](o3, res1=o2ss, res2=o3s, act_in=ACT_RELU)
+        skip = p["skip"](x) if self.downsample is not None else x
+        return p[5](o4, res1=skip, act_in=ACT_RELU, act_out=ACT_RELU)
+
+    # ------------------------------------------------------------------ ATen (training / autograd)
+    def _forward_autograd(self, x):
+        strided = self.stride != 1
+        o1 = F.relu(self.bn1(self.conv1(x)))
+        o2 = self.bn2(self.conv2(o1))
+        o3 = self.bn3(self.conv3(F.relu(o2)))
+        if strided:
+            o2 = self.downsample2(o2)
+        o3 = o3 + o2
+        o4 = self.bn4(self.conv4(F.relu(o3)))
+        if strided:
+            o2 = self.downsample3(o2)
+            o3 = self.downsample4(o3)
+        o4 = o4 + o2 + o3
+        o5 = self.bn5(self.conv5(F.relu(o4)))
+        skip = x if self.downsample is None else self.downsample(x)
+        return F.relu(o5 + skip)
+
+    def forward(self, x):
+        if self.training:
+            return self._forward_autograd(x)
+        return self.forward_vox(as_vox(x)).ncdhw()

@@ -1,0 +1,224 @@
+"""OccDepth top module (mirror of occdepth/models/OccDepth.py:30-376, the forward hot path).
+
+Constructor signature, config attributes read, sub-module names (`net_rgb`, `projects`,
+`flosp_depth`, `net_3d_decoder`) and the `forward(batch) -> dict` contract are the reference's.
+Eval-mode forward:
+    2-D UNet per view (PyTorch-ROCm / MIOpen, both views in one batch)
+ -> K1a FLoSP-Depth frustum sample + K1b fused multi-scale Stereo-SFA lift   (HIP, HBM-bound)
+ -> channels-last 3-D UNet + CRP + cascade head on fp32-MFMA implicit GEMM     (HIP, MFMA-bound)
+Training mode keeps the reference's per-sample / per-scale structure on ATen autograd; the
+Lightning `*_step` hooks (losses, metrics, optimiser) are SURVEY 8(f) row N1 and not built yet.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .SFA import SFA, lift_scales
+from .flosp_depth import flosp_depth_conf_map
+from .flosp_depth.flosp_depth import FlospDepth
+from .unet2d import UNet2D
+from .unet3d_kitti import UNet3D as UNet3DKitti
+from .unet3d_nyu import UNet3D as UNet3DNYU
+
+try:  # the reference's base class; absent in this image -> plain nn.Module with the hooks it uses
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - depends on the environment
+    class _Base(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class OccDepth(_Base):
+    def __init__(self, class_names, class_weights, class_weights_occ=None, full_scene_size=None, project_res=[],
+                 config=None, infer_mode=False):
+        super().__init__()
+        self.project_res = project_res
+        self.full_scene_size = full_scene_size
+        self.class_names = class_names
+        self.class_weights = class_weights
+        self.class_weights_occ = class_weights_occ
+        for key in ("dataset", "frustum_size", "project_scale", "n_relations", "lr", "weight_decay", "fp_loss",
+                    "context_prior", "relation_loss", "CE_ssc_loss", "sem_scal_loss", "geo_scal_loss", "n_classes",
+                    "feature", "feature_2d_oc", "trans_2d_to_3d", "cascade_cls", "occluded_cls",
+                    "sem_step_decay_loss", "multi_view_mode", "share_2d_backbone_gradient", "use_stereo_depth_gt",
+                    "use_lidar_depth_gt", "use_depth_gt"):
+            setattr(self, key, getattr(config, key))
+        print("INFO: Use cascade cls: {}".format(self.cascade_cls))
+        print("INFO: Use occluded cls: {}".format(self.occluded_cls))
+        self.infer_mode = infer_mode
+        if infer_mode:
+            self.context_prior = False
+        assert not (config.use_stereo_depth_gt and config.use_lidar_depth_gt), "only with one depth data supported."
+        self.with_depth_gt = self.use_stereo_depth_gt or self.use_lidar_depth_gt or self.use_depth_gt
+        self.depth_loss_w = config.depth_loss_weight
+
+        if self.dataset == "NYU":
+            self.net_3d_decoder = UNet3DNYU(self.n_classes, nn.BatchNorm3d, n_relations=self.n_relations,
+                                            feature=self.feature, full_scene_size=self.full_scene_size,
+                                            context_prior=self.context_prior, cascade_cls=self.cascade_cls,
+                                            infer_mode=self.infer_mode)
+        elif self.dataset == "kitti":
+            self.net_3d_decoder = UNet3DKitti(self.n_classes, nn.BatchNorm3d, project_scale=self.project_scale,
+                                              feature=self.feature, full_scene_size=self.full_scene_size,
+                                              context_prior=self.context_prior, cascade_cls=self.cascade_cls,
+                                              occluded_cls=self.occluded_cls, infer_mode=self.infer_mode)
+        self.net_rgb = UNet2D.build(out_feature=self.feature_2d_oc, use_decoder=True,
+                                    backbone_2d_name=config.backbone_2d_name,
+                                    return_up_feats=config.return_up_feats)
+        self.save_hyperparameters()
+        self.init_2d_to_3d_trans(config)
+        print("INFO: Use step decay loss: {}".format(self.sem_step_decay_loss))
+        batch_size = config.batch_size_per_gpu * config.n_gpus
+        if self.dataset == "kitti":
+            self.total_batch = (3834 // batch_size) * 30
+        elif self.dataset == "NYU":
+            self.total_batch = (795 // batch_size) * 30
+        else:
+            raise NotImplementedError(self.dataset)
+        self.cur_batch = 0
+
+    def init_2d_to_3d_trans(self, config):
+        print("INFO: Selected 2d->3d transformation method: {}".format(self.trans_2d_to_3d))
+        if self.trans_2d_to_3d not in ("flosp", "flosp_depth"):
+            raise NotImplementedError(f"{self.trans_2d_to_3d} is not supported yet.")
+        self.scale_2ds = [1, 2, 4, 8]
+        self.projects = nn.ModuleDict({
+            str(s): SFA(config.full_scene_size, project_scale=self.project_scale, dataset=self.dataset)
+            for s in self.scale_2ds})
+        if self.trans_2d_to_3d == "flosp_depth":
+            conf = dict(flosp_depth_conf_map[self.dataset])
+            conf.update({
+                "scene_size": config.full_scene_size,
+                "project_scale": config.project_scale,
+                "output_channels": config.feature,
+                "depth_net_conf": dict(in_channels=config.feature,
+                                       mid_channels=conf["depth_net_conf"]["mid_channels"]),
+                "return_depth": self.with_depth_gt,
+                "infer_mode": self.infer_mode,
+            })
+            self.flosp_depth_conf = conf
+            self.flosp_depth = FlospDepth(**conf)
+
+    # ---------------------------------------------------------------- 2-D side
+    def process_rgbs(self, img, batch, n_views):
+        bs = img.shape[0]
+        if not self.training:
+            # eval: BN uses running stats, so the views can share one batched pass
+            both = self.net_rgb(img.reshape(bs * n_views, *img.shape[2:]))
+            x_rgb = [{k: v.reshape(bs, n_views, *v.shape[1:])[:, i] for k, v in both.items()}
+                     for i in range(n_views)]
+        else:
+            x_rgb = [self.net_rgb(img[:, 0])]
+            for i in range(1, n_views):
+                if self.share_2d_backbone_gradient:
+                    with torch.no_grad():
+                        x_rgb.append(self.net_rgb(img[:, i]))
+                else:
+                    x_rgb.append(self.net_rgb(img[:, i]))
+        if n_views == 1 and "gt_depth" in batch:
+            bf = batch["virtual_bf"][0].to(device) if "virtual_bf" in batch else None
+            x_rgb.append({"1_" + str(s): self.generate_virtual_img(batch, x_rgb[0]["1_" + str(s)], s, bf)
+                          for s in self.project_res})
+            n_views = 2
+        return x_rgb, n_views
+
+    def generate_virtual_img(self, batch, x_single_rgb, scale_2d, bf):
+        """Virtual right view: shift the sampling grid by the disparity bf / depth (reference :233-260,
+        including its use of sample 0's disparity for the whole batch)."""
+        depth = batch["gt_depth"].to(device)
+        n, c, h, w = x_single_rgb.shape
+        depth_s = F.interpolate(depth, size=(h, w), mode="bilinear", align_corners=False)
+        dx = torch.div(bf / int(scale_2d), depth_s).type_as(x_single_rgb)
+        dx = torch.where(torch.isinf(dx), torch.zeros_like(dx), dx)
+        ys = torch.arange(-1, 1, 2 / h)
+        xs = torch.arange(-1, 1, 2 / w)
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        grid = torch.stack((gx, gy), dim=2).unsqueeze(0).repeat(n, 1, 1, 1).to(device).type_as(dx)
+        grid[..., 0] = grid[..., 0] + (dx * 2 / w)[0]
+        return F.grid_sample(x_single_rgb, grid, mode="bilinear", padding_mode="border", align_corners=False)
+
+    # ---------------------------------------------------------------- 2D -> 3D
+    def _depth_volume(self, batch, x_rgb, vox_origin):
+        layer = "1_{}".format(self.flosp_depth_conf["downsample_factor"])
+        n_views = 1 if self.dataset == "NYU" else len(x_rgb)
+        img_feat = torch.stack([x_rgb[j][layer] for j in range(n_views)], 1).to(device)
+        if self.infer_mode:
+            kw = {"img_feat": img_feat, "grids": batch["grids"], "scaled_pixel_size": batch["scaled_pixel_size"]}
+        else:
+            kw = {"img_feat": img_feat, "cam_k": batch["cam_k"], "T_velo_2_cam": batch["T_velo_2_cam"],
+                  "ida_mats": batch["ida_mats"], "vox_origin": vox_origin}
+        if self.with_depth_gt:
+            return self.flosp_depth(**kw)
+        return self.flosp_depth(**kw), None
+
+    def _forward_2d_to_3d(self, batch, x_rgb, img, bs, vox_origin):
+        """eval: returns (Vox, depth_pred); training: ((B, C, X, Y, Z) tensor, depth_pred)."""
+        key = "projected_pix_{}".format(self.project_scale)
+        mkey = "fov_mask_{}".format(self.project_scale)
+        scales = [int(s) for s in self.project_res]
+        depth_vol = depth_pred = None
+        if self.trans_2d_to_3d == "flosp_depth":
+            depth_vol, depth_pred = self._depth_volume(batch, x_rgb, vox_origin)
+        if not self.training:
+            pix = torch.stack([p.to(device) for p in batch[key]])
+            fov = torch.stack([m.to(device) for m in batch[mkey]])
+            feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
+            flat = depth_vol.reshape(bs, -1).contiguous() if depth_vol is not None else None
+            vox = lift_scales(feats, scales, pix, fov, self.projects[str(scales[0])].scene_size,
+                              self.project_scale, self.dataset, depth_scale=flat, scale_const=100.0)
+            return vox, depth_pred
+        x3ds = []
+        for i in range(bs):
+            pix, fov = batch[key][i].to(device), batch[mkey][i].to(device)
+            x3d = None
+            for s in scales:
+                stack = torch.stack([x_rgb[j]["1_" + str(s)] for j in range(len(x_rgb))], 1).to(device)
+                part = self.projects[str(s)](stack[i], torch.div(pix, s, rounding_mode="floor"), fov)
+                x3d = part if x3d is None else x3d + part
+            x3ds.append(x3d)
+        x3ds = torch.stack(x3ds)
+        if depth_vol is not None:
+            if self.dataset == "NYU":
+                depth_vol = depth_vol.permute(0, 1, 2, 4, 3).contiguous()
+            x3ds = x3ds * depth_vol * 100
+        return x3ds, depth_pred
+
+    def forward(self, batch):
+        img = batch["img"].to(device)
+        bs, n_views = img.shape[:2]
+        x_rgb, n_views = self.process_rgbs(img, batch, n_views)
+        if self.dataset in ("NYU", "tartanair"):
+            vox_origin = batch["vox_origin"]
+        elif self.dataset == "kitti":
+            vox_origin = None
+        else:
+            raise NotImplementedError("dataset is not supported: {}".format(self.dataset))
+        x3ds, depth_pred = self._forward_2d_to_3d(batch, x_rgb, img, bs, vox_origin)
+        out = dict(self.net_3d_decoder({"x3d": x3ds}))
+        if self.with_depth_gt and self.trans_2d_to_3d == "flosp_depth":
+            out["depth_pred"] = depth_pred
+        return out
+
+    # ---------------------------------------------------------------- Lightning hooks
+    def step(self, batch, step_type, metric):
+        raise NotImplementedError("loss / metric step is SURVEY.md 8(f) row N1 (training step), not built yet")
+
+    def training_step(self, batch, batch_idx):
+        return self.step(batch, "train", None)
+
+    def validation_step(self, batch, batch_idx):
+        return self.step(batch, "val", None)
+
+    def test_step(self, batch, batch_idx):
+        return self.step(batch, "test", None)
+
+    def configure_optimizers(self):
+        from torch.optim.lr_scheduler import MultiStepLR
+        opt = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        return [opt], [MultiStepLR(opt, milestones=[18, 24], gamma=0.4)]

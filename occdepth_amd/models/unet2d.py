@@ -1,0 +1,141 @@
+"""2-D UNet: EfficientNet encoder + AdaBins-style BN decoder (mirror of occdepth/models/unet2d.py).
+
+Stays on PyTorch-ROCm / MIOpen (north_star); the HIP work starts at its output dict
+{"1_1","1_2","1_4","1_8","1_16"}.  Faithful quirks: the decoder taps encoder features
+[4, 5, 6, 8, 11] (conv_head output BEFORE bn2), `conv2` is a 1x1 conv with padding=1 (grows the
+1/32 map by 2), and `up1` concatenates the raw image.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .efficientnet import EfficientNet
+
+MODEL_NAME = "tf_efficientnet_b3_ns"
+MODEL_CHANNELS = {
+    "tf_efficientnet_b3_ns": [3, 24, 32, 48, 136],
+    "tf_efficientnet_b4_ns": [3, 24, 32, 56, 160],
+    "tf_efficientnet_b5_ns": [3, 32, 40, 64, 176],
+    "tf_efficientnet_b7_ns": [3, 32, 48, 80, 224],
+}
+NUM_FEATURES = {
+    "tf_efficientnet_b3_ns": 1536,
+    "tf_efficientnet_b4_ns": 1792,
+    "tf_efficientnet_b5_ns": 2048,
+    "tf_efficientnet_b7_ns": 2560,
+}
+_SCALES = (16, 8, 4, 2, 1)
+
+
+class UpSampleBN(nn.Module):
+    def __init__(self, skip_input, output_features):
+        super().__init__()
+        layers = []
+        for cin in (skip_input, output_features):
+            layers += [nn.Conv2d(cin, output_features, kernel_size=3, stride=1, padding=1),
+                       nn.BatchNorm2d(output_features), nn.LeakyReLU()]
+        self._net = nn.Sequential(*layers)
+
+    def forward(self, x, concat_with):
+        up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
+        return self._net(torch.cat([up, concat_with], dim=1))
+
+
+class DecoderBN(nn.Module):
+    def __init__(self, num_features, bottleneck_features, out_feature, use_decoder=True, backbone_2d_name=None,
+                 return_up_feats=None):
+        super().__init__()
+        features = int(num_features)
+        self.use_decoder = use_decoder
+        self.backbone_2d_name = backbone_2d_name
+        self.return_up_feats = return_up_feats
+        self.conv2 = nn.Conv2d(bottleneck_features, features, kernel_size=1, stride=1, padding=1)
+        for s in _SCALES:
+            setattr(self, f"out_feature_1_{s}", out_feature)
+            setattr(self, f"feature_1_{s}", features // (32 // s))
+        if not use_decoder:
+            self.resize_output_1_1 = nn.Conv2d(3, out_feature, kernel_size=1)
+            self.resize_output_1_2 = nn.Conv2d(32, out_feature * 2, kernel_size=1)
+            self.resize_output_1_4 = nn.Conv2d(48, out_feature * 4, kernel_size=1)
+            return
+        skips = MODEL_CHANNELS[backbone_2d_name]
+        prev = features
+        for s, skip in zip(_SCALES, reversed(skips)):
+            if return_up_feats > s:
+                continue
+            width = getattr(self, f"feature_1_{s}")
+            setattr(self, f"resize_output_1_{s}", nn.Conv2d(width, out_feature, kernel_size=1))
+            setattr(self, f"up{s}", UpSampleBN(skip_input=prev + skip, output_features=width))
+            prev = width
+
+    def forward(self, features):
+        taps = {16: features[8], 8: features[6], 4: features[5], 2: features[4], 1: features[0]}
+        x = self.conv2(features[11])
+        if not self.use_decoder:
+            bs = features[4].shape[0]
+            return {"1_1": self.resize_output_1_1(features[0]), "1_2": self.resize_output_1_2(features[4]),
+                    "1_4": self.resize_output_1_4(features[5]),
+                    "global": features[-1].reshape(bs, 2560, -1).mean(2)}
+        res = {}
+        for s in _SCALES:
+            if self.return_up_feats > s:
+                continue
+            x = getattr(self, f"up{s}")(x, taps[s])
+            res[f"1_{s}"] = getattr(self, f"resize_output_1_{s}")(x)
+        return res
+
+
+class Encoder(nn.Module):
+    def __init__(self, backend):
+        super().__init__()
+        self.original_model = backend
+
+    def forward(self, x):
+        features = [x]
+        for name, mod in self.original_model._modules.items():
+            if name == "blocks":
+                for stage in mod._modules.values():
+                    features.append(stage(features[-1]))
+            else:
+                features.append(mod(features[-1]))
+        return features
+
+
+class UNet2D(nn.Module):
+    def __init__(self, backend, num_features, out_feature, use_decoder=True, backbone_2d_name=None,
+                 return_up_feats=1):
+        super().__init__()
+        self.use_decoder = use_decoder
+        self.encoder = Encoder(backend)
+        self.decoder = DecoderBN(out_feature=out_feature, use_decoder=use_decoder, bottleneck_features=num_features,
+                                 num_features=num_features, backbone_2d_name=backbone_2d_name,
+                                 return_up_feats=return_up_feats)
+
+    def forward(self, x, **kwargs):
+        return self.decoder(self.encoder(x), **kwargs)
+
+    def get_encoder_params(self):
+        return self.encoder.parameters()
+
+    def get_decoder_params(self):
+        return self.decoder.parameters()
+
+    @classmethod
+    def build(cls, **kwargs):
+        """Same contract as the reference (unet2d.py:232-255).  The encoder is the in-repo
+        EfficientNet restatement (random init); hub weights, when a local file is named by
+        OCCDEPTH_BACKBONE_WEIGHTS, are loaded by key."""
+        name = kwargs["backbone_2d_name"]
+        print("Loading base model {}...".format(name), end="")
+        basemodel = EfficientNet(name)
+        weights = os.environ.get("OCCDEPTH_BACKBONE_WEIGHTS")
+        if weights:
+            basemodel.load_state_dict(torch.load(weights, map_location="cpu"), strict=True)
+        print("Done.")
+        basemodel.global_pool = nn.Identity()
+        basemodel.classifier = nn.Identity()
+        m = cls(basemodel, num_features=NUM_FEATURES[name], **kwargs)
+        print("INFO: return_up_feats set to : {}.".format(kwargs["return_up_feats"]))
+        return m
