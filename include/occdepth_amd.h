@@ -188,7 +188,7 @@ int occd_softmax_channels(const float* src, float* dst, int64_t rows,
  * per kernel tag, launches / total ms / total algorithmic flops / bytes.
  * ------------------------------------------------------------------------ */
 typedef struct occd_prof_row {
-    char tag[48];
+    char tag[64];
     int64_t launches;
     double ms;
     double flops;

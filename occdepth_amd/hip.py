@@ -71,7 +71,7 @@ class LiftArgs(Structure):
 
 
 class ProfRow(Structure):
-    _fields_ = [("tag", c_char * 48), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
+    _fields_ = [("tag", c_char * 64), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
                 ("bytes", c_double)]
 
 
@@ -94,6 +94,7 @@ EXPORTS = {
 }
 
 _lib = None
+_PROFILING = False
 
 
 def load():
@@ -249,6 +250,9 @@ def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1)
     a.act_in, a.act_out = act_in, act_out
     a.cout_store = min(round_up(cout, 8), out.cs - out.coff, round_up(cout, 32))
     a.tile_hint = tile_hint
+    if _PROFILING:
+        set_tag("%d>%d k%d%d%d s%d%d%d d%d%d%d @%dx%dx%d" % ((a.cin, a.cout) + tuple(kernel) + tuple(stride)
+                                                              + tuple(dilation) + tuple(x.dims)))
     _check(load().occd_conv3d_fwd(ctypes.byref(a), _stream()), "occd_conv3d_fwd")
     return out
 
@@ -352,13 +356,18 @@ class profile:
         self.rows = {}
 
     def __enter__(self):
+        global _PROFILING
         load().occd_prof_report(None, 0)  # drop stale records
         load().occd_prof_enable(1)
+        _PROFILING = True
         return self
 
     def __exit__(self, *exc):
+        global _PROFILING
         lib = load()
         lib.occd_prof_enable(0)
+        _PROFILING = False
+        set_tag(None)
         buf = (ProfRow * 512)()
         n = lib.occd_prof_report(buf, 512)
         if n < 0:

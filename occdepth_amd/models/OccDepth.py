@@ -52,6 +52,7 @@ class OccDepth(_Base):
         print("INFO: Use cascade cls: {}".format(self.cascade_cls))
         print("INFO: Use occluded cls: {}".format(self.occluded_cls))
         self.infer_mode = infer_mode
+        self.batch_views = False  # eval: run all views through net_rgb as one batch (faster, not bit-equal)
         if infer_mode:
             self.context_prior = False
         assert not (config.use_stereo_depth_gt and config.use_lidar_depth_gt), "only with one depth data supported."
@@ -108,8 +109,9 @@ class OccDepth(_Base):
     # ---------------------------------------------------------------- 2-D side
     def process_rgbs(self, img, batch, n_views):
         bs = img.shape[0]
-        if not self.training:
-            # eval: BN uses running stats, so the views can share one batched pass
+        if not self.training and self.batch_views and n_views > 1:
+            # eval: BN uses running stats, so the views can share one batched pass (opt-in: a different
+            # conv batch size changes backend algorithm choice and hence fp32 round-off)
             both = self.net_rgb(img.reshape(bs * n_views, *img.shape[2:]))
             x_rgb = [{k: v.reshape(bs, n_views, *v.shape[1:])[:, i] for k, v in both.items()}
                      for i in range(n_views)]

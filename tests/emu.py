@@ -1,0 +1,185 @@
+"""TEST-ONLY CPU emulation of the C-ABI entry points (include/occdepth_amd.h) in plain torch.
+
+`patched()` swaps the ctypes wrappers in occdepth_amd.hip for these functions so the host-side
+orchestration of the eval path (plans, BN folding, transposed-conv phase slicing, concat-slice
+bookkeeping, layout digits) can be executed and checked against the oracle without a GPU.
+It is not importable from the product and is never used by the `-m gpu` tests.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+from occdepth_amd import fused, hip
+from occdepth_amd.hip import ACT_RELU, ACT_RELU_PRE, ACT_SIGMOID, Vox, round_up
+
+
+class _Packed:
+    def __init__(self, w):
+        self.w = w
+
+    @property
+    def device(self):
+        return self.w.device
+
+
+def pack_weights(w, scale=None, layout=0):
+    w = w.detach().float()
+    if layout == 2:
+        w = w.t().reshape(w.shape[1], w.shape[0], 1, 1, 1)
+    if scale is not None:
+        w = w * scale.reshape(-1, 1, 1, 1, 1)
+    return _Packed(w.contiguous())
+
+
+def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0), res1=None,
+           res2=None, act_in=0, act_out=0, out_pos=None, o_stride=(1, 1, 1), o_off=(0, 0, 0), cin=None,
+           tile_hint=0):
+    cin = x.C if cin is None else cin
+    assert x.coff % 4 == 0 and x.cs % 4 == 0 and x.coff + round_up(cin, 8) <= x.cs, "input row alignment"
+    xin = x.buf[..., x.coff:x.coff + cin].permute(0, 4, 1, 2, 3)
+    # the channel pad the kernel would read must be zero (or be multiplied by zero weights and finite)
+    pad_ch = x.buf[..., x.coff + cin:x.coff + round_up(cin, 8)]
+    assert torch.isfinite(pad_ch).all(), "non-finite values in a channel pad"
+    if act_in == ACT_RELU:
+        xin = F.relu(xin)
+    elif act_in == ACT_SIGMOID:
+        xin = torch.sigmoid(xin)
+    if out_pos is None:
+        out_pos = tuple((n + 2 * p - d * (k - 1) - 1) // s + 1
+                        for n, p, d, k, s in zip(x.dims, padding, dilation, kernel, stride))
+    pads = []
+    for n, p, d, k, s, o in reversed(list(zip(x.dims, padding, dilation, kernel, stride, out_pos))):
+        right = max(0, (o - 1) * s - p + (k - 1) * d - (n - 1))
+        pads += [p, right]
+    y = F.conv3d(F.pad(xin, pads), wpk.w[:, :cin], None, stride=stride, dilation=dilation)
+    y = y[:, :, :out_pos[0], :out_pos[1], :out_pos[2]]
+    if bias is not None:
+        y = y + bias[:cout].reshape(1, -1, 1, 1, 1)
+    if act_out == ACT_RELU_PRE:
+        y = F.relu(y)
+    store = min(round_up(cout, 8), out.cs - out.coff, round_up(cout, 32))
+    sl = (slice(None),) + tuple(slice(off, off + st * (n - 1) + 1, st) for off, st, n in zip(o_off, o_stride, out_pos))
+    yl = y.permute(0, 2, 3, 4, 1)
+    full = torch.zeros(yl.shape[:-1] + (store,))
+    full[..., :cout] = yl
+    for r in (res1, res2):
+        if r is not None:
+            assert r.dims == out.dims
+            full = full + r.buf[sl][..., r.coff:r.coff + store]
+    if act_out == ACT_RELU:
+        full = F.relu(full)
+    out.buf[sl + (slice(out.coff, out.coff + store),)] = full
+    return out
+
+
+def nchw_to_nhwc(x, cs=None):
+    C = x.shape[1]
+    cs = cs if cs is not None else round_up(C, 4)
+    out = torch.zeros((x.shape[0],) + tuple(x.shape[2:]) + (cs,))
+    out[..., :C] = x.permute(0, *range(2, x.dim()), 1)
+    return out
+
+
+def vox_from_ncdhw(x):
+    C = x.shape[1]
+    return Vox(nchw_to_nhwc(x.float(), round_up(C, 8)), C)
+
+
+def softmax_channels(src, dst, n, dst_pad=0):
+    dst.buf[..., dst.coff:dst.coff + n] = F.softmax(src.buf[..., src.coff:src.coff + n], dim=-1)
+    dst.buf[..., dst.coff + n:dst.coff + n + dst_pad] = 0
+    return dst
+
+
+def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, mean_mode=True, grids=None):
+    """K1a semantics from the published algorithm (oracle.frustum_grid is NOT used: trans already
+    contains grid_to_lidar), one camera at a time."""
+    from oracle.occdepth_oracle import _from_homogeneous
+    B, V, D, h, w = depth.shape
+    A, Bd, C = (int(v) for v in voxel_num)
+    idx = torch.stack(torch.meshgrid(torch.arange(A), torch.arange(Bd), torch.arange(C), indexing="ij"), -1)
+    pts = F.pad((idx.float() + 0.5).reshape(1, -1, 3), [0, 1], value=1.0).repeat(B, 1, 1)
+    feat = mask = 0
+    for v in range(V):
+        if grids is not None:
+            g = grids[v].reshape(B, -1, 3)
+        else:
+            cam = _from_homogeneous(torch.bmm(pts, trans[:, v].transpose(1, 2)))
+            img = torch.bmm(F.pad(cam, [0, 1], value=1.0), proj[:, v].transpose(1, 2))
+            uv = _from_homogeneous(img)
+            dep = img[..., 2] - proj[:, v, None, 2, 3]
+            bin_size = 2 * (d_max - d_min) / (D * (1 + D))
+            bins = -0.5 + 0.5 * torch.sqrt(1 + 8 * (dep - d_min) / bin_size)
+            fr = _from_homogeneous(torch.bmm(F.pad(torch.cat([uv, bins.unsqueeze(-1)], -1), [0, 1], value=1.0),
+                                             ida[:, v].transpose(1, 2)))
+            g = fr / (torch.tensor([final_dim[1], final_dim[0], D], dtype=torch.float32) - 1) * 2 - 1
+            g = torch.where(torch.isfinite(g), g, torch.full_like(g, -2.0))
+        g = g.reshape(B, A, Bd, C, 3)
+        vol = depth[:, v].unsqueeze(1)
+        feat = feat + F.grid_sample(vol, g, mode="bilinear", padding_mode="zeros", align_corners=False)
+        mask = mask + F.grid_sample(torch.ones_like(vol), g, mode="bilinear", padding_mode="zeros",
+                                    align_corners=False)
+    if V > 1 and mean_mode:
+        feat = torch.where(mask > 0, feat / mask.clamp_min(1e-30), feat)
+    return feat.reshape(B, -1)
+
+
+def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0):
+    from oracle.occdepth_oracle import sfa
+    B = pix.shape[0]
+    C = out.C
+    dims = tuple(n_dims)
+    for b in range(B):
+        total = None
+        for s, per_scale in enumerate(feats):
+            x2d = torch.stack([f[b, ..., :C].permute(2, 0, 1) for f in per_scale])
+            part = sfa(x2d, torch.div(pix[b], int(scale_divs[s]), rounding_mode="floor"), fov[b].bool(), dims, 1,
+                       "kitti").reshape(C, -1)
+            total = part if total is None else total + part
+        if depth_scale is not None:
+            total = total * depth_scale[b].reshape(1, -1) * scale_const
+        n = torch.arange(total.shape[1])
+        a = n // (dims[1] * dims[2])
+        bb = (n // dims[2]) % dims[1]
+        c = n % dims[2]
+        rows = a * row_strides[0] + bb * row_strides[1] + c * row_strides[2]
+        flat = out.buf[b].reshape(-1, out.cs)
+        flat[rows, :C] = total.t()
+        flat[rows, C:] = 0
+    return out
+
+
+@contextlib.contextmanager
+def patched():
+    saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
+                                          "flosp_sample", "lift")}
+    saved_from = Vox.from_ncdhw
+    saved_as_vox = fused.as_vox
+    hip.pack_weights, hip.conv3d, hip.nchw_to_nhwc = pack_weights, conv3d, nchw_to_nhwc
+    hip.softmax_channels, hip.flosp_sample, hip.lift = softmax_channels, flosp_sample, lift
+    Vox.from_ncdhw = staticmethod(vox_from_ncdhw)
+
+    def as_vox_cpu(x):
+        if isinstance(x, Vox):
+            return x
+        cl = x.float().permute(0, 2, 3, 4, 1)
+        return Vox(cl, x.shape[1]) if cl.is_contiguous() and x.shape[1] % 8 == 0 else vox_from_ncdhw(x)
+
+    import occdepth_amd.models.CRP3D as crp
+    import occdepth_amd.models.DDR as ddr
+    import occdepth_amd.models.modules as mods
+    import occdepth_amd.models.unet3d_kitti as u3k
+    import occdepth_amd.models.unet3d_nyu as u3n
+    users = [fused, crp, ddr, mods, u3k, u3n]
+    old = [(m, m.as_vox) for m in users if hasattr(m, "as_vox")]
+    for m, _ in old:
+        m.as_vox = as_vox_cpu
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(hip, k, v)
+        Vox.from_ncdhw = saved_from
+        for m, f in old:
+            m.as_vox = f

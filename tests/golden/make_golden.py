@@ -1,0 +1,234 @@
+"""Generate the golden fixtures by running the REAL reference (/root/reference) on CPU.
+
+Run in the build container only:   python tests/golden/make_golden.py [case ...]
+Outputs tests/golden/*.npz (+ state_keys_*.json).  Inputs are rebuilt from seeds by
+tests/golden_cases.py (shared with the tests); weights come from oracle/fill.py; only the
+reference's OUTPUTS are stored (sub-sampled for the full-size config).
+torch version is recorded in every file (CPU kernel semantics: grid_sample, cosine_similarity).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_shims  # noqa: E402
+from oracle.fill import bn_stats, calibrate_bn, fill_state_dict  # noqa: E402
+import golden_cases as gc  # noqa: E402
+
+ref_shims.install()
+from occdepth_amd.models.efficientnet import EfficientNet  # noqa: E402  (the only non-reference piece: encoder)
+
+ref_unet2d = ref_shims.patch_unet2d_build(lambda name: EfficientNet(name))
+
+import occdepth.models.SFA as ref_sfa  # noqa: E402
+import occdepth.models.DDR as ref_ddr  # noqa: E402
+import occdepth.models.modules as ref_modules  # noqa: E402
+import occdepth.models.CRP3D as ref_crp  # noqa: E402
+import occdepth.models.unet3d_kitti as ref_u3k  # noqa: E402
+import occdepth.models.unet3d_nyu as ref_u3n  # noqa: E402
+import occdepth.models.flosp_depth.flosp_depth as ref_flosp  # noqa: E402
+import occdepth.models.flosp_depth as ref_flosp_pkg  # noqa: E402
+import occdepth.models.OccDepth as ref_occ  # noqa: E402
+
+BN3 = torch.nn.BatchNorm3d
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def _save(name, arrays, meta=None):
+    meta = dict(meta or {}, torch=torch.__version__, generated=time.strftime("%Y-%m-%d"))
+    arrays = dict(arrays)
+    arrays["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def _load_filled(mod, seed, run=None, tag=None, arrays=None):
+    """Seeded weights; when `run` is given, BatchNorm statistics are calibrated on that forward pass
+    and stored in `arrays` as '<tag>::<key>' so the tests can rebuild the identical state_dict."""
+    mod.load_state_dict(fill_state_dict(mod.state_dict(), seed), strict=True)
+    mod.eval()
+    if run is not None:
+        calibrate_bn(mod, run)
+        for k, v in bn_stats(mod.state_dict()).items():
+            arrays[f"{tag}::{k}"] = v
+    return mod.eval()
+
+
+def _flat(out, prefix=""):
+    res = {}
+    if isinstance(out, dict):
+        for k, v in out.items():
+            res.update(_flat(v, f"{prefix}{k}"))
+    elif isinstance(out, (tuple, list)):
+        for i, v in enumerate(out):
+            res.update(_flat(v, f"{prefix}{i}"))
+    elif out is not None:
+        res[prefix] = _np(out)
+    return res
+
+
+# --------------------------------------------------------------------------------------------- cases
+def case_sfa():
+    arrays = {}
+    for name, spec in gc.SFA_CASES.items():
+        x2d, pix, fov = gc.sfa_inputs(spec)
+        m = ref_sfa.SFA(spec["scene"], spec["dataset"], spec["ps"])
+        arrays[name] = _np(m(x2d, pix, fov))
+    _save("sfa", arrays)
+
+
+def case_blocks3d():
+    arrays = {}
+    makers = {
+        "bottleneck_d2": lambda: ref_ddr.Bottleneck3D(32, 8, BN3, dilation=[2, 2, 2]),
+        "bottleneck_odd": lambda: ref_ddr.Bottleneck3D(100, 25, BN3, dilation=[3, 3, 3]),
+        "process": lambda: ref_modules.Process(32, BN3, 0.1),
+        "downsample": lambda: ref_modules.Downsample(32, BN3, 0.1),
+        "downsample_odd": lambda: ref_modules.Downsample(24, BN3, 0.1),
+        "upsample": lambda: ref_modules.Upsample(64, 32, BN3, 0.1),
+        "upsample_odd": lambda: ref_modules.Upsample(40, 20, BN3, 0.1),
+        "convblock": lambda: ref_modules.Convblock3d(32, 16, BN3, 0.1),
+        "aspp": lambda: ref_modules.ASPP(32, [1, 2, 3]),
+        "head": lambda: ref_modules.SegmentationHead(16, 16, 12, [1, 2, 3]),
+        "head_cascade": lambda: ref_modules.SegmentationHeadCascadeCLS(8, 8, 20, [1, 2, 3]),
+        "head_occluded": lambda: ref_modules.SegmentationHeadOccludedCLS(16, 16, 20, [1, 2, 3]),
+        "crp": lambda: ref_crp.CPMegaVoxels(64, (8, 8, 2), bn_momentum=0.1),
+        "crp_odd": lambda: ref_crp.CPMegaVoxels(32, (5, 3, 5), n_relations=2, bn_momentum=0.1),
+    }
+    for name, shape in gc.BLOCK_CASES.items():
+        x = gc.randn(shape, name)
+        m = _load_filled(makers[name](), gc.SEED, lambda mm: mm(x), name, arrays)
+        with torch.no_grad():
+            out = m(x)
+        for k, v in _flat(out).items():
+            arrays[name + ("." + k if k else "")] = v
+    _save("blocks3d", arrays)
+
+
+def case_unet3d():
+    arrays = {}
+    for name, spec in gc.UNET3D_CASES.items():
+        if spec["kind"] == "nyu":
+            m = ref_u3n.UNet3D(spec["classes"], BN3, feature=spec["feature"], full_scene_size=spec["scene"],
+                               context_prior=True, n_relations=spec["n_relations"])
+        else:
+            m = ref_u3k.UNet3D(spec["classes"], BN3, spec["scene"], spec["feature"], spec["ps"], context_prior=True,
+                               cascade_cls=True, occluded_cls=spec["occluded"])
+        x = gc.randn(spec["x"], name)
+        m = _load_filled(m, gc.SEED, lambda mm: mm({"x3d": x}), name, arrays)
+        with torch.no_grad():
+            out = m({"x3d": x})
+        for k, v in _flat(out).items():
+            arrays[f"{name}.{k}"] = gc.maybe_subsample(v)
+    _save("unet3d", arrays)
+
+
+def case_flosp():
+    arrays = {}
+    for name, spec in gc.FLOSP_CASES.items():
+        m = ref_flosp.FlospDepth(**spec["ctor"])
+        feat, cam_k, t_v2c, idas = gc.flosp_inputs(spec)
+        m = _load_filled(m, gc.SEED, lambda mm: mm(feat, cam_k, t_v2c, idas), name, arrays)
+        with torch.no_grad():
+            vox, depth = m(feat, cam_k, t_v2c, idas)
+            ida = torch.stack(idas)
+            tv = torch.stack(t_v2c).float()
+            k3 = torch.stack(cam_k).float()
+            intr = k3.new_zeros(1, k3.shape[1], 4, 4)
+            intr[:, :, :3, :3] = k3
+            intr[:, :, 3, 3] = 1
+            shape = k3.new_zeros(1, 2)
+            shape[:, 0:2] = torch.as_tensor(spec["ctor"]["final_dim"])
+            grid = m.grid_generator(lidar_to_cam=tv[:, 0], cam_to_img=intr[:, 0, :3, :], ida_mats=ida[:, 0],
+                                    image_shape=shape)
+        arrays[name + ".vox"] = _np(vox)
+        arrays[name + ".depth"] = _np(depth)
+        arrays[name + ".grid0"] = _np(grid)
+    _save("flosp", arrays)
+
+
+def case_decoder2d():
+    name = "tf_efficientnet_b3_ns"
+    m = ref_unet2d.UNet2D.build(out_feature=16, use_decoder=True, backbone_2d_name=name, return_up_feats=1)
+    arrays = {}
+    x = gc.randn((1, 3, 74, 122), "decoder2d")
+    m = _load_filled(m, gc.SEED, lambda mm: mm(x), "decoder2d", arrays)
+    with torch.no_grad():
+        out = m(x)
+    arrays.update({k: _np(v) for k, v in out.items()})
+    _save("decoder2d", arrays)
+
+
+_PRISTINE_CONF = {}
+
+
+def _build_ref_occdepth(cfg_name, arrays):
+    cfg, conf_override = gc.occdepth_config(cfg_name)
+    conf_map = ref_flosp_pkg.flosp_depth_conf_map
+    if cfg.dataset not in _PRISTINE_CONF:
+        _PRISTINE_CONF[cfg.dataset] = dict(conf_map[cfg.dataset])
+    conf_map[cfg.dataset].clear()          # the reference mutates this module-level dict in place
+    conf_map[cfg.dataset].update(_PRISTINE_CONF[cfg.dataset])
+    if conf_override:
+        conf_map[cfg.dataset].update(conf_override)
+    from occdepth_amd.configs import PROJECT_RES
+    m = ref_occ.OccDepth(class_names=[str(i) for i in range(cfg.n_classes)], class_weights=torch.ones(cfg.n_classes),
+                         class_weights_occ=torch.ones(2), full_scene_size=tuple(cfg.full_scene_size),
+                         project_res=PROJECT_RES, config=cfg)
+    batch = gc.occdepth_batch(cfg_name)
+    return _load_filled(m, gc.SEED, lambda mm: mm(batch), cfg_name, arrays), cfg, batch
+
+
+def case_occdepth_small():
+    arrays, keys = {}, {}
+    for cfg_name in ("kitti_small", "nyu_small", "kitti_flosp_small"):
+        m, cfg, batch = _build_ref_occdepth(cfg_name, arrays)
+        with torch.no_grad():
+            out = m(batch)
+        for k, v in _flat(out).items():
+            arrays[f"{cfg_name}.{k}"] = gc.maybe_subsample(v)
+        keys[cfg_name] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    _save("occdepth_small", arrays)
+    with open(os.path.join(HERE, "state_keys_small.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+
+def case_occdepth_full():
+    """BASELINE config 2 (B7, 370x1220 stereo, 256x256x32): one reference frame, sub-sampled outputs."""
+    t0 = time.time()
+    arrays = {}
+    m, cfg, batch = _build_ref_occdepth("kitti_a100", arrays)
+    t0 = time.time()
+    with torch.no_grad():
+        out = m(batch)
+    print("reference config-2 forward: %.1f s" % (time.time() - t0))
+    for k, v in _flat(out).items():
+        arrays[k] = gc.subsample(torch.from_numpy(v)).numpy()
+        arrays[k + ".absmax"] = np.float32(np.abs(v).max())
+        arrays[k + ".sum"] = np.float64(v.astype(np.float64).sum())
+    _save("occdepth_kitti_a100", arrays, meta={"subsample": "tests/golden_cases.py:subsample"})
+    keys = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(HERE, "state_keys_kitti_a100.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+
+CASES = {"sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "flosp": case_flosp,
+         "decoder2d": case_decoder2d, "occdepth_small": case_occdepth_small, "occdepth_full": case_occdepth_full}
+
+if __name__ == "__main__":
+    torch.set_num_threads(os.cpu_count())
+    for c in (sys.argv[1:] or list(CASES)):
+        print("==", c)
+        CASES[c]()

@@ -1,0 +1,73 @@
+"""CPU: libocc_hip.so builds, loads, and exports exactly what include/occdepth_amd.h declares; the
+ctypes structures in occdepth_amd/hip.py have the C layout (checked against gcc's sizeof/offsetof)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "occdepth_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(occd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(hip_lib):
+    from occdepth_amd import hip
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in the header but not exported"
+        assert n in hip.EXPORTS, f"{n} has no ctypes prototype"
+    assert sorted(hip.EXPORTS) == names
+    assert hip_lib.occd_abi_version() == hip.ABI_VERSION
+    assert hip_lib.occd_strerror(-1).decode().startswith("invalid")
+
+
+def test_argument_validation_without_gpu(hip_lib):
+    """Pure host-side argument checks (no launch happens for invalid arguments)."""
+    from occdepth_amd import hip
+    assert hip_lib.occd_conv3d_fwd(None, None) == -1
+    a = hip.Conv3dArgs()
+    assert hip_lib.occd_conv3d_fwd(ctypes.byref(a), None) == -1
+    assert hip_lib.occd_lift_fwd(None, None) == -1
+    assert hip_lib.occd_flosp_sample_fwd(None, None) == -1
+    assert hip_lib.occd_packed_weight_floats(32, 32, 27) == 27 * 4 * 1 * 256
+    assert hip_lib.occd_packed_weight_floats(20, 34, 27) == 27 * 5 * 1 * 256
+    assert hip_lib.occd_packed_weight_floats(0, 1, 1) < 0
+
+
+def test_ctypes_structs_match_c_layout(tmp_path):
+    from occdepth_amd import hip
+    structs = {"occd_conv3d_args": hip.Conv3dArgs, "occd_flosp_args": hip.FlospArgs, "occd_lift_args": hip.LiftArgs,
+               "occd_prof_row": hip.ProfRow}
+    rename = {"inp": "in"}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {rename.get(fname, fname)}));')
+    lines += ["return 0;}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", str(src), "-o", str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, st in structs.items():
+        assert int(out[cname]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from occdepth_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="missing"):
+        hip.load()

@@ -1,0 +1,98 @@
+"""CPU: the host-side orchestration of the eval path, executed with the C-ABI entry points replaced
+by their plain-torch emulation (tests/emu.py), must reproduce the REAL reference outputs held in
+tests/golden.  This checks BatchNorm folding, pooled-branch folding, transposed-conv phase slicing,
+concat-slice bookkeeping, residual wiring and the voxel index digits without a GPU; the kernels
+themselves are checked by the `-m gpu` tests.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import emu
+import golden_cases as gc
+from test_oracle_vs_golden import (_block_module, _unet3d_module, build_product, close, flat, gold, sd_for)
+
+
+def test_product_refuses_cpu_tensors_without_emulation():
+    m = _block_module("bottleneck_d2").eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 32, 4, 4, 4))
+
+
+@pytest.mark.parametrize("name", list(gc.BLOCK_CASES))
+def test_blocks_eval_path(name):
+    m = _block_module(name)
+    m.load_state_dict(sd_for(m, "blocks3d", name))
+    m.eval()
+    g = gold("blocks3d")
+    with emu.patched(), torch.no_grad():
+        out = m(gc.randn(gc.BLOCK_CASES[name], name))
+    for k, v in flat(out).items():
+        close(v, g[name + ("." + k if k else "")], tol=2e-5, what=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("name", list(gc.UNET3D_CASES))
+def test_unet3d_eval_path(name):
+    spec = gc.UNET3D_CASES[name]
+    m = _unet3d_module(spec)
+    m.load_state_dict(sd_for(m, "unet3d", name))
+    m.eval()
+    g = gold("unet3d")
+    with emu.patched(), torch.no_grad():
+        out = m({"x3d": gc.randn(spec["x"], name)})
+    assert len(out) == len([k for k in g.files if k.startswith(name + ".")])
+    for k, v in out.items():
+        close(gc.maybe_subsample(v.contiguous()), g[f"{name}.{k}"], tol=3e-4, what=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])
+def test_occdepth_eval_path(cfg_name):
+    m, cfg, sd = build_product(cfg_name)
+    g = gold("occdepth_small")
+    with emu.patched(), torch.no_grad():
+        out = m(gc.occdepth_batch(cfg_name))
+    assert len([v for v in out.values() if v is not None]) == len([k for k in g.files if k.startswith(cfg_name + ".")])
+    for k, v in out.items():
+        close(gc.maybe_subsample(v.contiguous()), g[f"{cfg_name}.{k}"], tol=3e-4, what=f"{cfg_name}.{k}")
+
+
+@pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small"])
+def test_training_graph_matches_eval_math(cfg_name):
+    """The ATen (autograd) graph used in training mode computes the same function (BN in eval mode)."""
+    import torch.nn as nn
+    m, cfg, sd = build_product(cfg_name)
+    g = gold("occdepth_small")
+    for sub in m.modules():
+        sub.training = not isinstance(sub, (nn.BatchNorm2d, nn.BatchNorm3d, nn.Dropout))
+    with torch.no_grad():
+        out = m(gc.occdepth_batch(cfg_name))
+    for k in ("ssc_logit",):
+        close(gc.maybe_subsample(out[k].contiguous()), g[f"{cfg_name}.{k}"], tol=3e-4, what=k)
+
+
+def test_voxel_layout_digits():
+    from occdepth_amd.models.SFA import voxel_layout
+    n_dims, out_dims, strides = voxel_layout((60, 36, 60), 1, "NYU")
+    assert n_dims == (60, 60, 36) and out_dims == (60, 36, 60) and strides == (36 * 60, 1, 60)
+    n_dims, out_dims, strides = voxel_layout((256, 256, 32), 2, "kitti")
+    assert n_dims == out_dims == (128, 128, 16) and strides == (128 * 16, 16, 1)
+    with pytest.raises(NotImplementedError):
+        voxel_layout((8, 8, 8), 1, "tartanair")
+
+
+def test_fill_is_deterministic_and_name_keyed():
+    from oracle.fill import fill_state_dict
+    a = fill_state_dict({"x.weight": torch.zeros(4, 3, 1, 1, 1), "x.bias": torch.zeros(4)}, 3)
+    b = fill_state_dict({"x.bias": torch.zeros(4), "x.weight": torch.zeros(4, 3, 1, 1, 1)}, 3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert abs(float(a["x.bias"][0]) - 0.0) > 0
+
+
+def test_synthetic_inputs_match_survey_statistics():
+    from oracle import inputs
+    b = inputs.kitti_batch()
+    fov = b["fov_mask_2"][0].float().mean(dim=(1, 2))
+    assert b["projected_pix_2"][0].shape == (2, 262144, 1, 2) and b["projected_pix_2"][0].dtype == torch.int64
+    assert torch.allclose(fov, torch.tensor([0.68, 0.68]), atol=0.01)
+    assert b["cam_k"][0].dtype == torch.float64 and b["T_velo_2_cam"][0].dtype == torch.float32

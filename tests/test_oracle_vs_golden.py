@@ -1,0 +1,248 @@
+"""CPU: pin the oracle (oracle/occdepth_oracle.py) to the REAL reference.
+
+tests/golden/*.npz hold outputs of the reference's own modules (generated in the build container by
+tests/golden/make_golden.py through oracle/ref_shims.py).  Each test rebuilds the seeded inputs and
+weights and requires the functional restatement to reproduce them.  Tolerance 2e-6 of the tensor's
+scale: same torch CPU kernels on both sides, only op grouping differs.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import occdepth_oracle as orc
+from oracle.fill import fill_state_dict, overlay
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 2e-6
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def close(got, ref, tol=TOL, what=""):
+    got = torch.as_tensor(got).float()
+    ref = torch.as_tensor(ref).float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().clamp_min(1e-20)
+    err = ((got - ref).abs().max() / scale).item()
+    assert err < tol, (what, err)
+
+
+def sd_for(module, file=None, tag=None, seed=gc.SEED):
+    """Seeded weights (+ the BatchNorm statistics the golden generator calibrated for this case)."""
+    sd = fill_state_dict(module.state_dict(), seed)
+    return overlay(sd, gold(file), tag) if file else sd
+
+
+@pytest.mark.parametrize("name", list(gc.SFA_CASES))
+def test_sfa(name):
+    spec = gc.SFA_CASES[name]
+    x2d, pix, fov = gc.sfa_inputs(spec)
+    close(orc.sfa(x2d, pix, fov, spec["scene"], spec["ps"], spec["dataset"]), gold("sfa")[name], what=name)
+
+
+def _block_module(name):
+    import torch.nn as nn
+    from occdepth_amd.models.CRP3D import CPMegaVoxels
+    from occdepth_amd.models.DDR import Bottleneck3D
+    from occdepth_amd.models import modules as M
+    bn = nn.BatchNorm3d
+    return {
+        "bottleneck_d2": lambda: Bottleneck3D(32, 8, bn, dilation=[2, 2, 2]),
+        "bottleneck_odd": lambda: Bottleneck3D(100, 25, bn, dilation=[3, 3, 3]),
+        "process": lambda: M.Process(32, bn, 0.1),
+        "downsample": lambda: M.Downsample(32, bn, 0.1),
+        "downsample_odd": lambda: M.Downsample(24, bn, 0.1),
+        "upsample": lambda: M.Upsample(64, 32, bn, 0.1),
+        "upsample_odd": lambda: M.Upsample(40, 20, bn, 0.1),
+        "convblock": lambda: M.Convblock3d(32, 16, bn, 0.1),
+        "aspp": lambda: M.ASPP(32, [1, 2, 3]),
+        "head": lambda: M.SegmentationHead(16, 16, 12, [1, 2, 3]),
+        "head_cascade": lambda: M.SegmentationHeadCascadeCLS(8, 8, 20, [1, 2, 3]),
+        "head_occluded": lambda: M.SegmentationHeadOccludedCLS(16, 16, 20, [1, 2, 3]),
+        "crp": lambda: CPMegaVoxels(64, (8, 8, 2), bn_momentum=0.1),
+        "crp_odd": lambda: CPMegaVoxels(32, (5, 3, 5), n_relations=2, bn_momentum=0.1),
+    }[name]()
+
+
+def oracle_block(name, sd, x):
+    """The oracle's statement of each block; `sd` keys are the module's own (prefix-free)."""
+    sd = {"m." + k: v for k, v in sd.items()}
+    if name == "bottleneck_d2":
+        return orc.bottleneck3d(sd, "m", x, 1, (2, 2, 2))
+    if name == "bottleneck_odd":
+        return orc.bottleneck3d(sd, "m", x, 1, (3, 3, 3))
+    if name == "process":
+        return orc.process(sd, "m", x)
+    if name.startswith("downsample"):
+        return orc.downsample(sd, "m", x)
+    if name.startswith("upsample"):
+        return orc.upsample(sd, "m", x)
+    if name == "convblock":
+        return orc.upsample(sd, "m", x, stride=1)
+    if name == "aspp":
+        return orc.dilated_branches(sd, "m", x)
+    if name == "head":
+        return orc.seg_head(sd, "m", x)
+    if name == "head_cascade":
+        return orc.seg_head(sd, "m", x, kind="cascade")
+    if name == "head_occluded":
+        return orc.seg_head(sd, "m", x, kind="occluded")
+    if name == "crp":
+        return orc.crp(sd, "m", x, (8, 8, 2), 4)
+    if name == "crp_odd":
+        return orc.crp(sd, "m", x, (5, 3, 5), 2)
+    raise KeyError(name)
+
+
+def flat(out, prefix=""):
+    res = {}
+    if isinstance(out, dict):
+        for k, v in out.items():
+            res.update(flat(v, f"{prefix}{k}"))
+    elif isinstance(out, (tuple, list)):
+        for i, v in enumerate(out):
+            res.update(flat(v, f"{prefix}{i}"))
+    elif out is not None:
+        res[prefix] = out
+    return res
+
+
+@pytest.mark.parametrize("name", list(gc.BLOCK_CASES))
+def test_blocks3d(name):
+    g = gold("blocks3d")
+    sd = sd_for(_block_module(name), "blocks3d", name)
+    out = oracle_block(name, sd, gc.randn(gc.BLOCK_CASES[name], name))
+    for k, v in flat(out).items():
+        close(v, g[name + ("." + k if k else "")], what=f"{name}.{k}")
+
+
+def _unet3d_module(spec):
+    import torch.nn as nn
+    if spec["kind"] == "nyu":
+        from occdepth_amd.models.unet3d_nyu import UNet3D
+        return UNet3D(spec["classes"], nn.BatchNorm3d, feature=spec["feature"], full_scene_size=spec["scene"],
+                      context_prior=True, n_relations=spec["n_relations"])
+    from occdepth_amd.models.unet3d_kitti import UNet3D
+    return UNet3D(spec["classes"], nn.BatchNorm3d, spec["scene"], spec["feature"], spec["ps"], context_prior=True,
+                  cascade_cls=True, occluded_cls=spec["occluded"])
+
+
+def oracle_unet3d(spec, sd, x):
+    if spec["kind"] == "nyu":
+        return orc.unet3d_nyu(sd, x, spec["scene"], True, False, spec["n_relations"], p="")
+    return orc.unet3d_kitti(sd, x, spec["scene"], spec["ps"], True, True, spec["occluded"], p="")
+
+
+@pytest.mark.parametrize("name", list(gc.UNET3D_CASES))
+def test_unet3d(name):
+    spec = gc.UNET3D_CASES[name]
+    g = gold("unet3d")
+    out = oracle_unet3d(spec, sd_for(_unet3d_module(spec), "unet3d", name), gc.randn(spec["x"], name))
+    keys = [k for k in g.files if k.startswith(name + ".")]
+    assert len(keys) == len(out)
+    for k, v in out.items():
+        close(gc.maybe_subsample(v), g[f"{name}.{k}"], what=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("name", list(gc.FLOSP_CASES))
+def test_flosp(name):
+    from occdepth_amd.models.flosp_depth.flosp_depth import FlospDepth
+    spec = gc.FLOSP_CASES[name]
+    g = gold("flosp")
+    ctor = spec["ctor"]
+    sd = {"f." + k: v for k, v in sd_for(FlospDepth(**ctor), "flosp", name).items()}
+    feat, cam_k, t_v2c, idas = gc.flosp_inputs(spec)
+    bounds = [ctor["x_bound"], ctor["y_bound"], ctor["z_bound"]]
+    voxel_num = [int(v) for v in torch.LongTensor([(r[1] - r[0]) / r[2] / ctor["project_scale"] for r in bounds])]
+    pc_range = [r[0] for r in bounds] + [r[1] for r in bounds]
+    vox, depth = orc.flosp_depth(sd, "f", feat, cam_k, t_v2c, idas, ctor, voxel_num, pc_range)
+    close(depth, g[name + ".depth"], what="depth")
+    close(vox, g[name + ".vox"], what="vox")
+    k3 = torch.stack(cam_k).float()
+    intr = torch.zeros(1, k3.shape[1], 4, 4)
+    intr[:, :, :3, :3] = k3
+    intr[:, :, 3, 3] = 1
+    nb = int((ctor["d_bound"][1] - ctor["d_bound"][0]) / ctor["d_bound"][2])
+    grid = orc.frustum_grid(torch.stack(t_v2c).float()[:, 0], intr[:, 0, :3, :], torch.stack(idas)[:, 0], voxel_num,
+                            pc_range, ctor["d_bound"], nb, ctor["final_dim"])
+    close(grid, g[name + ".grid0"], what="grid")
+
+
+def test_decoder2d():
+    from occdepth_amd.models.unet2d import UNet2D
+    m = UNet2D.build(out_feature=16, use_decoder=True, backbone_2d_name="tf_efficientnet_b3_ns", return_up_feats=1)
+    sd = sd_for(m, "decoder2d", "decoder2d")
+    m.load_state_dict(sd)
+    m.eval()
+    g = gold("decoder2d")
+    with torch.no_grad():
+        feats = orc.encoder_features(m.encoder.original_model, gc.randn((1, 3, 74, 122), "decoder2d"))
+        out = orc.decoder_bn(sd, "decoder", feats)
+    assert set(out) == {"1_1", "1_2", "1_4", "1_8", "1_16"}
+    for k, v in out.items():
+        close(v, g[k], what=k)
+
+
+def build_product(cfg_name):
+    """The product model (CPU-constructible) with the seeded weights; also the oracle's state dict."""
+    import occdepth_amd.models.flosp_depth as fpkg
+    from occdepth_amd.configs import PROJECT_RES
+    from occdepth_amd.models.OccDepth import OccDepth
+    cfg, conf = gc.occdepth_config(cfg_name)
+    pristine = dict(fpkg.flosp_depth_conf_map[cfg.dataset])
+    if conf:
+        fpkg.flosp_depth_conf_map[cfg.dataset].update(conf)
+    try:
+        m = OccDepth(class_names=[str(i) for i in range(cfg.n_classes)], class_weights=torch.ones(cfg.n_classes),
+                     class_weights_occ=torch.ones(2), full_scene_size=tuple(cfg.full_scene_size),
+                     project_res=PROJECT_RES, config=cfg)
+    finally:
+        fpkg.flosp_depth_conf_map[cfg.dataset].clear()
+        fpkg.flosp_depth_conf_map[cfg.dataset].update(pristine)
+    sd = sd_for(m, "occdepth_kitti_a100" if cfg_name == "kitti_a100" else "occdepth_small", cfg_name)
+    m.load_state_dict(sd, strict=True)
+    return m.eval(), cfg, sd
+
+
+def oracle_cfg(m, cfg):
+    d = dict(cfg)
+    if cfg.trans_2d_to_3d == "flosp_depth":
+        d["flosp_depth_conf"] = m.flosp_depth_conf
+    return d
+
+
+@pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])
+def test_state_dict_keys_match_reference(cfg_name):
+    m, cfg, sd = build_product(cfg_name)
+    with open(os.path.join(GOLD, "state_keys_small.json")) as f:
+        ref = json.load(f)[cfg_name]
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref
+
+
+def test_state_dict_keys_match_reference_config2():
+    m, cfg, sd = build_product("kitti_a100")
+    with open(os.path.join(GOLD, "state_keys_kitti_a100.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref
+    assert len([k for k in mine if not k.startswith("net_rgb.encoder")]) == 692
+
+
+@pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])
+def test_occdepth_forward_small(cfg_name):
+    m, cfg, sd = build_product(cfg_name)
+    g = gold("occdepth_small")
+    with torch.no_grad():
+        out = orc.occdepth_forward(sd, oracle_cfg(m, cfg), gc.occdepth_batch(cfg_name),
+                                   m.net_rgb.encoder.original_model)
+    keys = [k for k in g.files if k.startswith(cfg_name + ".")]
+    assert len(keys) == len([v for v in out.values() if v is not None])
+    for k, v in out.items():
+        close(gc.maybe_subsample(v), g[f"{cfg_name}.{k}"], tol=5e-6, what=f"{cfg_name}.{k}")
