@@ -1,0 +1,258 @@
+"""GPU parity proper: the HIP eval path (through the C ABI) against
+  (1) the committed golden fixtures = outputs of the REAL reference, and
+  (2) the CPU oracle run live on the same seeded inputs,
+plus size-independent properties at BASELINE config-2 size.
+
+Tolerances (north_star: voxel logits within 1e-3 relative, fp32):
+  * kernel-level (same inputs into the HIP kernels as into the oracle): 2e-4 of the tensor scale;
+  * end-to-end including the MIOpen 2-D networks: 1e-3 of the tensor scale for the voxel logits.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from test_oracle_vs_golden import (_block_module, _unet3d_module, build_product, close, flat, gold, oracle_cfg, sd_for)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+
+def to_dev(batch):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, list):
+            out[k] = [t.to(DEV) if torch.is_tensor(t) else t for t in v]
+        else:
+            out[k] = v.to(DEV) if torch.is_tensor(v) else v
+    return out
+
+
+@pytest.mark.parametrize("name", list(gc.SFA_CASES))
+def test_sfa_vs_golden(name):
+    from occdepth_amd.models.SFA import SFA
+    spec = gc.SFA_CASES[name]
+    x2d, pix, fov = gc.sfa_inputs(spec)
+    m = SFA(spec["scene"], spec["dataset"], spec["ps"]).to(DEV).eval()
+    with torch.no_grad():
+        got = m(x2d.to(DEV), pix.to(DEV), fov.to(DEV))
+    close(got.cpu(), gold("sfa")[name], tol=1e-5, what=name)
+
+
+@pytest.mark.parametrize("name", list(gc.BLOCK_CASES))
+def test_blocks_vs_golden(name):
+    m = _block_module(name)
+    m.load_state_dict(sd_for(m, "blocks3d", name))
+    m = m.to(DEV).eval()
+    g = gold("blocks3d")
+    with torch.no_grad():
+        out = m(gc.randn(gc.BLOCK_CASES[name], name).to(DEV))
+    for k, v in flat(out).items():
+        close(v.cpu(), g[name + ("." + k if k else "")], tol=2e-4, what=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("name", list(gc.UNET3D_CASES))
+def test_unet3d_vs_golden(name):
+    spec = gc.UNET3D_CASES[name]
+    m = _unet3d_module(spec)
+    m.load_state_dict(sd_for(m, "unet3d", name))
+    m = m.to(DEV).eval()
+    g = gold("unet3d")
+    with torch.no_grad():
+        out = m({"x3d": gc.randn(spec["x"], name).to(DEV)})
+    assert len(out) == len([k for k in g.files if k.startswith(name + ".")])
+    for k, v in out.items():
+        close(gc.maybe_subsample(v.cpu().contiguous()), g[f"{name}.{k}"], tol=3e-4, what=f"{name}.{k}")
+
+
+@pytest.mark.parametrize("name", list(gc.FLOSP_CASES))
+def test_flosp_vs_golden(name):
+    from occdepth_amd.models.flosp_depth.flosp_depth import FlospDepth
+    spec = gc.FLOSP_CASES[name]
+    m = FlospDepth(**spec["ctor"])
+    m.load_state_dict(sd_for(m, "flosp", name))
+    m = m.to(DEV).eval()
+    feat, cam_k, t_v2c, idas = gc.flosp_inputs(spec)
+    with torch.no_grad():
+        vox, depth = m(feat.to(DEV), [k.to(DEV) for k in cam_k], [t.to(DEV) for t in t_v2c],
+                       [i.to(DEV) for i in idas])
+    g = gold("flosp")
+    close(depth.cpu(), g[name + ".depth"], tol=2e-4, what="depth")
+    close(vox.cpu(), g[name + ".vox"], tol=2e-4, what="vox")
+
+
+@pytest.mark.parametrize("name", list(gc.FLOSP_CASES))
+def test_flosp_kernel_vs_oracle_same_depth(name):
+    """K1a alone: feed the GOLDEN depth volume so only the frustum-sample kernel is under test."""
+    from occdepth_amd import hip
+    from occdepth_amd.models.flosp_depth.flosp_depth import _grid_to_lidar
+    spec = gc.FLOSP_CASES[name]
+    ctor = spec["ctor"]
+    g = gold("flosp")
+    feat, cam_k, t_v2c, idas = gc.flosp_inputs(spec)
+    depth = torch.from_numpy(g[name + ".depth"]).to(DEV)
+    bounds = [ctor["x_bound"], ctor["y_bound"], ctor["z_bound"]]
+    vnum = [int(v) for v in torch.LongTensor([(r[1] - r[0]) / r[2] / ctor["project_scale"] for r in bounds])]
+    pc_range = [r[0] for r in bounds] + [r[1] for r in bounds]
+    tv = torch.stack(t_v2c).float()
+    k3 = torch.stack(cam_k).float()
+    intr = torch.zeros(1, k3.shape[1], 4, 4)
+    intr[:, :, :3, :3] = k3
+    intr[:, :, 3, 3] = 1
+    trans = (tv @ _grid_to_lidar(pc_range, vnum)).contiguous().to(DEV)
+    flat_vol = hip.flosp_sample(depth, trans, intr[:, :, :3, :].contiguous().to(DEV),
+                                torch.stack(idas).float().contiguous().to(DEV), vnum, ctor["final_dim"],
+                                ctor["d_bound"][0], ctor["d_bound"][1], True)
+    close(flat_vol.cpu().reshape(g[name + ".vox"].shape), g[name + ".vox"], tol=2e-5, what="vox")
+
+
+@pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])
+def test_occdepth_small_vs_golden(cfg_name):
+    m, cfg, sd = build_product(cfg_name)
+    m = m.to(DEV).eval()
+    g = gold("occdepth_small")
+    with torch.no_grad():
+        out = m(to_dev(gc.occdepth_batch(cfg_name)))
+    assert len([v for v in out.values() if v is not None]) == len([k for k in g.files if k.startswith(cfg_name + ".")])
+    errs = {}
+    for k, v in out.items():
+        ref = torch.from_numpy(g[f"{cfg_name}.{k}"])
+        got = gc.maybe_subsample(v.cpu().contiguous())
+        assert got.shape == ref.shape, k
+        errs[k] = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(cfg_name, "end-to-end relative errors vs reference:", {k: f"{e:.1e}" for k, e in errs.items()})
+    # the voxel logits carry the 1e-3 bar; intermediates downstream of the MIOpen 2-D nets and the depth
+    # softmax are un-normalised sums (|x| ~ 4e3) and get a looser sanity bound
+    # End-to-end on these REDUCED configs the error is dominated by MIOpen-vs-CPU round-off inside the
+    # EfficientNet-B3 2-D net (not by the HIP kernels: see test_lift_and_3d_stack_vs_oracle_same_features,
+    # 2e-4, and test_config2_vs_reference_golden, where the full-size logits meet the 1e-3 bar).
+    assert errs["ssc_logit"] < 3e-3 and errs.get("occ_logit", 0.0) < 3e-3, errs
+    assert max(errs.values()) < 5e-3, errs
+
+
+def test_lift_and_3d_stack_vs_oracle_same_features():
+    """Hand-written path in isolation: identical 2-D feature maps go to the oracle (CPU) and to the HIP
+    lift + 3-D stack (GPU).  This is the parity claim for the kernels this repo owns."""
+    from oracle import occdepth_oracle as orc
+    from occdepth_amd.models.SFA import lift_scales
+    cfg_name = "kitti_small"
+    m, cfg, sd = build_product(cfg_name)
+    batch = gc.occdepth_batch(cfg_name)
+    ocfg = oracle_cfg(m, cfg)
+    with torch.no_grad():
+        x_rgb = []
+        for v in range(2):
+            feats = orc.encoder_features(m.net_rgb.encoder.original_model, batch["img"][:, v])
+            x_rgb.append(orc.decoder_bn(sd, "net_rgb.decoder", feats))
+        ps = cfg.project_scale
+        x3d = orc.lift(x_rgb, ["1", "2", "4", "8"], batch[f"projected_pix_{ps}"], batch[f"fov_mask_{ps}"],
+                       cfg.full_scene_size, ps, cfg.dataset)
+        ref = orc.unet3d_kitti(sd, x3d, cfg.full_scene_size, ps, True, True, False, False)
+        m = m.to(DEV)
+        feats_dev = [[x_rgb[v]["1_" + s].to(DEV) for v in range(2)] for s in ("1", "2", "4", "8")]
+        pix = torch.stack(batch[f"projected_pix_{ps}"]).to(DEV)
+        fov = torch.stack(batch[f"fov_mask_{ps}"]).to(DEV)
+        vox = lift_scales(feats_dev, [1, 2, 4, 8], pix, fov, cfg.full_scene_size, ps, cfg.dataset)
+        close(vox.ncdhw().cpu(), x3d, tol=1e-5, what="lift")
+        got = m.net_3d_decoder({"x3d": vox})
+    for k in ref:
+        close(got[k].cpu(), ref[k], tol=2e-4, what=k)
+
+
+# ----------------------------------------------------------------------------- BASELINE config 2
+@pytest.fixture(scope="module")
+def config2():
+    m, cfg, sd = build_product("kitti_a100")
+    m = m.to(DEV).eval()
+    batch = to_dev(gc.occdepth_batch("kitti_a100"))
+    with torch.no_grad():
+        out = m(batch)
+    return m, cfg, batch, out
+
+
+def test_config2_vs_reference_golden(config2):
+    """Full-size forward (B7, 370x1220 stereo -> 256x256x32) against the sub-sampled outputs of the real
+    reference run in the build container (tests/golden/occdepth_kitti_a100.npz)."""
+    m, cfg, batch, out = config2
+    g = gold("occdepth_kitti_a100")
+    assert out["ssc_logit"].shape == (1, 20, 256, 256, 32) and out["occ_logit"].shape == (1, 2, 256, 256, 32)
+    assert out["P_logits"].shape == (1, 4, 512, 4096) and out["depth_pred"].shape == (1, 2, 104, 47, 153)
+    worst = {}
+    for k, v in out.items():
+        ref = torch.from_numpy(g[k])
+        got = gc.subsample(v.cpu().contiguous())
+        assert got.shape == ref.shape, k
+        worst[k] = ((got - ref).abs().max() / ref.abs().max()).item()
+    print("config-2 relative errors vs reference:", {k: f"{e:.2e}" for k, e in worst.items()})
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/config2_parity.txt", "w") as f:
+        f.write(repr(worst) + "\n")
+    assert worst["ssc_logit"] < 1e-3 and worst["occ_logit"] < 1e-3, worst
+    assert max(worst.values()) < 5e-3, worst
+
+
+def test_config2_properties(config2):
+    """Size-independent properties at full size."""
+    m, cfg, batch, out = config2
+    # determinism of the hand-written path: the same lifted volume through the HIP 3-D stack twice is
+    # bit-identical (no atomics, fixed reduction order).  The MIOpen 2-D nets may switch algorithm after
+    # their first (find-mode) call, so whole-forward repeats are only required to agree to round-off.
+    from occdepth_amd import hip
+    vox = hip.Vox.from_ncdhw(torch.randn(1, 64, 128, 128, 16, device=DEV))
+    with torch.no_grad():
+        a = m.net_3d_decoder({"x3d": vox})
+        b = m.net_3d_decoder({"x3d": vox})
+        again = m(batch)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for k in out:
+        assert ((out[k] - again[k]).abs().max() / out[k].abs().max()).item() < 1e-3, k
+    # batch independence: frames in a batch of 2 equal their single-frame results (eval BN)
+    b2 = {k: ([v[0], v[0]] if isinstance(v, list) else torch.cat([v, v.flip(1)])) for k, v in batch.items()}
+    b2["projected_pix_2"] = [batch["projected_pix_2"][0], batch["projected_pix_2"][0].flip(0)]
+    b2["fov_mask_2"] = [batch["fov_mask_2"][0], batch["fov_mask_2"][0].flip(0)]
+    b2["cam_k"] = [batch["cam_k"][0], batch["cam_k"][0].flip(0)]
+    b2["T_velo_2_cam"] = [batch["T_velo_2_cam"][0], batch["T_velo_2_cam"][0].flip(0)]
+    with torch.no_grad():
+        o2 = m(b2)
+    assert o2["ssc_logit"].shape[0] == 2
+    e = ((o2["ssc_logit"][0] - out["ssc_logit"][0]).abs().max() / out["ssc_logit"].abs().max()).item()
+    assert e < 1e-4, e
+    # swapping the stereo views (features, projections, calibration) leaves the SFA fusion symmetric:
+    # the lifted volume, hence every logit, is unchanged up to round-off
+    e = ((o2["ssc_logit"][1] - out["ssc_logit"][0]).abs().max() / out["ssc_logit"].abs().max()).item()
+    assert e < 1e-3, e
+
+
+def test_lift_properties_full_size():
+    """K1b at config-2 size: linearity in the features, zero rows for voxels outside both FOVs."""
+    from occdepth_amd.models.SFA import lift_scales
+    from oracle import inputs
+    b = inputs.kitti_batch(seed=1)
+    pix = torch.stack(b["projected_pix_2"]).to(DEV)
+    fov = torch.stack(b["fov_mask_2"]).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    sizes = [(370, 1220), (185, 610), (93, 305), (47, 153)]
+
+    def feats(scale):
+        return [[scale * torch.randn(1, 64, h, w, device=DEV, generator=torch.Generator(device=DEV).manual_seed(
+            97 * s + v)) for v in range(2)] for s, (h, w) in enumerate(sizes)]
+
+    one = lift_scales(feats(1.0), [1, 2, 4, 8], pix, fov, (256, 256, 32), 2, "kitti").buf
+    two = lift_scales(feats(2.0), [1, 2, 4, 8], pix, fov, (256, 256, 32), 2, "kitti").buf
+    # cosine weights are scale invariant => the fused feature is homogeneous of degree 1
+    assert ((two - 2 * one).abs().max() / one.abs().max()).item() < 1e-5
+    outside = ~(fov[0, 0, :, 0] | fov[0, 1, :, 0])
+    rows = one.reshape(-1, 64)
+    assert rows[outside].abs().max().item() == 0.0
+    assert rows[~outside].abs().max().item() > 0.0
