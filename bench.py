@@ -71,7 +71,7 @@ def cpu_baseline(model, cfg, batch_cpu, budget_s=45.0):
     times = []
     t_start = time.time()
     with torch.no_grad():
-        for i in range(3):
+        for i in range(2):
             t0 = time.time()
             orc.occdepth_forward(sd, ocfg, batch_cpu, enc)
             times.append(time.time() - t0)
@@ -105,7 +105,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
-    torch.backends.cudnn.benchmark = True
+    # MIOpen exhaustive find costs minutes of untimed warm-up on a fresh box; opt in with OCCDEPTH_MIOPEN_FIND=1
+    torch.backends.cudnn.benchmark = os.environ.get("OCCDEPTH_MIOPEN_FIND", "0") == "1"
 
     from occdepth_amd import build, hip
     if rank == 0:
@@ -143,6 +144,28 @@ def main():
         elapsed = float(t.item())
     assert out["ssc_logit"].shape == (1, 20, 256, 256, 32)
 
+    # untimed diagnostic pass: per-stage GPU time with events on the current stream
+    stages = {}
+
+    def timed(name, fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            stages[name] = (e0, e1)
+            return r
+        return wrapper
+
+    orig = (model.process_rgbs, model._forward_2d_to_3d, model.net_3d_decoder.forward)
+    model.process_rgbs = timed("net_rgb_2d_ms", orig[0])
+    model._forward_2d_to_3d = timed("lift_2d_to_3d_ms", orig[1])
+    model.net_3d_decoder.forward = timed("stack_3d_ms", orig[2])
+    step()
+    torch.cuda.synchronize()
+    model.process_rgbs, model._forward_2d_to_3d, model.net_3d_decoder.forward = orig
+    stages = {k: e0.elapsed_time(e1) for k, (e0, e1) in stages.items()}
+
     if rank == 0:
         fps = world * args.steps / elapsed
         head = [(k, v) for k, v in prof.rows.items() if k.startswith(HEAD_CONV_TAG)]
@@ -173,6 +196,7 @@ def main():
                          "gflop_per_launch": flops / max(n_launch, 1) / 1e9},
             "stack3d": {"ms_per_frame": conv_ms, "tflops": STACK3D_GFLOP / conv_ms if conv_ms else 0.0,
                         "frac_of_fp32_mfma_peak": STACK3D_GFLOP / conv_ms / FP32_MFMA_PEAK_TFLOPS if conv_ms else 0.0},
+            "stages_ms": stages,
             "lift": {"ms_per_frame": lift_ms, "gbps": LIFT_MBYTES / lift_ms if lift_ms else 0.0,
                      "frac_of_8TBps": LIFT_MBYTES / lift_ms / 8000.0 if lift_ms else 0.0},
         }
