@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-HEAD_CONV_TAG = "conv3d_igemm:32>32 k333 s111"   # 7 launches/frame, 2*256*256*32*27*32*32 = 115.96 GFLOP each
+HEAD_CONV_TAG = ":32>32 k333 s111"   # 7 launches/frame, 2*256*256*32*27*32*32 = 115.96 GFLOP each
 STACK3D_GFLOP = 1068.3                 # conv 1059.74 + CRP bmm 8.59
 LIFT_MBYTES = 249.0                    # BASELINE.md / SURVEY.md 8(d) algorithmic HBM bytes of the lift
 
@@ -124,10 +124,10 @@ def main():
         with torch.no_grad():
             return model(batch)
 
+    from occdepth_amd import shard
+
     def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.fence(dist)
 
     for _ in range(args.warmup):
         step()
@@ -138,10 +138,7 @@ def main():
             out = step()
         fence()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, device)
     assert out["ssc_logit"].shape == (1, 20, 256, 256, 32)
 
     # untimed diagnostic pass: per-stage GPU time with events on the current stream
@@ -168,12 +165,12 @@ def main():
 
     if rank == 0:
         fps = world * args.steps / elapsed
-        head = [(k, v) for k, v in prof.rows.items() if k.startswith(HEAD_CONV_TAG)]
+        head = [(k, v) for k, v in prof.rows.items() if HEAD_CONV_TAG in k and k.startswith("conv3d")]
         n_launch = sum(v["launches"] for _, v in head)
         ms = sum(v["ms"] for _, v in head)
         flops = sum(v["flops"] for _, v in head)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("conv3d_igemm")) / args.steps
+        conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("conv3d_")) / args.steps
         lift_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("sfa_lift")) / args.steps
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "head_conv_hbm_bytes.json")
@@ -189,7 +186,7 @@ def main():
                                    "feature 64, flosp_depth + CRP + cascade head, 256x256x32 voxels, batch 1/GPU",
                        "frames_per_step": world, "parallelism": f"dp{world} (frames sharded, no collective)",
                        "batch_views": bool(model.batch_views)},
-            "roofline": {"bound": "mfma", "kernel": "conv3d_igemm 3x3x3 32->32 @256x256x32 (fp32 MFMA 32x32x2)",
+            "roofline": {"bound": "mfma", "kernel": "conv3d_c32_persist_kernel: 3x3x3 32->32 @256x256x32 (v_mfma_f32_32x32x2_f32)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": int(n_launch), "avg_launch_ms": ms / max(n_launch, 1),

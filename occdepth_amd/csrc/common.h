@@ -14,6 +14,10 @@ struct ProfScope {
     hipStream_t stream;
 };
 
+// conv3d_c32p.hip: persistent weights-stationary kernel for the full-resolution head convolutions.
+// 1 = launched, 0 = geometry does not qualify (use the generic kernel), <0 = error.
+int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream);
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? OCCD_OK : OCCD_ELAUNCH;

@@ -1,0 +1,229 @@
+// K2p -- persistent, weights-stationary 3x3x3 convolution for <=32 -> <=32 channels on Z = 32 columns:
+// the segmentation-head convolutions at full resolution (7-8 launches, 87 % of the 3-D stack's FLOPs).
+//
+// Same math as conv3d_igemm_kernel (v_mfma_f32_32x32x2_f32, exact fp32), different dataflow:
+//   * one 512-thread workgroup per CU stays resident and walks output tiles of 8 (y) x 32 (z) voxels at one x;
+//     XCD k owns a contiguous range of x-planes and each workgroup walks along x at a fixed y-tile, so the
+//     kx halo planes of consecutive tiles are L2 hits;
+//   * ALL 27 x 32 x 32 weights (110.6 KB, MFMA B-fragment order) are loaded into LDS once per workgroup:
+//     no per-wave weight stream from L2 (which was 3x the activation traffic in the generic kernel);
+//   * the input slab of one (kx, 16-channel half) is register-staged: its global loads are issued right
+//     after the previous slab was written to LDS and land while the 18 MFMA steps of the current slab run
+//     (global -> VGPR -> LDS split, one LDS slab buffer, two barriers per slab);
+//   * wave w owns the 32 voxels of row y0+w (one M tile, one accumulator), 2 waves per SIMD.
+// LDS: 110,592 B weights + (8+2d)(32+2d) rows x 80 B  (d=1: 137.8 KB, d=3: 153.2 KB) -> 1 workgroup / CU.
+//
+// Reference semantics replaced: occdepth/models/modules.py:158-175 (conv0, conv1.*, conv2.*, conv_classes).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct PersistP {
+    const float* in;
+    const float* wpk;
+    const float* bias;
+    const float* res1;
+    const float* res2;
+    float* out;
+    int batch, X, Y, in_cs, in_coff;
+    int out_cs, out_coff, res1_cs, res1_coff, res2_cs, res2_coff;
+    int act_in, act_out, cout_store;
+    int ytiles, tiles_total;
+};
+
+constexpr int kTY = 8, kTZ = 32, kWTaps = 27, kWFloat4 = kWTaps * 4 * 64;  // 6912 float4 = 110,592 B
+
+template <int D>
+__global__ void __launch_bounds__(512, 2) conv3d_c32_persist_kernel(const PersistP p) {
+    constexpr int YIN = kTY + 2 * D, ZIN = kTZ + 2 * D, ROWS = YIN * ZIN;
+    constexpr int RS4 = 5;                       // 16 floats + 4 pad per LDS row: odd number of 16-B slots
+    constexpr int NF4 = ROWS * 4;                // float4 slots of one slab
+    constexpr int NLOAD = (NF4 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
+    f32x4* const w4 = lds4;
+    f32x4* const slab4 = lds4 + kWFloat4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7 = local y row
+    const int li = lane & 31, kk = lane >> 5;
+
+    // weights: global (packed) -> LDS, once
+    for (int i = tid; i < kWFloat4; i += 512) w4[i] = ((const f32x4*)p.wpk)[i];
+
+    // per-thread staging descriptors (constant over tiles)
+    int sdst[NLOAD], syi[NLOAD], szoff[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int f = tid + i * 512;
+        const bool live = f < NF4;
+        const int row = f >> 2, c4 = f & 3;
+        const int yi = row / ZIN, zi = row - yi * ZIN;
+        const int z = zi - D;
+        sdst[i] = live ? row * RS4 + c4 : -1;
+        syi[i] = yi;
+        szoff[i] = (live && z >= 0 && z < kTZ) ? z * p.in_cs + c4 * 4 : -1;
+    }
+    const int rowbase = (wave * ZIN + li) * RS4 + kk;   // A fragment row of this lane (tap (0,0), kt 0)
+
+    // tile walk: XCD-major ranges of the (b, x, ytile) list, workgroups of one XCD interleaved by y-tile
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wg_per_xcd = (nwg + 7 - xcd) >> 3;          // workgroups that landed on this XCD id
+    const int per_xcd = (p.tiles_total + 7) >> 3;
+    const int t_end = min((xcd + 1) * per_xcd, p.tiles_total);
+    int tile = xcd * per_xcd + slot;
+    if (tile >= t_end) return;
+
+    f32x4 v[NLOAD];
+    auto issue = [&](int t, int ci) {
+        const int yt = t % p.ytiles;
+        const int bx = t / p.ytiles;                       // b * X + x
+        const int x = bx % p.X;
+        const int kx = ci >> 1, h = ci & 1;
+        const int xi = x - D + kx * D;
+        const bool plane_ok = xi >= 0 && xi < p.X;
+        const float* base = p.in + ((size_t)(bx - x + (plane_ok ? xi : 0)) * p.Y) * kTZ * p.in_cs + p.in_coff + h * 16;
+        const int y0 = yt * kTY - D;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int y = y0 + syi[i];
+            const bool ok = plane_ok && szoff[i] >= 0 && y >= 0 && y < p.Y;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) v[i] = *(const f32x4*)(base + (size_t)y * kTZ * p.in_cs + szoff[i]);
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    issue(tile, 0);
+    const float bias_v = (p.bias != nullptr && li < p.cout_store) ? p.bias[li] : 0.f;
+
+    while (true) {
+        const int next_tile = tile + wg_per_xcd;
+        const bool has_next = next_tile < t_end;
+#pragma unroll 1
+        for (int ci = 0; ci < 6; ++ci) {
+            __syncthreads();                      // previous slab fully consumed (and weights visible)
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i)
+                if (sdst[i] >= 0) {
+                    f32x4 a = v[i];
+                    if (p.act_in == OCCD_ACT_RELU) {
+                        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    }
+                    slab4[sdst[i]] = a;
+                }
+            __syncthreads();
+            if (ci < 5) issue(tile, ci + 1);      // lands while the MFMAs below run
+            else if (has_next) issue(next_tile, 0);
+
+            const int kx = ci >> 1, h = ci & 1;
+            const f32x4* wb = w4 + (kx * 9 * 4 + h * 2) * 64 + lane;
+            const f32x4* ab = slab4 + rowbase;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+                    for (int ktl = 0; ktl < 2; ++ktl) {
+                        const f32x4 a = ab[(ky * D * ZIN + kz * D) * RS4 + ktl * 2];
+                        const f32x4 b = wb[((ky * 3 + kz) * 4 + ktl) * 64];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+                    }
+        }
+        // ---- epilogue of this tile (the next tile's first slab is already in flight)
+        {
+            const int yt = tile % p.ytiles;
+            const int bx = tile / p.ytiles;
+            const int y = yt * kTY + wave;
+            if (y < p.Y && li < p.cout_store) {
+                const size_t vox0 = ((size_t)bx * p.Y + y) * kTZ;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int z = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    const size_t vox = vox0 + z;
+                    float o = acc[r] + bias_v;
+                    if (p.act_out == OCCD_ACT_RELU_PRE) o = fmaxf(o, 0.f);
+                    if (p.res1 != nullptr) o += p.res1[vox * p.res1_cs + p.res1_coff + li];
+                    if (p.res2 != nullptr) o += p.res2[vox * p.res2_cs + p.res2_coff + li];
+                    if (p.act_out == OCCD_ACT_RELU) o = fmaxf(o, 0.f);
+                    p.out[vox * p.out_cs + p.out_coff + li] = o;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        if (!has_next) break;
+        tile = next_tile;
+    }
+}
+
+bool g_attr_done[4] = {};
+int g_num_cu = 0;
+
+template <int D>
+int launch(const PersistP& p, hipStream_t st) {
+    constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D);
+    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * 5 * 16;
+    if (!g_attr_done[D]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_persist_kernel<D>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return OCCD_ELAUNCH;
+        g_attr_done[D] = true;
+    }
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCCD_ELAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int grid = g_num_cu;
+    if (grid > p.tiles_total) grid = p.tiles_total;
+    hipLaunchKernelGGL(conv3d_c32_persist_kernel<D>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    return occd::check_launch();
+}
+
+}  // namespace
+
+namespace occd {
+
+// Returns 1 when the launch was taken by the persistent kernel, 0 when the geometry does not qualify,
+// <0 on error.
+int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
+    const int d = a->dx;
+    const bool geom = a->kx == 3 && a->ky == 3 && a->kz == 3 && a->sx == 1 && a->sy == 1 && a->sz == 1 &&
+                      a->dy == d && a->dz == d && d >= 1 && d <= 3 && a->px == d && a->py == d && a->pz == d;
+    const bool shape = a->Z == kTZ && a->Xo == a->X && a->Yo == a->Y && a->Zo == a->Z && a->OX == a->X &&
+                       a->OY == a->Y && a->OZ == a->Z && a->o_stride_x == 1 && a->o_stride_y == 1 &&
+                       a->o_stride_z == 1 && a->o_off_x == 0 && a->o_off_y == 0 && a->o_off_z == 0;
+    const int cin8 = (a->cin + 7) & ~7;
+    const bool chans = cin8 <= 32 && a->cout <= 32 && a->in_coff + 32 <= a->in_cs && a->act_in != OCCD_ACT_SIGMOID;
+    // enough tiles to keep every CU busy for several rounds, otherwise the generic kernel tiles finer
+    const long tiles = (long)a->batch * a->X * ((a->Y + kTY - 1) / kTY);
+    if (!(geom && shape && chans) || cin8 != 32 || tiles < 512 || a->tile_hint != 0) return 0;
+    PersistP p;
+    p.in = a->in; p.wpk = a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
+    p.batch = a->batch; p.X = a->X; p.Y = a->Y; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
+    p.out_cs = a->out_cs; p.out_coff = a->out_coff;
+    p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
+    p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
+    p.ytiles = (a->Y + kTY - 1) / kTY;
+    p.tiles_total = (int)tiles;
+    const double pos = (double)a->batch * a->X * a->Y * a->Z;
+    const double flops = 2.0 * pos * 27 * a->cin * a->cout;
+    const double bytes = 4.0 * (pos * a->cin + pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) +
+                                27.0 * a->cin * a->cout);
+    ProfScope prof("conv3d_c32p", stream, flops, bytes);
+    int rc = d == 1 ? launch<1>(p, stream) : d == 2 ? launch<2>(p, stream) : launch<3>(p, stream);
+    return rc == OCCD_OK ? 1 : rc;
+}
+
+}  // namespace occd

@@ -350,6 +350,11 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
     if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
         return OCCD_EINVAL;
 
+    {
+        const int taken = occd::try_conv3d_c32_persist(a, (hipStream_t)stream);
+        if (taken != 0) return taken > 0 ? OCCD_OK : taken;
+    }
+
     // ---- variant choice: widest N tile the layer fills, then the largest M
     // tile that fits LDS and still yields >= 2 workgroups per CU.
     int order[kNumVariants];

@@ -39,8 +39,48 @@ struct LiftP {
     occd_lift_args a;
 };
 
-template <int LPV>
-__global__ void __launch_bounds__(256) lift_kernel(const LiftP pp) {
+// Stereo-SFA fusion of the V per-view feature vectors of one voxel (SFA.py:46-89).
+template <int LPV, int V>
+__device__ __forceinline__ f32x4 sfa_fuse(const f32x4 (&f)[V], const float (&m)[V]) {
+    if (V == 1) return f[0];
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+        for (int j = i + 1; j < V; ++j) {
+            // torch.cosine_similarity: normalise each vector by max(||.||, eps) first
+            float ni = f[i].x * f[i].x + f[i].y * f[i].y + f[i].z * f[i].z + f[i].w * f[i].w;
+            float nj = f[j].x * f[j].x + f[j].y * f[j].y + f[j].z * f[j].z + f[j].w * f[j].w;
+            ni = fmaxf(sqrtf(group_sum<LPV>(ni)), 1e-8f);
+            nj = fmaxf(sqrtf(group_sum<LPV>(nj)), 1e-8f);
+            const f32x4 xi = f[i] / ni, xj = f[j] / nj;
+            float d = xi.x * xj.x + xi.y * xj.y + xi.z * xj.z + xi.w * xj.w;
+            d = group_sum<LPV>(d) * (m[i] * m[j]);
+            const float wi = d + (m[i] > m[j] ? 1.f : 0.f);
+            const float wj = d + (m[j] > m[i] ? 1.f : 0.f);
+            o += wi * f[i] + wj * f[j];
+        }
+    }
+    const float den = (float)(V * (V - 1));
+    o.x /= den; o.y /= den; o.z /= den; o.w /= den;
+    return o;
+}
+
+__device__ __forceinline__ void store_voxel_row(const occd_lift_args& a, int b, long n, int c, bool ch_ok, f32x4 v) {
+    const long bc = a.dimB * (long)a.dimC;
+    const long ia = n / bc;
+    const long rem = n - ia * bc;
+    const long ib = rem / a.dimC, ic = rem - ib * a.dimC;
+    const long row = ia * a.row_a + ib * a.row_b + ic * a.row_c;
+    float* o = a.out + ((size_t)b * a.out_rows + row) * a.out_cs + c;
+    *(f32x4*)o = ch_ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Fast path: one pattern point (every shipped config), V views.  The kernel is latency-bound, so the
+// projection indices are fetched first and then the gathers of ALL scales and views are put in flight
+// together (V*S independent 16-byte loads per lane) before any arithmetic.
+template <int LPV, int V>
+__global__ void __launch_bounds__(256) lift_p1_kernel(const LiftP pp) {
     const occd_lift_args& a = pp.a;
     const int tid = threadIdx.x;
     const int sub = tid % LPV;
@@ -50,89 +90,101 @@ __global__ void __launch_bounds__(256) lift_kernel(const LiftP pp) {
     const long nn = vox_ok ? n : (long)a.N - 1;
     const int c = sub * 4;
     const bool ch_ok = c < a.C;
-    const int V = a.n_views, P = a.P;
+    const int64_t* pix = a.pix + ((size_t)b * V) * a.N * 2;
+    const uint8_t* fov = a.fov + ((size_t)b * V) * a.N;
 
-    // projected pixels / FOV flags of this voxel: identical address for the LPV
-    // lanes of a group (one broadcast transaction).
+    int px[V], py[V];
+    float m[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const size_t pi = (size_t)v * a.N + nn;
+        const bool in = fov[pi] != 0;
+        px[v] = in ? (int)pix[pi * 2] : 0;       // in-FOV pixels are non-negative image coordinates
+        py[v] = in ? (int)pix[pi * 2 + 1] : 0;
+        m[v] = in ? 1.f : 0.f;
+    }
+    f32x4 g[OCCD_MAX_SCALES][V];
+#pragma unroll
+    for (int s = 0; s < OCCD_MAX_SCALES; ++s)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            g[s][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s < a.n_scales && m[v] != 0.f && ch_ok) {
+                const int dv = a.scale_div[s], w = a.feat_w[s], cs = a.feat_cs[s];
+                const int idx = (py[v] / dv) * w + (px[v] / dv);
+                g[s][v] = *(const f32x4*)(a.feat[s][v] + ((size_t)b * a.feat_h[s] * w + idx) * cs + c);
+            }
+        }
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < OCCD_MAX_SCALES; ++s)
+        if (s < a.n_scales) {
+            const f32x4 o = sfa_fuse<LPV, V>(g[s], m);   // count == 1: mean over pattern points is the point
+            if (s == 0) total = o; else total += o;
+        }
+    if (a.depth_scale != nullptr) total = total * a.depth_scale[(size_t)b * a.N + nn] * a.scale_const;
+    if (vox_ok && c < a.out_cs) store_voxel_row(a, b, n, c, ch_ok, total);
+}
+
+// General path: any pattern size P (DSO patterns up to 25 points), V views.
+template <int LPV, int V>
+__global__ void __launch_bounds__(256) lift_any_kernel(const LiftP pp) {
+    const occd_lift_args& a = pp.a;
+    const int tid = threadIdx.x;
+    const int sub = tid % LPV;
+    const long n = ((long)blockIdx.x * 256 + tid) / LPV;
+    const int b = blockIdx.y;
+    const bool vox_ok = n < a.N;
+    const long nn = vox_ok ? n : (long)a.N - 1;
+    const int c = sub * 4;
+    const bool ch_ok = c < a.C;
+    const int P = a.P;
     const int64_t* pix = a.pix + (((size_t)b * V) * a.N) * P * 2;
     const uint8_t* fov = a.fov + (((size_t)b * V) * a.N) * P;
 
     f32x4 total = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < a.n_scales; ++s) {
-        const int div = a.scale_div[s];
-        const int w = a.feat_w[s];
-        const int cs = a.feat_cs[s];
+        const int div = a.scale_div[s], w = a.feat_w[s], cs = a.feat_cs[s];
         const size_t bstride = (size_t)a.feat_h[s] * w * cs;
-        f32x4 f[OCCD_MAX_VIEWS];
-        float m[OCCD_MAX_VIEWS];
+        f32x4 f[V];
+        float m[V];
 #pragma unroll
-        for (int v = 0; v < OCCD_MAX_VIEWS; ++v) {
+        for (int v = 0; v < V; ++v) {
             f[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-            m[v] = 0.f;
-            if (v < V) {
-                const float* fm = a.feat[s][v] + (size_t)b * bstride + c;
-                int cnt = 0;
-                for (int q = 0; q < P; ++q) {
-                    const size_t pi = ((size_t)v * a.N + nn) * P + q;
-                    if (fov[pi]) {
-                        const long px = pix[pi * 2], py = pix[pi * 2 + 1];
-                        const long idx = (py / div) * w + (px / div);
-                        ++cnt;
-                        if (ch_ok) {
-                            const f32x4 g = *(const f32x4*)(fm + (size_t)idx * cs);
-                            f[v] += g;
-                        }
-                    }
-                }
-                if (cnt > 0) {
-                    const float fc = (float)cnt;
-                    f[v].x /= fc; f[v].y /= fc; f[v].z /= fc; f[v].w /= fc;
-                    m[v] = 1.f;
+            const float* fm = a.feat[s][v] + (size_t)b * bstride + c;
+            int cnt = 0;
+            for (int q = 0; q < P; ++q) {          // pattern points accumulate in index order (SFA.py:28-30)
+                const size_t pi = ((size_t)v * a.N + nn) * P + q;
+                if (fov[pi]) {
+                    const long idx = (pix[pi * 2 + 1] / div) * w + (pix[pi * 2] / div);
+                    ++cnt;
+                    if (ch_ok) f[v] += *(const f32x4*)(fm + (size_t)idx * cs);
                 }
             }
-        }
-        f32x4 o;
-        if (V == 1) {
-            o = f[0];
-        } else {
-            o = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < OCCD_MAX_VIEWS; ++i) {
-#pragma unroll
-                for (int j = i + 1; j < OCCD_MAX_VIEWS; ++j) {
-                    if (j < V) {
-                        // torch.cosine_similarity: normalise each vector by max(||.||, eps) first
-                        float ni = f[i].x * f[i].x + f[i].y * f[i].y + f[i].z * f[i].z + f[i].w * f[i].w;
-                        float nj = f[j].x * f[j].x + f[j].y * f[j].y + f[j].z * f[j].z + f[j].w * f[j].w;
-                        ni = fmaxf(sqrtf(group_sum<LPV>(ni)), 1e-8f);
-                        nj = fmaxf(sqrtf(group_sum<LPV>(nj)), 1e-8f);
-                        const f32x4 xi = f[i] / ni, xj = f[j] / nj;
-                        float d = xi.x * xj.x + xi.y * xj.y + xi.z * xj.z + xi.w * xj.w;
-                        d = group_sum<LPV>(d) * (m[i] * m[j]);
-                        const float wi = d + (m[i] > m[j] ? 1.f : 0.f);
-                        const float wj = d + (m[j] > m[i] ? 1.f : 0.f);
-                        o += wi * f[i] + wj * f[j];
-                    }
-                }
+            m[v] = cnt > 0 ? 1.f : 0.f;
+            if (cnt > 0) {
+                const float fc = (float)cnt;
+                f[v].x /= fc; f[v].y /= fc; f[v].z /= fc; f[v].w /= fc;
             }
-            const float den = (float)(V * (V - 1));
-            o.x /= den; o.y /= den; o.z /= den; o.w /= den;
         }
+        const f32x4 o = sfa_fuse<LPV, V>(f, m);
         if (s == 0) total = o; else total += o;
     }
-    if (a.depth_scale != nullptr) {
-        const float dsc = a.depth_scale[(size_t)b * a.N + nn];
-        total = total * dsc * a.scale_const;
+    if (a.depth_scale != nullptr) total = total * a.depth_scale[(size_t)b * a.N + nn] * a.scale_const;
+    if (vox_ok && c < a.out_cs) store_voxel_row(a, b, n, c, ch_ok, total);
+}
+
+template <int LPV>
+void launch_lift(const LiftP& p, dim3 grid, hipStream_t st) {
+    const int V = p.a.n_views;
+    const bool p1 = p.a.P == 1;
+#define OCCD_LIFT(VV)                                                                             \
+    if (V == VV) {                                                                                \
+        if (p1) hipLaunchKernelGGL((lift_p1_kernel<LPV, VV>), grid, dim3(256), 0, st, p);         \
+        else hipLaunchKernelGGL((lift_any_kernel<LPV, VV>), grid, dim3(256), 0, st, p);           \
     }
-    if (vox_ok && c < a.out_cs) {
-        const long bc = a.dimB * (long)a.dimC;
-        const long ia = n / bc;
-        const long rem = n - ia * bc;
-        const long ib = rem / a.dimC, ic = rem - ib * a.dimC;
-        const long row = ia * a.row_a + ib * a.row_b + ic * a.row_c;
-        float* o = a.out + ((size_t)b * a.out_rows + row) * a.out_cs + c;
-        *(f32x4*)o = ch_ok ? total : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    OCCD_LIFT(1) OCCD_LIFT(2) OCCD_LIFT(3) OCCD_LIFT(4)
+#undef OCCD_LIFT
 }
 
 // ------------------------------------------------------------ frustum sample
@@ -324,10 +376,10 @@ extern "C" int occd_lift_fwd(const occd_lift_args* a, void* stream) {
     occd::ProfScope prof("sfa_lift", (hipStream_t)stream, 0.0, bytes);
     hipStream_t st = (hipStream_t)stream;
     switch (lpv) {
-        case 8: hipLaunchKernelGGL(lift_kernel<8>, grid, dim3(256), 0, st, p); break;
-        case 16: hipLaunchKernelGGL(lift_kernel<16>, grid, dim3(256), 0, st, p); break;
-        case 32: hipLaunchKernelGGL(lift_kernel<32>, grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL(lift_kernel<64>, grid, dim3(256), 0, st, p); break;
+        case 8: launch_lift<8>(p, grid, st); break;
+        case 16: launch_lift<16>(p, grid, st); break;
+        case 32: launch_lift<32>(p, grid, st); break;
+        default: launch_lift<64>(p, grid, st); break;
     }
     return occd::check_launch();
 }

@@ -94,6 +94,41 @@ class ConvPlan:
                           res1=res1, res2=res2, act_in=act_in, act_out=act_out)
 
 
+class DerivedConvPlan:
+    """A K2 launch whose weights are a function of several modules' parameters (slices / concatenations),
+    e.g. the cascade head's merged `conv_classes[:, :planes] | occ_classes` convolution.
+
+    `derive()` returns (weight (Cout, Cin, kx, ky, kz), bias (Cout,) or None); geometry is fixed."""
+
+    def __init__(self, modules, derive, padding=(1, 1, 1), dilation=(1, 1, 1), stride=(1, 1, 1)):
+        self.modules, self.derive = list(modules), derive
+        self.padding, self.dilation, self.stride = padding, dilation, stride
+        self._key = None
+        self._wpk = self._bias = None
+        self.cout = self.kernel = None
+
+    def _prepare(self):
+        key = _stamp(*self.modules)
+        if key == self._key:
+            return
+        w, b = self.derive()
+        w = w.detach().float().contiguous()
+        self.cout, self.kernel = w.shape[0], tuple(w.shape[2:])
+        self._wpk = hip.pack_weights(w)
+        self._bias = _pad_bias(b.detach().float(), self.cout) if b is not None else None
+        self._key = key
+
+    def __call__(self, x, out=None, res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE, out_cs=None):
+        self._prepare()
+        if out is None:
+            dims = tuple((n + 2 * p - d * (k - 1) - 1) // s + 1
+                         for n, k, s, d, p in zip(x.dims, self.kernel, self.stride, self.dilation, self.padding))
+            out = Vox.empty(x.batch, dims, self.cout, x.buf.device, cs=out_cs)
+        return hip.conv3d(x, self._wpk, self._bias, self.cout, self.kernel, out, stride=self.stride,
+                          dilation=self.dilation, padding=self.padding, res1=res1, res2=res2, act_in=act_in,
+                          act_out=act_out)
+
+
 class ConvTransposePlan:
     """ConvTranspose3d(k=3, s=2, p=1, output_padding=1) (+BN) as 8 sub-pixel phase convolutions,
     or ConvTranspose3d(k=3, s=1, p=1) (+BN) as one flipped convolution."""

@@ -3,15 +3,15 @@ heads, Process / Upsample / Convblock3d / Downsample.
 
 State-dict names follow the reference (conv0, conv1.{i}, bn1.{i}, conv2.{i}, bn2.{i},
 conv_classes, occ_classes, main.*).  Eval mode runs on the HIP implicit-GEMM kernel with
-BatchNorm folded, ReLU / residual accumulation fused into the epilogues and the cascade
-head's softmax+concat written straight into the 34-channel input rows of `conv_classes`.
+BatchNorm folded, ReLU / residual accumulation fused into the epilogues; the cascade head splits
+`conv_classes` by linearity so its wide half shares one MFMA N-tile with `occ_classes`.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, Vox, as_vox
+from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox
 from .DDR import Bottleneck3D
 
 
@@ -121,20 +121,22 @@ class SegmentationHeadCascadeCLS(_HeadBase):
         self.planes = planes
 
     def _extra_plans(self, plans):
-        plans["cls"] = ConvPlan(self.conv_classes)
-        plans["occ"] = ConvPlan(self.occ_classes)
+        # conv_classes(cat[f, softmax(occ)]) = conv_classes[:, :planes](f) + conv_classes[:, planes:](softmax(occ))
+        # (linearity), so the wide part shares ONE N=32 MFMA tile with occ_classes: cout = nbr + 2 <= 32.
+        p, cls, occ = self.planes, self.conv_classes, self.occ_classes
+        plans["wide"] = DerivedConvPlan(
+            [cls, occ], lambda: (torch.cat([cls.weight[:, :p], occ.weight], 0), torch.cat([cls.bias, occ.bias], 0)))
+        plans["narrow"] = DerivedConvPlan([cls], lambda: (cls.weight[:, p:], None))
 
     def forward_vox(self, x):
         """returns (ssc_logit Vox, occ_logit Vox)."""
-        planes = self.planes
-        n_in = planes + 2
-        cs = hip.round_up(n_in, 8)
-        cat = torch.empty((x.batch,) + x.dims + (cs,), device=x.buf.device, dtype=torch.float32)
-        feat = Vox(cat, planes, 0)            # [0, planes): relu(y + x_in)
-        self._trunk_vox(x, out=feat)
-        occ = self._plans["occ"](feat)
-        hip.softmax_channels(occ, Vox(cat, 2, planes), 2, dst_pad=cs - n_in)  # [planes, planes+2) + zero pad
-        ssc = self._plans["cls"](Vox(cat, n_in, 0))
+        feat = self._trunk_vox(x)                       # relu(y + x_in), planes channels
+        nbr = self.conv_classes.out_channels
+        part = self._plans["wide"](feat)                # [0, nbr): partial class logits, [nbr, nbr+2): occ logits
+        occ = Vox(part.buf, 2, nbr)
+        soft = Vox.empty(x.batch, x.dims, 2, x.buf.device)
+        hip.softmax_channels(occ, soft, 2, dst_pad=soft.cs - 2)
+        ssc = self._plans["narrow"](soft, res1=Vox(part.buf, nbr, 0), out_cs=hip.round_up(nbr, 4))
         return ssc, occ
 
     def forward(self, x_in):

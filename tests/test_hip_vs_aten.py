@@ -96,6 +96,46 @@ def test_conv3d_vs_aten(hip, case):
     assert torch.equal(hip.nhwc_to_nchw(out), out.ncdhw().contiguous())
 
 
+PERSIST_CASES = [
+    # shapes that qualify for the persistent weights-stationary head kernel (Z == 32, 25..32 -> <=32 channels)
+    (1, 32, 32, (16, 256, 32), 1),
+    (1, 32, 32, (16, 256, 32), 3),
+    (2, 30, 22, (9, 250, 32), 2),
+    (1, 32, 2, (20, 208, 32), 1),
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES)
+def test_conv3d_persistent_head_kernel(hip, case):
+    B, cin, cout, dims, d = case
+    from occdepth_amd.fused import _pad_bias
+    torch.manual_seed(cin + cout + d)
+    x = torch.randn(B, cin, *dims, device=DEV)
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV) / (cin * 27) ** 0.5
+    bias = torch.randn(cout, device=DEV)
+    r1 = torch.randn(B, cout, *dims, device=DEV)
+    r2 = torch.randn(B, cout, *dims, device=DEV)
+    vx, wpk = hip.Vox.from_ncdhw(x), hip.pack_weights(w)
+    out = hip.Vox.empty(B, dims, cout, DEV)
+    with hip.profile() as prof:
+        hip.conv3d(vx, wpk, _pad_bias(bias, cout), cout, (3, 3, 3), out, dilation=(d,) * 3, padding=(d,) * 3)
+    assert any(k.startswith("conv3d_c32p") for k in prof.rows), prof.rows.keys()
+    ref = F.conv3d(x, w, bias, padding=d, dilation=d)
+    assert rel_err(out.ncdhw(), ref) < 2e-5
+    if out.cs > cout:
+        assert out.buf[..., cout:].abs().max().item() == 0.0
+    out2 = hip.Vox.empty(B, dims, cout, DEV)
+    hip.conv3d(vx, wpk, _pad_bias(bias, cout), cout, (3, 3, 3), out2, dilation=(d,) * 3, padding=(d,) * 3,
+               res1=hip.Vox.from_ncdhw(r1), res2=hip.Vox.from_ncdhw(r2), act_in=hip.ACT_RELU, act_out=hip.ACT_RELU)
+    ref2 = F.relu(F.conv3d(F.relu(x), w, bias, padding=d, dilation=d) + r1 + r2)
+    assert rel_err(out2.ncdhw(), ref2) < 2e-5
+    # the generic kernel (forced by a tile hint) gives the same numbers up to accumulation order
+    out3 = hip.Vox.empty(B, dims, cout, DEV)
+    hip.conv3d(vx, wpk, _pad_bias(bias, cout), cout, (3, 3, 3), out3, dilation=(d,) * 3, padding=(d,) * 3,
+               tile_hint=1)
+    assert rel_err(out3.ncdhw(), out.ncdhw()) < 1e-5
+
+
 @pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 7])
 def test_conv3d_all_variants(hip, hint):
     torch.manual_seed(hint)

@@ -1,58 +1,105 @@
-"""Micro-benchmarks of the HIP kernels at BASELINE config-2 shapes (dev tool; needs the GPU)."""
-import sys, os, time
+"""Micro-benchmarks of the HIP kernels at BASELINE config-2 shapes (dev tool; needs the GPU).
+
+    python tools/bench_kernels.py [head] [aspp] [lift] [stack]
+Variants of one shape are timed interleaved over several rounds; the median is reported."""
+import os
+import statistics
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn as nn
+
 from occdepth_amd import hip
 
 
-def timeit(fn, n=5, warm=2):
-    for _ in range(warm):
-        fn()
+def time_many(fns, rounds=5, iters=8):
+    """fns: {name: callable}; returns {name: median ms per call} with rounds interleaved."""
+    for f in fns.values():
+        f()
     torch.cuda.synchronize()
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(n):
-        fn()
-    t1.record(); torch.cuda.synchronize()
-    return t0.elapsed_time(t1) / n
+    res = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, f in fns.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            res[k].append(e0.elapsed_time(e1) / iters)
+    return {k: statistics.median(v) for k, v in res.items()}
 
 
-def head_conv(d, hint=0, dims=(256, 256, 32), cin=32, cout=32):
+def conv_case(dims, cin, cout, d, hints, k=3):
     cs = hip.round_up(cin, 8)
     buf = torch.zeros(1, *dims, cs, device="cuda")
     buf[..., :cin] = torch.randn(1, *dims, cin, device="cuda")
     x = hip.Vox(buf, cin)
-    w = torch.randn(cout, cin, 3, 3, 3, device="cuda") * 0.05
+    w = torch.randn(cout, cin, k, k, k, device="cuda") * 0.05
     wpk = hip.pack_weights(w)
     out = hip.Vox.empty(1, dims, cout, "cuda")
-    fn = lambda: hip.conv3d(x, wpk, None, cout, (3, 3, 3), out, dilation=(d,) * 3, padding=(d,) * 3, tile_hint=hint)
-    ms = timeit(fn)
-    fl = 2.0 * dims[0] * dims[1] * dims[2] * 27 * cin * cout
-    print(f"conv3x3x3 {cin}->{cout} @{dims} d={d} hint={hint}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF/s  ({fl/ms/1e9/157.3*100:.1f}% of 157.3)")
+    pad = (d * (k // 2),) * 3
+    fns = {h: (lambda h=h: hip.conv3d(x, wpk, None, cout, (k, k, k), out, dilation=(d,) * 3, padding=pad,
+                                      tile_hint=h)) for h in hints}
+    ms = time_many(fns)
+    fl = 2.0 * dims[0] * dims[1] * dims[2] * k ** 3 * cin * cout
+    for h, t in ms.items():
+        print(f"conv k{k} {cin}->{cout} @{dims} d={d} hint={h}: {t:.3f} ms {fl / t / 1e9:6.1f} TF/s "
+              f"({fl / t / 1e9 / 157.3 * 100:.1f}%)", flush=True)
 
 
-if __name__ == "__main__":
-    torch.manual_seed(0)
+def bench_head():
     for d in (1, 2, 3):
-        head_conv(d)
-    for h in (1, 5, 6):
-        for d in (1, 3):
-            head_conv(d, hint=h)
-    head_conv(1, cin=34, cout=20)
-    head_conv(1, cin=32, cout=2)
-    head_conv(1, dims=(32, 32, 4), cin=256, cout=256)
-    head_conv(1, dims=(128, 128, 16), cin=64, cout=64)
-    # whole 3-D stack at config 2
+        conv_case((256, 256, 32), 32, 32, d, [0, 1])
+    conv_case((256, 256, 32), 32, 22, 1, [0])
+    conv_case((256, 256, 32), 2, 20, 1, [0])
+
+
+def bench_aspp():
+    for d in (1, 3):
+        conv_case((32, 32, 4), 256, 256, d, [3, 4, 6, 7])
+    conv_case((128, 128, 16), 64, 64, 1, [0])
+
+
+def bench_lift():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from oracle import inputs
+    from occdepth_amd.models.SFA import voxel_layout
+    b = inputs.kitti_batch(seed=1)
+    pix = torch.stack(b["projected_pix_2"]).cuda()
+    fov = torch.stack(b["fov_mask_2"]).cuda()
+    sizes = [(370, 1220), (185, 610), (93, 305), (47, 153)]
+    rows = [[torch.randn(1, h, w, 64, device="cuda") for _ in range(2)] for h, w in sizes]
+    n_dims, out_dims, strides = voxel_layout((256, 256, 32), 2, "kitti")
+    out = hip.Vox.empty(1, out_dims, 64, "cuda")
+    depth = torch.rand(1, 262144, device="cuda")
+    ms = time_many({"lift": lambda: hip.lift(rows, [1, 2, 4, 8], pix, fov, n_dims, strides, out, depth_scale=depth)},
+                   rounds=5, iters=20)["lift"]
+    print(f"sfa_lift config2: {ms * 1e3:.1f} us -> {249.0 / ms / 1e3:.2f} TB/s of algorithmic bytes "
+          f"({249.0 / ms / 1e3 / 8 * 100:.1f}% of 8 TB/s)")
+    x = torch.randn(2, 64, 370, 1220, device="cuda")
+    ms = time_many({"t": lambda: hip.nchw_to_nhwc(x)}, rounds=3, iters=10)["t"]
+    print(f"nchw_to_nhwc 2x64x370x1220: {ms * 1e3:.1f} us ({2 * x.numel() * 4 / ms / 1e9:.2f} TB/s)")
+
+
+def bench_stack():
     from occdepth_amd.models.unet3d_kitti import UNet3D
     m = UNet3D(20, nn.BatchNorm3d, (256, 256, 32), 64, 2, context_prior=True, cascade_cls=True).cuda().eval()
     x = hip.Vox(torch.randn(1, 128, 128, 16, 64, device="cuda"), 64)
     with torch.no_grad():
-        m({"x3d": x})
-        ms = timeit(lambda: m({"x3d": x}), n=3, warm=1)
-        print(f"UNet3D kitti config2: {ms:.2f} ms/frame -> {1068.3/ms:.1f} TF/s ({1068.3/ms/157.3*100:.1f}% of fp32 MFMA peak)")
+        ms = time_many({"s": lambda: m({"x3d": x})}, rounds=3, iters=3)["s"]
+        print(f"UNet3D kitti config2: {ms:.2f} ms/frame -> {1068.3 / ms:.1f} TF/s "
+              f"({1068.3 / ms / 157.3 * 100:.1f}% of fp32 MFMA peak)")
         with hip.profile() as prof:
             m({"x3d": x})
-        for k, v in sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"]):
-            print(f"  {k:58s} n={v['launches']:3d} {v['ms']:7.3f} ms {v['flops']/1e9:8.2f} GF {v['flops']/max(v['ms'],1e-9)/1e9:7.1f} TF/s")
-    print("peak mem GB", torch.cuda.max_memory_allocated() / 2**30)
+        for k, v in sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:24]:
+            print(f"  {k:58s} n={v['launches']:3d} {v['ms']:7.3f} ms {v['flops'] / 1e9:8.2f} GF "
+                  f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    what = sys.argv[1:] or ["head", "aspp", "lift", "stack"]
+    for w in what:
+        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack}[w]()
