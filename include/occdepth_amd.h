@@ -182,6 +182,30 @@ int occd_softmax_channels(const float* src, float* dst, int64_t rows,
                           int32_t dst_coff, int32_t n, int32_t dst_pad, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * 2-D NCHW fused memory-bound helpers for the 2-D UNet (first step).
+ * act: 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 leaky relu with `slope`.
+ * ------------------------------------------------------------------------ */
+/* y = act(x * scale[c] + shift[c]) + res   (res_first = 0)
+ * y = act(x * scale[c] + shift[c] + res)   (res_first = 1)      x, res, y: (B, C, S); may alias.
+ * BatchNorm2d(eval) + Swish / LeakyReLU / ReLU (+ residual) of the EfficientNet blocks
+ * (third-party geffnet), unet2d.py:26-36 (conv+BN+LeakyReLU) and the DepthNet BasicBlocks
+ * (flosp_depth.py:211-222).                                                  */
+int occd_affine_act_nchw(const float* x, const float* res, float* y, const float* scale,
+                         const float* shift, int32_t batch, int32_t C, int64_t S, int32_t act,
+                         float slope, int32_t res_first, void* stream);
+/* depthwise k x k (k = 3 or 5) convolution, x (B, C, H, W), w (C, 1, k, k), explicit top/left
+ * zero padding (TensorFlow SAME), y (B, C, Ho, Wo) = act(conv * scale[c] + shift[c]).   */
+int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const float* shift,
+                       float* y, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
+                       int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
+                       int32_t act, void* stream);
+/* out (B, C + Cskip, H, W): [:, :C] = bilinear resize of x (B, C, h, w) with align_corners=True,
+ * [:, C:] = skip (B, Cskip, H, W)  -- F.interpolate + torch.cat of unet2d.py:38-46.          */
+int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* out, int32_t batch,
+                                    int32_t C, int32_t Cskip, int32_t h, int32_t w, int32_t H,
+                                    int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * In-library kernel timing (HIP events on the launch stream) used by bench.py
  * for `roofline.achieved`.  occd_prof_enable(1) starts recording one event pair
  * per launch; occd_prof_report() synchronises the recorded events and returns,

@@ -37,6 +37,17 @@ def _bn_affine(bn, cout, device):
     return scale, b - bn.running_mean.float() * scale
 
 
+def bn_affine_cached(bn):
+    """(scale, shift) of an eval-mode BatchNorm, cached on the module until its tensors change."""
+    key = _stamp(bn)
+    cached = getattr(bn, "_occd_affine", None)
+    if cached is None or cached[0] != key:
+        scale, shift = _bn_affine(bn, bn.num_features, bn.running_mean.device)
+        cached = (key, scale.contiguous(), shift.contiguous())
+        bn._occd_affine = cached
+    return cached[1], cached[2]
+
+
 def _pad_bias(bias, cout):
     out = torch.zeros(hip.round_up(cout, 32), device=bias.device, dtype=torch.float32)
     out[:cout] = bias

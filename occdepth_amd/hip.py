@@ -88,6 +88,10 @@ EXPORTS = {
     "occd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p]),
     "occd_softmax_channels": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                         c_int32, c_void_p]),
+    "occd_affine_act_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
+                                       c_int32, c_float, c_int32, c_void_p]),
+    "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
+    "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
@@ -347,6 +351,58 @@ def softmax_channels(src, dst, n, dst_pad=0):
     _check(load().occd_softmax_channels(_f32(src.buf, "src"), _f32(dst.buf, "dst"), rows, src.cs, src.coff, dst.cs,
                                         dst.coff, n, dst_pad, _stream()), "occd_softmax_channels")
     return dst
+
+
+# ----------------------------------------------------------------------------- 2-D NCHW helpers
+ACT2D = {None: 0, "none": 0, "relu": 1, "swish": 2, "leaky": 3}
+
+
+def affine_act(x, scale, shift, act=None, slope=0.01, res=None, res_first=False, out=None):
+    """y = act(x * scale[c] + shift[c]) (+ res) on (B, C, *spatial) float32; in place unless `out` is given."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    S = x.numel() // (B * C)
+    out = x if out is None else out
+    if res is not None and not res.is_contiguous():
+        res = res.contiguous()
+    _check(load().occd_affine_act_nchw(_f32(x, "x"), _f32(res, "res") if res is not None else None, _f32(out, "out"),
+                                       _f32(scale, "scale") if scale is not None else None,
+                                       _f32(shift, "shift") if shift is not None else None, B, C, S, ACT2D[act],
+                                       float(slope), 1 if res_first else 0, _stream()), "occd_affine_act_nchw")
+    return out
+
+
+def dwconv2d_same(x, w, scale, shift, stride, act=None):
+    """Depthwise conv with TensorFlow SAME padding + per-channel affine + activation, (B, C, H, W) float32."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, C, H, W = x.shape
+    k = w.shape[-1]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    pad_h = max((Ho - 1) * stride + k - H, 0)
+    pad_w = max((Wo - 1) * stride + k - W, 0)
+    y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    wc = w if w.is_contiguous() else w.contiguous()
+    _check(load().occd_dwconv2d_nchw(_f32(x, "x"), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
+                                     _f32(shift, "shift") if shift is not None else None, _f32(y, "y"), B, C, H, W, k,
+                                     stride, pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
+           "occd_dwconv2d_nchw")
+    return y
+
+
+def upsample_bilinear_cat(x, skip):
+    """cat([bilinear(x, skip's size, align_corners=True), skip], dim=1) in one pass."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if not skip.is_contiguous():
+        skip = skip.contiguous()
+    B, C, h, w = x.shape
+    Cs, H, W = skip.shape[1], skip.shape[2], skip.shape[3]
+    out = torch.empty((B, C + Cs, H, W), device=x.device, dtype=torch.float32)
+    _check(load().occd_upsample_bilinear_cat_nchw(_f32(x, "x"), _f32(skip, "skip"), _f32(out, "out"), B, C, Cs, h, w,
+                                                  H, W, _stream()), "occd_upsample_bilinear_cat_nchw")
+    return out
 
 
 class profile:

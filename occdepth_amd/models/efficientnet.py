@@ -14,6 +14,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip
+from ..fused import bn_affine_cached
+
+
+def _fast(x, module):
+    """eval-mode CUDA tensors take the fused HIP elementwise / depthwise kernels (occdepth_amd/csrc/nchw2d.hip)."""
+    return x.is_cuda and not module.training and x.dtype == torch.float32
+
 # (block type, repeats, kernel, stride, expand, channels) of EfficientNet-B0
 _B0_STAGES = (("ds", 1, 3, 1, 1, 16), ("ir", 2, 3, 2, 6, 24), ("ir", 2, 5, 2, 6, 40), ("ir", 3, 3, 2, 6, 80),
               ("ir", 3, 5, 1, 6, 112), ("ir", 4, 5, 2, 6, 192), ("ir", 1, 3, 1, 6, 320))
@@ -44,6 +52,8 @@ class Conv2dSame(nn.Conv2d):
 
 class Swish(nn.Module):
     def forward(self, x):
+        if _fast(x, self):
+            return hip.affine_act(x, None, None, "swish", out=torch.empty_like(x))
         return x * torch.sigmoid(x)
 
 
@@ -76,6 +86,10 @@ class DepthwiseSeparableConv(nn.Module):
         self.act2 = nn.Identity()
 
     def forward(self, x):
+        if _fast(x, self):
+            y = hip.dwconv2d_same(x, self.conv_dw.weight, *bn_affine_cached(self.bn1), self.conv_dw.stride[0], "swish")
+            y = F.conv2d(self.se(y), self.conv_pw.weight)
+            return hip.affine_act(y, *bn_affine_cached(self.bn2), None, res=x if self.skip else None)
         y = self.se(self.act1(self.bn1(self.conv_dw(x))))
         y = self.act2(self.bn2(self.conv_pw(y)))
         return y + x if self.skip else y
@@ -97,6 +111,11 @@ class InvertedResidual(nn.Module):
         self.bn3 = _bn(cout)
 
     def forward(self, x):
+        if _fast(x, self):
+            y = hip.affine_act(F.conv2d(x, self.conv_pw.weight), *bn_affine_cached(self.bn1), "swish")
+            y = hip.dwconv2d_same(y, self.conv_dw.weight, *bn_affine_cached(self.bn2), self.conv_dw.stride[0], "swish")
+            y = F.conv2d(self.se(y), self.conv_pwl.weight)
+            return hip.affine_act(y, *bn_affine_cached(self.bn3), None, res=x if self.skip else None)
         y = self.act1(self.bn1(self.conv_pw(x)))
         y = self.se(self.act2(self.bn2(self.conv_dw(y))))
         y = self.bn3(self.conv_pwl(y))

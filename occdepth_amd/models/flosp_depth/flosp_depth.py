@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import hip
+from ...fused import bn_affine_cached
 
 
 class BasicBlock(nn.Module):
@@ -28,6 +29,9 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
 
     def forward(self, x):
+        if x.is_cuda and not self.training and x.dtype == torch.float32:
+            y = hip.affine_act(self.conv1(x), *bn_affine_cached(self.bn1), "relu")
+            return hip.affine_act(self.conv2(y), *bn_affine_cached(self.bn2), "relu", res=x, res_first=True)
         out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
         return F.relu(out + x)
 

@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip
+from ..fused import bn_affine_cached
 from .efficientnet import EfficientNet
 
 MODEL_NAME = "tf_efficientnet_b3_ns"
@@ -39,6 +41,12 @@ class UpSampleBN(nn.Module):
         self._net = nn.Sequential(*layers)
 
     def forward(self, x, concat_with):
+        if x.is_cuda and not self.training and x.dtype == torch.float32:
+            # eval: bilinear-up + concat in one HIP pass, BatchNorm + LeakyReLU fused behind each MIOpen conv
+            f = hip.upsample_bilinear_cat(x, concat_with)
+            n = self._net
+            f = hip.affine_act(n[0](f), *bn_affine_cached(n[1]), "leaky", slope=n[2].negative_slope)
+            return hip.affine_act(n[3](f), *bn_affine_cached(n[4]), "leaky", slope=n[5].negative_slope)
         up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
         return self._net(torch.cat([up, concat_with], dim=1))
 

@@ -300,6 +300,62 @@ def test_flosp_depth_hip_vs_aten(hip, n_cams):
     assert (vox - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-7
 
 
+@pytest.mark.parametrize("act", [None, "relu", "swish", "leaky"])
+def test_affine_act_nchw(hip, act):
+    torch.manual_seed(7)
+    x = torch.randn(2, 19, 13, 21, device=DEV)
+    r = torch.randn_like(x)
+    s, t = torch.rand(19, device=DEV) + 0.5, torch.randn(19, device=DEV)
+    fn = {None: lambda v: v, "relu": F.relu, "swish": lambda v: v * torch.sigmoid(v),
+          "leaky": lambda v: F.leaky_relu(v, 0.01)}[act]
+    aff = x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+    assert rel_err(hip.affine_act(x.clone(), s, t, act), fn(aff)) < 1e-6
+    assert rel_err(hip.affine_act(x.clone(), s, t, act, res=r), fn(aff) + r) < 1e-6
+    assert rel_err(hip.affine_act(x.clone(), s, t, act, res=r, res_first=True), fn(aff + r)) < 1e-6
+    x4 = torch.randn(1, 8, 16, 16, device=DEV)                      # float4 path
+    assert rel_err(hip.affine_act(x4.clone(), None, None, act), fn(x4)) < 1e-6
+
+
+@pytest.mark.parametrize("k,stride,hw", [(3, 1, (37, 61)), (3, 2, (37, 61)), (5, 1, (24, 40)), (5, 2, (47, 153))])
+def test_dwconv2d_same(hip, k, stride, hw):
+    from occdepth_amd.models.efficientnet import Conv2dSame
+    torch.manual_seed(k + stride)
+    C = 24
+    conv = Conv2dSame(C, C, k, stride=stride, groups=C, bias=False).to(DEV)
+    x = torch.randn(2, C, *hw, device=DEV)
+    s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    with torch.no_grad():
+        ref = conv(x) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+        ref = ref * torch.sigmoid(ref)
+        got = hip.dwconv2d_same(x, conv.weight, s, t, stride, "swish")
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-5
+
+
+def test_upsample_bilinear_cat(hip):
+    torch.manual_seed(9)
+    x = torch.randn(2, 7, 12, 39, device=DEV)
+    skip = torch.randn(2, 5, 24, 77, device=DEV)
+    ref = torch.cat([F.interpolate(x, size=(24, 77), mode="bilinear", align_corners=True), skip], 1)
+    got = hip.upsample_bilinear_cat(x, skip)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-6
+
+
+def test_unet2d_fused_eval_matches_plain_torch(hip):
+    """The eval fast path of the 2-D UNet (fused BN+act, depthwise, upsample+cat kernels) against the
+    same module run through plain torch ops (forced by module.training=True with BatchNorm in eval)."""
+    from occdepth_amd.models.unet2d import UNet2D
+    torch.manual_seed(11)
+    m = UNet2D.build(out_feature=16, use_decoder=True, backbone_2d_name="tf_efficientnet_b3_ns", return_up_feats=1)
+    m = randomize_bn(m).to(DEV).eval()
+    x = torch.randn(1, 3, 74, 122, device=DEV)
+    with torch.no_grad():
+        got = m(x)
+    ref = aten_reference(m, x)
+    compare(got, ref, 2e-4, "unet2d")
+
+
 def test_layout_roundtrip(hip):
     x = torch.randn(2, 37, 5, 7, 9, device=DEV)
     v = hip.Vox.from_ncdhw(x)
