@@ -181,6 +181,15 @@ int occd_softmax_channels(const float* src, float* dst, int64_t rows,
                           int32_t src_cs, int32_t src_coff, int32_t dst_cs,
                           int32_t dst_coff, int32_t n, int32_t dst_pad, void* stream);
 
+/* Cascade-head tail (occdepth/models/modules.py:166-173, after splitting conv_classes by linearity):
+ *   out[v][o] = part[v][o] + sum_{tap<27, c<2} softmax(part[v+tap][occ_off : occ_off+2])[c] * wn[o][c][tap]
+ * part: (B, X, Y, Z, part_cs) rows with the wide-half class logits at [0, nbr) and the 2 occupancy logits at
+ * occ_off; wn: (nbr, 2, 3, 3, 3) = conv_classes.weight[:, planes:]; out: (B, X, Y, Z, out_cs); zero padding
+ * applies to the softmax output.  VALU kernel (K = 54 is too thin for MFMA).                        */
+int occd_cascade_tail_fwd(const float* part, const float* wn, float* out, int32_t batch, int32_t X,
+                          int32_t Y, int32_t Z, int32_t part_cs, int32_t occ_off, int32_t out_cs,
+                          int32_t nbr, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * 2-D NCHW fused memory-bound helpers for the 2-D UNet (first step).
  * act: 0 none, 1 relu, 2 swish (x * sigmoid(x)), 3 leaky relu with `slope`.

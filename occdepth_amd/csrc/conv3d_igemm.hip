@@ -55,16 +55,21 @@ __device__ __forceinline__ f32x4 apply_act(f32x4 v, int act) {
     return v;
 }
 
-template <int MT, int NT, int WM, int WN, int CK>
-__global__ void __launch_bounds__(WM* WN * 64) conv3d_igemm_kernel(const ConvP p) {
-    constexpr int NTH = WM * WN * 64;
-    constexpr int RS4 = CK / 4 + 1;  // LDS row stride in float4: odd number of 16-B slots
+// KS > 1: in-workgroup split-K.  The KS wave groups take interleaved cin chunks (each with its own LDS slab),
+// and their accumulators are summed through LDS before the epilogue.  It multiplies the waves per SIMD for
+// layers with few output tiles and a long K (the 32x32x4 ASPP / CRP level: 4096 voxels, K = 27 x 256).
+template <int MT, int NT, int WM, int WN, int CK, int KS = 1>
+__global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const ConvP p) {
+    constexpr int NTH = WM * WN * 64;  // threads of one K group
+    constexpr int RS4 = CK / 4 + 1;    // LDS row stride in float4: odd number of 16-B slots
     constexpr int C4 = CK / 4;
-    extern __shared__ __attribute__((aligned(16))) f32x4 slab4[];
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds_all[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = wave_all / (WM * WN);          // K group of this wave
+    const int wave = wave_all - kg * (WM * WN);
+    const int tid = threadIdx.x - kg * NTH;       // thread index inside the K group
     const int wm = wave / WN;
     const int wn = wave - wm * WN;
     const int li = lane & 31;
@@ -118,6 +123,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_igemm_kernel(const ConvP p
     const float* const wlane = p.wpk + lane * 4;
     const int rows = p.YIN * p.ZIN;
     const int F = rows * C4;
+    f32x4* const slab4 = lds_all + (size_t)kg * rows * RS4;   // this K group's slab
+    const int n_chunks = (p.cin8 + CK - 1) / CK;
+    const int chunk_iters = (n_chunks + KS - 1) / KS;
 
 #define OCCD_MFMA_BLOCK()                                                                              \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)   \
@@ -129,19 +137,22 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_igemm_kernel(const ConvP p
         if (xi < 0 || xi >= p.X) continue;  // workgroup-uniform
         const float* const in_plane =
             p.in + ((size_t)(b * p.X + xi) * p.Y) * p.Z * p.in_cs + p.in_coff;
-        for (int c0 = 0; c0 < p.cin8; c0 += CK) {
-            const int ck = min(CK, p.cin8 - c0);
+        for (int ci = 0; ci < chunk_iters; ++ci) {
+            const int c0 = (ci * KS + kg) * CK;
+            const bool active = c0 < p.cin8;      // uniform per K group; every group still joins the barriers
+            const int ck = active ? min(CK, p.cin8 - c0) : 8;
             const int ktn = ck >> 3;
-            const int S = p.KY * p.KZ * ktn;
+            const int S = active ? p.KY * p.KZ * ktn : 0;
             const float* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.KTtot + (c0 >> 3)) * w_step;
 
             // first B fragments fly while the slab is staged
             f32x4 b_cur[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b_cur[nt] = *(const f32x4*)(wp + wofs[nt]);
+            for (int nt = 0; nt < NT; ++nt)
+                b_cur[nt] = active ? *(const f32x4*)(wp + wofs[nt]) : f32x4{0.f, 0.f, 0.f, 0.f};
 
             __syncthreads();  // previous slab fully consumed
-            for (int f0 = 0; f0 < F; f0 += NTH * 4) {
+            for (int f0 = 0; active && f0 < F; f0 += NTH * 4) {
                 f32x4 v[4];
                 int dst[4];
                 bool okv[4];
@@ -196,10 +207,36 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_igemm_kernel(const ConvP p
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
             }
-            OCCD_MFMA_BLOCK();
+            if (active) { OCCD_MFMA_BLOCK(); }
         }
     }
 #undef OCCD_MFMA_BLOCK
+
+    if (KS > 1) {
+        // sum the K groups' accumulators through LDS (slabs are dead after the barrier), group 0 stores
+        float* red = reinterpret_cast<float*>(lds_all);
+        __syncthreads();
+        if (kg > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((kg - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mt][nt][r] += red[((((g - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane];
+    }
 
     // ---------------- epilogue: bias + residuals + activation, channels-last store
     float bias_v[NT];
@@ -260,12 +297,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
 }
 
 struct Variant {
-    int MT, NT, WM, WN, CK;
+    int MT, NT, WM, WN, CK, KS;
     void (*kern)(const ConvP);
 };
 
 #define OCCD_VARIANT(MT, NT, WM, WN, CK) \
-    Variant { MT, NT, WM, WN, CK, conv3d_igemm_kernel<MT, NT, WM, WN, CK> }
+    Variant { MT, NT, WM, WN, CK, 1, conv3d_igemm_kernel<MT, NT, WM, WN, CK, 1> }
+#define OCCD_VARIANT_KS(MT, NT, WM, WN, CK, KS) \
+    Variant { MT, NT, WM, WN, CK, KS, conv3d_igemm_kernel<MT, NT, WM, WN, CK, KS> }
 
 const Variant kVariants[] = {
     OCCD_VARIANT(2, 1, 4, 1, 32),  // 0: M256 x N32   (head, bottleneck mids)
@@ -275,10 +314,12 @@ const Variant kVariants[] = {
     OCCD_VARIANT(1, 1, 4, 1, 32),  // 4: M128 x N32
     OCCD_VARIANT(1, 1, 2, 2, 32),  // 5: M64  x N64
     OCCD_VARIANT(1, 1, 1, 4, 32),  // 6: M32  x N128
+    OCCD_VARIANT_KS(1, 1, 1, 4, 32, 4),  // 7: M32 x N128, 4-way in-workgroup split-K (16 waves)
+    OCCD_VARIANT_KS(1, 1, 2, 2, 32, 2),  // 8: M64 x N64, 2-way split-K (8 waves)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr size_t kMaxLds = 160 * 1024;
-bool g_attr_set[kNumVariants] = {};
+bool g_attr_set[16] = {};
 
 struct Tiling {
     int TY, TZ, YIN, ZIN, ytiles, ztiles, ngroups;
@@ -300,7 +341,9 @@ bool plan(const occd_conv3d_args* a, const Variant& v, int NTtot, Tiling* t) {
     t->ZIN = (t->TZ - 1) * a->sz + (a->kz - 1) * a->dz + 1;
     t->ytiles = (a->Yo + t->TY - 1) / t->TY;
     t->ztiles = (a->Zo + t->TZ - 1) / t->TZ;
-    t->lds = (size_t)t->YIN * t->ZIN * (v.CK + 4) * sizeof(float);
+    t->lds = (size_t)t->YIN * t->ZIN * (v.CK + 4) * sizeof(float) * v.KS;
+    const size_t red = (size_t)(v.KS - 1) * v.WM * v.WN * v.MT * v.NT * 4096;   // split-K reduction scratch
+    if (red > t->lds) t->lds = red;
     const int nwg_n = v.NT * v.WN;
     t->ngroups = (NTtot + nwg_n - 1) / nwg_n;
     t->nwg = (long)a->Xo * t->ytiles * t->ztiles;
@@ -378,6 +421,19 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
         if (t.nwg * t.ngroups * a->batch >= 512) break;  // else keep refining to the finest fit
     }
     if (pick < 0) return OCCD_ENOMEM;
+    if (a->tile_hint == 0 && til.nwg * til.ngroups * a->batch <= 320 && cin8 >= 128) {
+        // too few output tiles to fill 1024 SIMDs with one wave each: multiply the waves by splitting K
+        for (int cand : {7, 8}) {
+            Tiling t{};
+            const int nwn = kVariants[cand].NT * kVariants[cand].WN;
+            if (NTtot % nwn != 0 && NTtot > nwn) continue;
+            if (!plan(a, kVariants[cand], NTtot, &t)) continue;
+            if (t.nwg * t.ngroups * a->batch > 1024) continue;
+            pick = cand;
+            til = t;
+            break;
+        }
+    }
     const Variant& v = kVariants[pick];
 
     ConvP p;
@@ -411,6 +467,6 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
                                 taps * a->cin * a->cout);
     occd::ProfScope prof("conv3d_igemm", (hipStream_t)stream, flops, bytes);
     hipLaunchKernelGGL(v.kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
-                       dim3(v.WM * v.WN * 64), til.lds, (hipStream_t)stream, p);
+                       dim3(v.WM * v.WN * v.KS * 64), til.lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }

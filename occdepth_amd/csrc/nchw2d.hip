@@ -160,3 +160,105 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
                        rh, rw);
     return occd::check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cascade-head tail (occdepth/models/modules.py:166-173): the narrow half of `conv_classes`,
+//   ssc[v][o] = part[v][o] + sum_{tap, c<2} softmax(occ[v + tap])[c] * Wn[o][c][tap],
+// where `part` already holds conv_classes[:, :planes](feat) + bias (wide half, MFMA kernel) and the occ
+// logits.  K = 27 * 2 is far too thin for the matrix pipe (an N=32 x K=8 MFMA tile wastes 94 %), so this is
+// a VALU kernel: one thread per voxel, the 54 x nbr weights broadcast from LDS, the 2-way softmax of each
+// neighbour recomputed on the fly (no softmax / concat buffer exists).
+namespace {
+
+constexpr int kTailMaxOut = 32;
+
+template <int NG>   // NG float4 groups of outputs per voxel (ceil(nbr / 4))
+__global__ void __launch_bounds__(256) cascade_tail_kernel(const float* __restrict__ part, const float* __restrict__ wn,
+                                                           float* __restrict__ out, int B, int X, int Y, int Z,
+                                                           int part_cs, int occ_off, int out_cs, int nbr) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * 2 * NG * 4];   // [tap][c][o]
+    for (int i = threadIdx.x; i < 27 * 2 * NG * 4; i += 256) {
+        const int o = i % (NG * 4), c = (i / (NG * 4)) & 1, tap = i / (2 * NG * 4);
+        wl[i] = o < nbr ? wn[((size_t)o * 2 + c) * 27 + tap] : 0.f;
+    }
+    __syncthreads();
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * X * Y * Z;
+    if (n >= total) return;
+    const int z = (int)(n % Z);
+    long t = n / Z;
+    const int y = (int)(t % Y);
+    t /= Y;
+    const int x = (int)(t % X);
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* occ = part + (size_t)n * part_cs + occ_off;
+#pragma unroll 1
+    for (int dx = -1; dx <= 1; ++dx) {
+        if ((unsigned)(x + dx) >= (unsigned)X) continue;
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; ++dy) {
+            if ((unsigned)(y + dy) >= (unsigned)Y) continue;
+            // the three z-neighbours of one (dx, dy) are adjacent rows: issue their loads together
+            float l0[3], l1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int zz = z + k - 1;
+                const bool ok = (unsigned)zz < (unsigned)Z;
+                const float* l = occ + (((long)dx * Y + dy) * Z + (ok ? k - 1 : 0)) * part_cs;
+                l0[k] = ok ? l[0] : 0.f;
+                l1[k] = ok ? l[1] : 0.f;
+            }
+            const int tap0 = ((dx + 1) * 3 + (dy + 1)) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if ((unsigned)(z + k - 1) >= (unsigned)Z) continue;
+                const float m = fmaxf(l0[k], l1[k]);
+                const float e0 = expf(l0[k] - m), e1 = expf(l1[k] - m);
+                const float s0 = e0 / (e0 + e1), s1 = e1 / (e0 + e1);
+                const f32x4* w0 = (const f32x4*)(wl + ((tap0 + k) * 2 + 0) * NG * 4);
+                const f32x4* w1 = (const f32x4*)(wl + ((tap0 + k) * 2 + 1) * NG * 4);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] += s0 * w0[g] + s1 * w1[g];
+            }
+        }
+    }
+    const float* pr = part + (size_t)n * part_cs;
+    float* po = out + (size_t)n * out_cs;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 v = acc[g] + *(const f32x4*)(pr + g * 4);
+        if (g * 4 + 3 < nbr) {
+            *(f32x4*)(po + g * 4) = v;
+        } else {
+            if (g * 4 + 0 < nbr) po[g * 4 + 0] = v.x;
+            if (g * 4 + 1 < nbr) po[g * 4 + 1] = v.y;
+            if (g * 4 + 2 < nbr) po[g * 4 + 2] = v.z;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int occd_cascade_tail_fwd(const float* part, const float* wn, float* out, int32_t batch, int32_t X,
+                                     int32_t Y, int32_t Z, int32_t part_cs, int32_t occ_off, int32_t out_cs,
+                                     int32_t nbr, void* stream) {
+    if (!part || !wn || !out || batch <= 0 || X <= 0 || Y <= 0 || Z <= 0) return OCCD_EINVAL;
+    if (nbr <= 0 || nbr > kTailMaxOut || (part_cs & 3) || (out_cs & 3) || (occ_off & 1) || occ_off + 2 > part_cs ||
+        ((nbr + 3) & ~3) > part_cs || nbr > out_cs)
+        return OCCD_EINVAL;
+    const long total = (long)batch * X * Y * Z;
+    occd::ProfScope prof("cascade_tail", (hipStream_t)stream, 2.0 * total * 54 * nbr, 4.0 * total * (2.0 * nbr + 2));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const int ng = (nbr + 3) >> 2;
+    hipStream_t st = (hipStream_t)stream;
+#define OCCD_TAIL(NG)                                                                                        \
+    hipLaunchKernelGGL(cascade_tail_kernel<NG>, grid, dim3(256), 0, st, part, wn, out, batch, X, Y, Z, part_cs, \
+                       occ_off, out_cs, nbr)
+    if (ng <= 3) OCCD_TAIL(3);
+    else if (ng <= 5) OCCD_TAIL(5);
+    else OCCD_TAIL(8);
+#undef OCCD_TAIL
+    return occd::check_launch();
+}

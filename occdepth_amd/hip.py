@@ -92,6 +92,7 @@ EXPORTS = {
                                        c_int32, c_float, c_int32, c_void_p]),
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_cascade_tail_fwd": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
@@ -402,6 +403,16 @@ def upsample_bilinear_cat(x, skip):
     out = torch.empty((B, C + Cs, H, W), device=x.device, dtype=torch.float32)
     _check(load().occd_upsample_bilinear_cat_nchw(_f32(x, "x"), _f32(skip, "skip"), _f32(out, "out"), B, C, Cs, h, w,
                                                   H, W, _stream()), "occd_upsample_bilinear_cat_nchw")
+    return out
+
+
+def cascade_tail(part, occ_off, wn, nbr):
+    """ssc = part[..., :nbr] + conv3x3x3(softmax(part[..., occ_off:occ_off+2]), wn); returns a Vox with cs = ceil4(nbr)."""
+    out = Vox.empty(part.batch, part.dims, nbr, part.buf.device, cs=round_up(nbr, 4))
+    X, Y, Z = part.dims
+    wc = wn.detach().float().contiguous()
+    _check(load().occd_cascade_tail_fwd(_f32(part.buf, "part"), _f32(wc, "wn"), _f32(out.buf, "out"), part.batch, X, Y,
+                                        Z, part.cs, occ_off, out.cs, nbr, _stream()), "occd_cascade_tail_fwd")
     return out
 
 

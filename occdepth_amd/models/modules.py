@@ -126,7 +126,6 @@ class SegmentationHeadCascadeCLS(_HeadBase):
         p, cls, occ = self.planes, self.conv_classes, self.occ_classes
         plans["wide"] = DerivedConvPlan(
             [cls, occ], lambda: (torch.cat([cls.weight[:, :p], occ.weight], 0), torch.cat([cls.bias, occ.bias], 0)))
-        plans["narrow"] = DerivedConvPlan([cls], lambda: (cls.weight[:, p:], None))
 
     def forward_vox(self, x):
         """returns (ssc_logit Vox, occ_logit Vox)."""
@@ -134,9 +133,8 @@ class SegmentationHeadCascadeCLS(_HeadBase):
         nbr = self.conv_classes.out_channels
         part = self._plans["wide"](feat)                # [0, nbr): partial class logits, [nbr, nbr+2): occ logits
         occ = Vox(part.buf, 2, nbr)
-        soft = Vox.empty(x.batch, x.dims, 2, x.buf.device)
-        hip.softmax_channels(occ, soft, 2, dst_pad=soft.cs - 2)
-        ssc = self._plans["narrow"](soft, res1=Vox(part.buf, nbr, 0), out_cs=hip.round_up(nbr, 4))
+        # narrow half (K = 2 x 27) + softmax + concat: one VALU kernel, no softmax / concat buffer
+        ssc = hip.cascade_tail(part, nbr, self.conv_classes.weight[:, self.planes:], nbr)
         return ssc, occ
 
     def forward(self, x_in):

@@ -150,14 +150,23 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     return out
 
 
+def cascade_tail(part, occ_off, wn, nbr):
+    soft = F.softmax(part.buf[..., occ_off:occ_off + 2], dim=-1).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(soft, wn.detach().float(), None, padding=1).permute(0, 2, 3, 4, 1) + part.buf[..., :nbr]
+    out = Vox(torch.zeros(part.buf.shape[:-1] + (round_up(nbr, 4),)), nbr)
+    out.buf[..., :nbr] = y
+    return out
+
+
 @contextlib.contextmanager
 def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
-                                          "flosp_sample", "lift")}
+                                          "flosp_sample", "lift", "cascade_tail")}
     saved_from = Vox.from_ncdhw
     saved_as_vox = fused.as_vox
     hip.pack_weights, hip.conv3d, hip.nchw_to_nhwc = pack_weights, conv3d, nchw_to_nhwc
     hip.softmax_channels, hip.flosp_sample, hip.lift = softmax_channels, flosp_sample, lift
+    hip.cascade_tail = cascade_tail
     Vox.from_ncdhw = staticmethod(vox_from_ncdhw)
 
     def as_vox_cpu(x):

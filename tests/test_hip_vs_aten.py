@@ -136,7 +136,7 @@ def test_conv3d_persistent_head_kernel(hip, case):
     assert rel_err(out3.ncdhw(), out.ncdhw()) < 1e-5
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv3d_all_variants(hip, hint):
     torch.manual_seed(hint)
     B, cin, cout, dims = 1, 40, 136, (5, 7, 12)

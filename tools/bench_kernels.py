@@ -98,8 +98,29 @@ def bench_stack():
                   f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:7.1f} TF/s")
 
 
+def bench_dec2d():
+    """2-D decoder 3x3 convolutions as (1, 3, 3) kernels over (X=1, Y=H, Z=W) channels-last volumes."""
+    shapes = [((370, 1220), 163, 80), ((370, 1220), 80, 80), ((185, 610), 352, 160), ((93, 305), 688, 320),
+              ((47, 153), 1360, 640), ((24, 77), 2784, 1280), ((24, 77), 1280, 1280)]
+    for (H, W), cin, cout in shapes:
+        dims = (1, H, W)
+        cs = hip.round_up(cin, 8)
+        buf = torch.zeros(2, *dims, cs, device="cuda")
+        buf[..., :cin] = torch.randn(2, *dims, cin, device="cuda")
+        x = hip.Vox(buf, cin)
+        w = torch.randn(cout, cin, 1, 3, 3, device="cuda") * 0.02
+        wpk = hip.pack_weights(w)
+        out = hip.Vox.empty(2, dims, cout, "cuda")
+        fns = {h: (lambda h=h: hip.conv3d(x, wpk, None, cout, (1, 3, 3), out, padding=(0, 1, 1), tile_hint=h))
+               for h in (0, 2, 3)}
+        ms = time_many(fns, rounds=3, iters=4)
+        fl = 2.0 * 2 * H * W * 9 * cin * cout
+        for h, t in ms.items():
+            print(f"dec2d {cin}->{cout} @{H}x{W} B=2 hint={h}: {t:.3f} ms {fl / t / 1e9:6.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     what = sys.argv[1:] or ["head", "aspp", "lift", "stack"]
     for w in what:
-        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack}[w]()
+        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack, "dec2d": bench_dec2d}[w]()
