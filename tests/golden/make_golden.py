@@ -205,27 +205,36 @@ def case_occdepth_small():
         json.dump(keys, f, indent=0, sort_keys=True)
 
 
-def case_occdepth_full():
-    """BASELINE config 2 (B7, 370x1220 stereo, 256x256x32): one reference frame, sub-sampled outputs."""
-    t0 = time.time()
+def _full_case(cfg_name, what):
     arrays = {}
-    m, cfg, batch = _build_ref_occdepth("kitti_a100", arrays)
+    m, cfg, batch = _build_ref_occdepth(cfg_name, arrays)
     t0 = time.time()
     with torch.no_grad():
         out = m(batch)
-    print("reference config-2 forward: %.1f s" % (time.time() - t0))
+    print("reference %s forward: %.1f s" % (what, time.time() - t0))
     for k, v in _flat(out).items():
         arrays[k] = gc.subsample(torch.from_numpy(v)).numpy()
         arrays[k + ".absmax"] = np.float32(np.abs(v).max())
         arrays[k + ".sum"] = np.float64(v.astype(np.float64).sum())
-    _save("occdepth_kitti_a100", arrays, meta={"subsample": "tests/golden_cases.py:subsample"})
+    _save("occdepth_" + cfg_name, arrays, meta={"subsample": "tests/golden_cases.py:subsample"})
     keys = {k: list(v.shape) for k, v in m.state_dict().items()}
-    with open(os.path.join(HERE, "state_keys_kitti_a100.json"), "w") as f:
+    with open(os.path.join(HERE, "state_keys_%s.json" % cfg_name), "w") as f:
         json.dump(keys, f, indent=0, sort_keys=True)
 
 
+def case_occdepth_full():
+    """BASELINE config 2 (B7, 370x1220 stereo, 256x256x32): one reference frame, sub-sampled outputs."""
+    _full_case("kitti_a100", "config-2")
+
+
+def case_occdepth_nyu():
+    """BASELINE config 1 (NYUv2 RGB-D frame, B4, feature 100, 60x36x60, virtual stereo), full size."""
+    _full_case("nyu_2080ti", "config-1 (NYU)")
+
+
 CASES = {"sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "flosp": case_flosp,
-         "decoder2d": case_decoder2d, "occdepth_small": case_occdepth_small, "occdepth_full": case_occdepth_full}
+         "decoder2d": case_decoder2d, "occdepth_small": case_occdepth_small, "occdepth_full": case_occdepth_full,
+         "occdepth_nyu": case_occdepth_nyu}
 
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())

@@ -91,6 +91,8 @@ def occdepth_config(name):
     keep every structural switch of the shipped yaml they derive from."""
     if name == "kitti_a100":
         return configs.kitti_a100.clone(), None
+    if name == "nyu_2080ti":                      # BASELINE configs[0]: the reference's CPU-runnable NYUv2 case
+        return configs.nyu_2080ti.clone(), None
     if name == "kitti_small":
         cfg = configs.kitti_a100.clone(full_scene_size=(64, 64, 16), feature=16, feature_2d_oc=16,
                                        backbone_2d_name="tf_efficientnet_b3_ns")
@@ -115,6 +117,8 @@ def occdepth_batch(name):
     if name in ("kitti_small", "kitti_flosp_small"):
         b = inputs.kitti_batch(img_hw=(96, 320), scene=(64, 64, 16), project_scale=2, seed=SEED, scale_k=320 / 1220)
         return b
+    if name == "nyu_2080ti":
+        return inputs.nyu_batch(seed=SEED)
     if name == "nyu_small":
         return inputs.nyu_batch(img_hw=(120, 160), scene=(20, 12, 20), seed=SEED, scale_k=0.25)
     raise KeyError(name)

@@ -205,7 +205,8 @@ def build_product(cfg_name):
     finally:
         fpkg.flosp_depth_conf_map[cfg.dataset].clear()
         fpkg.flosp_depth_conf_map[cfg.dataset].update(pristine)
-    sd = sd_for(m, "occdepth_kitti_a100" if cfg_name == "kitti_a100" else "occdepth_small", cfg_name)
+    full = cfg_name in ("kitti_a100", "nyu_2080ti")
+    sd = sd_for(m, "occdepth_" + cfg_name if full else "occdepth_small", cfg_name)
     m.load_state_dict(sd, strict=True)
     return m.eval(), cfg, sd
 
@@ -233,6 +234,22 @@ def test_state_dict_keys_match_reference_config2():
     mine = {k: list(v.shape) for k, v in m.state_dict().items()}
     assert mine == ref
     assert len([k for k in mine if not k.startswith("net_rgb.encoder")]) == 692
+
+
+def test_nyu_config1_oracle_vs_reference():
+    """BASELINE configs[0] at FULL size (NYUv2 480x640 RGB-D frame, B4, feature 100, 60x36x60, virtual stereo
+    view): the oracle reproduces the real reference's sub-sampled outputs; state_dict keys identical."""
+    m, cfg, sd = build_product("nyu_2080ti")
+    with open(os.path.join(GOLD, "state_keys_nyu_2080ti.json")) as f:
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == json.load(f)
+    g = gold("occdepth_nyu_2080ti")
+    with torch.no_grad():
+        out = orc.occdepth_forward(sd, oracle_cfg(m, cfg), gc.occdepth_batch("nyu_2080ti"),
+                                   m.net_rgb.encoder.original_model)
+    assert set(out) == {"x3d_l1", "x3d_l2", "x3d_l3", "ssc_logit"}
+    assert out["ssc_logit"].shape == (1, 12, 60, 36, 60)
+    for k, v in out.items():
+        close(gc.subsample(v), g[k], tol=5e-6, what=k)
 
 
 @pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])

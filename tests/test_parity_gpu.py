@@ -234,6 +234,56 @@ def test_config2_properties(config2):
     assert e < 1e-3, e
 
 
+def test_nyu_config1_vs_reference_golden():
+    """BASELINE configs[0] at full size on the GPU: NYUv2 RGB-D frame + virtual stereo view, B4, feature 100
+    (channel pads 100 -> 104, 25 -> 32), odd volume sizes 60x36x60 -> 15x9x15."""
+    m, cfg, sd = build_product("nyu_2080ti")
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(to_dev(gc.occdepth_batch("nyu_2080ti")))
+    g = gold("occdepth_nyu_2080ti")
+    assert out["ssc_logit"].shape == (1, 12, 60, 36, 60)
+    errs = {}
+    for k, v in out.items():
+        ref = torch.from_numpy(g[k])
+        got = gc.subsample(v.cpu().contiguous())
+        assert got.shape == ref.shape, k
+        errs[k] = ((got - ref).abs().max() / ref.abs().max()).item()
+    print("config-1 (NYU) relative errors vs reference:", {k: f"{e:.2e}" for k, e in errs.items()})
+    assert errs["ssc_logit"] < 1e-3, errs
+    assert max(errs.values()) < 5e-3, errs
+
+
+def test_config5_synthetic_512_grid():
+    """BASELINE configs[4]: UNet3D(kitti) alone on a 512x512x64 grid (lift volume 256x256x32, feature 64; CRP
+    with N = 32768 voxels / M = 4096 mega voxels, P_logits 2.1 GB).  No reference output exists at this size
+    (9.3 TFLOP); checked through size-independent properties: shapes, finiteness, determinism, and one
+    full-resolution head convolution (Z = 64, generic kernel) against ATen."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from occdepth_amd import hip
+    from occdepth_amd.models.unet3d_kitti import UNet3D
+    torch.manual_seed(0)
+    m = UNet3D(20, nn.BatchNorm3d, (512, 512, 64), 64, 2, context_prior=True, cascade_cls=True).to(DEV).eval()
+    x = hip.Vox(torch.randn(1, 256, 256, 32, 64, device=DEV), 64)
+    with torch.no_grad():
+        out = m({"x3d": x})
+        assert out["ssc_logit"].shape == (1, 20, 512, 512, 64) and out["P_logits"].shape == (1, 4, 4096, 32768)
+        assert torch.isfinite(out["ssc_logit"]).all()
+        first = out["ssc_logit"][0, :, ::37, ::41, ::7].clone()
+        del out
+        again = m({"x3d": x})["ssc_logit"][0, :, ::37, ::41, ::7]
+        assert torch.equal(first, again)
+        # one head convolution at this resolution vs ATen
+        conv = m.ssc_head.conv1[1]
+        xin = torch.randn(1, 32, 48, 512, 64, device=DEV)
+        ref = F.conv3d(xin, conv.weight, None, padding=2, dilation=2)
+        o = hip.Vox.empty(1, (48, 512, 64), 32, DEV)
+        hip.conv3d(hip.Vox.from_ncdhw(xin), hip.pack_weights(conv.weight), None, 32, (3, 3, 3), o,
+                   dilation=(2, 2, 2), padding=(2, 2, 2))
+        assert ((o.ncdhw() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+
+
 def test_lift_properties_full_size():
     """K1b at config-2 size: linearity in the features, zero rows for voxels outside both FOVs."""
     from occdepth_amd.models.SFA import lift_scales
