@@ -163,6 +163,15 @@ typedef struct occd_lift_args {
 
 int occd_lift_fwd(const occd_lift_args* a, void* stream);
 
+/* voxel centroid -> pixel projection on the GPU instead of the dataloader's numba
+ * `vox2pix` (occdepth/data/utils/helpers.py:94-169, fusion.py:203-217,336-337,518-522), pattern_id 0.
+ * cam_E (4x4 row-major), cam_k (3x3), vox_origin (3) are small HOST arrays of doubles; outputs are device
+ * tensors shaped like the batch entries `projected_pix_{s}` (N, 1, 2) int64 and `fov_mask_{s}` (N, 1) bool,
+ * N = X*Y*Z voxels in (x, y, z) order; pix_z (N) float32 is optional.                              */
+int occd_project_voxels(const double* cam_E_host, const double* cam_k_host, const double* vox_origin_host,
+                        double voxel_size, int32_t X, int32_t Y, int32_t Z, int32_t img_w, int32_t img_h,
+                        int64_t* pix, uint8_t* fov, float* pix_z, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Layout / small fused helpers around the two big kernels.
  * ------------------------------------------------------------------------ */
@@ -213,6 +222,12 @@ int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const
 int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* out, int32_t batch,
                                     int32_t C, int32_t Cskip, int32_t h, int32_t w, int32_t H,
                                     int32_t W, void* stream);
+
+/* SURVEY 8(f) row N4 (first step): out[row] = lut[argmax_c x[row][coff + c]] (first maximum wins; lut may
+ * be NULL) as uint16 -- replaces the host softmax + numpy argmax of scripts/generate_output.py:94-95 and the
+ * learning_map_inv lookup of scripts/generate_kitti_submission.py:74-85.                               */
+int occd_argmax_channels(const float* x, int64_t rows, int32_t cs, int32_t coff, int32_t C,
+                         const uint16_t* lut, uint16_t* out, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * In-library kernel timing (HIP events on the launch stream) used by bench.py

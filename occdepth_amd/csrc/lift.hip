@@ -431,3 +431,82 @@ extern "C" int occd_softmax_channels(const float* src, float* dst, int64_t rows,
                        (hipStream_t)stream, src, dst, (long)rows, src_cs, src_coff, dst_cs, dst_coff, n, dst_pad);
     return occd::check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// voxel-centroid -> pixel projection on the GPU (the dataloader's numba `vox2pix`):
+// occdepth/data/utils/helpers.py:94-169 with fusion.py:203-217 (vox2world: float32 origin, float64 arithmetic,
+// float32 store), :518-522 (rigid transform in float64) and :336-337 (round(x * fx / z + cx), float32
+// intrinsics, numpy round-half-even).  Integer outputs: every product / sum below is an explicitly rounded
+// IEEE double operation (no FMA contraction) so the pixels are the ones numpy computes.
+namespace {
+
+struct ProjP {
+    double E[16];                 // cam_E (world/lidar -> camera), row major
+    double fx, fy, cx, cy;        // float32-rounded intrinsics, widened
+    double vox_size;
+    float origin[3];              // float32(vox_origin)
+    int X, Y, Z;                  // voxel grid (ceil(scene / voxel_size))
+    int img_w, img_h;
+    int64_t* pix;                 // (N, 1, 2) int64
+    uint8_t* fov;                 // (N, 1) bool
+    float* pix_z;                 // (N,) or nullptr
+};
+
+__global__ void __launch_bounds__(256) project_voxels_kernel(const ProjP p) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.X * p.Y * p.Z;
+    if (n >= total) return;
+    const int iz = (int)(n % p.Z);
+    const long t = n / p.Z;
+    const int iy = (int)(t % p.Y), ix = (int)(t / p.Y);
+    const int idx[3] = {ix, iy, iz};
+    double pt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double a = __dadd_rn((double)p.origin[j], __dmul_rn(p.vox_size, (double)(float)idx[j]));
+        pt[j] = (double)(float)__dadd_rn(a, __dmul_rn(p.vox_size, 0.5));
+    }
+    double cam[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double acc = __dmul_rn(p.E[r * 4 + 0], pt[0]);
+        acc = __dadd_rn(acc, __dmul_rn(p.E[r * 4 + 1], pt[1]));
+        acc = __dadd_rn(acc, __dmul_rn(p.E[r * 4 + 2], pt[2]));
+        cam[r] = __dadd_rn(acc, p.E[r * 4 + 3]);
+    }
+    double xr = rint(__dadd_rn(__ddiv_rn(__dmul_rn(cam[0], p.fx), cam[2]), p.cx));
+    double yr = rint(__dadd_rn(__ddiv_rn(__dmul_rn(cam[1], p.fy), cam[2]), p.cy));
+    // non-finite projections (z == 0) are clamped like oracle/inputs.py; they are out of the FOV anyway
+    xr = isnan(xr) ? -1e9 : fmin(fmax(xr, -1e9), 1e9);
+    yr = isnan(yr) ? -1e9 : fmin(fmax(yr, -1e9), 1e9);
+    const long px = (long)xr, py = (long)yr;
+    p.pix[n * 2] = px;
+    p.pix[n * 2 + 1] = py;
+    p.fov[n] = (px >= 0 && px < p.img_w && py >= 0 && py < p.img_h && cam[2] > 0.0) ? 1 : 0;
+    if (p.pix_z) p.pix_z[n] = (float)cam[2];
+}
+
+}  // namespace
+
+extern "C" int occd_project_voxels(const double* cam_E_host, const double* cam_k_host, const double* vox_origin_host,
+                                   double voxel_size, int32_t X, int32_t Y, int32_t Z, int32_t img_w, int32_t img_h,
+                                   int64_t* pix, uint8_t* fov, float* pix_z, void* stream) {
+    if (!cam_E_host || !cam_k_host || !vox_origin_host || !pix || !fov || X <= 0 || Y <= 0 || Z <= 0 ||
+        voxel_size <= 0)
+        return OCCD_EINVAL;
+    ProjP p;
+    for (int i = 0; i < 16; ++i) p.E[i] = cam_E_host[i];
+    p.fx = (double)(float)cam_k_host[0];
+    p.fy = (double)(float)cam_k_host[4];
+    p.cx = (double)(float)cam_k_host[2];
+    p.cy = (double)(float)cam_k_host[5];
+    p.vox_size = voxel_size;
+    for (int j = 0; j < 3; ++j) p.origin[j] = (float)vox_origin_host[j];
+    p.X = X; p.Y = Y; p.Z = Z; p.img_w = img_w; p.img_h = img_h;
+    p.pix = pix; p.fov = fov; p.pix_z = pix_z;
+    const long total = (long)X * Y * Z;
+    occd::ProfScope prof("project_voxels", (hipStream_t)stream, 0.0, 17.0 * total);
+    hipLaunchKernelGGL(project_voxels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       p);
+    return occd::check_launch();
+}

@@ -55,31 +55,47 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const float* __restrict
     }
 }
 
-template <int K>
+// each thread produces 4 horizontally adjacent outputs of one (b, c) plane: a row of the window is loaded once
+// ((4-1)*stride + K values) and reused by the 4 outputs; the K*K weights live in registers.
+template <int K, int STRIDE>
 __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
-                                                       int stride, int pad_t, int pad_l, int act) {
-    const int plane = blockIdx.z;
+                                                       int pad_t, int pad_l, int act) {
+    constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K;
+    const int plane = blockIdx.y;
     const int c = plane % C;
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ox >= Wo || oy >= Ho) return;
+    const int wq = (Wo + NX - 1) / NX;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= Ho * wq) return;
+    const int oy = item / wq, ox0 = (item - oy * wq) * NX;
     const float* xp = x + (size_t)plane * H * W;
-    const float* wp = w + (size_t)c * K * K;
-    float acc = 0.f;
+    float wr[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)c * K * K + i];
+    float acc[NX] = {0.f, 0.f, 0.f, 0.f};
+    const int ix0 = ox0 * STRIDE - pad_l;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * stride - pad_t + ky;
+        const int iy = oy * STRIDE - pad_t + ky;
         if ((unsigned)iy >= (unsigned)H) continue;
+        const float* row = xp + (size_t)iy * W;
+        float v[SPAN];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const int ix = ox * stride - pad_l + kx;
-            if ((unsigned)ix < (unsigned)W) acc += xp[(size_t)iy * W + ix] * wp[ky * K + kx];
+        for (int j = 0; j < SPAN; ++j) {
+            const int ix = ix0 + j;
+            v[j] = (unsigned)ix < (unsigned)W ? row[ix] : 0.f;
         }
+#pragma unroll
+        for (int o = 0; o < NX; ++o)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[o] += v[o * STRIDE + kx] * wr[ky * K + kx];
     }
     const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
-    y[((size_t)plane * Ho + oy) * Wo + ox] = act_apply(acc * s + t, act, 0.f);
+    float* yp = y + ((size_t)plane * Ho + oy) * Wo + ox0;
+#pragma unroll
+    for (int o = 0; o < NX; ++o)
+        if (ox0 + o < Wo) yp[o] = act_apply(acc[o] * s + t, act, 0.f);
 }
 
 __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restrict__ x, const float* __restrict__ skip,
@@ -132,15 +148,20 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
     if (!x || !w || !y || batch <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0)
         return OCCD_EINVAL;
     if ((k != 3 && k != 5) || act < 0 || act > 2 || (long)batch * C > 65535) return OCCD_EINVAL;
-    const dim3 grid((unsigned)((Wo + 63) / 64), (unsigned)((Ho + 3) / 4), (unsigned)(batch * C));
+    if (stride != 1 && stride != 2) return OCCD_EINVAL;
+    const int items = Ho * ((Wo + 3) / 4);
+    const dim3 grid((unsigned)((items + 255) / 256), (unsigned)(batch * C));
     occd::ProfScope prof("dwconv2d_nchw", (hipStream_t)stream, 2.0 * batch * C * (double)Ho * Wo * k * k,
                          4.0 * batch * C * ((double)H * W + (double)Ho * Wo));
-    if (k == 3)
-        hipLaunchKernelGGL(dwconv2d_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, C, H, W,
-                           Ho, Wo, stride, pad_top, pad_left, act);
-    else
-        hipLaunchKernelGGL(dwconv2d_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y, C, H, W,
-                           Ho, Wo, stride, pad_top, pad_left, act);
+    hipStream_t st = (hipStream_t)stream;
+#define OCCD_DW(KK, SS)                                                                                          \
+    hipLaunchKernelGGL((dwconv2d_kernel<KK, SS>), grid, dim3(256), 0, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
+                       pad_top, pad_left, act)
+    if (k == 3 && stride == 1) OCCD_DW(3, 1);
+    else if (k == 3) OCCD_DW(3, 2);
+    else if (stride == 1) OCCD_DW(5, 1);
+    else OCCD_DW(5, 2);
+#undef OCCD_DW
     return occd::check_launch();
 }
 
@@ -260,5 +281,36 @@ extern "C" int occd_cascade_tail_fwd(const float* part, const float* wn, float* 
     else if (ng <= 5) OCCD_TAIL(5);
     else OCCD_TAIL(8);
 #undef OCCD_TAIL
+    return occd::check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SURVEY.md 8(f) row N4 (first step): class prediction on the GPU.  scripts/generate_output.py:94-95 copies
+// the (B, 20, 256, 256, 32) logits to the host, soft-maxes and arg-maxes them in numpy; argmax(softmax(x)) ==
+// argmax(x), so one pass over the channels-last rows yields the uint8 label volume (first maximum wins, like
+// numpy), optionally mapped through a LUT (learning_map_inv of generate_kitti_submission.py:74-85).
+namespace {
+__global__ void __launch_bounds__(256) argmax_rows_kernel(const float* __restrict__ x, long rows, int cs, int coff,
+                                                          int C, const uint16_t* __restrict__ lut,
+                                                          uint16_t* __restrict__ out) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = x + (size_t)r * cs + coff;
+    float best = p[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = p[c];
+        if (v > best) { best = v; arg = c; }
+    }
+    out[r] = lut ? lut[arg] : (uint16_t)arg;
+}
+}  // namespace
+
+extern "C" int occd_argmax_channels(const float* x, int64_t rows, int32_t cs, int32_t coff, int32_t C,
+                                    const uint16_t* lut, uint16_t* out, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || coff < 0 || coff + C > cs) return OCCD_EINVAL;
+    occd::ProfScope prof("argmax_channels", (hipStream_t)stream, 0.0, (double)rows * (4.0 * C + 2));
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)rows, cs, coff, C, lut, out);
     return occd::check_launch();
 }

@@ -92,6 +92,9 @@ EXPORTS = {
                                        c_int32, c_float, c_int32, c_void_p]),
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_project_voxels": (c_int32, [c_void_p, c_void_p, c_void_p, c_double] + [c_int32] * 5
+                            + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "occd_cascade_tail_fwd": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
@@ -404,6 +407,47 @@ def upsample_bilinear_cat(x, skip):
     _check(load().occd_upsample_bilinear_cat_nchw(_f32(x, "x"), _f32(skip, "skip"), _f32(out, "out"), B, C, Cs, h, w,
                                                   H, W, _stream()), "occd_upsample_bilinear_cat_nchw")
     return out
+
+
+def project_voxels(cam_E, cam_k, vox_origin, voxel_size, grid_dims, img_w, img_h, device="cuda", with_z=False):
+    """GPU `vox2pix` (pattern 0): -> projected_pix (N, 1, 2) int64, fov_mask (N, 1) bool [, pix_z (N,) float32]."""
+    import numpy as np
+    e = np.ascontiguousarray(np.asarray(cam_E, dtype=np.float64).reshape(16))
+    k = np.ascontiguousarray(np.asarray(cam_k, dtype=np.float64).reshape(9))
+    o = np.ascontiguousarray(np.asarray(vox_origin, dtype=np.float64).reshape(3))
+    X, Y, Z = (int(v) for v in grid_dims)
+    n = X * Y * Z
+    pix = torch.empty((n, 1, 2), dtype=torch.int64, device=device)
+    fov = torch.empty((n, 1), dtype=torch.bool, device=device)
+    z = torch.empty((n,), dtype=torch.float32, device=device) if with_z else None
+    _check(load().occd_project_voxels(e.ctypes.data, k.ctypes.data, o.ctypes.data, float(voxel_size), X, Y, Z,
+                                      int(img_w), int(img_h), _ptr(pix, "pix"), _ptr(fov.view(torch.uint8), "fov"),
+                                      _ptr(z, "pix_z") if z is not None else None, _stream()), "occd_project_voxels")
+    return (pix, fov, z) if with_z else (pix, fov)
+
+
+def argmax_labels(logits, lut=None):
+    """(B, C, X, Y, Z) float32 GPU logits -> (B, X, Y, Z) int32 class volume (argmax over C, first maximum wins),
+    optionally mapped through `lut` (e.g. SemanticKITTI learning_map_inv).  Channels-last views returned by the
+    eval path (rows of a possibly wider buffer) are consumed in place."""
+    if logits.dtype != torch.float32 or not logits.is_cuda:
+        raise RuntimeError("argmax_labels needs float32 GPU logits")
+    cl = logits.permute(0, 2, 3, 4, 1)
+    B, X, Y, Z, C = cl.shape
+    cs = cl.stride(3)
+    rows_ok = cl.stride(4) == 1 and cs >= C and cl.stride(2) == cs * Z and cl.stride(1) == cs * Z * Y and \
+        cl.stride(0) == cs * Z * Y * X
+    if not rows_ok:
+        cl = cl.contiguous()
+        cs = C
+    rows = B * X * Y * Z
+    out = torch.empty(rows, dtype=torch.int16, device=logits.device)
+    lut_t = None
+    if lut is not None:
+        lut_t = torch.as_tensor(lut, dtype=torch.int32).to(torch.int16).to(logits.device).contiguous()
+    _check(load().occd_argmax_channels(cl.data_ptr(), rows, cs, 0, C, lut_t.data_ptr() if lut_t is not None else None,
+                                       out.data_ptr(), _stream()), "occd_argmax_channels")
+    return (out.to(torch.int32) & 0xFFFF).view(B, X, Y, Z)
 
 
 def cascade_tail(part, occ_off, wn, nbr):

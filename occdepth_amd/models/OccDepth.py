@@ -168,8 +168,11 @@ class OccDepth(_Base):
         if self.trans_2d_to_3d == "flosp_depth":
             depth_vol, depth_pred = self._depth_volume(batch, x_rgb, vox_origin)
         if not self.training:
-            pix = torch.stack([p.to(device) for p in batch[key]])
-            fov = torch.stack([m.to(device) for m in batch[mkey]])
+            if key in batch:
+                pix = torch.stack([p.to(device) for p in batch[key]])
+                fov = torch.stack([m.to(device) for m in batch[mkey]])
+            else:
+                pix, fov = self.project_voxels_on_gpu(batch, img)
             feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
             flat = depth_vol.reshape(bs, -1).contiguous() if depth_vol is not None else None
             vox = lift_scales(feats, scales, pix, fov, self.projects[str(scales[0])].scene_size,
@@ -190,6 +193,25 @@ class OccDepth(_Base):
                 depth_vol = depth_vol.permute(0, 1, 2, 4, 3).contiguous()
             x3ds = x3ds * depth_vol * 100
         return x3ds, depth_pred
+
+    def project_voxels_on_gpu(self, batch, img):
+        """when the batch carries no `projected_pix_{s}` / `fov_mask_{s}` (the dataloader's
+        numba `vox2pix`, kitti_dataset.py:253-273), compute them on the GPU from the calibration
+        (SemanticKITTI geometry: vox_origin (0, -25.6, -2), 0.2 m voxels x project_scale, pattern_id 0)."""
+        from .. import hip
+        if self.dataset != "kitti":
+            raise NotImplementedError("on-GPU voxel projection is wired for the SemanticKITTI geometry only")
+        ps = self.project_scale
+        dims = tuple(int(s) // ps for s in self.full_scene_size)
+        H, W = img.shape[-2:]
+        pix, fov = [], []
+        for i in range(img.shape[0]):
+            views = [hip.project_voxels(batch["T_velo_2_cam"][i][v].detach().cpu().double().numpy(),
+                                        batch["cam_k"][i][v].detach().cpu().double().numpy(), (0.0, -25.6, -2.0),
+                                        0.2 * ps, dims, W, H, device=img.device) for v in range(img.shape[1])]
+            pix.append(torch.stack([p for p, _ in views]))
+            fov.append(torch.stack([m for _, m in views]))
+        return torch.stack(pix), torch.stack(fov)
 
     def forward(self, batch):
         img = batch["img"].to(device)

@@ -284,6 +284,72 @@ def test_config5_synthetic_512_grid():
         assert ((o.ncdhw() - ref).abs().max() / ref.abs().max()).item() < 2e-5
 
 
+@pytest.mark.parametrize("geom", ["kitti_ps2", "kitti_ps1_right", "nyu"])
+def test_project_voxels_bit_exact(geom):
+    """the GPU voxel->pixel projection reproduces the numpy restatement of the dataloader's
+    numba vox2pix integer-exactly (int64 pixels, bool FOV mask), full-size grids."""
+    import numpy as np
+    from occdepth_amd import hip
+    from oracle import inputs
+    if geom.startswith("kitti"):
+        ps = 2 if geom == "kitti_ps2" else 1
+        E = inputs.KITTI_TR.copy()
+        if geom.endswith("right"):
+            E[0, 3] = -0.54
+        k, origin, vs, dims, wh, scene_m = inputs.KITTI_K, (0, -25.6, -2), 0.2 * ps, (256 // ps, 256 // ps, 32 // ps), \
+            (1220, 370), (51.2, 51.2, 6.4)
+    else:
+        pose = np.array([[1, 0, 0, 2.4], [0, 0, 1, -0.5], [0, -1, 0, 1.44], [0, 0, 0, 1]], dtype=np.float64)
+        E, k, origin, vs, dims, wh, scene_m = np.linalg.inv(pose), inputs.NYU_K, (0.3, -0.2, 0.1), 0.08, \
+            (60, 60, 36), (640, 480), (4.8, 4.8, 2.88)
+    ref_pix, ref_fov, ref_z = inputs.vox2pix(E, k, origin, vs, wh[0], wh[1], scene_m, 0)
+    pix, fov, z = hip.project_voxels(E, k, origin, vs, dims, wh[0], wh[1], with_z=True)
+    assert pix.shape == (ref_pix.shape[0], 1, 2) and pix.dtype == torch.int64 and fov.dtype == torch.bool
+    assert np.array_equal(fov.cpu().numpy(), ref_fov)
+    inside = torch.from_numpy(ref_fov[:, 0])
+    assert np.array_equal(pix.cpu().numpy()[ref_fov[:, 0]], ref_pix[ref_fov[:, 0]])
+    # outside the FOV only the (masked) values of degenerate z == 0 projections may differ; none here
+    assert np.array_equal(pix.cpu().numpy(), ref_pix)
+    assert np.allclose(z.cpu().numpy(), ref_z.astype(np.float32), rtol=1e-6, atol=1e-6)
+    assert 0.3 < inside.float().mean().item() < 0.95
+
+
+def test_forward_without_projection_inputs(config2):
+    """N2 end to end: dropping `projected_pix_2` / `fov_mask_2` from the batch makes the model project the voxels
+    on the GPU from (cam_k, T_velo_2_cam); the batch carries float32 extrinsics (the dataloader used float64), so
+    individual pixels may move by one in rare rounding ties -- the logits stay within 1e-3."""
+    m, cfg, batch, out = config2
+    b = {k: v for k, v in batch.items() if not (k.startswith("projected_pix") or k.startswith("fov_mask"))}
+    with torch.no_grad():
+        pix, fov = m.project_voxels_on_gpu(b, batch["img"])
+        o = m(b)
+    ref_pix = torch.stack(batch["projected_pix_2"])
+    ref_fov = torch.stack(batch["fov_mask_2"])
+    assert (fov != ref_fov).float().mean().item() < 1e-4
+    both = fov & ref_fov
+    assert ((pix != ref_pix).any(-1) & both).float().mean().item() < 1e-4
+    e = ((o["ssc_logit"] - out["ssc_logit"]).abs().max() / out["ssc_logit"].abs().max()).item()
+    assert e < 2e-3, e
+
+
+def test_argmax_labels(config2):
+    """N4: GPU arg-max over the channels-last logits == numpy argmax of the softmax (generate_output.py:94-95)."""
+    import numpy as np
+    from occdepth_amd import hip
+    m, cfg, batch, out = config2
+    labels = hip.argmax_labels(out["ssc_logit"])
+    ref = np.argmax(torch.softmax(out["ssc_logit"], dim=1).cpu().numpy(), axis=1)
+    assert labels.shape == (1, 256, 256, 32)
+    assert (labels.cpu().numpy() != ref).mean() < 1e-6       # softmax rounding can only flip exact ties
+    ref_raw = np.argmax(out["ssc_logit"].cpu().numpy(), axis=1)
+    assert np.array_equal(labels.cpu().numpy(), ref_raw)
+    lut = np.arange(20)[::-1].copy() * 3
+    mapped = hip.argmax_labels(out["ssc_logit"], lut=lut)
+    assert np.array_equal(mapped.cpu().numpy(), lut[ref_raw])
+    occ = hip.argmax_labels(out["occ_logit"])               # a channel slice of a wider row buffer
+    assert np.array_equal(occ.cpu().numpy(), np.argmax(out["occ_logit"].cpu().numpy(), axis=1))
+
+
 def test_lift_properties_full_size():
     """K1b at config-2 size: linearity in the features, zero rows for voxels outside both FOVs."""
     from occdepth_amd.models.SFA import lift_scales
