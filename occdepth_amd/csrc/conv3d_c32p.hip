@@ -118,7 +118,6 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_persist_kernel(const Persis
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     issue(tile, 0);
-    const float bias_v = (p.bias != nullptr && li < p.cout_store) ? p.bias[li] : 0.f;
 
     while (true) {
         const int next_tile = tile + wg_per_xcd;
@@ -151,27 +150,35 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_persist_kernel(const Persis
                         const f32x4 b = wb[((ky * 3 + kz) * 4 + ktl) * 64];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc, 0, 0, 0);   // D = W^T . X^T
                     }
         }
-        // ---- epilogue of this tile (the next tile's first slab is already in flight)
+        // ---- epilogue of this tile (the next tile's first slab is already in flight).  Operands are
+        // (weights, activations): lane -> voxel z = li, registers -> couts (r & 3) + 8 (r >> 2) + 4 kk, i.e. four
+        // float4 groups of consecutive channels per lane -> 16-byte residual loads / stores.
         {
             const int yt = tile % p.ytiles;
             const int bj = tile / p.ytiles;
             const int bx = bj - bj % p.X + plane_of<D>(bj % p.X, p.X);
             const int y = yt * kTY + wave;
-            if (y < p.Y && li < p.cout_store) {
-                const size_t vox0 = ((size_t)bx * p.Y + y) * kTZ;
+            if (y < p.Y) {
+                const size_t vox = ((size_t)bx * p.Y + y) * kTZ + li;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int z = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    const size_t vox = vox0 + z;
-                    float o = acc[r] + bias_v;
-                    if (p.act_out == OCCD_ACT_RELU_PRE) o = fmaxf(o, 0.f);
-                    if (p.res1 != nullptr) o += p.res1[vox * p.res1_cs + p.res1_coff + li];
-                    if (p.res2 != nullptr) o += p.res2[vox * p.res2_cs + p.res2_coff + li];
-                    if (p.act_out == OCCD_ACT_RELU) o = fmaxf(o, 0.f);
-                    p.out[vox * p.out_cs + p.out_coff + li] = o;
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 8 * g + 4 * kk;
+                    if (c < p.cout_store) {
+                        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        if (p.bias != nullptr) o += *(const f32x4*)(p.bias + c);
+                        if (p.act_out == OCCD_ACT_RELU_PRE) {
+                            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                        }
+                        if (p.res1 != nullptr) o += *(const f32x4*)(p.res1 + vox * p.res1_cs + p.res1_coff + c);
+                        if (p.res2 != nullptr) o += *(const f32x4*)(p.res2 + vox * p.res2_cs + p.res2_coff + c);
+                        if (p.act_out == OCCD_ACT_RELU) {
+                            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                        }
+                        *(f32x4*)(p.out + vox * p.out_cs + p.out_coff + c) = o;
+                    }
                 }
             }
 #pragma unroll

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
 #define OCCD_MFMA_BLOCK()                                                                              \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)   \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] =                               \
-            __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0)
+            __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nt][q], a_cur[mt][q], acc[mt][nt], 0, 0, 0)
 
     for (int kx = 0; kx < p.KX; ++kx) {
         const int xi = xo * p.SX - p.PX + kx * p.DX;
@@ -238,34 +238,37 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
                         acc[mt][nt][r] += red[((((g - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane];
     }
 
-    // ---------------- epilogue: bias + residuals + activation, channels-last store
-    float bias_v[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int c = (nt0 + nt) * 32 + li;
-        bias_v[nt] = (p.bias != nullptr && c < p.cout_store) ? p.bias[c] : 0.f;
-    }
+    // ---------------- epilogue: bias + residuals + activation, channels-last store.
+    // The MFMA operands are (weights, activations), i.e. D = W^T . X^T: lane -> voxel `li` of the M tile and the
+    // 16 accumulator registers -> couts (r & 3) + 8 (r >> 2) + 4 kk, so every lane owns four float4 groups of
+    // consecutive output channels of ONE voxel: 16-byte residual loads and stores instead of 4-byte ones.
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        const uint32_t m = (wm * MT + mt) * 32 + li;
+        const uint32_t yl = occd_fastdiv(m, p.div_tz);
+        const uint32_t zl = m - yl * p.TZ;
+        const int yo = yt * p.TY + (int)yl, zo = zt * p.TZ + (int)zl;
+        const bool ok = yl < (uint32_t)p.TY && yo < p.Yo && zo < p.Zo;
+        const size_t vox = ((size_t)(b * p.OX + xo * p.osx + p.oox) * p.OY + (yo * p.osy + p.ooy)) * p.OZ +
+                           (zo * p.osz + p.ooz);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const uint32_t yl = occd_fastdiv(m, p.div_tz);
-            const uint32_t zl = m - yl * p.TZ;
-            const int yo = yt * p.TY + (int)yl, zo = zt * p.TZ + (int)zl;
-            const bool ok = yl < (uint32_t)p.TY && yo < p.Yo && zo < p.Zo;
-            const size_t vox = ((size_t)(b * p.OX + xo * p.osx + p.oox) * p.OY + (yo * p.osy + p.ooy)) * p.OZ +
-                               (zo * p.osz + p.ooz);
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int c = (nt0 + nt) * 32 + li;
+            for (int g = 0; g < 4; ++g) {
+                const int c = (nt0 + nt) * 32 + 8 * g + 4 * kk;
                 if (ok && c < p.cout_store) {
-                    float v = acc[mt][nt][r] + bias_v[nt];
-                    if (p.act_out == OCCD_ACT_RELU_PRE) v = fmaxf(v, 0.f);
-                    if (p.res1 != nullptr) v += p.res1[vox * p.res1_cs + p.res1_coff + c];
-                    if (p.res2 != nullptr) v += p.res2[vox * p.res2_cs + p.res2_coff + c];
-                    if (p.act_out == OCCD_ACT_RELU) v = fmaxf(v, 0.f);
-                    p.out[vox * p.out_cs + p.out_coff + c] = v;
+                    f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
+                               acc[mt][nt][4 * g + 3]};
+                    if (p.bias != nullptr) v += *(const f32x4*)(p.bias + c);
+                    if (p.act_out == OCCD_ACT_RELU_PRE) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (p.res1 != nullptr) v += *(const f32x4*)(p.res1 + vox * p.res1_cs + p.res1_coff + c);
+                    if (p.res2 != nullptr) v += *(const f32x4*)(p.res2 + vox * p.res2_cs + p.res2_coff + c);
+                    if (p.act_out == OCCD_ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *(f32x4*)(p.out + vox * p.out_cs + p.out_coff + c) = v;
                 }
             }
         }
@@ -385,6 +388,14 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
     if ((reinterpret_cast<uintptr_t>(a->in) & 15) || (reinterpret_cast<uintptr_t>(a->wpk) & 15)) return OCCD_EINVAL;
     if (a->cout_store < a->cout || a->cout_store > NTtot * 32 || a->out_coff + a->cout_store > a->out_cs)
         return OCCD_EINVAL;
+    // float4 epilogue: rows, slices and the stored width are multiples of 4 floats, buffers 16-byte aligned
+    if ((a->cout_store & 3) || (a->out_cs & 3) || (a->out_coff & 3) || (reinterpret_cast<uintptr_t>(a->out) & 15))
+        return OCCD_EINVAL;
+    if (a->res1 && ((a->res1_cs & 3) || (a->res1_coff & 3) || (reinterpret_cast<uintptr_t>(a->res1) & 15)))
+        return OCCD_EINVAL;
+    if (a->res2 && ((a->res2_cs & 3) || (a->res2_coff & 3) || (reinterpret_cast<uintptr_t>(a->res2) & 15)))
+        return OCCD_EINVAL;
+    if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 15)) return OCCD_EINVAL;
     if (a->res1 && a->res1_coff + a->cout_store > a->res1_cs) return OCCD_EINVAL;
     if (a->res2 && a->res2_coff + a->cout_store > a->res2_cs) return OCCD_EINVAL;
     if ((a->Xo - 1) * a->o_stride_x + a->o_off_x >= a->OX || (a->Yo - 1) * a->o_stride_y + a->o_off_y >= a->OY ||
