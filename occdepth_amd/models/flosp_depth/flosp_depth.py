@@ -76,14 +76,22 @@ class DepthNet(nn.Module):
         self.infer_mode = infer_mode
 
     @staticmethod
-    def scaled_pixel_size(sweep_intrins, scale_depth_factor=1000.0):
-        inv = torch.inverse(sweep_intrins)
-        size = torch.norm(torch.stack([inv[..., 0, 0], inv[..., 1, 1]], dim=-1), dim=-1).reshape(-1, 1)
+    def scaled_pixel_size(sweep_intrins, scale_depth_factor=1000.0, sync_free=False):
+        if sync_free:
+            # pinhole intrinsics are upper triangular, so diag(K^-1) = 1 / diag(K) exactly (what LU computes too);
+            # torch.inverse on the GPU goes through rocSOLVER and synchronises the host, which drains the launch
+            # queue in the middle of the forward pass
+            d0, d1 = 1.0 / sweep_intrins[..., 0, 0], 1.0 / sweep_intrins[..., 1, 1]
+        else:
+            inv = torch.inverse(sweep_intrins)
+            d0, d1 = inv[..., 0, 0], inv[..., 1, 1]
+        size = torch.norm(torch.stack([d0, d1], dim=-1), dim=-1).reshape(-1, 1)
         return size * scale_depth_factor
 
     def forward(self, x=None, sweep_intrins=None, scaled_pixel_size=None, scale_depth_factor=1000.0):
         if not self.infer_mode:
-            scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor)
+            scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
+                                                       sync_free=sweep_intrins.is_cuda and not self.training)
         x = self.reduce_conv(x)
         x = self.se(x, self.mlp(scaled_pixel_size)[..., None, None])
         return self.depth_pred(self.depth_conv(x))
@@ -178,7 +186,11 @@ class FlospDepth(nn.Module):
                 flat = hip.flosp_sample(dvol, None, None, None, self._grid_dims, self.final_dim, self.d_bound[0],
                                         self.d_bound[1], self.agg_voxel_mode == "mean", grids=g)
             else:
-                g2l = _grid_to_lidar(self._pc_range, self._grid_dims).to(t_v2c.device)
+                gkey = (tuple(self._pc_range), self._grid_dims, t_v2c.device)
+                if getattr(self, "_g2l_key", None) != gkey:     # cached on the device: no per-frame H2D copy
+                    self._g2l_dev = _grid_to_lidar(self._pc_range, self._grid_dims).to(t_v2c.device)
+                    self._g2l_key = gkey
+                g2l = self._g2l_dev
                 trans = (t_v2c @ g2l).contiguous()
                 proj = intrins[:, :, :3, :].contiguous()
                 flat = hip.flosp_sample(dvol, trans, proj, ida.contiguous(), self._grid_dims, self.final_dim,
