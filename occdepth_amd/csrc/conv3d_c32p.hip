@@ -14,6 +14,7 @@
 // LDS: 110,592 B weights + (8+2d)(32+2d) rows x 80 B  (d=1: 137.8 KB, d=3: 153.2 KB) -> 1 workgroup / CU.
 //
 // Reference semantics replaced: occdepth/models/modules.py:158-175 (conv0, conv1.*, conv2.*, conv_classes).
+#include <cstdlib>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -189,6 +190,272 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_persist_kernel(const Persis
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2s -- sliding-window form of the persistent kernel.  A workgroup walks a run of x planes (step D) at a fixed
+// y tile and keeps THREE accumulators per wave: acc0 = out[x+D] (fed by kx = 0), acc1 = out[x] (kx = 1),
+// acc2 = out[x-D] (kx = 2).  Every staged input slab (plane x, 16-channel half) therefore feeds all three kx
+// taps: each input plane is staged ONCE per workgroup instead of three times, each A fragment read from LDS is
+// used by 12 MFMAs instead of 4, consecutive MFMAs are independent, and there are 216 MFMAs per wave between
+// barrier pairs instead of 72.  After a plane, acc2 is complete -> epilogue; the accumulators rotate.
+// Work list: per (b, y tile) column the X planes in residue-class order (plane_of) are cut into `segs_per_col`
+// equal position ranges; a range that crosses a residue boundary is walked as two runs.  Ranges are handed out
+// through a global counter.
+struct SlideP {
+    PersistP base;
+    int* counter;            // zeroed before the launch
+    int segs_per_col;        // position ranges per (b, ytile) column
+    int seg_len;             // planes per range (the last one of a column may be shorter)
+    int total_segs;
+};
+
+template <int D>
+__global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP sp) {
+    const PersistP& p = sp.base;
+    constexpr int YIN = kTY + 2 * D, ZIN = kTZ + 2 * D, ROWS = YIN * ZIN;
+    constexpr int RS4 = 5;
+    constexpr int NF4 = ROWS * 4;
+    constexpr int NLOAD = (NF4 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
+    f32x4* const w4 = lds4;
+    f32x4* const slab4 = lds4 + kWFloat4;
+    int* const mailbox = reinterpret_cast<int*>(slab4 + ROWS * RS4);   // 16 bytes after the slab
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+
+    for (int i = tid; i < kWFloat4; i += 512) w4[i] = ((const f32x4*)p.wpk)[i];
+
+    int sdst[NLOAD], syi[NLOAD], szoff[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int f = tid + i * 512;
+        const bool live = f < NF4;
+        const int row = f >> 2, c4 = f & 3;
+        const int yi = row / ZIN, zi = row - yi * ZIN;
+        const int z = zi - D;
+        sdst[i] = live ? row * RS4 + c4 : -1;
+        syi[i] = yi;
+        szoff[i] = (live && z >= 0 && z < kTZ) ? z * p.in_cs + c4 * 4 : -1;
+    }
+    const f32x4* const ab = slab4 + (wave * ZIN + li) * RS4 + kk;
+    const size_t plane_stride = (size_t)p.Y * kTZ * p.in_cs;
+
+    // per-column staging addresses (element offsets of plane x = 0), refreshed per segment
+    size_t coloff[NLOAD];
+    bool colok[NLOAD];
+    f32x4 v[NLOAD];
+    auto issue = [&](int xi, int h) {        // global -> registers; xi inside the volume
+        const float* base = p.in + (size_t)xi * plane_stride + h * 16;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (colok[i]) v[i] = *(const f32x4*)(base + coloff[i]);
+        }
+    };
+    auto commit = [&]() {                    // registers -> LDS slab
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i)
+            if (sdst[i] >= 0) {
+                f32x4 a = v[i];
+                if (p.act_in == OCCD_ACT_RELU) {
+                    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                }
+                slab4[sdst[i]] = a;
+            }
+    };
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = 0.f;
+
+    // interior plane: all three kx taps, LDS reads of step s + 1 in flight under the 12 MFMAs of step s
+    auto mma3 = [&](int h) {
+        const f32x4* wb = w4 + (h * 2) * 64 + lane;
+        constexpr int KXS = 9 * 4 * 64;
+        auto aoff = [](int s) { return (((s / 6) * D * ZIN) + ((s / 2) % 3) * D) * RS4 + (s & 1) * 2; };
+        auto woff = [](int s) { return ((s >> 1) * 4 + (s & 1)) * 64; };
+        f32x4 an = ab[aoff(0)], b0n = wb[woff(0)], b1n = wb[woff(0) + KXS], b2n = wb[woff(0) + 2 * KXS];
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const f32x4 a = an, b0 = b0n, b1 = b1n, b2 = b2n;
+            if (s < 17) {
+                an = ab[aoff(s + 1)];
+                b0n = wb[woff(s + 1)];
+                b1n = wb[woff(s + 1) + KXS];
+                b2n = wb[woff(s + 1) + 2 * KXS];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[q], a[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[q], a[q], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b2[q], a[q], acc2, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // first / last planes of a run: only the taps whose output plane belongs to the run (flags are uniform)
+    auto mma_edge = [&](int h, bool use0, bool use1, bool use2) {
+        const f32x4* wb = w4 + (h * 2) * 64 + lane;
+        constexpr int KXS = 9 * 4 * 64;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kz = t - 3 * ky;
+#pragma unroll
+            for (int ktl = 0; ktl < 2; ++ktl) {
+                const f32x4 a = ab[(ky * D * ZIN + kz * D) * RS4 + ktl * 2];
+                const int wo = (t * 4 + ktl) * 64;
+                if (use0) {
+                    const f32x4 b = wb[wo];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc0, 0, 0, 0);
+                }
+                if (use1) {
+                    const f32x4 b = wb[wo + KXS];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc1, 0, 0, 0);
+                }
+                if (use2) {
+                    const f32x4 b = wb[wo + 2 * KXS];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc2, 0, 0, 0);
+                }
+            }
+        }
+    };
+    // epilogue of acc2 (output plane x of column (b, yt)): lane -> voxel z = li, registers -> couts
+    // (r & 3) + 8 (r >> 2) + 4 kk, i.e. four float4 groups of consecutive channels per lane
+    auto store2 = [&](int b, int yt, int x) {
+        const int y = yt * kTY + wave;
+        if (y < p.Y) {
+            const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * kTZ + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 8 * g + 4 * kk;
+                if (c < p.cout_store) {
+                    f32x4 o = {acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]};
+                    if (p.bias != nullptr) o += *(const f32x4*)(p.bias + c);
+                    if (p.act_out == OCCD_ACT_RELU_PRE) {
+                        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                    }
+                    if (p.res1 != nullptr) o += *(const f32x4*)(p.res1 + vox * p.res1_cs + p.res1_coff + c);
+                    if (p.res2 != nullptr) o += *(const f32x4*)(p.res2 + vox * p.res2_cs + p.res2_coff + c);
+                    if (p.act_out == OCCD_ACT_RELU) {
+                        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                    }
+                    *(f32x4*)(p.out + vox * p.out_cs + p.out_coff + c) = o;
+                }
+            }
+        }
+    };
+
+    while (true) {
+        __syncthreads();                                   // mailbox / slab free, weights visible
+        if (tid == 0) mailbox[0] = atomicAdd(sp.counter, 1);
+        __syncthreads();
+        const int seg = mailbox[0];
+        if (seg >= sp.total_segs) break;
+        // segments are ordered (b, range, ytile) with ytile fastest
+        const int yt = seg % p.ytiles;
+        const int rest = seg / p.ytiles;
+        const int b = rest / sp.segs_per_col;
+        const int q0 = (rest - b * sp.segs_per_col) * sp.seg_len;
+        const int q1 = min(q0 + sp.seg_len, p.X);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int y = yt * kTY - D + syi[i];
+            colok[i] = szoff[i] >= 0 && y >= 0 && y < p.Y;
+            coloff[i] = ((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * kTZ * p.in_cs + p.in_coff + max(szoff[i], 0);
+        }
+        int q = q0;
+        while (q < q1) {
+            // run: positions q .. q + cnt - 1 of one residue class -> outputs x0, x0 + D, ...
+            int r = 0, idx = q, n_r = p.X;
+            if (D > 1) {
+#pragma unroll
+                for (int rr = 0; rr < D; ++rr) {
+                    const int n = (p.X - rr + D - 1) / D;
+                    if (idx < n || rr == D - 1) { r = rr; n_r = n; break; }
+                    idx -= n;
+                }
+            }
+            const int cnt = min(q1 - q, n_r - idx);
+            const int x0 = r + D * idx;
+            q += cnt;
+            // input planes j = 0 .. cnt + 1 : xi = x0 + (j - 1) D feeds out[j] (kx 0), out[j-1] (kx 1), out[j-2] (kx 2)
+            const int nj = cnt + 2;
+            const int jfirst = x0 - D < 0 ? 1 : 0;                         // plane -D.. is padding
+            const int jlast = x0 + cnt * D >= p.X ? (p.X - 1 - x0) / D + 1 : nj - 1;   // last plane inside the volume
+            __syncthreads();                                               // previous run's slab consumed
+            issue(x0 + (jfirst - 1) * D, 0);
+            for (int j = 0; j < nj; ++j) {
+                const int xi = x0 + (j - 1) * D;
+                const bool u0 = j < cnt, u1 = j >= 1 && j <= cnt, u2 = j >= 2;
+                if (j >= jfirst && j <= jlast) {
+#pragma unroll 1
+                    for (int h = 0; h < 2; ++h) {
+                        __syncthreads();                                   // previous slab consumed
+                        commit();
+                        __syncthreads();
+                        if (h == 0) issue(xi, 1);
+                        else if (j < jlast) issue(xi + D, 0);
+                        if (u0 && u1 && u2) mma3(h);
+                        else mma_edge(h, u0, u1, u2);
+                    }
+                }
+                if (u2) store2(b, yt, x0 + (j - 2) * D);
+                acc2 = acc1;
+                acc1 = acc0;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc0[rr] = 0.f;
+            }
+        }
+    }
+}
+
+int* g_counter = nullptr;
+bool g_slide_attr[4] = {};
+
+template <int D>
+int launch_slide(const PersistP& base, hipStream_t st, int num_cu) {
+    constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D);
+    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * 5 * 16 + 16;
+    if (!g_slide_attr[D]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return OCCD_ELAUNCH;
+        g_slide_attr[D] = true;
+    }
+    if (g_counter == nullptr && hipMalloc(&g_counter, 256) != hipSuccess) return OCCD_ELAUNCH;
+    SlideP sp;
+    sp.base = base;
+    sp.counter = g_counter;
+    // ranges per column: k rounds over the grid; a range of L planes costs L + 2 stagings per run (D > 1: up to two
+    // runs).  Few long ranges amortise the two extra planes, but the list must fill whole rounds.
+    const int cols = base.batch * base.ytiles;
+    int best_s = 1;
+    double best_cost = 1e30;
+    for (int k = 1; k <= 16; ++k) {
+        int S = (int)((long)k * num_cu / cols);
+        if (S < 1) S = 1;
+        if (S > base.X) S = base.X;
+        const int L = (base.X + S - 1) / S;
+        const long total = (long)cols * ((base.X + L - 1) / L);
+        const long rounds = (total + num_cu - 1) / num_cu;
+        const double cost = (double)rounds * (L + 2.0 + (D > 1 ? 1.0 : 0.0));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_s = S; }
+    }
+    sp.seg_len = (base.X + best_s - 1) / best_s;
+    sp.segs_per_col = (base.X + sp.seg_len - 1) / sp.seg_len;
+    sp.total_segs = cols * sp.segs_per_col;
+    if (hipMemsetAsync(g_counter, 0, sizeof(int), st) != hipSuccess) return OCCD_ELAUNCH;
+    int grid = num_cu < sp.total_segs ? num_cu : sp.total_segs;
+    hipLaunchKernelGGL(conv3d_c32_slide_kernel<D>, dim3((unsigned)grid), dim3(512), lds, st, sp);
+    return occd::check_launch();
+}
+
 bool g_attr_done[4] = {};
 int g_num_cu = 0;
 
@@ -245,7 +512,20 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
     const double bytes = 4.0 * (pos * a->cin + pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) +
                                 27.0 * a->cin * a->cout);
     ProfScope prof("conv3d_c32p", stream, flops, bytes);
-    int rc = d == 1 ? launch<1>(p, stream) : d == 2 ? launch<2>(p, stream) : launch<3>(p, stream);
+    static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
+    int rc;
+    if (tiled) {
+        rc = d == 1 ? launch<1>(p, stream) : d == 2 ? launch<2>(p, stream) : launch<3>(p, stream);
+    } else {
+        if (g_num_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCCD_ELAUNCH;
+            g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        rc = d == 1 ? launch_slide<1>(p, stream, g_num_cu) : d == 2 ? launch_slide<2>(p, stream, g_num_cu)
+                                                                  : launch_slide<3>(p, stream, g_num_cu);
+    }
     return rc == OCCD_OK ? 1 : rc;
 }
 

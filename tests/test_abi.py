@@ -71,3 +71,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="missing"):
         hip.load()
+
+
+def test_new_entry_points_validate_arguments(hip_lib):
+    """Host-side validation of the 2-D helper / projection / tail entry points (no launch for bad arguments)."""
+    import ctypes
+    assert hip_lib.occd_affine_act_nchw(None, None, None, None, None, 1, 1, 1, 0, 0.0, 0, None) == -1
+    assert hip_lib.occd_dwconv2d_nchw(None, None, None, None, None, 1, 1, 1, 1, 3, 1, 0, 0, 1, 1, 0, None) == -1
+    assert hip_lib.occd_upsample_bilinear_cat_nchw(None, None, None, 1, 1, 0, 1, 1, 1, 1, None) == -1
+    assert hip_lib.occd_cascade_tail_fwd(None, None, None, 1, 1, 1, 1, 24, 20, 20, 20, None) == -1
+    assert hip_lib.occd_argmax_channels(None, 1, 4, 0, 4, None, None, None) == -1
+    e = (ctypes.c_double * 16)()
+    assert hip_lib.occd_project_voxels(ctypes.addressof(e), None, None, 0.2, 1, 1, 1, 1, 1, None, None, None, None) == -1
