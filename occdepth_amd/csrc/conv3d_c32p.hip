@@ -14,6 +14,7 @@
 // LDS: 110,592 B weights + (8+2d)(32+2d) rows x 80 B  (d=1: 137.8 KB, d=3: 153.2 KB) -> 1 workgroup / CU.
 //
 // Reference semantics replaced: occdepth/models/modules.py:158-175 (conv0, conv1.*, conv2.*, conv_classes).
+#include <atomic>
 #include <cstdlib>
 #include "common.h"
 
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_persist_kernel(const Persis
 // through a global counter.
 struct SlideP {
     PersistP base;
-    int* counter;            // zeroed before the launch
+    int* counter;            // {next segment, workgroups finished}: both 0 at launch, re-armed by the kernel itself
     int segs_per_col;        // position ranges per (b, ytile) column
     int seg_len;             // planes per range (the last one of a column may be shorter)
     int total_segs;
@@ -225,7 +226,23 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
 
-    for (int i = tid; i < kWFloat4; i += 512) w4[i] = ((const f32x4*)p.wpk)[i];
+    {   // weights: global (packed) -> LDS, once; 7 loads in flight per thread (6912 float4 = 13.5 x 512)
+        static_assert(kWFloat4 == 13 * 512 + 256, "weight staging loop");
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 wv[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = tid + (half * 7 + u) * 512;
+                if (i < kWFloat4) wv[u] = ((const f32x4*)p.wpk)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = tid + (half * 7 + u) * 512;
+                if (i < kWFloat4) w4[i] = wv[u];
+            }
+        }
+    }
 
     int sdst[NLOAD], syi[NLOAD], szoff[NLOAD];
 #pragma unroll
@@ -243,7 +260,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     const size_t plane_stride = (size_t)p.Y * kTZ * p.in_cs;
 
     // per-column staging addresses (element offsets of plane x = 0), refreshed per segment
-    size_t coloff[NLOAD];
+    unsigned coloff[NLOAD];                  // < 2^32 elements: checked by the host
     bool colok[NLOAD];
     f32x4 v[NLOAD];
     auto issue = [&](int xi, int h) {        // global -> registers; xi inside the volume
@@ -326,7 +343,27 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
         }
     };
     // epilogue of acc2 (output plane x of column (b, yt)): lane -> voxel z = li, registers -> couts
-    // (r & 3) + 8 (r >> 2) + 4 kk, i.e. four float4 groups of consecutive channels per lane
+    // (r & 3) + 8 (r >> 2) + 4 kk, i.e. four float4 groups of consecutive channels per lane.  The residual rows
+    // are fetched one slab early (res_fetch) so their latency hides under 216 MFMAs.
+    f32x4 r1[4], r2[4];
+    f32x4* const bias4 = slab4 + ROWS * RS4 + 1;                        // 32 floats after the mailbox
+    if (tid < 8) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && 4 * tid < p.cout_store) bv = *(const f32x4*)(p.bias + 4 * tid);
+        bias4[tid] = bv;
+    }
+    auto res_fetch = [&](int b, int yt, int x) {
+        const int y = min(yt * kTY + wave, p.Y - 1);
+        const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * kTZ + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 8 * g + 4 * kk;
+            if (c < p.cout_store) {
+                if (p.res1 != nullptr) r1[g] = *(const f32x4*)(p.res1 + vox * p.res1_cs + p.res1_coff + c);
+                if (p.res2 != nullptr) r2[g] = *(const f32x4*)(p.res2 + vox * p.res2_cs + p.res2_coff + c);
+            }
+        }
+    };
     auto store2 = [&](int b, int yt, int x) {
         const int y = yt * kTY + wave;
         if (y < p.Y) {
@@ -336,12 +373,12 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
                 const int c = 8 * g + 4 * kk;
                 if (c < p.cout_store) {
                     f32x4 o = {acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]};
-                    if (p.bias != nullptr) o += *(const f32x4*)(p.bias + c);
+                    o += bias4[2 * g + kk];
                     if (p.act_out == OCCD_ACT_RELU_PRE) {
                         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
                     }
-                    if (p.res1 != nullptr) o += *(const f32x4*)(p.res1 + vox * p.res1_cs + p.res1_coff + c);
-                    if (p.res2 != nullptr) o += *(const f32x4*)(p.res2 + vox * p.res2_cs + p.res2_coff + c);
+                    if (p.res1 != nullptr) o += r1[g];
+                    if (p.res2 != nullptr) o += r2[g];
                     if (p.act_out == OCCD_ACT_RELU) {
                         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
                     }
@@ -356,7 +393,15 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
         if (tid == 0) mailbox[0] = atomicAdd(sp.counter, 1);
         __syncthreads();
         const int seg = mailbox[0];
-        if (seg >= sp.total_segs) break;
+        if (seg >= sp.total_segs) {
+            // the last workgroup to run dry re-arms the pair of counters for the next launch that uses this slot
+            if (tid == 0 && atomicAdd(sp.counter + 1, 1) == (int)gridDim.x - 1) {
+                sp.counter[1] = 0;
+                __threadfence();
+                atomicExch(sp.counter, 0);
+            }
+            break;
+        }
         // segments are ordered (b, range, ytile) with ytile fastest
         const int yt = seg % p.ytiles;
         const int rest = seg / p.ytiles;
@@ -367,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
         for (int i = 0; i < NLOAD; ++i) {
             const int y = yt * kTY - D + syi[i];
             colok[i] = szoff[i] >= 0 && y >= 0 && y < p.Y;
-            coloff[i] = ((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * kTZ * p.in_cs + p.in_coff + max(szoff[i], 0);
+            coloff[i] = (unsigned)(((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * kTZ * p.in_cs + p.in_coff + max(szoff[i], 0));
         }
         int q = q0;
         while (q < q1) {
@@ -400,12 +445,18 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
                         commit();
                         __syncthreads();
                         if (h == 0) issue(xi, 1);
-                        else if (j < jlast) issue(xi + D, 0);
+                        else {
+                            if (j < jlast) issue(xi + D, 0);
+                            if (u2) res_fetch(b, yt, xi - D);              // out[j-2] completes with this slab
+                        }
                         if (u0 && u1 && u2) mma3(h);
                         else mma_edge(h, u0, u1, u2);
                     }
                 }
-                if (u2) store2(b, yt, x0 + (j - 2) * D);
+                if (u2) {
+                    if (j < jfirst || j > jlast) res_fetch(b, yt, xi - D);   // padding plane: nothing was staged
+                    store2(b, yt, xi - D);
+                }
                 acc2 = acc1;
                 acc1 = acc0;
 #pragma unroll
@@ -416,22 +467,28 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
 }
 
 int* g_counter = nullptr;
+std::atomic<unsigned> g_slot{0};
 bool g_slide_attr[4] = {};
 
 template <int D>
 int launch_slide(const PersistP& base, hipStream_t st, int num_cu) {
     constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D);
-    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * 5 * 16 + 16;
+    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * 5 * 16 + 16 + 128;
     if (!g_slide_attr[D]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return OCCD_ELAUNCH;
         g_slide_attr[D] = true;
     }
-    if (g_counter == nullptr && hipMalloc(&g_counter, 256) != hipSuccess) return OCCD_ELAUNCH;
+    // a ring of self re-arming counter pairs: launches in flight on different streams never share one
+    constexpr int kSlots = 256;
+    if (g_counter == nullptr) {
+        if (hipMalloc(&g_counter, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
+        if (hipMemset(g_counter, 0, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
+    }
     SlideP sp;
     sp.base = base;
-    sp.counter = g_counter;
+    sp.counter = g_counter + 2 * (g_slot.fetch_add(1) % kSlots);
     // ranges per column: k rounds over the grid; a range of L planes costs L + 2 stagings per run (D > 1: up to two
     // runs).  Few long ranges amortise the two extra planes, but the list must fill whole rounds.
     const int cols = base.batch * base.ytiles;
@@ -450,7 +507,6 @@ int launch_slide(const PersistP& base, hipStream_t st, int num_cu) {
     sp.seg_len = (base.X + best_s - 1) / best_s;
     sp.segs_per_col = (base.X + sp.seg_len - 1) / sp.seg_len;
     sp.total_segs = cols * sp.segs_per_col;
-    if (hipMemsetAsync(g_counter, 0, sizeof(int), st) != hipSuccess) return OCCD_ELAUNCH;
     int grid = num_cu < sp.total_segs ? num_cu : sp.total_segs;
     hipLaunchKernelGGL(conv3d_c32_slide_kernel<D>, dim3((unsigned)grid), dim3(512), lds, st, sp);
     return occd::check_launch();
@@ -499,6 +555,7 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
     // enough tiles to keep every CU busy for several rounds, otherwise the generic kernel tiles finer
     const long tiles = (long)a->batch * a->X * ((a->Y + kTY - 1) / kTY);
     if (!(geom && shape && chans) || cin8 != 32 || tiles < 512 || a->tile_hint != 0) return 0;
+    if ((double)a->batch * a->X * a->Y * a->Z * a->in_cs >= 4294967296.0) return 0;   // 32-bit staging offsets
     PersistP p;
     p.in = a->in; p.wpk = a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
     p.batch = a->batch; p.X = a->X; p.Y = a->Y; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
