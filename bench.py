@@ -186,7 +186,7 @@ def main():
                                    "feature 64, flosp_depth + CRP + cascade head, 256x256x32 voxels, batch 1/GPU",
                        "frames_per_step": world, "parallelism": f"dp{world} (frames sharded, no collective)",
                        "batch_views": bool(model.batch_views)},
-            "roofline": {"bound": "mfma", "kernel": "conv3d_c32_persist_kernel: 3x3x3 32->32 @256x256x32 (v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "kernel": "conv3d_c32_slide_kernel: 3x3x3 32->32 @256x256x32 (v_mfma_f32_32x32x2_f32)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "launches": int(n_launch), "avg_launch_ms": ms / max(n_launch, 1),

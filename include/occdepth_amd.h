@@ -229,6 +229,37 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
 int occd_argmax_channels(const float* x, int64_t rows, int32_t cs, int32_t coff, int32_t C,
                          const uint16_t* lut, uint16_t* out, void* stream);
 
+/* SURVEY 8(f) row N1 (first step): the scene-completion losses of one training step as ONE pass over the
+ * logits.  Everything occdepth/loss/ssc_loss.py:17-99 (geo_scal_loss, sem_scal_loss, CE_ssc_loss) and the inline
+ * frustum-proportion loss of occdepth/models/OccDepth.py:487-521 compute is a function of these sums over voxels
+ * (p = softmax over C of logits (B, C, S); t = target (B, S) uint8, 255 = unlabelled; map_occ != 0 applies the
+ * cascade-head relabelling of OccDepth.py:413-415 to t first):
+ *   stats[0 .. C)        P[c]  = sum_{t != 255} p_c            Q32 fixed point
+ *   stats[C .. 2C)       N[c]  = sum_{t == c} p_c              Q32
+ *   stats[2C .. 3C)      T[c]  = #{t == c}                     exact
+ *   stats[3C]            M     = #{t != 255}                   exact
+ *   stats[3C + 1]        sum_{t != 255} w_t * (-log p_t)       Q24   (w = weights, NULL = 1)
+ *   stats[3C + 2]        sum_{t != 255} w_t                    Q24
+ *   stats[3C + 3 + f*C + c]  sum_{masks[b, f, s] != 0} p_c     Q32   (masks (B, F, S) bytes; all voxels, labelled
+ *                                                                     or not, as the reference)
+ * Integer accumulation: results are independent of the order of the atomics (deterministic).  C <= 32.        */
+int64_t occd_ssc_stats_len(int32_t C, int32_t F);
+int occd_ssc_loss_stats_fwd(const float* logits, const uint8_t* target, const uint8_t* masks,
+                            const float* weights, int64_t* stats, int64_t batch, int32_t C, int64_t S,
+                            int32_t F, int32_t map_occ, void* stream);
+/* grad (B, C, S) = d loss / d logits given gstats = d loss / d (the REAL-valued sums above, same layout; the
+ * entries of the counts are ignored):  grad_c = p_c (g_c - sum_k p_k g_k) + [t != 255] gstats[3C+1] w_t (p_c - [c == t])
+ * with g_c = [t != 255] (gP[c] + [t == c] gN[c]) + sum_{f : mask} gF[f][c].                                     */
+int occd_ssc_loss_stats_bwd(const float* logits, const uint8_t* target, const uint8_t* masks,
+                            const float* weights, const float* gstats, float* grad, int64_t batch, int32_t C,
+                            int64_t S, int32_t F, int32_t map_occ, void* stream);
+/* hist[t * C + pred] += 1 over voxels with t != 255 -- every counter
+ * occdepth/loss/sscMetrics.py:70-204 (SSCMetrics.add_batch) keeps derives from this matrix.  pred is either
+ * `labels` (B, S) uint8 or the arg-max over C of `logits` (B, C, S) (first maximum wins, as np.argmax in
+ * OccDepth.py:523-526); exactly one of the two is non-NULL.  hist is NOT cleared (it accumulates).         */
+int occd_ssc_confusion(const float* logits, const uint8_t* labels, const uint8_t* target, int64_t* hist,
+                       int64_t batch, int32_t C, int64_t S, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * In-library kernel timing (HIP events on the launch stream) used by bench.py
  * for `roofline.achieved`.  occd_prof_enable(1) starts recording one event pair

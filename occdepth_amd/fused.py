@@ -12,6 +12,25 @@ from . import hip
 from .hip import ACT_NONE, ACT_RELU, ACT_RELU_PRE, ACT_SIGMOID, Vox  # noqa: F401 (re-exported)
 
 
+_warned_eval_with_grad = False
+
+
+def needs_autograd(module):
+    """True when the differentiable ATen graph must be built (training, or eval with gradients enabled);
+    the HIP eval path is forward-only and is taken under torch.no_grad() / torch.inference_mode()."""
+    if module.training:
+        return True
+    if torch.is_grad_enabled():
+        global _warned_eval_with_grad
+        if not _warned_eval_with_grad:
+            _warned_eval_with_grad = True
+            import warnings
+            warnings.warn("occdepth_amd: eval-mode forward with autograd enabled runs the differentiable ATen path; "
+                          "wrap inference in torch.no_grad() to take the HIP eval path", stacklevel=3)
+        return True
+    return False
+
+
 def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * 3
 

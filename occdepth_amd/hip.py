@@ -96,6 +96,12 @@ EXPORTS = {
                             + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "occd_cascade_tail_fwd": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p]),
+    "occd_ssc_stats_len": (c_int64, [c_int32, c_int32]),
+    "occd_ssc_loss_stats_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
+                                          c_int32, c_int32, c_void_p]),
+    "occd_ssc_loss_stats_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                          c_int64, c_int32, c_int32, c_void_p]),
+    "occd_ssc_confusion": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
@@ -448,6 +454,78 @@ def argmax_labels(logits, lut=None):
     _check(load().occd_argmax_channels(cl.data_ptr(), rows, cs, 0, C, lut_t.data_ptr() if lut_t is not None else None,
                                        out.data_ptr(), _stream()), "occd_argmax_channels")
     return (out.to(torch.int32) & 0xFFFF).view(B, X, Y, Z)
+
+
+# ----------------------------------------------------------------------------- training-step statistics (N1 / N4)
+SSC_Q32 = 4294967296.0
+SSC_Q24 = 16777216.0
+
+
+def ssc_stats_scale(C, F, device):
+    """Multipliers that turn the fixed-point int64 statistics of occd_ssc_loss_stats_fwd into real sums."""
+    sc = torch.ones(3 * C + 3 + F * C, dtype=torch.float64)
+    sc[:2 * C] = 1.0 / SSC_Q32
+    sc[3 * C + 1:3 * C + 3] = 1.0 / SSC_Q24
+    sc[3 * C + 3:] = 1.0 / SSC_Q32
+    return sc.to(device)
+
+
+def _loss_operands(logits, target, masks, weights):
+    if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() < 3:
+        raise RuntimeError("ssc loss statistics need float32 GPU logits of shape (B, C, ...)")
+    B, C = logits.shape[:2]
+    S = logits[0, 0].numel()
+    if target.dtype != torch.uint8 or tuple(target.shape) != (B,) + tuple(logits.shape[2:]):
+        raise RuntimeError("target must be uint8 of shape (B, ...)")
+    F = 0
+    if masks is not None:
+        if masks.dtype not in (torch.bool, torch.uint8) or masks.shape[0] != B or masks[0, 0].numel() != S:
+            raise RuntimeError("frustum masks must be bool/uint8 of shape (B, F, ...)")
+        F = masks.shape[1]
+    if weights is not None and (weights.dtype != torch.float32 or weights.numel() != C):
+        raise RuntimeError("class weights must be float32 of length C")
+    return B, C, S, F
+
+
+def ssc_loss_stats(logits, target, masks=None, weights=None, map_occ=False):
+    """-> int64 (3C + 3 + F*C) fixed-point sums (see include/occdepth_amd.h); one pass over the logits."""
+    B, C, S, F = _loss_operands(logits, target, masks, weights)
+    stats = torch.empty(3 * C + 3 + F * C, dtype=torch.int64, device=logits.device)
+    _check(load().occd_ssc_loss_stats_fwd(_ptr(logits, "logits"), _ptr(target, "target"), _ptr(masks, "masks"),
+                                          _ptr(weights, "weights"), stats.data_ptr(), B, C, S, F, int(bool(map_occ)),
+                                          _stream()), "occd_ssc_loss_stats_fwd")
+    return stats
+
+
+def ssc_loss_grad(logits, target, masks, weights, gstats, map_occ=False):
+    """d loss / d logits from d loss / d sums (float32, the layout of ssc_loss_stats)."""
+    B, C, S, F = _loss_operands(logits, target, masks, weights)
+    if gstats.dtype != torch.float32 or gstats.numel() != 3 * C + 3 + F * C:
+        raise RuntimeError("gstats must be float32 of length 3C + 3 + F*C")
+    grad = torch.empty_like(logits)
+    _check(load().occd_ssc_loss_stats_bwd(_ptr(logits, "logits"), _ptr(target, "target"), _ptr(masks, "masks"),
+                                          _ptr(weights, "weights"), _ptr(gstats, "gstats"), grad.data_ptr(), B, C, S, F,
+                                          int(bool(map_occ)), _stream()), "occd_ssc_loss_stats_bwd")
+    return grad
+
+
+def ssc_confusion(hist, target, logits=None, labels=None):
+    """hist (C, C) int64 += confusion counts [target, prediction] over labelled voxels; the prediction is `labels`
+    (uint8) or the arg-max of `logits` (B, C, ...)."""
+    C = hist.shape[0]
+    if hist.dtype != torch.int64 or hist.shape != (C, C) or target.dtype != torch.uint8:
+        raise RuntimeError("hist must be int64 (C, C) and target uint8")
+    if (logits is None) == (labels is None):
+        raise RuntimeError("give exactly one of logits / labels")
+    B = target.shape[0]
+    S = target[0].numel()
+    if logits is not None and (logits.dtype != torch.float32 or logits.shape[:2] != (B, C) or logits[0, 0].numel() != S):
+        raise RuntimeError("logits must be float32 (B, C, ...) matching target")
+    if labels is not None and (labels.dtype != torch.uint8 or labels.shape != target.shape):
+        raise RuntimeError("labels must be uint8 with the shape of target")
+    _check(load().occd_ssc_confusion(_ptr(logits, "logits"), _ptr(labels, "labels"), _ptr(target, "target"),
+                                     _ptr(hist, "hist"), B, C, S, _stream()), "occd_ssc_confusion")
+    return hist
 
 
 def cascade_tail(part, occ_off, wn, nbr):

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows
+from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows, needs_autograd
 from .modules import ASPP, Process
 
 
@@ -92,7 +92,7 @@ class CPMegaVoxels(nn.Module):
         return {"P_logits": torch.cat(logits, dim=1), "x": x}
 
     def forward(self, input):
-        if self.training:
+        if needs_autograd(self):
             return self._forward_autograd(input)
         ret = self.forward_vox(as_vox(input))
         ret["x"] = ret["x"].ncdhw()

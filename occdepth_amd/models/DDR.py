@@ -14,7 +14,7 @@ k = stride = window convolutions.
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..fused import ACT_RELU, ConvPlan, as_vox
+from ..fused import ACT_RELU, ConvPlan, as_vox, needs_autograd
 
 
 def _axis(value, axis, other):
@@ -101,6 +101,6 @@ class Bottleneck3D(nn.Module):
         return F.relu(o5 + skip)
 
     def forward(self, x):
-        if self.training:
+        if needs_autograd(self):
             return self._forward_autograd(x)
         return self.forward_vox(as_vox(x)).ncdhw()

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..fused import needs_autograd
 from .SFA import SFA, lift_scales
 from .flosp_depth import flosp_depth_conf_map
 from .flosp_depth.flosp_depth import FlospDepth
@@ -105,11 +106,14 @@ class OccDepth(_Base):
             })
             self.flosp_depth_conf = conf
             self.flosp_depth = FlospDepth(**conf)
+            if self.with_depth_gt:
+                from ..loss.depth_loss import DepthClsLoss
+                self.depth_loss_fn = DepthClsLoss(downsample_factor=conf["downsample_factor"], d_bound=conf["d_bound"])
 
     # ---------------------------------------------------------------- 2-D side
     def process_rgbs(self, img, batch, n_views):
         bs = img.shape[0]
-        if not self.training and self.batch_views and n_views > 1:
+        if not needs_autograd(self) and self.batch_views and n_views > 1:
             # eval: BN uses running stats, so the views can share one batched pass (opt-in: a different
             # conv batch size changes backend algorithm choice and hence fp32 round-off)
             both = self.net_rgb(img.reshape(bs * n_views, *img.shape[2:]))
@@ -167,7 +171,7 @@ class OccDepth(_Base):
         depth_vol = depth_pred = None
         if self.trans_2d_to_3d == "flosp_depth":
             depth_vol, depth_pred = self._depth_volume(batch, x_rgb, vox_origin)
-        if not self.training:
+        if not needs_autograd(self):
             if key in batch:
                 pix = torch.stack([p.to(device) for p in batch[key]])
                 fov = torch.stack([m.to(device) for m in batch[mkey]])
@@ -230,17 +234,95 @@ class OccDepth(_Base):
         return out
 
     # ---------------------------------------------------------------- Lightning hooks
+    def _log(self, key, value):
+        self.logged[key] = value.detach()
+        self.log(key, value.detach(), on_epoch=True, sync_dist=True)
+
     def step(self, batch, step_type, metric):
-        raise NotImplementedError("loss / metric step is SURVEY.md 8(f) row N1 (training step), not built yet")
+        """Loss assembly of occdepth/models/OccDepth.py:378-533.  Same terms, same switches, same log keys; the
+        scene-completion terms (CE, sem_scal, geo_scal, frustum proportion) come from one statistics pass over
+        `ssc_logit` (loss/ssc_loss.py), and the metric update stays on the GPU (no `.cpu().numpy()` per step)."""
+        from ..loss import ssc_loss
+        from ..loss.CRP_loss import compute_super_CP_multilabel_loss
+        self.logged = {}
+        out_dict = self(batch)
+        ssc_pred = out_dict["ssc_logit"]
+        dev = ssc_pred.device
+        target = batch["target"].to(dev)
+        loss = 0
+        if self.context_prior and self.relation_loss:
+            loss_rel_ce = compute_super_CP_multilabel_loss(out_dict["P_logits"], batch["CP_mega_matrices"])
+            loss = loss + loss_rel_ce
+            self._log(step_type + "/loss_relation_ce_super", loss_rel_ce)
+
+        use_fp = self.fp_loss and step_type != "test"
+        masks = dists = None
+        if use_fp:
+            masks = torch.stack(list(batch["frustums_masks"])).to(dev)
+            dists = torch.stack(list(batch["frustums_class_dists"])).float().to(dev)
+        terms = ssc_loss.ssc_losses(ssc_pred, target, self.class_weights.to(dev).float(), masks, dists,
+                                    ce=self.CE_ssc_loss, sem_scal=self.sem_scal_loss, geo_scal=self.geo_scal_loss)
+        if self.CE_ssc_loss:
+            loss = loss + terms["loss_ssc"]
+            self._log(step_type + "/loss_ssc", terms["loss_ssc"])
+            if self.cascade_cls:
+                loss_occ = ssc_loss.occ_ce_loss(out_dict["occ_logit"], target, self.class_weights_occ.to(dev).float())
+                loss = loss + loss_occ
+                self._log(step_type + "/loss_occ", loss_occ)
+            if self.occluded_cls and "occluded" in batch:
+                loss_occluded = ssc_loss.CE_ssc_loss(out_dict["occluded_logit"], batch["occluded"].to(dev),
+                                                     torch.ones(2, device=dev))
+                loss = loss + loss_occluded
+                self._log(step_type + "/loss_occluded", loss_occluded)
+
+        if self.with_depth_gt and self.trans_2d_to_3d == "flosp_depth" and "gt_depth" in batch:
+            if self.use_stereo_depth_gt:
+                depth_pred = out_dict["depth_pred"][:, 0].unsqueeze(1)        # only the left camera has ground truth
+            elif self.use_lidar_depth_gt or self.use_depth_gt:
+                depth_pred = out_dict["depth_pred"]
+            else:
+                raise NotImplementedError("Only stereo depth gt supported.")
+            loss_depth = self.depth_loss_fn.get_depth_loss(batch["gt_depth"].to(dev), depth_pred) * self.depth_loss_w
+            loss = loss + loss_depth
+            self._log(step_type + "/loss_depth", loss_depth)
+
+        if self.sem_scal_loss:
+            decay = max(0.1, (1 - self.cur_batch / self.total_batch)) if self.sem_step_decay_loss else 1.0
+            loss_sem_scal = terms["loss_sem_scal"] * decay
+            loss = loss + loss_sem_scal
+            self._log(step_type + "/loss_sem_scal", loss_sem_scal)
+        if self.geo_scal_loss:
+            loss = loss + terms["loss_geo_scal"]
+            self._log(step_type + "/loss_geo_scal", terms["loss_geo_scal"])
+        if use_fp:
+            loss = loss + terms["loss_frustums"]
+            self._log(step_type + "/loss_frustums", terms["loss_frustums"])
+
+        if metric is not None:
+            if hasattr(metric, "add_batch_logits"):
+                metric.add_batch_logits(ssc_pred, target)
+            else:                                        # a reference-style (numpy) metric object
+                metric.add_batch(ssc_pred.detach().argmax(1).cpu().numpy(), target.cpu().numpy())
+        self._log(step_type + "/loss", loss)
+        return loss
+
+    def _metrics(self, name):
+        from ..loss.sscMetrics import SSCMetrics
+        if not hasattr(self, "_metric_objs"):
+            self._metric_objs = {}
+        if name not in self._metric_objs:
+            self._metric_objs[name] = SSCMetrics(self.n_classes)
+        return self._metric_objs[name]
 
     def training_step(self, batch, batch_idx):
-        return self.step(batch, "train", None)
+        self.cur_batch += 1
+        return self.step(batch, "train", self._metrics("train"))
 
     def validation_step(self, batch, batch_idx):
-        return self.step(batch, "val", None)
+        return self.step(batch, "val", self._metrics("val"))
 
     def test_step(self, batch, batch_idx):
-        return self.step(batch, "test", None)
+        return self.step(batch, "test", self._metrics("test"))
 
     def configure_optimizers(self):
         from torch.optim.lr_scheduler import MultiStepLR

@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
+from ..fused import needs_autograd
 from ..hip import Vox
 
 
@@ -50,7 +51,7 @@ class SFA(nn.Module):
         self.project_scale = project_scale
 
     def forward(self, x2d, projected_pix, fov_mask):
-        if self.training:
+        if needs_autograd(self):
             return self._forward_autograd(x2d, projected_pix, fov_mask)
         feats = [[x2d[v:v + 1] for v in range(x2d.shape[0])]]
         vox = lift_scales(feats, [1], projected_pix.unsqueeze(0), fov_mask.unsqueeze(0), self.scene_size,

@@ -15,12 +15,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from ..fused import bn_affine_cached
+from ..fused import bn_affine_cached, needs_autograd
 
 
 def _fast(x, module):
     """eval-mode CUDA tensors take the fused HIP elementwise / depthwise kernels (occdepth_amd/csrc/nchw2d.hip)."""
-    return x.is_cuda and not module.training and x.dtype == torch.float32
+    return x.is_cuda and not needs_autograd(module) and x.dtype == torch.float32
 
 # (block type, repeats, kernel, stride, expand, channels) of EfficientNet-B0
 _B0_STAGES = (("ds", 1, 3, 1, 1, 16), ("ir", 2, 3, 2, 6, 24), ("ir", 2, 5, 2, 6, 40), ("ir", 3, 3, 2, 6, 80),

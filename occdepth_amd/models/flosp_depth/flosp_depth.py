@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import hip
-from ...fused import bn_affine_cached
+from ...fused import bn_affine_cached, needs_autograd
 
 
 class BasicBlock(nn.Module):
@@ -29,7 +29,7 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
 
     def forward(self, x):
-        if x.is_cuda and not self.training and x.dtype == torch.float32:
+        if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
             y = hip.affine_act(self.conv1(x), *bn_affine_cached(self.bn1), "relu")
             return hip.affine_act(self.conv2(y), *bn_affine_cached(self.bn2), "relu", res=x, res_first=True)
         out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
@@ -91,7 +91,7 @@ class DepthNet(nn.Module):
     def forward(self, x=None, sweep_intrins=None, scaled_pixel_size=None, scale_depth_factor=1000.0):
         if not self.infer_mode:
             scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
-                                                       sync_free=sweep_intrins.is_cuda and not self.training)
+                                                       sync_free=sweep_intrins.is_cuda and not needs_autograd(self))
         x = self.reduce_conv(x)
         x = self.se(x, self.mlp(scaled_pixel_size)[..., None, None])
         return self.depth_pred(self.depth_conv(x))
@@ -177,7 +177,7 @@ class FlospDepth(nn.Module):
             logits = self.depth_net[0](x=feat, sweep_intrins=intrins, scaled_pixel_size=None)
         depth = logits.softmax(1).reshape(bs, n_cams, self.depth_channels, h, w)
 
-        if self.training:
+        if needs_autograd(self):
             vox = self._sample_autograd(depth, None if self.infer_mode else (t_v2c, intrins, ida), grids)
         else:
             dvol = depth.float().contiguous()

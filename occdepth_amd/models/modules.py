@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox
+from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox, needs_autograd
 from .DDR import Bottleneck3D
 
 
@@ -66,7 +66,7 @@ class ASPP(_DilatedBranches):
         return self._branches_vox(self._plans, x)
 
     def forward(self, x_in):
-        if self.training:
+        if needs_autograd(self):
             return self._branches_autograd(x_in)
         return self.forward_vox(as_vox(x_in)).ncdhw()
 
@@ -105,7 +105,7 @@ class SegmentationHead(_HeadBase):
         return self._plans["cls"](feat)
 
     def forward(self, x_in):
-        if self.training:
+        if needs_autograd(self):
             return self.conv_classes(self._trunk_autograd(x_in))
         return self.forward_vox(as_vox(x_in)).ncdhw()
 
@@ -138,7 +138,7 @@ class SegmentationHeadCascadeCLS(_HeadBase):
         return ssc, occ
 
     def forward(self, x_in):
-        if self.training:
+        if needs_autograd(self):
             feat = self._trunk_autograd(x_in)
             x_occ = self.occ_classes(feat)
             return self.conv_classes(torch.cat([feat, self.softmax(x_occ)], dim=1)), x_occ
@@ -160,7 +160,7 @@ class SegmentationHeadOccludedCLS(_HeadBase):
         return self._plans["occ"](feat)
 
     def forward(self, x_in):
-        if self.training:
+        if needs_autograd(self):
             return self.occ_classes(self._trunk_autograd(x_in))
         return self.forward_vox(as_vox(x_in)).ncdhw()
 
@@ -178,7 +178,7 @@ class Process(nn.Module):
         return x
 
     def forward(self, x):
-        if self.training:
+        if needs_autograd(self):
             return self.main(x)
         return self.forward_vox(as_vox(x)).ncdhw()
 
@@ -203,7 +203,7 @@ class _TransposedBlock(nn.Module):
         return self._plan(x, res1=skip, act_out=ACT_RELU_PRE)
 
     def forward(self, x):
-        if self.training:
+        if needs_autograd(self):
             return self.main(x)
         return self.forward_vox(as_vox(x)).ncdhw()
 
@@ -235,6 +235,6 @@ class Downsample(nn.Module):
         return self.main.forward_vox(x)
 
     def forward(self, x):
-        if self.training:
+        if needs_autograd(self):
             return self.main(x)
         return self.forward_vox(as_vox(x)).ncdhw()

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from ..fused import bn_affine_cached
+from ..fused import bn_affine_cached, needs_autograd
 from .efficientnet import EfficientNet
 
 MODEL_NAME = "tf_efficientnet_b3_ns"
@@ -41,7 +41,7 @@ class UpSampleBN(nn.Module):
         self._net = nn.Sequential(*layers)
 
     def forward(self, x, concat_with):
-        if x.is_cuda and not self.training and x.dtype == torch.float32:
+        if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
             # eval: bilinear-up + concat in one HIP pass, BatchNorm + LeakyReLU fused behind each MIOpen conv
             f = hip.upsample_bilinear_cat(x, concat_with)
             n = self._net

@@ -8,7 +8,7 @@ tensors are logical (B, C, X, Y, Z) views with channels_last_3d strides.
 """
 import torch.nn as nn
 
-from ..fused import as_vox
+from ..fused import as_vox, needs_autograd
 from .CRP3D import CPMegaVoxels
 from .modules import (Convblock3d, Downsample, Process, SegmentationHead, SegmentationHeadCascadeCLS,
                       SegmentationHeadOccludedCLS, Upsample)
@@ -106,6 +106,6 @@ class UNet3D(nn.Module):
 
     def forward(self, input_dict):
         x = input_dict["x3d"]
-        if self.training:
+        if needs_autograd(self):
             return self._forward_autograd(x)
         return self._forward_vox(as_vox(x))

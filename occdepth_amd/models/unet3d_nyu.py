@@ -3,7 +3,7 @@ final x2 upsampling -- the head runs at the lift resolution -- and with `n_relat
 import numpy as np
 import torch.nn as nn
 
-from ..fused import as_vox
+from ..fused import as_vox, needs_autograd
 from .CRP3D import CPMegaVoxels
 from .modules import Downsample, Process, SegmentationHead, SegmentationHeadCascadeCLS, Upsample
 
@@ -82,6 +82,6 @@ class UNet3D(nn.Module):
 
     def forward(self, input_dict):
         x = input_dict["x3d"]
-        if self.training:
+        if needs_autograd(self):
             return self._forward_autograd(x)
         return self._forward_vox(as_vox(x))

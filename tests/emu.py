@@ -158,10 +158,74 @@ def cascade_tail(part, occ_off, wn, nbr):
     return out
 
 
+def _softmax_and_target(logits, target, map_occ):
+    B, C = logits.shape[:2]
+    p = F.softmax(logits.detach().double().reshape(B, C, -1), 1)        # (B, C, S)
+    t = target.reshape(B, -1).long()
+    if map_occ:
+        t = torch.where((t != 0) & (t != 255), torch.ones_like(t), t)
+    return p, t
+
+
+def ssc_loss_stats(logits, target, masks=None, weights=None, map_occ=False):
+    """Fixed-point statistics exactly as include/occdepth_amd.h lays them out (float64 math, then quantised)."""
+    B, C = logits.shape[:2]
+    p, t = _softmax_and_target(logits, target, map_occ)
+    lab = (t != 255)
+    w = torch.ones(C, dtype=torch.float64) if weights is None else weights.double()
+    onehot = torch.zeros(B, C, t.shape[1], dtype=torch.float64)
+    onehot.scatter_(1, t.clamp(max=C - 1).unsqueeze(1), 1.0)
+    onehot = onehot * (lab & (t < C)).unsqueeze(1)
+    P = (p * lab.unsqueeze(1)).sum((0, 2))
+    N = (p * onehot).sum((0, 2))
+    T = onehot.sum((0, 2))
+    M = lab.sum().double()
+    logp = torch.log_softmax(logits.detach().float().reshape(B, C, -1), 1).double()
+    wt = (onehot * w.view(1, C, 1)).sum(1)
+    num = -(logp * onehot).sum(1).mul(wt).sum()
+    den = wt.sum()
+    parts = [P * hip.SSC_Q32, N * hip.SSC_Q32, T, M.view(1), (num * hip.SSC_Q24).view(1), (den * hip.SSC_Q24).view(1)]
+    if masks is not None:
+        m = masks.reshape(B, masks.shape[1], -1).double()
+        parts.append((torch.einsum("bfs,bcs->fc", m, p) * hip.SSC_Q32).reshape(-1))
+    return torch.cat(parts).round().to(torch.int64)
+
+
+def ssc_loss_grad(logits, target, masks, weights, gstats, map_occ=False):
+    B, C = logits.shape[:2]
+    p, t = _softmax_and_target(logits, target, map_occ)
+    lab = (t != 255)
+    g = gstats.double()
+    onehot = torch.zeros_like(p)
+    onehot.scatter_(1, t.clamp(max=C - 1).unsqueeze(1), 1.0)
+    onehot = onehot * (lab & (t < C)).unsqueeze(1)
+    gv = lab.unsqueeze(1) * g[:C].view(1, C, 1) + onehot * g[C:2 * C].view(1, C, 1)
+    if masks is not None:
+        m = masks.reshape(B, masks.shape[1], -1).double()
+        gv = gv + torch.einsum("bfs,fc->bcs", m, g[3 * C + 3:].view(-1, C))
+    dot = (p * gv).sum(1, keepdim=True)
+    w = torch.ones(C, dtype=torch.float64) if weights is None else weights.double()
+    wt = (onehot * w.view(1, C, 1)).sum(1, keepdim=True)
+    grad = p * (gv - dot) + g[3 * C + 1] * wt * (p * onehot.sum(1, keepdim=True) - onehot)
+    return grad.float().reshape(logits.shape)
+
+
+def ssc_confusion(hist, target, logits=None, labels=None):
+    C = hist.shape[0]
+    t = target.reshape(-1).long()
+    pred = labels.reshape(-1).long() if labels is not None else \
+        logits.reshape(logits.shape[0], C, -1).argmax(1).reshape(-1)
+    keep = (t != 255) & (t < C) & (pred < C)
+    hist += torch.bincount(t[keep] * C + pred[keep], minlength=C * C).reshape(C, C)
+    return hist
+
+
 @contextlib.contextmanager
 def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
-                                          "flosp_sample", "lift", "cascade_tail")}
+                                          "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
+                                          "ssc_confusion")}
+    hip.ssc_loss_stats, hip.ssc_loss_grad, hip.ssc_confusion = ssc_loss_stats, ssc_loss_grad, ssc_confusion
     saved_from = Vox.from_ncdhw
     saved_as_vox = fused.as_vox
     hip.pack_weights, hip.conv3d, hip.nchw_to_nhwc = pack_weights, conv3d, nchw_to_nhwc

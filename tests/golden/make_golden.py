@@ -232,9 +232,107 @@ def case_occdepth_nyu():
     _full_case("nyu_2080ti", "config-1 (NYU)")
 
 
+def case_losses():
+    """Training-step losses (N1) and SSC metrics (N4): the reference's own functions, and its `OccDepth.step`
+    with the forward pass replaced by a fixed out_dict, on the seeded inputs of golden_cases.loss_case."""
+    import occdepth.loss.ssc_loss as ref_ssc
+    import occdepth.loss.CRP_loss as ref_crp_loss
+    import occdepth.loss.depth_loss as ref_depth
+    import occdepth.loss.sscMetrics as ref_metrics
+    arrays = {}
+    for name, cfg_name in (("kitti_like", "kitti_small"), ("nyu_like", "nyu_small")):
+        d = gc.loss_case(name)
+        ssc, tgt = d["ssc_logit"], d["target"]
+        arrays[f"{name}.ce"] = np.float64(ref_ssc.CE_ssc_loss(ssc, tgt, d["class_weights"]))
+        arrays[f"{name}.sem_scal"] = np.float64(ref_ssc.sem_scal_loss(ssc, tgt))
+        arrays[f"{name}.geo_scal"] = np.float64(ref_ssc.geo_scal_loss(ssc, tgt))
+        arrays[f"{name}.relation"] = np.float64(ref_crp_loss.compute_super_CP_multilabel_loss(d["P_logits"],
+                                                                                             d["CP_mega_matrices"]))
+        dl = ref_depth.DepthClsLoss(d["depth_factor"], d["d_bound"])
+        arrays[f"{name}.depth"] = np.float64(dl.get_depth_loss(d["gt_depth"], d["depth_pred"]))
+        arrays[f"{name}.depth_onehot"] = _np(dl._get_downsampled_gt_depth(
+            d["gt_depth"][:, :, : d["depth_pred"].shape[3] * d["depth_factor"], : d["depth_pred"].shape[4] * d["depth_factor"]]
+            .contiguous()))
+        # the step itself: every loss the shipped config switches on + the inline frustum loss + the metric update
+        m, cfg, _ = _build_ref_occdepth(cfg_name, {})
+        m.class_weights, m.class_weights_occ = d["class_weights"], d["class_weights_occ"]
+        if hasattr(m, "depth_loss_fn"):
+            m.depth_loss_fn = dl
+        leaves = {k: d[k].clone().requires_grad_(True) for k in ("ssc_logit", "occ_logit", "P_logits", "depth_pred")}
+        m.forward = lambda batch: dict(leaves)
+        logged = {}
+        m.log = lambda key, val, **kw: logged.__setitem__(key, float(val))
+        bs = ssc.shape[0]
+        batch = {"img": torch.zeros(bs, 1), "target": tgt, "CP_mega_matrices": d["CP_mega_matrices"],
+                 "gt_depth": d["gt_depth"], "frustums_masks": list(d["frustums_masks"]),
+                 "frustums_class_dists": list(d["frustums_class_dists"])}
+        metric = ref_metrics.SSCMetrics(d["n_classes"])
+        m.cur_batch = 7
+        loss = m.step(batch, "train", metric)
+        loss.backward()
+        for k, v in logged.items():
+            arrays[f"{name}.step.{k}"] = np.float64(v)
+        arrays[f"{name}.step.total"] = np.float64(loss.detach())
+        for k, t in leaves.items():
+            if t.grad is not None:
+                arrays[f"{name}.grad.{k}"] = _np(t.grad)
+        st = metric.get_stats()
+        for k in ("precision", "recall", "iou", "iou_ssc_mean"):
+            arrays[f"{name}.metric.{k}"] = np.float64(st[k])
+        arrays[f"{name}.metric.iou_ssc"] = np.asarray(st["iou_ssc"], np.float64)
+        arrays[f"{name}.metric.tps"] = np.asarray(metric.tps, np.float64)
+        arrays[f"{name}.metric.fps"] = np.asarray(metric.fps, np.float64)
+        arrays[f"{name}.metric.fns"] = np.asarray(metric.fns, np.float64)
+        arrays[f"{name}.metric.completion"] = np.array([metric.completion_tp, metric.completion_fp,
+                                                         metric.completion_fn], np.float64)
+        print(name, {k: round(v, 5) for k, v in logged.items()})
+    _save("losses", arrays)
+
+
+def case_train_step():
+    """End-to-end step (N1): forward + the reference's own `step` + backward on the small configs, BatchNorm in
+    eval mode (running statistics) so that the result is a deterministic function of the stored state."""
+    import occdepth.loss.sscMetrics as ref_metrics
+    arrays = {}
+    for cfg_name in ("kitti_small", "nyu_small"):
+        m, cfg, batch = _build_ref_occdepth(cfg_name, {})
+        m.eval()
+        # random-init classifier convolutions give logits of +-300 (softmax in float32 denormals): scale them so
+        # that the step is conditioned like a real one; the scaled tensors travel in the fixture
+        with torch.no_grad():
+            for k, p_ in m.named_parameters():
+                if gc.is_classifier_param(k):
+                    p_.mul_(gc.CLASSIFIER_SCALE)
+                    arrays[f"{cfg_name}.override.{k}"] = _np(p_)
+            out = m(batch)
+        print(cfg_name, "ssc_logit absmax", float(out["ssc_logit"].abs().max()))
+        shapes = {k: tuple(v.shape) for k, v in out.items() if torch.is_tensor(v)}
+        extras = gc.train_extras(cfg_name, shapes, tuple(cfg.full_scene_size), cfg.n_classes, batch["img"].shape[-2:])
+        batch = dict(batch, **extras)
+        logged = {}
+        m.log = lambda key, val, **kw: logged.__setitem__(key, float(val))
+        metric = ref_metrics.SSCMetrics(cfg.n_classes)
+        m.cur_batch = 3
+        m.zero_grad()
+        loss = m.step(batch, "train", metric)
+        loss.backward()
+        grads = {k: p.grad for k, p in m.named_parameters()}
+        for k, v in logged.items():
+            arrays[f"{cfg_name}.{k}"] = np.float64(v)
+        arrays[f"{cfg_name}.no_grad_keys"] = np.frombuffer(
+            json.dumps(sorted(k for k, g in grads.items() if g is None)).encode(), dtype=np.uint8)
+        for k in gc.pick_grad_keys(grads):
+            arrays[f"{cfg_name}.grad.{k}"] = _np(grads[k]).reshape(-1)[:4096]
+            arrays[f"{cfg_name}.gradnorm.{k}"] = np.float64(grads[k].double().norm())
+        arrays[f"{cfg_name}.metric.tps"] = np.asarray(metric.tps, np.float64)
+        print(cfg_name, {k: round(v, 5) for k, v in logged.items()}, "params without grad:",
+              sum(g is None for g in grads.values()), "/", len(grads))
+    _save("train_step_small", arrays)
+
+
 CASES = {"sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "flosp": case_flosp,
          "decoder2d": case_decoder2d, "occdepth_small": case_occdepth_small, "occdepth_full": case_occdepth_full,
-         "occdepth_nyu": case_occdepth_nyu}
+         "occdepth_nyu": case_occdepth_nyu, "losses": case_losses, "train_step": case_train_step}
 
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())

@@ -142,3 +142,93 @@ def maybe_subsample(a, limit=60000):
         return a
     r = subsample(t)
     return r.numpy() if isinstance(a, np.ndarray) else r
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training-step inputs (N1): logits / targets / frustum masks / relation matrices / depth maps, all from seeds
+LOSS_CASES = {
+    # name: (bs, n_classes, (X, Y, Z), n_frustums per side, n_relations, (mega voxels, N), depth (ncam, D, h, w, factor))
+    "kitti_like": (2, 20, (16, 16, 8), 4, 4, (24, 40), (1, 24, 6, 10, 4)),
+    "nyu_like": (1, 12, (10, 6, 10), 2, 4, (15, 30), (2, 24, 5, 7, 4)),
+}
+LOSS_D_BOUND = [2.0, 14.0, 0.5]
+
+
+def loss_case(name):
+    """Seeded inputs of one training step.  Some classes are absent from the target, a band of voxels is
+    unlabelled (255), one frustum is empty and one has no ground-truth counts: every branch of the reference runs."""
+    import torch
+    bs, c, dims, fside, nrel, (mega, nvox), (ncam, dbins, dh, dw, factor) = LOSS_CASES[name]
+    g = torch.Generator().manual_seed(SEED + 17 + len(name))
+    ssc = torch.randn(bs, c, *dims, generator=g) * 2.0
+    occ = torch.randn(bs, 2, *dims, generator=g)
+    present = [0, 1, 2, 3, 5, 8, c - 1]                           # the other classes never appear
+    target = torch.tensor(present)[torch.randint(0, len(present), (bs, *dims), generator=g)]
+    target[torch.rand(bs, *dims, generator=g) < 0.55] = 0         # mostly empty, like a real scene
+    target[:, :, :, : dims[2] // 4][torch.rand(bs, dims[0], dims[1], dims[2] // 4, generator=g) < 0.7] = 255
+    # frustums: fside x fside image-plane grid; a voxel belongs to at most one frustum
+    nf = fside * fside
+    fid = torch.randint(0, nf + 2, (bs, *dims), generator=g)      # ids nf, nf+1: outside the field of view
+    masks = torch.stack([fid == f for f in range(nf)], 1)         # (bs, F, X, Y, Z) bool
+    masks[:, 1] = False                                           # an empty frustum (total_prob == 0)
+    dists = torch.zeros(bs, nf, c)
+    for b in range(bs):
+        for f in range(nf):
+            sel = masks[b, f] & (target[b] != 255)
+            dists[b, f] = torch.bincount(target[b][sel], minlength=c).float()
+    dists[:, 2] = 0                                               # a frustum without any count (total_cnt == 0)
+    p_logits = torch.randn(bs, nrel, mega, nvox, generator=g)
+    cp = [(torch.rand(nrel, nvox, mega, generator=g) < 0.2).float() for _ in range(bs)]
+    depth_pred = torch.softmax(torch.randn(bs, ncam, dbins, dh, dw, generator=g), 2)
+    gt_depth = torch.rand(bs, ncam, dh * factor + 3, dw * factor + 5, generator=g) * 16.0
+    gt_depth[torch.rand(gt_depth.shape, generator=g) < 0.6] = 0.0  # sparse lidar-like ground truth
+    weights = 0.5 + torch.rand(c, generator=g) * 2.0
+    weights_occ = torch.tensor([0.7, 1.9])
+    return {"ssc_logit": ssc, "occ_logit": occ, "target": target, "frustums_masks": masks,
+            "frustums_class_dists": dists, "P_logits": p_logits, "CP_mega_matrices": cp, "depth_pred": depth_pred,
+            "gt_depth": gt_depth, "class_weights": weights, "class_weights_occ": weights_occ,
+            "depth_factor": factor, "d_bound": LOSS_D_BOUND, "n_classes": c}
+
+
+def train_extras(cfg_name, out_shapes, scene, n_classes, img_hw):
+    """Seeded training-only batch entries for an end-to-end step of a small config: target, frustum masks and
+    class distributions, relation matrices (shaped after the model's P_logits), sparse ground-truth depth."""
+    import torch
+    g = torch.Generator().manual_seed(SEED + 101 + len(cfg_name))
+    bs = 1
+    target = torch.randint(0, n_classes, (bs, *scene), generator=g)
+    target[torch.rand(bs, *scene, generator=g) < 0.5] = 0
+    target[torch.rand(bs, *scene, generator=g) < 0.15] = 255
+    nf = 4
+    fid = torch.randint(0, nf + 1, (bs, *scene), generator=g)
+    masks = torch.stack([fid == f for f in range(nf)], 1)
+    dists = torch.zeros(bs, nf, n_classes)
+    for f in range(nf):
+        sel = masks[0, f] & (target[0] != 255)
+        dists[0, f] = torch.bincount(target[0][sel], minlength=n_classes).float()
+    extras = {"target": target.to(torch.uint8), "frustums_masks": list(masks), "frustums_class_dists": list(dists)}
+    if "P_logits" in out_shapes:
+        _, r, a, b = out_shapes["P_logits"]
+        extras["CP_mega_matrices"] = [(torch.rand(r, b, a, generator=g) < 0.3).float() for _ in range(bs)]
+    if "depth_pred" in out_shapes:
+        gt = torch.rand(bs, 1, *img_hw, generator=g) * 14.0 + 1.0
+        gt[torch.rand(gt.shape, generator=g) < 0.7] = 0.0
+        extras["gt_depth"] = gt
+    return extras
+
+
+TRAIN_GRAD_KEYS = 12      # parameters (sorted by name, evenly spaced) whose gradients are stored in the fixture
+
+
+def pick_grad_keys(named_grads):
+    keys = sorted(k for k, g in named_grads.items() if g is not None)
+    step = max(1, len(keys) // TRAIN_GRAD_KEYS)
+    return keys[::step][:TRAIN_GRAD_KEYS]
+
+
+CLASSIFIER_SCALE = 0.02
+
+
+def is_classifier_param(key):
+    import re
+    return re.search(r"(conv_classes|occ_classes)\.(weight|bias)$", key) is not None

@@ -16,8 +16,11 @@ from test_oracle_vs_golden import (_block_module, _unet3d_module, build_product,
 
 def test_product_refuses_cpu_tensors_without_emulation():
     m = _block_module("bottleneck_d2").eval()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError), torch.no_grad():       # the forward-only HIP eval path: no CPU implementation
         m(torch.zeros(1, 32, 4, 4, 4))
+    from occdepth_amd.loss import ssc_loss
+    with pytest.raises(RuntimeError):                          # the loss statistics kernels likewise
+        ssc_loss.CE_ssc_loss(torch.zeros(1, 3, 2, 2, 2), torch.zeros(1, 2, 2, 2, dtype=torch.uint8), torch.ones(3))
 
 
 @pytest.mark.parametrize("name", list(gc.BLOCK_CASES))

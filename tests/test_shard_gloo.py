@@ -67,3 +67,67 @@ def test_shards_partition_the_frames():
         got = sorted(i for r in range(world) for i in shard.frames_for_rank(11, r, world))
         assert got == list(range(11))
     assert shard.max_over_ranks(3.5) == 3.5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _toy():
+    torch.manual_seed(4)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                            torch.nn.Linear(16, 3))
+    m.unused = torch.nn.Parameter(torch.ones(5))              # never touched by forward (cf. SURVEY 2.1 dead branches)
+    return m
+
+
+def _toy_batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(7, 6, generator=g), torch.randn(7, 3, generator=g)
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _toy()
+    buckets = shard.GradBuckets(m.parameters(), dist, bucket_bytes=600)      # several small buckets
+    out = []
+    for step in range(2):                                                    # buckets are reusable
+        m.zero_grad(set_to_none=True)
+        x, y = _toy_batch(rank + 10 * step)
+        ((m(x) - y) ** 2).mean().backward()
+        buckets.finish()
+        out.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    hist = torch.full((3, 3), rank + 1, dtype=torch.int64)
+    shard.allreduce_confusion(hist, dist)
+    q.put((rank, out, hist, len(buckets.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_buckets_average_like_one_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        rank, out, hist, nb = q.get(timeout=120)
+        got[rank] = (out, hist, nb)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][2] > 2                                                     # the toy really spans several buckets
+    assert torch.equal(got[0][1], torch.full((3, 3), 3, dtype=torch.int64))
+    for step in range(2):
+        want = None
+        for r in range(world):                                               # single-process mean of the per-rank grads
+            m = _toy()
+            x, y = _toy_batch(r + 10 * step)
+            ((m(x) - y) ** 2).mean().backward()
+            g = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+            want = g if want is None else {k: want[k] + g[k] for k in g}
+        for r in range(world):
+            for k, v in got[r][0][step].items():
+                assert torch.allclose(v, want[k] / world, atol=1e-7), (step, r, k)

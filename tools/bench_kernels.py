@@ -119,8 +119,72 @@ def bench_dec2d():
             print(f"dec2d {cin}->{cout} @{H}x{W} B=2 hint={h}: {t:.3f} ms {fl / t / 1e9:6.1f} TF/s", flush=True)
 
 
+def bench_loss():
+    """One training step's scene-completion losses at config-2 size: the statistics path (K5 + K6) against the
+    reference's formulation (a softmax per loss, 20-class loop, 64-frustum loop) written with the same torch ops."""
+    import torch.nn.functional as F
+    from occdepth_amd.loss import ssc_loss
+    B, C, dims, NF = 1, 20, (256, 256, 32), 64
+    logits = (torch.randn(B, C, *dims, device="cuda") * 2).requires_grad_(True)
+    target = torch.randint(0, C, (B, *dims), device="cuda").to(torch.uint8)
+    target[torch.rand(B, *dims, device="cuda") < 0.2] = 255
+    fid = torch.randint(0, NF + 8, (B, *dims), device="cuda")
+    masks = torch.stack([fid == f for f in range(NF)], 1)
+    dists = torch.rand(B, NF, C, device="cuda")
+    w = torch.rand(C, device="cuda") + 0.5
+
+    def ours():
+        logits.grad = None
+        sum(ssc_loss.ssc_losses(logits, target, w, masks, dists).values()).backward()
+
+    def reference_form():
+        logits.grad = None
+        t = target.long()
+        loss = F.cross_entropy(logits, t, weight=w, ignore_index=255)
+        mask = t != 255
+        p = F.softmax(logits, 1)
+        tm = t[mask]
+        sem, cnt = 0, 0
+        for i in range(C):                                     # ssc_loss.py:44-87
+            pi = p[:, i][mask]
+            ct = (tm == i).float()
+            if ct.sum() > 0:
+                cnt += 1
+                nom = (pi * ct).sum()
+                sem = sem - torch.log(nom / pi.sum()) - torch.log(nom / ct.sum()) \
+                    - torch.log(((1 - pi) * (1 - ct)).sum() / (1 - ct).sum())
+        loss = loss + sem / cnt
+        p2 = F.softmax(logits, 1)                              # geo_scal: ssc_loss.py:17-41
+        e = p2[:, 0][mask]
+        nt = (tm != 0).float()
+        inter = (nt * (1 - e)).sum()
+        loss = loss - torch.log(inter / (1 - e).sum()) - torch.log(inter / nt.sum()) \
+            - torch.log(((1 - nt) * e).sum() / (1 - nt).sum())
+        p3 = F.softmax(logits, 1)                              # frustums: OccDepth.py:487-521
+        cntf = dists.sum(0)
+        fl, ne = 0, 0
+        for f in range(NF):
+            prob = (masks[:, f].unsqueeze(1).float() * p3).reshape(B, C, -1).permute(1, 0, 2).reshape(C, -1)
+            cum = prob.sum(1)
+            tp = prob.sum()
+            if tp > 0 and cntf[f].sum() > 0:
+                tgt = cntf[f] / cntf[f].sum()
+                fl = fl + (tgt * (torch.log(tgt) - torch.log(cum / tp))).sum()
+                ne += 1
+        (loss + fl / ne).backward()
+
+    ms = time_many({"hip statistics path (fwd+bwd)": ours, "reference formulation in torch (fwd+bwd)": reference_form},
+                   rounds=3, iters=2)
+    for k, t in ms.items():
+        print(f"loss step @(1,20,256,256,32), 64 frustums: {k}: {t:.3f} ms", flush=True)
+    with hip.profile() as prof:
+        ours()
+    for k, v in prof.rows.items():
+        print(f"  {k:40s} n={v['launches']:3d} {v['ms']:7.3f} ms  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:7.1f} GB/s")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     what = sys.argv[1:] or ["head", "aspp", "lift", "stack"]
     for w in what:
-        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack, "dec2d": bench_dec2d}[w]()
+        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack, "dec2d": bench_dec2d, "loss": bench_loss}[w]()

@@ -2,7 +2,7 @@
 
 The first forward of a process runs MIOpen's first-call fallbacks (naive convolutions, 25 ms each) and hipcc-free
 JIT lookups; `--stats` mixes them into the averages.  This script keeps only the last N forwards, delimited by the
-persistent head kernel `conv3d_c32_persist_kernel<1>` (4 launches per forward: conv0, conv1.0, conv2.0, wide cls).
+persistent head kernel `conv3d_c32_slide_kernel<1>` (4 launches per forward: conv0, conv1.0, conv2.0, wide cls).
 
     python tools/summarize_trace.py <kernel_trace.csv> <out.csv> [n_forwards=5]
 """
@@ -15,7 +15,7 @@ from collections import defaultdict
 def main(path, out, n_fwd=5):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "conv3d_c32_persist_kernel<1>" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "conv3d_c32_slide_kernel<1>" in r["Kernel_Name"]]
     assert len(marks) >= 4 * (n_fwd + 1), "not enough forwards in the trace"
     # a forward ends with its 4th <1> launch (+ the cascade tail right after); start after forward (F - n_fwd)'s end
     fwd_ends = marks[3::4]
@@ -25,7 +25,7 @@ def main(path, out, n_fwd=5):
     agg = defaultdict(lambda: [0, 0.0])
     for r in sel:
         n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-        n = re.sub(r"\((ConvP|LiftP|FlospP|PersistP)\)", "", n)[:110]
+        n = re.sub(r"\((ConvP|LiftP|FlospP|PersistP|SlideP)\)", "", n)[:110]
         a = agg[n]
         a[0] += 1
         a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
