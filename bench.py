@@ -58,10 +58,19 @@ def to_dev(batch, device):
     return out
 
 
-def cpu_baseline(model, cfg, batch_cpu, budget_s=45.0):
-    """The CPU oracle on the host cores, same weights / inputs as the GPU run (reported, not a target)."""
+def cpu_baseline(model, cfg, batch, seed, budget_s=45.0):
+    """The CPU oracle on the host cores, same weights / inputs as the GPU run (reported, not a target).
+    This leg is the only place bench.py touches oracle/: the oracle builds its own batch from the same seed
+    (numpy restatement of the dataloader's vox2pix) and it must equal the GPU-projected one bit for bit."""
     import copy
+    from oracle import inputs
     from oracle import occdepth_oracle as orc
+    batch_cpu = inputs.kitti_batch(seed=seed)
+    for k, v in batch_cpu.items():
+        got = batch[k]
+        same = all(torch.equal(a.cpu(), b) for a, b in zip(got, v)) if isinstance(v, list) else torch.equal(got.cpu(), v)
+        if not same:
+            raise SystemExit(f"bench.py: synthetic batch entry {k!r} differs between the product and the oracle")
     threads = os.cpu_count() or 1
     torch.set_num_threads(min(threads, 64))          # torch's CPU pool stops scaling long before 256 threads
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -115,10 +124,12 @@ def main():
         dist.barrier()
     hip.load()
 
-    from oracle import inputs
+    from occdepth_amd import synthetic
     model, cfg = build_model(device)
-    batch_cpu = inputs.kitti_batch(seed=rank)           # one stereo frame per rank
-    batch = to_dev(batch_cpu, device)
+    # one stereo frame per rank; the voxel->pixel tables come from the product's GPU projection (dataloader work,
+    # done once, outside the timed region -- exactly what the reference's dataloader hands to the model)
+    with torch.no_grad():
+        batch = synthetic.attach_projection(model, synthetic.to_device(synthetic.kitti_frame(seed=rank), device))
 
     def step():
         with torch.no_grad():
@@ -199,7 +210,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(model, cfg, batch_cpu)
+                res["cpu_baseline"] = cpu_baseline(model, cfg, batch, rank)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -229,6 +229,30 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
 int occd_argmax_channels(const float* x, int64_t rows, int32_t cs, int32_t coff, int32_t C,
                          const uint16_t* lut, uint16_t* out, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * K8: weight gradient of a 3-D convolution (training step):
+ *   dw[co][ci][kx][ky][kz] = sum_{b,xo,yo,zo} gy[b,xo,yo,zo][co] * x[b, xo*sx - px + kx*dx, ...][ci]
+ * -- what autograd computes for nn.Conv3d.weight in the reference's training step
+ * (occdepth/models/OccDepth.py:535-537 -> every nn.Conv3d of models/DDR.py, modules.py, CRP3D.py).  The data
+ * gradient needs no kernel of its own: it is occd_conv3d_fwd on gy with the flipped, channel-transposed weights
+ * (stride 1) or the sub-pixel phases of the transposed convolution (stride > 1).
+ * x, gy: channels-last fp32 like occd_conv3d_args; dw: PyTorch weight layout, overwritten.
+ * `workspace` must hold occd_conv3d_wgrad_workspace_floats() floats (partial tiles; summed in a fixed order,
+ * so the result is deterministic).  At most 28 taps.                                                           */
+typedef struct occd_conv3d_wgrad_args {
+    const float* x;      /* (B, X, Y, Z, x_cs) input of the convolution        */
+    const float* gy;     /* (B, Xo, Yo, Zo, gy_cs) gradient w.r.t. its output  */
+    float* dw;           /* (cout, cin, kx, ky, kz)                            */
+    float* workspace;
+    int64_t workspace_floats;
+    int32_t batch;
+    int32_t X, Y, Z, cin, x_cs, x_coff;
+    int32_t Xo, Yo, Zo, cout, gy_cs, gy_coff;
+    int32_t kx, ky, kz, sx, sy, sz, dx, dy, dz, px, py, pz;
+} occd_conv3d_wgrad_args;
+int64_t occd_conv3d_wgrad_workspace_floats(const occd_conv3d_wgrad_args* a);
+int occd_conv3d_wgrad(const occd_conv3d_wgrad_args* a, void* stream);
+
 /* SURVEY 8(f) row N1 (first step): the scene-completion losses of one training step as ONE pass over the
  * logits.  Everything occdepth/loss/ssc_loss.py:17-99 (geo_scal_loss, sem_scal_loss, CE_ssc_loss) and the inline
  * frustum-proportion loss of occdepth/models/OccDepth.py:487-521 compute is a function of these sums over voxels

@@ -43,6 +43,13 @@ class Conv3dArgs(Structure):
     ]
 
 
+class WgradArgs(Structure):
+    _fields_ = [("x", c_void_p), ("gy", c_void_p), ("dw", c_void_p), ("workspace", c_void_p),
+                ("workspace_floats", c_int64), ("batch", c_int32)] + \
+        [(n, c_int32) for n in ("X", "Y", "Z", "cin", "x_cs", "x_coff", "Xo", "Yo", "Zo", "cout", "gy_cs", "gy_coff",
+                                "kx", "ky", "kz", "sx", "sy", "sz", "dx", "dy", "dz", "px", "py", "pz")]
+
+
 class FlospArgs(Structure):
     _fields_ = [
         ("depth", c_void_p), ("trans", c_void_p), ("proj", c_void_p), ("ida", c_void_p), ("grids", c_void_p),
@@ -96,6 +103,8 @@ EXPORTS = {
                             + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "occd_cascade_tail_fwd": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p]),
+    "occd_conv3d_wgrad_workspace_floats": (c_int64, [POINTER(WgradArgs)]),
+    "occd_conv3d_wgrad": (c_int32, [POINTER(WgradArgs), c_void_p]),
     "occd_ssc_stats_len": (c_int64, [c_int32, c_int32]),
     "occd_ssc_loss_stats_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
                                           c_int32, c_int32, c_void_p]),
@@ -269,6 +278,39 @@ def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1)
                                                               + tuple(dilation) + tuple(x.dims)))
     _check(load().occd_conv3d_fwd(ctypes.byref(a), _stream()), "occd_conv3d_fwd")
     return out
+
+
+_wgrad_ws = {}
+
+
+def conv3d_wgrad(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0)):
+    """dW (cout, cin, kx, ky, kz) of a convolution y = conv(x, W) from channels-last x and gy = dL/dy (K8)."""
+    a = WgradArgs()
+    a.x, a.gy = _f32(x.buf, "x"), _f32(gy.buf, "gy")
+    a.batch = x.batch
+    a.X, a.Y, a.Z = x.dims
+    a.cin, a.x_cs, a.x_coff = cin, x.cs, x.coff
+    a.Xo, a.Yo, a.Zo = gy.dims
+    a.cout, a.gy_cs, a.gy_coff = cout, gy.cs, gy.coff
+    a.kx, a.ky, a.kz = kernel
+    a.sx, a.sy, a.sz = stride
+    a.dx, a.dy, a.dz = dilation
+    a.px, a.py, a.pz = padding
+    need = load().occd_conv3d_wgrad_workspace_floats(ctypes.byref(a))
+    if need <= 0:
+        raise RuntimeError(f"occd_conv3d_wgrad_workspace_floats failed (code {need})")
+    dev = x.buf.device
+    ws = _wgrad_ws.get(dev)                      # one growing scratch buffer per device (stream-ordered reuse)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=dev)
+        _wgrad_ws[dev] = ws
+    dw = torch.empty((cout, cin) + tuple(kernel), dtype=torch.float32, device=dev)
+    a.dw, a.workspace, a.workspace_floats = dw.data_ptr(), ws.data_ptr(), ws.numel()
+    if _PROFILING:
+        set_tag("%d>%d k%d%d%d s%d%d%d d%d%d%d @%dx%dx%d" % ((cin, cout) + tuple(kernel) + tuple(stride)
+                                                              + tuple(dilation) + tuple(x.dims)))
+    _check(load().occd_conv3d_wgrad(ctypes.byref(a), _stream()), "occd_conv3d_wgrad")
+    return dw
 
 
 # ----------------------------------------------------------------------------- K1

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
 from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows, needs_autograd
 from .modules import ASPP, Process
 
@@ -30,13 +31,13 @@ class CPMegaVoxels(nn.Module):
         padding = tuple((s + 1) % 2 for s in self.size)
 
         self.mega_context = nn.Sequential(
-            nn.Conv3d(feature, self.context_feature, stride=2, padding=padding, kernel_size=3))
+            Conv3d(feature, self.context_feature, stride=2, padding=padding, kernel_size=3))
         self.context_prior_logits = nn.ModuleList([
-            nn.Sequential(nn.Conv3d(self.feature, self.flatten_context_size, padding=0, kernel_size=1))
+            nn.Sequential(Conv3d(self.feature, self.flatten_context_size, padding=0, kernel_size=1))
             for _ in range(n_relations)])
         self.aspp = ASPP(feature, [1, 2, 3])
         self.resize = nn.Sequential(
-            nn.Conv3d(self.context_feature * self.n_relations + feature, feature, kernel_size=1, padding=0,
+            Conv3d(self.context_feature * self.n_relations + feature, feature, kernel_size=1, padding=0,
                       bias=False),
             Process(feature, nn.BatchNorm3d, bn_momentum, dilations=[1]))
         self._plans = None

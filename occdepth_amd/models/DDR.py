@@ -14,6 +14,7 @@ k = stride = window convolutions.
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
 from ..fused import ACT_RELU, ConvPlan, as_vox, needs_autograd
 
 
@@ -30,16 +31,16 @@ class Bottleneck3D(nn.Module):
         self.expansion = expansion
         self.stride = stride
         self.dilation = dilation
-        self.conv1 = nn.Conv3d(inplanes, planes, kernel_size=1, bias=False)
+        self.conv1 = Conv3d(inplanes, planes, kernel_size=1, bias=False)
         self.bn1 = norm_layer(planes, momentum=bn_momentum)
         # conv2 / conv3 / conv4 filter along Z / Y / X respectively (tensor dims are X, Y, Z)
         for idx, axis in ((2, 2), (3, 1), (4, 0)):
             d = dilation[idx - 2]
-            setattr(self, f"conv{idx}", nn.Conv3d(
+            setattr(self, f"conv{idx}", Conv3d(
                 planes, planes, kernel_size=_axis(3, axis, 1), stride=_axis(stride, axis, 1),
                 dilation=_axis(d, axis, 1), padding=_axis(d, axis, 0), bias=False))
             setattr(self, f"bn{idx}", norm_layer(planes, momentum=bn_momentum))
-        self.conv5 = nn.Conv3d(planes, planes * expansion, kernel_size=1, bias=False)
+        self.conv5 = Conv3d(planes, planes * expansion, kernel_size=1, bias=False)
         self.bn5 = norm_layer(planes * expansion, momentum=bn_momentum)
         self.relu = nn.ReLU(inplace=False)
         self.relu_inplace = nn.ReLU(inplace=True)
@@ -47,7 +48,7 @@ class Bottleneck3D(nn.Module):
 
         def side(window):
             return nn.Sequential(nn.AvgPool3d(kernel_size=window, stride=window),
-                                 nn.Conv3d(planes, planes, kernel_size=1, stride=1, bias=False),
+                                 Conv3d(planes, planes, kernel_size=1, stride=1, bias=False),
                                  norm_layer(planes, momentum=bn_momentum))
 
         self.downsample2 = side((1, stride, 1))

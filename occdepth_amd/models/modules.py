@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
+from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
 from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox, needs_autograd
 from .DDR import Bottleneck3D
 
@@ -22,7 +23,7 @@ class _DilatedBranches(nn.Module):
         self.conv_list = dilations
 
         def convs():
-            return nn.ModuleList([nn.Conv3d(planes, planes, kernel_size=3, padding=d, dilation=d, bias=False)
+            return nn.ModuleList([Conv3d(planes, planes, kernel_size=3, padding=d, dilation=d, bias=False)
                                   for d in dilations])
 
         def norms():
@@ -73,7 +74,7 @@ class ASPP(_DilatedBranches):
 
 class _HeadBase(_DilatedBranches):
     def _make_head(self, inplanes, planes, dilations):
-        self.conv0 = nn.Conv3d(inplanes, planes, kernel_size=3, padding=1, stride=1)
+        self.conv0 = Conv3d(inplanes, planes, kernel_size=3, padding=1, stride=1)
         self._make_branches(planes, dilations)
         self._plans = None
 
@@ -95,7 +96,7 @@ class SegmentationHead(_HeadBase):
     def __init__(self, inplanes, planes, nbr_classes, dilations_conv_list):
         super().__init__()
         self._make_head(inplanes, planes, dilations_conv_list)
-        self.conv_classes = nn.Conv3d(planes, nbr_classes, kernel_size=3, padding=1, stride=1)
+        self.conv_classes = Conv3d(planes, nbr_classes, kernel_size=3, padding=1, stride=1)
 
     def _extra_plans(self, plans):
         plans["cls"] = ConvPlan(self.conv_classes)
@@ -115,8 +116,8 @@ class SegmentationHeadCascadeCLS(_HeadBase):
         super().__init__()
         self._make_head(inplanes, planes, dilations_conv_list)
         occ_classes = 2
-        self.conv_classes = nn.Conv3d(planes + occ_classes, nbr_classes, kernel_size=3, padding=1, stride=1)
-        self.occ_classes = nn.Conv3d(planes, occ_classes, kernel_size=3, padding=1, stride=1)
+        self.conv_classes = Conv3d(planes + occ_classes, nbr_classes, kernel_size=3, padding=1, stride=1)
+        self.occ_classes = Conv3d(planes, occ_classes, kernel_size=3, padding=1, stride=1)
         self.softmax = nn.Softmax(dim=1)
         self.planes = planes
 
@@ -150,7 +151,7 @@ class SegmentationHeadOccludedCLS(_HeadBase):
     def __init__(self, inplanes, planes, nbr_classes, dilations_conv_list):
         super().__init__()
         self._make_head(inplanes, planes, dilations_conv_list)
-        self.occ_classes = nn.Conv3d(planes, 2, kernel_size=3, padding=1, stride=1)
+        self.occ_classes = Conv3d(planes, 2, kernel_size=3, padding=1, stride=1)
 
     def _extra_plans(self, plans):
         plans["occ"] = ConvPlan(self.occ_classes)
@@ -189,7 +190,7 @@ class _TransposedBlock(nn.Module):
 
     def _make(self, in_channels, out_channels, norm_layer, bn_momentum, stride, output_padding):
         self.main = nn.Sequential(
-            nn.ConvTranspose3d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, dilation=1,
+            ConvTranspose3d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, dilation=1,
                                output_padding=output_padding),
             norm_layer(out_channels, momentum=bn_momentum),
             nn.ReLU())
@@ -227,7 +228,7 @@ class Downsample(nn.Module):
         self.main = Bottleneck3D(
             feature, feature // 4, bn_momentum=bn_momentum, expansion=expansion, stride=2,
             downsample=nn.Sequential(nn.AvgPool3d(kernel_size=2, stride=2),
-                                     nn.Conv3d(feature, wide, kernel_size=1, stride=1, bias=False),
+                                     Conv3d(feature, wide, kernel_size=1, stride=1, bias=False),
                                      norm_layer(wide, momentum=bn_momentum)),
             norm_layer=norm_layer)
 

@@ -158,6 +158,13 @@ def cascade_tail(part, occ_off, wn, nbr):
     return out
 
 
+def conv3d_wgrad(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0)):
+    xin = x.buf[..., x.coff:x.coff + cin].permute(0, 4, 1, 2, 3).contiguous()
+    g = gy.buf[..., gy.coff:gy.coff + cout].permute(0, 4, 1, 2, 3).contiguous()
+    return torch.nn.grad.conv3d_weight(xin.double(), (cout, cin) + tuple(kernel), g.double(), stride=stride,
+                                       padding=padding, dilation=dilation).float()
+
+
 def _softmax_and_target(logits, target, map_occ):
     B, C = logits.shape[:2]
     p = F.softmax(logits.detach().double().reshape(B, C, -1), 1)        # (B, C, S)
@@ -224,7 +231,8 @@ def ssc_confusion(hist, target, logits=None, labels=None):
 def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
-                                          "ssc_confusion")}
+                                          "ssc_confusion", "conv3d_wgrad")}
+    hip.conv3d_wgrad = conv3d_wgrad
     hip.ssc_loss_stats, hip.ssc_loss_grad, hip.ssc_confusion = ssc_loss_stats, ssc_loss_grad, ssc_confusion
     saved_from = Vox.from_ncdhw
     saved_as_vox = fused.as_vox

@@ -63,12 +63,13 @@ def bench_aspp():
 
 
 def bench_lift():
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    from oracle import inputs
+    from occdepth_amd import synthetic
     from occdepth_amd.models.SFA import voxel_layout
-    b = inputs.kitti_batch(seed=1)
-    pix = torch.stack(b["projected_pix_2"]).cuda()
-    fov = torch.stack(b["fov_mask_2"]).cuda()
+    b = synthetic.kitti_frame(seed=1)
+    views = [hip.project_voxels(b["T_velo_2_cam"][0][v].double().numpy(), b["cam_k"][0][v].numpy(), (0.0, -25.6, -2.0),
+                                0.4, (128, 128, 16), 1220, 370, device="cuda") for v in range(2)]
+    pix = torch.stack([p for p, _ in views]).unsqueeze(0)
+    fov = torch.stack([m for _, m in views]).unsqueeze(0)
     sizes = [(370, 1220), (185, 610), (93, 305), (47, 153)]
     rows = [[torch.randn(1, h, w, 64, device="cuda") for _ in range(2)] for h, w in sizes]
     n_dims, out_dims, strides = voxel_layout((256, 256, 32), 2, "kitti")
