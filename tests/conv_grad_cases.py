@@ -15,11 +15,20 @@ CONV_CASES = {
     "k3_s2_p0": (16, 32, (3, 3, 3), (2, 2, 2), (0, 0, 0), (1, 1, 1), (9, 7, 9), True),        # CRP3D.py:33 (odd size)
     "wide": (72, 100, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (4, 4, 6), True),           # channel tiles > 1, ragged
     "nyu_z15": (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), (5, 4, 15), False),         # Z not a multiple of 8
+    # the reduced NYU config of the train-step fixture: feature 20 -> planes 5 (ragged channel counts everywhere)
+    "nyu_p5_axis": (5, 5, (1, 1, 3), (1, 1, 1), (0, 0, 1), (1, 1, 1), (10, 6, 10), False),
+    "nyu_p5_s2": (5, 5, (1, 3, 1), (1, 2, 1), (0, 1, 0), (1, 1, 1), (10, 6, 10), False),
+    "nyu_p5_s2x": (5, 5, (3, 1, 1), (2, 1, 1), (1, 0, 0), (1, 1, 1), (5, 3, 5), False),
+    "nyu_20_5": (20, 5, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (10, 6, 10), False),
+    "nyu_5_20": (5, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (10, 6, 10), False),
+    "nyu_head": (20, 12, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), (20, 12, 20), True),
+    "nyu_aspp": (20, 20, (3, 3, 3), (1, 1, 1), (3, 3, 3), (3, 3, 3), (20, 12, 20), False),
 }
 # name: (cin, cout, kernel, stride, padding, output_padding, dims, bias)
 CONVT_CASES = {
     "up_s2": (32, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), (4, 5, 4), True),           # modules.py:192
     "up_s1": (16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), (0, 0, 0), (5, 4, 8), False),
+    "nyu_up": (40, 20, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), (5, 3, 5), True),
 }
 
 
