@@ -120,6 +120,21 @@ def bench_dec2d():
             print(f"dec2d {cin}->{cout} @{H}x{W} B=2 hint={h}: {t:.3f} ms {fl / t / 1e9:6.1f} TF/s", flush=True)
 
 
+def bench_wgrad():
+    """Weight gradient K8 at the training step's dominant shapes."""
+    shapes = [((256, 256, 32), 32, 32, 3, 1), ((256, 256, 32), 32, 32, 3, 3), ((256, 256, 32), 34, 20, 3, 1),
+              ((128, 128, 16), 64, 64, 1, 1), ((32, 32, 4), 256, 256, 3, 1)]
+    for dims, cin, cout, k, d in shapes:
+        x = hip.Vox(torch.randn(1, *dims, hip.round_up(cin, 8), device="cuda"), cin)
+        gy = hip.Vox(torch.randn(1, *dims, hip.round_up(cout, 8), device="cuda"), cout)
+        pad = (d * (k // 2),) * 3
+        ms = time_many({"wgrad": lambda: hip.conv3d_wgrad(x, gy, cin, cout, (k,) * 3, dilation=(d,) * 3, padding=pad)},
+                       rounds=3, iters=4)["wgrad"]
+        fl = 2.0 * dims[0] * dims[1] * dims[2] * k ** 3 * cin * cout
+        print(f"wgrad k{k} {cin}->{cout} @{dims} d={d}: {ms:.3f} ms {fl / ms / 1e9:6.1f} TF/s "
+              f"({fl / ms / 1e9 / 157.3 * 100:.1f}%)", flush=True)
+
+
 def bench_loss():
     """One training step's scene-completion losses at config-2 size: the statistics path (K5 + K6) against the
     reference's formulation (a softmax per loss, 20-class loop, 64-frustum loop) written with the same torch ops."""
@@ -188,4 +203,4 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     what = sys.argv[1:] or ["head", "aspp", "lift", "stack"]
     for w in what:
-        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack, "dec2d": bench_dec2d, "loss": bench_loss}[w]()
+        {"head": bench_head, "aspp": bench_aspp, "lift": bench_lift, "stack": bench_stack, "dec2d": bench_dec2d, "loss": bench_loss, "wgrad": bench_wgrad}[w]()
