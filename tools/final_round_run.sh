@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box (everything lands under gpurun_out/final/; copy the summaries to profiles/).
+#   gpurun --timeout 2400 -- 'bash tools/final_round_run.sh'
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout 1200 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> /tmp/prof_bench.err
+f=$(ls /tmp/prof_bench/*/*kernel_trace.csv | head -1)
+python $R/tools/summarize_trace.py $f $O/steady_state_kernel_stats.csv 5 > /dev/null; head -12 $O/steady_state_kernel_stats.csv | cut -c1-140
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/tools/pmc_head.py > /tmp/pmc_$c.log 2>&1
+  g=$(ls /tmp/pmc_$c/*/*counter_collection.csv | head -1)
+  grep "Counter_Name\|conv3d_c32" $g > $O/pmc_head_$c.csv
+done
+python $R/tools/pmc_to_json.py $O/pmc_head_FETCH_SIZE.csv $O/pmc_head_WRITE_SIZE.csv $O/head_conv_hbm_bytes.json
+cd $R
+timeout 300 python tools/bench_kernels.py head stack wgrad loss > $O/bench_kernels.txt 2>&1; grep "^conv\|^wgrad\|^loss\|UNet3D\|sfa_lift" $O/bench_kernels.txt
