@@ -66,7 +66,7 @@ def cpu_baseline(model, cfg, batch, seed, budget_s=45.0):
     from oracle import inputs
     from oracle import occdepth_oracle as orc
     batch_cpu = inputs.kitti_batch(seed=seed)
-    for k, v in batch_cpu.items():
+    for k, v in batch_cpu.items():                     # (the product batch has one extra key: T_velo_2_cam_f64)
         got = batch[k]
         same = all(torch.equal(a.cpu(), b) for a, b in zip(got, v)) if isinstance(v, list) else torch.equal(got.cpu(), v)
         if not same:

@@ -210,7 +210,10 @@ class OccDepth(_Base):
         H, W = img.shape[-2:]
         pix, fov = [], []
         for i in range(img.shape[0]):
-            views = [hip.project_voxels(batch["T_velo_2_cam"][i][v].detach().cpu().double().numpy(),
+            # the dataloader projects with the calibration file's float64 extrinsics; the batch only carries their
+            # float32 copy.  `T_velo_2_cam_f64`, when present, reproduces the dataloader's tables bit for bit.
+            ext = batch.get("T_velo_2_cam_f64", batch["T_velo_2_cam"])
+            views = [hip.project_voxels(ext[i][v].detach().cpu().double().numpy(),
                                         batch["cam_k"][i][v].detach().cpu().double().numpy(), (0.0, -25.6, -2.0),
                                         0.2 * ps, dims, W, H, device=img.device) for v in range(img.shape[1])]
             pix.append(torch.stack([p for p, _ in views]))

@@ -25,6 +25,7 @@ def kitti_frame(batch=1, img_hw=(370, 1220), seed=0):
         "img": torch.randn(batch, 2, 3, H, W, generator=g),
         "cam_k": [torch.from_numpy(np.stack([KITTI_K, KITTI_K])) for _ in range(batch)],
         "T_velo_2_cam": [torch.from_numpy(np.stack([KITTI_TR, tr_right]).astype(np.float32)) for _ in range(batch)],
+        "T_velo_2_cam_f64": [torch.from_numpy(np.stack([KITTI_TR, tr_right])) for _ in range(batch)],
         "ida_mats": [torch.eye(4).repeat(2, 1, 1) for _ in range(batch)],
     }
 

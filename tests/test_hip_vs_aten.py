@@ -373,5 +373,5 @@ def test_errors_are_loud(hip):
         hip.Vox.from_ncdhw(x)  # CPU tensor: there is no CPU path
     from occdepth_amd.models.DDR import Bottleneck3D
     m = Bottleneck3D(8, 2, nn.BatchNorm3d).eval()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError), torch.no_grad():          # the forward-only HIP eval path
         m(x)

@@ -372,3 +372,19 @@ def test_lift_properties_full_size():
     rows = one.reshape(-1, 64)
     assert rows[outside].abs().max().item() == 0.0
     assert rows[~outside].abs().max().item() > 0.0
+
+
+def test_product_synthetic_frame_equals_oracle_batch(config2):
+    """bench.py's frames (occdepth_amd/synthetic.py + the GPU projection kernel) are bit-identical to the oracle's
+    numpy restatement of the dataloader (oracle/inputs.py): images, calibration, pixel tables, FOV masks."""
+    from occdepth_amd import synthetic
+    from oracle import inputs
+    m = config2[0]
+    with torch.no_grad():
+        got = synthetic.attach_projection(m, synthetic.to_device(synthetic.kitti_frame(seed=5), DEV))
+    want = inputs.kitti_batch(seed=5)
+    for k, v in want.items():
+        if isinstance(v, list):
+            assert all(torch.equal(a.cpu(), b) and a.dtype == b.dtype for a, b in zip(got[k], v)), k
+        else:
+            assert torch.equal(got[k].cpu(), v), k
