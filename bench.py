@@ -70,7 +70,7 @@ def cpu_baseline(model, cfg, batch, seed, budget_s=45.0):
         got = batch[k]
         same = all(torch.equal(a.cpu(), b) for a, b in zip(got, v)) if isinstance(v, list) else torch.equal(got.cpu(), v)
         if not same:
-            raise SystemExit(f"bench.py: synthetic batch entry {k!r} differs between the product and the oracle")
+            raise RuntimeError(f"synthetic batch entry {k!r} differs between the product and the oracle")
     threads = os.cpu_count() or 1
     torch.set_num_threads(min(threads, 64))          # torch's CPU pool stops scaling long before 256 threads
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

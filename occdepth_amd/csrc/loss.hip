@@ -35,60 +35,93 @@ __device__ __forceinline__ int map_target(int t, int map_occ) {
     return (map_occ && t != 0 && t != 255) ? 1 : t;
 }
 
-// probabilities of one voxel; x[] statically indexed (fully unrolled, c < C uniform)
-__device__ __forceinline__ float softmax_regs(const float* lp, int C, int S, float (&p)[kMaxC], float& lse) {
+// probabilities of one voxel; p[] statically indexed (fully unrolled over the class bucket CB >= C, c < C uniform)
+template <int CB>
+__device__ __forceinline__ void softmax_regs(const float* lp, int C, int S, float (&p)[CB], float& lse) {
     float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c)
+    for (int c = 0; c < CB; ++c)
         if (c < C) {
             p[c] = lp[(size_t)c * S];
             m = fmaxf(m, p[c]);
         }
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c)
+    for (int c = 0; c < CB; ++c)
         if (c < C) {
             p[c] = __expf(p[c] - m);
             sum += p[c];
         }
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c)
+    for (int c = 0; c < CB; ++c)
         if (c < C) p[c] *= inv;
     lse = m + __logf(sum);
-    return inv;
 }
 
+// Every wave owns a contiguous span of voxels and walks it 64 at a time, so the successive voxels of one LANE are
+// 64 apart in memory: two columns over at Z = 32 -- almost always the same frustum and very often the same label.
+// The target- and frustum-indexed sums therefore sit in per-lane registers and are flushed to LDS (64-bit integer
+// atomics) only when the lane's label / frustum changes; the uniform-address sums never leave registers until the end.
+template <int CB>
 __global__ void __launch_bounds__(256) ssc_stats_kernel(const StatsP q) {
     extern __shared__ u64 acc[];                       // 3C + 3 + F*C
     const int C = q.C, n_stats = 3 * C + 3 + q.F * C;
     for (int i = threadIdx.x; i < n_stats; i += 256) acc[i] = 0;
     __syncthreads();
-    u64 regP[kMaxC];                                   // uniform-address sums stay in registers until the end
+    u64 regP[CB], accF[CB];
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) regP[c] = 0;
-    u64 regM = 0, regNum = 0, regDen = 0;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < q.total; v += (long)gridDim.x * 256) {
+    for (int c = 0; c < CB; ++c) regP[c] = accF[c] = 0;
+    u64 regM = 0, regNum = 0, regDen = 0, accN = 0;
+    unsigned accT = 0;
+    int cur_t = -1, cur_f = -1;
+    auto flush_t = [&]() {
+        if (cur_t >= 0) {
+            atomicAdd(&acc[C + cur_t], accN);
+            atomicAdd(&acc[2 * C + cur_t], (u64)accT);
+        }
+        accN = 0;
+        accT = 0;
+    };
+    auto flush_f = [&]() {
+        if (cur_f >= 0) {
+            u64* dst = acc + 3 * C + 3 + cur_f * C;
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                if (c < C && accF[c]) atomicAdd(&dst[c], accF[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) accF[c] = 0;
+    };
+    const long n_waves = (long)gridDim.x * 4;
+    const long span = ((q.total + n_waves - 1) / n_waves + 63) & ~63L;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long v_end = min(w * span + span, q.total);
+    for (long v = w * span + (threadIdx.x & 63); v < v_end; v += 64) {
         const long b = v / q.S;
         const int s = (int)(v - b * q.S);
         const float* lp = q.logits + (size_t)b * C * q.S + s;
-        float p[kMaxC], lse;
-        softmax_regs(lp, C, q.S, p, lse);
+        float p[CB], lse;
+        softmax_regs<CB>(lp, C, q.S, p, lse);
         const int t = map_target(q.target[v], q.map_occ);
         if (t != 255) {
             float pt = 0.f, xt = 0.f;
 #pragma unroll
-            for (int c = 0; c < kMaxC; ++c)
+            for (int c = 0; c < CB; ++c)
                 if (c < C) {
                     regP[c] += (u64)((double)p[c] * kQ32);
                     if (c == t) { pt = p[c]; xt = lp[(size_t)c * q.S]; }
                 }
             if (t < C) {
-                atomicAdd(&acc[C + t], (u64)((double)pt * kQ32));
-                atomicAdd(&acc[2 * C + t], (u64)1);
-                const float w = q.weights != nullptr ? q.weights[t] : 1.f;
-                regNum += (u64)((double)(w * (lse - xt)) * kQ24);
-                regDen += (u64)((double)w * kQ24);
+                if (t != cur_t) {
+                    flush_t();
+                    cur_t = t;
+                }
+                accN += (u64)((double)pt * kQ32);
+                accT += 1;
+                const float wt = q.weights != nullptr ? q.weights[t] : 1.f;
+                regNum += (u64)((double)(wt * (lse - xt)) * kQ24);
+                regDen += (u64)((double)wt * kQ24);
             }
             regM += 1;
         }
@@ -96,15 +129,20 @@ __global__ void __launch_bounds__(256) ssc_stats_kernel(const StatsP q) {
             const uint8_t* mp = q.masks + (size_t)b * q.F * q.S + s;
             for (int f = 0; f < q.F; ++f)
                 if (mp[(size_t)f * q.S]) {
-                    u64* dst = acc + 3 * C + 3 + f * C;
+                    if (f != cur_f) {
+                        flush_f();
+                        cur_f = f;
+                    }
 #pragma unroll
-                    for (int c = 0; c < kMaxC; ++c)
-                        if (c < C) atomicAdd(&dst[c], (u64)((double)p[c] * kQ32));
+                    for (int c = 0; c < CB; ++c)
+                        if (c < C) accF[c] += (u64)((double)p[c] * kQ32);
                 }
         }
     }
+    flush_t();
+    flush_f();
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c)
+    for (int c = 0; c < CB; ++c)
         if (c < C && regP[c]) atomicAdd(&acc[c], regP[c]);
     if (regM) atomicAdd(&acc[3 * C], regM);
     if (regNum) atomicAdd(&acc[3 * C + 1], regNum);
@@ -116,6 +154,7 @@ __global__ void __launch_bounds__(256) ssc_stats_kernel(const StatsP q) {
 
 // d loss / d logit_c = p_c (g_c - sum_k p_k g_k) + [t != 255] gCEnum w_t (p_c - [c == t]),
 // g_c = [t != 255] (gP[c] + [t == c] gN[c]) + sum_{f : mask_f} gF[f][c]
+template <int CB>
 __global__ void __launch_bounds__(256) ssc_grad_kernel(const StatsP q) {
     extern __shared__ float gs[];                      // the gradient table, 3C + 3 + F*C floats
     const int C = q.C, n_stats = 3 * C + 3 + q.F * C;
@@ -126,12 +165,12 @@ __global__ void __launch_bounds__(256) ssc_grad_kernel(const StatsP q) {
         const long b = v / q.S;
         const int s = (int)(v - b * q.S);
         const float* lp = q.logits + (size_t)b * C * q.S + s;
-        float p[kMaxC], g[kMaxC], lse;
-        softmax_regs(lp, C, q.S, p, lse);
+        float p[CB], g[CB], lse;
+        softmax_regs<CB>(lp, C, q.S, p, lse);
         const int t = map_target(q.target[v], q.map_occ);
         const bool lab = t != 255;
 #pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
+        for (int c = 0; c < CB; ++c)
             if (c < C) g[c] = lab ? gs[c] + (c == t ? gs[C + c] : 0.f) : 0.f;
         if (q.masks != nullptr) {
             const uint8_t* mp = q.masks + (size_t)b * q.F * q.S + s;
@@ -139,18 +178,18 @@ __global__ void __launch_bounds__(256) ssc_grad_kernel(const StatsP q) {
                 if (mp[(size_t)f * q.S]) {
                     const float* src = gs + 3 * C + 3 + f * C;
 #pragma unroll
-                    for (int c = 0; c < kMaxC; ++c)
+                    for (int c = 0; c < CB; ++c)
                         if (c < C) g[c] += src[c];
                 }
         }
         float dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
+        for (int c = 0; c < CB; ++c)
             if (c < C) dot += p[c] * g[c];
         const float ce = (lab && t < C) ? g_num * (q.weights != nullptr ? q.weights[t] : 1.f) : 0.f;
         float* gp = q.grad + (size_t)b * C * q.S + s;
 #pragma unroll
-        for (int c = 0; c < kMaxC; ++c)
+        for (int c = 0; c < CB; ++c)
             if (c < C) gp[(size_t)c * q.S] = p[c] * (g[c] - dot) + ce * (p[c] - (c == t ? 1.f : 0.f));
     }
 }
@@ -216,7 +255,11 @@ int occd_ssc_loss_stats_fwd(const float* logits, const uint8_t* target, const ui
     if (hipMemsetAsync(stats, 0, n * sizeof(int64_t), st) != hipSuccess) return OCCD_ELAUNCH;
     const double bytes = (double)q.total * (4.0 * C + 1 + F);
     occd::ProfScope prof("ssc_loss_stats", st, (double)q.total * C * 8.0, bytes);
-    hipLaunchKernelGGL(ssc_stats_kernel, dim3(grid_for(q.total)), dim3(256), n * sizeof(u64), st, q);
+    const dim3 grid(grid_for(q.total));
+    if (C <= 4) hipLaunchKernelGGL(ssc_stats_kernel<4>, grid, dim3(256), n * sizeof(u64), st, q);
+    else if (C <= 12) hipLaunchKernelGGL(ssc_stats_kernel<12>, grid, dim3(256), n * sizeof(u64), st, q);
+    else if (C <= 20) hipLaunchKernelGGL(ssc_stats_kernel<20>, grid, dim3(256), n * sizeof(u64), st, q);
+    else hipLaunchKernelGGL(ssc_stats_kernel<32>, grid, dim3(256), n * sizeof(u64), st, q);
     return occd::check_launch();
 }
 
@@ -233,7 +276,11 @@ int occd_ssc_loss_stats_bwd(const float* logits, const uint8_t* target, const ui
     const size_t n = (size_t)occd_ssc_stats_len(C, F);
     const double bytes = (double)q.total * (8.0 * C + 1 + F);
     occd::ProfScope prof("ssc_loss_grad", st, (double)q.total * C * 12.0, bytes);
-    hipLaunchKernelGGL(ssc_grad_kernel, dim3(grid_for(q.total)), dim3(256), n * sizeof(float), st, q);
+    const dim3 grid(grid_for(q.total));
+    if (C <= 4) hipLaunchKernelGGL(ssc_grad_kernel<4>, grid, dim3(256), n * sizeof(float), st, q);
+    else if (C <= 12) hipLaunchKernelGGL(ssc_grad_kernel<12>, grid, dim3(256), n * sizeof(float), st, q);
+    else if (C <= 20) hipLaunchKernelGGL(ssc_grad_kernel<20>, grid, dim3(256), n * sizeof(float), st, q);
+    else hipLaunchKernelGGL(ssc_grad_kernel<32>, grid, dim3(256), n * sizeof(float), st, q);
     return occd::check_launch();
 }
 

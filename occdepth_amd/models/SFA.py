@@ -67,7 +67,8 @@ class SFA(nn.Module):
         cnt = fov_mask.sum(-1)                                              # (V, N)
         feats, vis = [], []
         for v in range(V):
-            g = flat[v][:, idx[v].reshape(-1)].reshape(C, idx.shape[1], idx.shape[2]).sum(-1)
+            # index_select: its backward is an atomic index_add_ (the advanced-indexing form sorts: 1.8 ms per scale)
+            g = torch.index_select(flat[v], 1, idx[v].reshape(-1)).reshape(C, idx.shape[1], idx.shape[2]).sum(-1)
             seen = cnt[v] > 0
             feats.append(torch.where(seen, g / cnt[v].clamp(min=1), torch.zeros_like(g)))
             vis.append(seen.to(x2d.dtype))

@@ -136,3 +136,14 @@ def allreduce_confusion(hist, dist=None):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist
+
+
+def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20):
+    """What `Trainer(accelerator="ddp", sync_batchnorm=True)` does for the reference (scripts/train.py:176-206),
+    without Lightning: BatchNorm -> SyncBatchNorm (statistics all-reduced over RCCL; with 1 frame per GPU the
+    per-rank statistics would otherwise be those of a single scene) and the gradient buckets.
+    Returns (model, GradBuckets or None)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return model, None
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    return model, GradBuckets(model.parameters(), dist, bucket_bytes)

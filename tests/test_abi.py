@@ -46,7 +46,7 @@ def test_argument_validation_without_gpu(hip_lib):
 def test_ctypes_structs_match_c_layout(tmp_path):
     from occdepth_amd import hip
     structs = {"occd_conv3d_args": hip.Conv3dArgs, "occd_flosp_args": hip.FlospArgs, "occd_lift_args": hip.LiftArgs,
-               "occd_prof_row": hip.ProfRow}
+               "occd_prof_row": hip.ProfRow, "occd_conv3d_wgrad_args": hip.WgradArgs}
     rename = {"inp": "in"}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
@@ -83,3 +83,32 @@ def test_new_entry_points_validate_arguments(hip_lib):
     assert hip_lib.occd_argmax_channels(None, 1, 4, 0, 4, None, None, None) == -1
     e = (ctypes.c_double * 16)()
     assert hip_lib.occd_project_voxels(ctypes.addressof(e), None, None, 0.2, 1, 1, 1, 1, 1, None, None, None, None) == -1
+
+
+def test_training_entry_points_validate_arguments(hip_lib):
+    """Loss statistics / confusion / weight-gradient entry points reject bad arguments before any launch."""
+    import ctypes
+    from occdepth_amd import hip
+    assert hip_lib.occd_ssc_stats_len(20, 64) == 3 * 20 + 3 + 64 * 20
+    assert hip_lib.occd_ssc_loss_stats_fwd(None, None, None, None, None, 1, 20, 8, 0, 0, None) == -1
+    one = ctypes.c_float(0.0)
+    ptr = ctypes.addressof(one)
+    assert hip_lib.occd_ssc_loss_stats_fwd(ptr, ptr, None, None, ptr, 1, 33, 8, 0, 0, None) == -1      # C > 32
+    assert hip_lib.occd_ssc_loss_stats_fwd(ptr, ptr, None, None, ptr, 1, 20, 8, 4, 0, None) == -1       # masks missing
+    assert hip_lib.occd_ssc_loss_stats_bwd(ptr, ptr, None, None, None, ptr, 1, 20, 8, 0, 0, None) == -1
+    assert hip_lib.occd_ssc_confusion(ptr, ptr, ptr, ptr, 1, 20, 8, None) == -1                         # both predictions
+    assert hip_lib.occd_ssc_confusion(None, None, ptr, ptr, 1, 20, 8, None) == -1                       # neither
+    a = hip.WgradArgs()
+    assert hip_lib.occd_conv3d_wgrad_workspace_floats(ctypes.byref(a)) == -1
+    a.x = a.gy = ptr
+    a.batch, a.X, a.Y, a.Z, a.cin, a.x_cs = 1, 4, 4, 8, 32, 32
+    a.Xo, a.Yo, a.Zo, a.cout, a.gy_cs = 4, 4, 8, 32, 32
+    a.kx = a.ky = a.kz = 3
+    a.sx = a.sy = a.sz = a.dx = a.dy = a.dz = 1
+    a.px = a.py = a.pz = 1
+    need = hip_lib.occd_conv3d_wgrad_workspace_floats(ctypes.byref(a))
+    assert need > 0 and need % (27 * 1024) == 0
+    assert hip_lib.occd_conv3d_wgrad(ctypes.byref(a), None) == -1                                        # no dw / workspace
+    a.kx = 6
+    a.ky = 6
+    assert hip_lib.occd_conv3d_wgrad_workspace_floats(ctypes.byref(a)) == -1                             # > 32 taps

@@ -142,9 +142,16 @@ def bench_loss():
     from occdepth_amd.loss import ssc_loss
     B, C, dims, NF = 1, 20, (256, 256, 32), 64
     logits = (torch.randn(B, C, *dims, device="cuda") * 2).requires_grad_(True)
-    target = torch.randint(0, C, (B, *dims), device="cuda").to(torch.uint8)
+    # scene-like inputs: labels in 16x16-voxel patches over mostly empty space, frustums = an 8x8 grid over (x, y)
+    xs = torch.arange(dims[0], device="cuda").view(-1, 1, 1)
+    ys = torch.arange(dims[1], device="cuda").view(1, -1, 1)
+    zs = torch.arange(dims[2], device="cuda").view(1, 1, -1)
+    target = (((xs // 16) + 3 * (ys // 16) + zs // 8) % C).expand(*dims).clone().unsqueeze(0)
+    target[torch.rand(B, *dims, device="cuda") < 0.7] = 0
+    target = target.to(torch.uint8)
     target[torch.rand(B, *dims, device="cuda") < 0.2] = 255
-    fid = torch.randint(0, NF + 8, (B, *dims), device="cuda")
+    fid = ((xs * 8 // dims[0]) * 8 + ys * 8 // dims[1] + 0 * zs).unsqueeze(0)
+    fid = torch.where(zs.unsqueeze(0) < 4, torch.full_like(fid, NF + 1), fid)        # below the field of view
     masks = torch.stack([fid == f for f in range(NF)], 1)
     dists = torch.rand(B, NF, C, device="cuda")
     w = torch.rand(C, device="cuda") + 0.5
