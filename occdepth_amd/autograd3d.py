@@ -73,7 +73,9 @@ def _out_dims(dims, K, stride, padding, dilation):
 
 
 class _Conv3dFn(torch.autograd.Function):
+    # under torch.autocast the 3-D convolutions stay in float32 (exact-fp32 MFMA; the tensors are cast on entry)
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, w, b, stride, padding, dilation):
         xv = _to_vox(x.detach())
         cout, cin = w.shape[:2]
@@ -92,11 +94,12 @@ class _Conv3dFn(torch.autograd.Function):
         return out.ncdhw()
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         xbuf, w = ctx.saved_tensors
         C, coff, stride, padding, dilation, has_bias = ctx.geom
         xv = Vox(xbuf, C, coff)
-        gyv = _to_vox(gy)
+        gyv = _to_vox(gy.float())
         cout, cin = w.shape[:2]
         K = tuple(w.shape[2:])
         dx = dw = db = None
@@ -113,6 +116,7 @@ class _ConvTranspose3dFn(torch.autograd.Function):
     """y = conv_transpose3d(x, w (cin, cout, k)) == the data gradient of the convolution whose weight is w."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, w, b, stride, padding, output_padding, dilation):
         xv = _to_vox(x.detach())
         cin, cout = w.shape[:2]
@@ -128,11 +132,12 @@ class _ConvTranspose3dFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         xbuf, w = ctx.saved_tensors
         C, coff, stride, padding, dilation, has_bias = ctx.geom
         xv = Vox(xbuf, C, coff)
-        gyv = _to_vox(gy)
+        gyv = _to_vox(gy.float())
         cin, cout = w.shape[:2]
         K = tuple(w.shape[2:])
         dx = dw = db = None
@@ -151,7 +156,8 @@ class _ConvTranspose3dFn(torch.autograd.Function):
 
 
 def _hip_ok(mod, x):
-    return (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32 and mod.groups == 1
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and mod.weight.dtype == torch.float32
+            and mod.groups == 1
             and mod.padding_mode == "zeros" and not isinstance(mod.padding, str))
 
 

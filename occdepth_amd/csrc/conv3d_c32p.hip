@@ -15,6 +15,7 @@
 //
 // Reference semantics replaced: occdepth/models/modules.py:158-175 (conv0, conv1.*, conv2.*, conv_classes).
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 #include "common.h"
 
@@ -213,8 +214,11 @@ template <int D>
 __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP sp) {
     const PersistP& p = sp.base;
     constexpr int YIN = kTY + 2 * D, ZIN = kTZ + 2 * D, ROWS = YIN * ZIN;
-    constexpr int RS4 = 5;
-    constexpr int NF4 = ROWS * 4;
+    // channels staged per slab.  (CH = 32 for D = 1 fits LDS -- 110.6 KB of weights + 49 KB -- and halves the barrier
+    // pairs, but its 6 staging float4 per thread push the kernel past 256 VGPRs: measured as spills, not as a gain.)
+    constexpr int CH = 16, KT = CH / 8, NH = 32 / CH;
+    constexpr int RS4 = CH / 4 + 1;              // CH floats + 4 pad per LDS row: odd number of 16-B slots
+    constexpr int NF4 = ROWS * (CH / 4);
     constexpr int NLOAD = (NF4 + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) f32x4 lds4[];
     f32x4* const w4 = lds4;
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     for (int i = 0; i < NLOAD; ++i) {
         const int f = tid + i * 512;
         const bool live = f < NF4;
-        const int row = f >> 2, c4 = f & 3;
+        const int row = f / (CH / 4), c4 = f - row * (CH / 4);
         const int yi = row / ZIN, zi = row - yi * ZIN;
         const int z = zi - D;
         sdst[i] = live ? row * RS4 + c4 : -1;
@@ -264,7 +268,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     bool colok[NLOAD];
     f32x4 v[NLOAD];
     auto issue = [&](int xi, int h) {        // global -> registers; xi inside the volume
-        const float* base = p.in + (size_t)xi * plane_stride + h * 16;
+        const float* base = p.in + (size_t)xi * plane_stride + h * CH;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -287,61 +291,40 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = 0.f;
 
-    // interior plane: all three kx taps, LDS reads of step s + 1 in flight under the 12 MFMAs of step s
-    auto mma3 = [&](int h) {
-        const f32x4* wb = w4 + (h * 2) * 64 + lane;
-        constexpr int KXS = 9 * 4 * 64;
-        auto aoff = [](int s) { return (((s / 6) * D * ZIN) + ((s / 2) % 3) * D) * RS4 + (s & 1) * 2; };
-        auto woff = [](int s) { return ((s >> 1) * 4 + (s & 1)) * 64; };
-        f32x4 an = ab[aoff(0)], b0n = wb[woff(0)], b1n = wb[woff(0) + KXS], b2n = wb[woff(0) + 2 * KXS];
+    // one staged slab into the accumulators whose output plane exists (U0: kx = 0 -> acc0, U1: kx = 1 -> acc1,
+    // U2: kx = 2 -> acc2; compile-time so every variant is straight-line code); the LDS reads of step s + 1 are in
+    // flight under the MFMAs of step s (sched_barrier: the scheduler sinks them otherwise)
+    auto mma = [&](int h, auto u0, auto u1, auto u2) {
+        constexpr bool U0 = decltype(u0)::value, U1 = decltype(u1)::value, U2 = decltype(u2)::value;
+        const f32x4* wb = w4 + (h * KT) * 64 + lane;
+        constexpr int KXS = 9 * 4 * 64, NS = 9 * KT;
+        auto aoff = [](int s) { return (((s / (3 * KT)) * D * ZIN) + ((s / KT) % 3) * D) * RS4 + (s % KT) * 2; };
+        auto woff = [](int s) { return ((s / KT) * 4 + (s % KT)) * 64; };
+        f32x4 an = ab[aoff(0)], b0n, b1n, b2n;
+        if (U0) b0n = wb[woff(0)];
+        if (U1) b1n = wb[woff(0) + KXS];
+        if (U2) b2n = wb[woff(0) + 2 * KXS];
 #pragma unroll
-        for (int s = 0; s < 18; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const f32x4 a = an, b0 = b0n, b1 = b1n, b2 = b2n;
-            if (s < 17) {
+            if (s < NS - 1) {
                 an = ab[aoff(s + 1)];
-                b0n = wb[woff(s + 1)];
-                b1n = wb[woff(s + 1) + KXS];
-                b2n = wb[woff(s + 1) + 2 * KXS];
+                if (U0) b0n = wb[woff(s + 1)];
+                if (U1) b1n = wb[woff(s + 1) + KXS];
+                if (U2) b2n = wb[woff(s + 1) + 2 * KXS];
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (the scheduler sinks it otherwise)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[q], a[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[q], a[q], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b2[q], a[q], acc2, 0, 0, 0);
+                if (U0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[q], a[q], acc0, 0, 0, 0);
+                if (U1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[q], a[q], acc1, 0, 0, 0);
+                if (U2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b2[q], a[q], acc2, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // first / last planes of a run: only the taps whose output plane belongs to the run (flags are uniform)
-    auto mma_edge = [&](int h, bool use0, bool use1, bool use2) {
-        const f32x4* wb = w4 + (h * 2) * 64 + lane;
-        constexpr int KXS = 9 * 4 * 64;
-#pragma unroll 1
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kz = t - 3 * ky;
-#pragma unroll
-            for (int ktl = 0; ktl < 2; ++ktl) {
-                const f32x4 a = ab[(ky * D * ZIN + kz * D) * RS4 + ktl * 2];
-                const int wo = (t * 4 + ktl) * 64;
-                if (use0) {
-                    const f32x4 b = wb[wo];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc0, 0, 0, 0);
-                }
-                if (use1) {
-                    const f32x4 b = wb[wo + KXS];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc1, 0, 0, 0);
-                }
-                if (use2) {
-                    const f32x4 b = wb[wo + 2 * KXS];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[q], a[q], acc2, 0, 0, 0);
-                }
-            }
-        }
-    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     // epilogue of acc2 (output plane x of column (b, yt)): lane -> voxel z = li, registers -> couts
     // (r & 3) + 8 (r >> 2) + 4 kk, i.e. four float4 groups of consecutive channels per lane.  The residual rows
     // are fetched one slab early (res_fetch) so their latency hides under 216 MFMAs.
@@ -440,17 +423,21 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
                 const bool u0 = j < cnt, u1 = j >= 1 && j <= cnt, u2 = j >= 2;
                 if (j >= jfirst && j <= jlast) {
 #pragma unroll 1
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         __syncthreads();                                   // previous slab consumed
                         commit();
                         __syncthreads();
-                        if (h == 0) issue(xi, 1);
+                        if (h + 1 < NH) issue(xi, h + 1);
                         else {
                             if (j < jlast) issue(xi + D, 0);
                             if (u2) res_fetch(b, yt, xi - D);              // out[j-2] completes with this slab
                         }
-                        if (u0 && u1 && u2) mma3(h);
-                        else mma_edge(h, u0, u1, u2);
+                        if (u0 && u1 && u2) mma(h, T_{}, T_{}, T_{});      // interior plane
+                        else if (u0 && u1) mma(h, T_{}, T_{}, F_{});       // second plane of a run
+                        else if (u1 && u2) mma(h, F_{}, T_{}, T_{});       // second to last
+                        else if (u0) mma(h, T_{}, F_{}, F_{});             // first
+                        else if (u2) mma(h, F_{}, F_{}, T_{});             // last
+                        else mma(h, F_{}, T_{}, F_{});                     // run of a single output plane
                     }
                 }
                 if (u2) {
@@ -472,8 +459,8 @@ bool g_slide_attr[4] = {};
 
 template <int D>
 int launch_slide(const PersistP& base, hipStream_t st, int num_cu) {
-    constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D);
-    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * 5 * 16 + 16 + 128;
+    constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D), RS4 = 16 / 4 + 1;
+    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * RS4 * 16 + 16 + 128;
     if (!g_slide_attr[D]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

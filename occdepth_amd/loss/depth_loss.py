@@ -32,5 +32,6 @@ class DepthClsLoss:
         preds = depth_preds.reshape(N_pred * n_cam_pred, D, H, W).permute(0, 2, 3, 1).reshape(-1, self.depth_channels)
         fg = onehot.amax(1) > 0.0
         # masked sum instead of boolean indexing: same value, no host sync on the number of foreground cells
-        bce = F.binary_cross_entropy(preds.float(), onehot, reduction="none").sum(1)
-        return (bce * fg).sum() / torch.clamp(fg.sum().float(), min=1.0)
+        with torch.autocast(preds.device.type, enabled=False):      # BCE on probabilities is banned under autocast
+            bce = F.binary_cross_entropy(preds.float(), onehot, reduction="none").sum(1)
+            return (bce * fg).sum() / torch.clamp(fg.sum().float(), min=1.0)

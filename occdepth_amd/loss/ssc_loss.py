@@ -17,6 +17,7 @@ class _SscStats(torch.autograd.Function):
     """logits (B, C, ...) -> float64 vector of sums [P(C) | N(C) | T(C) | M | CEnum | CEden | F(F*C)]."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, logits, target, masks, weights, map_occ):
         logits = logits.contiguous()
         raw = hip.ssc_loss_stats(logits, target, masks, weights, map_occ)
@@ -27,6 +28,7 @@ class _SscStats(torch.autograd.Function):
         return raw.double() * hip.ssc_stats_scale(C, F, raw.device)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         logits, target, masks, weights = ctx.saved_tensors
         grad = hip.ssc_loss_grad(logits, target, masks, weights, g.float().contiguous(), ctx.map_occ)

@@ -144,3 +144,22 @@ def test_wgrad_full_size_head_properties(hip_lib):
     scale = centre.abs().max()
     assert float((dw[:, :, 1, 1, 1].double() - centre).abs().max() / scale) < 2e-5
     assert float((dw[:, :, 0, 0, 0].double() - corner).abs().max() / scale) < 2e-5
+
+
+@pytest.mark.gpu
+def test_autocast_keeps_3d_convolutions_in_fp32(hip_lib):
+    """BASELINE config 4 trains under bf16 autocast: the HIP convolutions and the loss statistics take bf16 / fp32
+    inputs, compute in exact fp32 and return fp32 (custom_fwd cast_inputs), gradients flow in the callers' dtypes."""
+    from occdepth_amd.loss import ssc_loss
+    torch.manual_seed(1)
+    conv = ag.Conv3d(16, 20, 3, padding=1).cuda()
+    x = torch.randn(1, 16, 8, 8, 8, device="cuda", requires_grad=True)
+    target = torch.randint(0, 20, (1, 8, 8, 8), device="cuda").to(torch.uint8)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x.to(torch.bfloat16))
+        assert y.dtype == torch.float32
+        loss = ssc_loss.CE_ssc_loss(y.to(torch.bfloat16), target, torch.ones(20, device="cuda"))
+    loss.backward()
+    ref = F.conv3d(x.detach().to(torch.bfloat16).float(), conv.weight.detach(), conv.bias.detach(), padding=1)
+    close(y, ref.double().cpu(), 2e-5, "autocast y")
+    assert x.grad is not None and conv.weight.grad.dtype == torch.float32 and torch.isfinite(conv.weight.grad).all()

@@ -1,7 +1,7 @@
 """Training-step baseline for SURVEY 8(f) row N1 (dev tool; needs the GPU):  forward (ATen / MIOpen autograd graph)
 + the fused loss statistics kernels + backward + AdamW on one synthetic config-2 stereo frame.
 
-    python tools/bench_train.py [steps=3] [config=kitti_a100|kitti_2080ti]
+    python tools/bench_train.py [steps=3] [config=kitti_a100|kitti_2080ti] [bf16]
 Prints ms per phase.  This is the number later rounds' hand-written backward kernels have to beat."""
 import os
 import sys
@@ -15,7 +15,7 @@ from occdepth_amd.loss.sscMetrics import SSCMetrics
 from occdepth_amd.models.OccDepth import OccDepth
 
 
-def main(steps=3, cfg_name="kitti_a100"):
+def main(steps=3, cfg_name="kitti_a100", amp=None):
     torch.manual_seed(0)
     dev = torch.device("cuda")
     cfg = getattr(configs, cfg_name).clone()
@@ -52,7 +52,8 @@ def main(steps=3, cfg_name="kitti_a100"):
             torch.cuda.synchronize()
             t0 = time.time()
         opt.zero_grad(set_to_none=True)
-        loss = model.step(batch, "train", metric)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp == "bf16"):
+            loss = model.step(batch, "train", metric)
         torch.cuda.synchronize()
         t1 = time.time()
         loss.backward()
@@ -65,14 +66,17 @@ def main(steps=3, cfg_name="kitti_a100"):
         print(f"step {it}: loss {float(loss):.4f}  fwd+loss {1e3 * (t1 - t0):.1f} ms  bwd {1e3 * (t2 - t1):.1f} ms  "
               f"adamw {1e3 * (t3 - t2):.1f} ms  mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
     best = min(times[1:], key=sum)
-    print(f"{cfg_name} train step (fp32, batch 1): {1e3 * sum(best):.1f} ms -> {1 / sum(best):.2f} steps/s "
+    print(f"{cfg_name} train step ({'bf16 autocast (3-D convolutions + losses fp32)' if amp == 'bf16' else 'fp32'}, batch 1): {1e3 * sum(best):.1f} ms -> {1 / sum(best):.2f} steps/s "
           f"(fwd+loss {1e3 * best[0]:.1f}, bwd {1e3 * best[1]:.1f}, opt {1e3 * best[2]:.1f})")
     with hip.profile() as prof:
         opt.zero_grad(set_to_none=True)
-        model.step(batch, "train", metric).backward()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp == "bf16"):
+            loss = model.step(batch, "train", metric)
+        loss.backward()
     for k, v in prof.rows.items():
         print(f"  {k:40s} n={v['launches']:3d} {v['ms']:7.3f} ms")
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, sys.argv[2] if len(sys.argv) > 2 else "kitti_a100")
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, sys.argv[2] if len(sys.argv) > 2 else "kitti_a100",
+         sys.argv[3] if len(sys.argv) > 3 else None)
