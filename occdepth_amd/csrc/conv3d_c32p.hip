@@ -1,16 +1,18 @@
-// K2p -- persistent, weights-stationary 3x3x3 convolution for <=32 -> <=32 channels on Z = 32 columns:
-// the segmentation-head convolutions at full resolution (7-8 launches, 87 % of the 3-D stack's FLOPs).
+// Persistent, weights-stationary 3x3x3 convolutions for <=32 -> <=32 channels on Z = 32 columns: the
+// segmentation-head convolutions at full resolution (7-8 launches, 87 % of the 3-D stack's FLOPs) and, in training,
+// their data gradients.  Two kernels, same math as conv3d_igemm_kernel (v_mfma_f32_32x32x2_f32, exact fp32):
 //
-// Same math as conv3d_igemm_kernel (v_mfma_f32_32x32x2_f32, exact fp32), different dataflow:
-//   * one 512-thread workgroup per CU stays resident and walks output tiles of 8 (y) x 32 (z) voxels at one x;
-//     XCD k owns a contiguous range of x-planes and each workgroup walks along x at a fixed y-tile, so the
-//     kx halo planes of consecutive tiles are L2 hits;
-//   * ALL 27 x 32 x 32 weights (110.6 KB, MFMA B-fragment order) are loaded into LDS once per workgroup:
-//     no per-wave weight stream from L2 (which was 3x the activation traffic in the generic kernel);
-//   * the input slab of one (kx, 16-channel half) is register-staged: its global loads are issued right
-//     after the previous slab was written to LDS and land while the 18 MFMA steps of the current slab run
-//     (global -> VGPR -> LDS split, one LDS slab buffer, two barriers per slab);
-//   * wave w owns the 32 voxels of row y0+w (one M tile, one accumulator), 2 waves per SIMD.
+//   K2s conv3d_c32_slide_kernel  (default)  sliding window along x with three accumulators per wave: every staged
+//       input plane feeds all three kx taps (staged once instead of three times); see the comment above it.
+//   K2p conv3d_c32_persist_kernel (OCCD_C32P_TILED=1, kept for A/B runs) one accumulator per wave, tile by tile:
+//       XCD k owns a contiguous range of x-planes, each workgroup walks along x at a fixed y-tile so the kx halo
+//       planes of consecutive tiles are L2 hits; each (kx, 16-channel) slab is register-staged (global -> VGPR -> LDS,
+//       one LDS slab buffer, two barriers per slab) under the 72 MFMAs of the previous one.
+// Common to both: one 512-thread workgroup per CU stays resident; ALL 27 x 32 x 32 weights (110.6 KB, MFMA B-fragment
+// order) are loaded into LDS once per workgroup -- no per-wave weight stream from L2 (3x the activation traffic in the
+// generic kernel); wave w owns the 32 voxels of row y0+w (one M tile), 2 waves per SIMD; operands are
+// (weights, activations) so a lane ends up with four float4 groups of consecutive couts of ONE voxel (16-byte
+// residual loads / stores).
 // LDS: 110,592 B weights + (8+2d)(32+2d) rows x 80 B  (d=1: 137.8 KB, d=3: 153.2 KB) -> 1 workgroup / CU.
 //
 // Reference semantics replaced: occdepth/models/modules.py:158-175 (conv0, conv1.*, conv2.*, conv_classes).

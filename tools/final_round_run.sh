@@ -19,5 +19,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   grep "Counter_Name\|conv3d_c32" $g > $O/pmc_head_$c.csv
 done
 python $R/tools/pmc_to_json.py $O/pmc_head_FETCH_SIZE.csv $O/pmc_head_WRITE_SIZE.csv $O/head_conv_hbm_bytes.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcl_$c -- python $R/tools/pmc_lift.py > /tmp/pmcl_$c.log 2>&1
+  g=$(ls /tmp/pmcl_$c/*/*counter_collection.csv | head -1)
+  grep "Counter_Name\|lift_" $g > $O/pmc_lift_$c.csv
+done
+python - <<PY
+import csv
+for c, mul in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open("$O/pmc_lift_%s.csv" % c)) if r["Counter_Name"] == c]
+    print("lift %s: %.1f MB per launch (KB counter%s)" % (c, sum(v) / len(v) * mul / 1e6, ", doubled per the gfx950 correction" if mul > 1024 else ""))
+PY
 cd $R
 timeout 300 python tools/bench_kernels.py head stack wgrad loss > $O/bench_kernels.txt 2>&1; grep "^conv\|^wgrad\|^loss\|UNet3D\|sfa_lift" $O/bench_kernels.txt

@@ -1,0 +1,26 @@
+"""Run the config-2 lift (K1b) a few times, for rocprofv3 --pmc passes (HBM bytes of the gather kernel):
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python tools/pmc_lift.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from occdepth_amd import hip, synthetic
+from occdepth_amd.models.SFA import voxel_layout
+
+torch.manual_seed(0)
+b = synthetic.kitti_frame(seed=1)
+views = [hip.project_voxels(b["T_velo_2_cam_f64"][0][v].numpy(), b["cam_k"][0][v].numpy(), (0.0, -25.6, -2.0), 0.4,
+                            (128, 128, 16), 1220, 370, device="cuda") for v in range(2)]
+pix = torch.stack([p for p, _ in views]).unsqueeze(0)
+fov = torch.stack([m for _, m in views]).unsqueeze(0)
+sizes = [(370, 1220), (185, 610), (93, 305), (47, 153)]
+rows = [[torch.randn(1, h, w, 64, device="cuda") for _ in range(2)] for h, w in sizes]
+n_dims, out_dims, strides = voxel_layout((256, 256, 32), 2, "kitti")
+out = hip.Vox.empty(1, out_dims, 64, "cuda")
+depth = torch.rand(1, 262144, device="cuda")
+for _ in range(5):
+    hip.lift(rows, [1, 2, 4, 8], pix, fov, n_dims, strides, out, depth_scale=depth)
+torch.cuda.synchronize()
+print("done")
