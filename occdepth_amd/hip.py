@@ -99,6 +99,9 @@ EXPORTS = {
                                        c_int32, c_float, c_int32, c_void_p]),
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_wino_input_transform_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "occd_wino_output_transform_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                  c_int32, c_int32, c_int32, c_float, c_int32, c_void_p]),
     "occd_project_voxels": (c_int32, [c_void_p, c_void_p, c_void_p, c_double] + [c_int32] * 5
                             + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -423,6 +426,48 @@ def affine_act(x, scale, shift, act=None, slope=0.01, res=None, res_first=False,
                                        _f32(shift, "shift") if shift is not None else None, B, C, S, ACT2D[act],
                                        float(slope), 1 if res_first else 0, _stream()), "occd_affine_act_nchw")
     return out
+
+
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def winograd_weights(w):
+    """(Cout, Cin, 3, 3) -> U (16, Cin, Cout) with U[4i+j][ci][co] = (G g G^T)[i][j] (float64 arithmetic, once per weight)."""
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum("ia,ocab,jb->ijco", G, w.detach().double(), G)
+    return u.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
+
+
+def wino_input_transform(x):
+    B, C, H, W = x.shape
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    V = torch.empty((16, T, C), device=x.device, dtype=torch.float32)
+    xc = x if x.is_contiguous() else x.contiguous()
+    _check(load().occd_wino_input_transform_nchw(_f32(xc, "x"), V.data_ptr(), B, C, H, W, _stream()),
+           "occd_wino_input_transform_nchw")
+    return V
+
+
+def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False):
+    B, C, H, W = shape
+    y = torch.empty(shape, device=M.device, dtype=torch.float32)
+    if res is not None and not res.is_contiguous():
+        res = res.contiguous()
+    _check(load().occd_wino_output_transform_nchw(_f32(M, "M"), _f32(scale, "scale") if scale is not None else None,
+                                                  _f32(shift, "shift") if shift is not None else None,
+                                                  _f32(res, "res") if res is not None else None, y.data_ptr(), B, C, H, W,
+                                                  ACT2D[act], float(slope), 1 if res_first else 0, _stream()),
+           "occd_wino_output_transform_nchw")
+    return y
+
+
+def conv2d_3x3_winograd(x, U, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False):
+    """act(scale * conv3x3(x, g, pad 1) + shift) (+res) with U = winograd_weights(g): HIP transforms around 16 batched
+    fp32 GEMMs on the MFMA pipe (rocBLAS)."""
+    B, Cin, H, W = x.shape
+    V = wino_input_transform(x)
+    M = torch.bmm(V, U)
+    return wino_output_transform(M, (B, U.shape[2], H, W), scale, shift, act, slope, res, res_first)
 
 
 def dwconv2d_same(x, w, scale, shift, stride, act=None):

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from ..fused import bn_affine_cached, needs_autograd
+from ..fused import _stamp, bn_affine_cached, needs_autograd
 from .efficientnet import EfficientNet
 
 MODEL_NAME = "tf_efficientnet_b3_ns"
@@ -40,13 +40,39 @@ class UpSampleBN(nn.Module):
                        nn.BatchNorm2d(output_features), nn.LeakyReLU()]
         self._net = nn.Sequential(*layers)
 
+    # Winograd-domain GEMMs on the MFMA pipe instead of MIOpen's VALU Winograd: pays when tiles are few and channels
+    # many (the 1/16, 1/8, 1/4 levels of config 2; tools/bench_wino.py has the per-level numbers)
+    WINOGRAD = os.environ.get("OCCDEPTH_WINOGRAD", "1") == "1"
+    WINOGRAD_MAX_PIXELS = 80000      # B * H * W
+    WINOGRAD_MIN_CIN = 256
+
+    def _wino_operands(self, conv, bn):
+        key = _stamp(conv, bn)
+        cache = self.__dict__.setdefault("_wino_cache", {})
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            scale, shift = bn_affine_cached(bn)
+            if conv.bias is not None:
+                shift = shift + scale * conv.bias.detach().float()
+            hit = (key, hip.winograd_weights(conv.weight), scale.contiguous(), shift.contiguous())
+            cache[id(conv)] = hit
+        return hit[1:]
+
+    def _conv_bn_act(self, f, conv, bn, act):
+        B, C, H, W = f.shape
+        if self.WINOGRAD and C >= self.WINOGRAD_MIN_CIN and B * H * W <= self.WINOGRAD_MAX_PIXELS:
+            U, scale, shift = self._wino_operands(conv, bn)
+            return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope)
+        return hip.affine_act(conv(f), *bn_affine_cached(bn), "leaky", slope=act.negative_slope)
+
     def forward(self, x, concat_with):
         if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
-            # eval: bilinear-up + concat in one HIP pass, BatchNorm + LeakyReLU fused behind each MIOpen conv
+            # eval: bilinear-up + concat in one HIP pass; BatchNorm + LeakyReLU fused into the Winograd output transform
+            # or applied in one pass behind the MIOpen convolution
             f = hip.upsample_bilinear_cat(x, concat_with)
             n = self._net
-            f = hip.affine_act(n[0](f), *bn_affine_cached(n[1]), "leaky", slope=n[2].negative_slope)
-            return hip.affine_act(n[3](f), *bn_affine_cached(n[4]), "leaky", slope=n[5].negative_slope)
+            f = self._conv_bn_act(f, n[0], n[1], n[2])
+            return self._conv_bn_act(f, n[3], n[4], n[5])
         up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
         return self._net(torch.cat([up, concat_with], dim=1))
 

@@ -165,6 +165,41 @@ def conv3d_wgrad(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1),
                                        padding=padding, dilation=dilation).float()
 
 
+_BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0., 1., 0., -1.]], dtype=torch.float64)
+_AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]], dtype=torch.float64)
+
+
+def wino_input_transform(x):
+    B, C, H, W = x.shape
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    xp = F.pad(x.double(), (1, 2 * tw + 1 - W, 1, 2 * th + 1 - H))
+    d = F.unfold(xp, kernel_size=4, stride=2).reshape(B, C, 4, 4, th * tw)            # patches at (2ty-1, 2tx-1)
+    v = torch.einsum("ia,bcakt,jk->ijbtc", _BT, d, _BT)
+    return v.reshape(16, B * th * tw, C).float()
+
+
+def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False):
+    B, C, H, W = shape
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    m = M.double().reshape(4, 4, B, th, tw, C)
+    y = torch.einsum("ri,ijbyxc,sj->bcyrxs", _AT, m, _AT).reshape(B, C, 2 * th, 2 * tw)[:, :, :H, :W]
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    if res is not None and res_first:
+        y = y + res.double()
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "leaky":
+        y = F.leaky_relu(y, slope)
+    elif act == "swish":
+        y = y * torch.sigmoid(y)
+    if res is not None and not res_first:
+        y = y + res.double()
+    return y.float()
+
+
 def _softmax_and_target(logits, target, map_occ):
     B, C = logits.shape[:2]
     p = F.softmax(logits.detach().double().reshape(B, C, -1), 1)        # (B, C, S)
@@ -231,8 +266,9 @@ def ssc_confusion(hist, target, logits=None, labels=None):
 def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
-                                          "ssc_confusion", "conv3d_wgrad")}
+                                          "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform")}
     hip.conv3d_wgrad = conv3d_wgrad
+    hip.wino_input_transform, hip.wino_output_transform = wino_input_transform, wino_output_transform
     hip.ssc_loss_stats, hip.ssc_loss_grad, hip.ssc_confusion = ssc_loss_stats, ssc_loss_grad, ssc_confusion
     saved_from = Vox.from_ncdhw
     saved_as_vox = fused.as_vox
