@@ -43,8 +43,8 @@ class UpSampleBN(nn.Module):
     # Winograd-domain GEMMs on the MFMA pipe instead of MIOpen's VALU Winograd: pays when tiles are few and channels
     # many (the 1/16, 1/8, 1/4 levels of config 2; tools/bench_wino.py has the per-level numbers)
     WINOGRAD = os.environ.get("OCCDEPTH_WINOGRAD", "1") == "1"
-    WINOGRAD_MAX_PIXELS = 80000      # B * H * W
-    WINOGRAD_MIN_CIN = 256
+    WINOGRAD_MAX_PIXELS = int(os.environ.get("OCCDEPTH_WINOGRAD_MAX_PIXELS", "80000"))      # B * H * W
+    WINOGRAD_MIN_CIN = int(os.environ.get("OCCDEPTH_WINOGRAD_MIN_CIN", "256"))
 
     def _wino_operands(self, conv, bn):
         key = _stamp(conv, bn)
