@@ -48,6 +48,7 @@ def build_model(device):
                      class_weights_occ=torch.ones(2), full_scene_size=tuple(cfg.full_scene_size),
                      project_res=configs.PROJECT_RES, config=cfg)
     m.batch_views = os.environ.get("OCCDEPTH_BATCH_VIEWS", "1") == "1"
+    m.graph_2d = m.batch_views and os.environ.get("OCCDEPTH_GRAPH_2D", "1") == "1"
     return m.to(device).eval(), cfg
 
 
@@ -196,7 +197,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: SemanticKITTI stereo 370x1220, tf_efficientnet_b7_ns, "
                                    "feature 64, flosp_depth + CRP + cascade head, 256x256x32 voxels, batch 1/GPU",
                        "frames_per_step": world, "parallelism": f"dp{world} (frames sharded, no collective)",
-                       "batch_views": bool(model.batch_views)},
+                       "batch_views": bool(model.batch_views), "graph_2d": bool(model.graph_2d)},
             "roofline": {"bound": "mfma", "kernel": "conv3d_c32_slide_kernel: 3x3x3 32->32 @256x256x32 (v_mfma_f32_32x32x2_f32)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,

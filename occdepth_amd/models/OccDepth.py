@@ -54,6 +54,8 @@ class OccDepth(_Base):
         print("INFO: Use occluded cls: {}".format(self.occluded_cls))
         self.infer_mode = infer_mode
         self.batch_views = False  # eval: run all views through net_rgb as one batch (faster, not bit-equal)
+        self.graph_2d = False     # eval + batch_views: replay the 2-D network as one captured hipGraph
+        self._graphs = {}
         if infer_mode:
             self.context_prior = False
         assert not (config.use_stereo_depth_gt and config.use_lidar_depth_gt), "only with one depth data supported."
@@ -111,12 +113,44 @@ class OccDepth(_Base):
                 self.depth_loss_fn = DepthClsLoss(downsample_factor=conf["downsample_factor"], d_bound=conf["d_bound"])
 
     # ---------------------------------------------------------------- 2-D side
+    def _net_rgb_graphed(self, x):
+        """The 2-D network is ~1200 launches of mostly 5-40 us kernels: with `graph_2d` (opt-in, eval only) it is
+        captured once per input shape into a hipGraph and replayed, so the host never gates the GPU there.  The 3-D
+        stack stays outside (its launches are few, long, and individually timed by bench.py)."""
+        if not self.graph_2d or not x.is_cuda:
+            return self.net_rgb(x)
+        key = (tuple(x.shape), x.device)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = x.clone()
+            try:
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):                         # warm-up: lazy initialisation, weight caches, MIOpen solvers
+                        self.net_rgb(static_in)
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self.net_rgb(static_in)
+                entry = (graph, static_in, static_out)
+            except Exception as e:                             # capture is an optimisation, never a requirement
+                import warnings
+                warnings.warn(f"occdepth_amd: hipGraph capture of the 2-D network failed ({e!r}); running eagerly")
+                self.graph_2d = False
+                return self.net_rgb(x)
+            self._graphs[key] = entry
+        graph, static_in, static_out = entry
+        static_in.copy_(x)
+        graph.replay()
+        return static_out
+
     def process_rgbs(self, img, batch, n_views):
         bs = img.shape[0]
         if not needs_autograd(self) and self.batch_views and n_views > 1:
             # eval: BN uses running stats, so the views can share one batched pass (opt-in: a different
             # conv batch size changes backend algorithm choice and hence fp32 round-off)
-            both = self.net_rgb(img.reshape(bs * n_views, *img.shape[2:]))
+            both = self._net_rgb_graphed(img.reshape(bs * n_views, *img.shape[2:]))
             x_rgb = [{k: v.reshape(bs, n_views, *v.shape[1:])[:, i] for k, v in both.items()}
                      for i in range(n_views)]
         else:

@@ -388,3 +388,32 @@ def test_product_synthetic_frame_equals_oracle_batch(config2):
             assert all(torch.equal(a.cpu(), b) and a.dtype == b.dtype for a, b in zip(got[k], v)), k
         else:
             assert torch.equal(got[k].cpu(), v), k
+
+
+def test_graph_replay_of_2d_network_matches_eager(config2):
+    """bench.py's `graph_2d` (hipGraph capture of the 2-D network, replayed per frame) reproduces the eager forward
+    on fresh inputs -- the captured graph reads the new image, not the one it was captured with."""
+    from occdepth_amd import synthetic
+    m = config2[0]
+    saved = (m.batch_views, m.graph_2d)
+    try:
+        m.batch_views = True
+        frames = [synthetic.attach_projection(m, synthetic.to_device(synthetic.kitti_frame(seed=s), DEV)) for s in (11, 12)]
+        with torch.no_grad():
+            m.graph_2d = False
+            eager = [{k: v.clone() for k, v in m(f).items()} for f in frames]
+            m.graph_2d = True
+            m._graphs = {}
+            graphed = [{k: v.clone() for k, v in m(f).items()} for f in frames]        # first call captures
+            again = {k: v.clone() for k, v in m(frames[0]).items()}                      # replay with frame 0 again
+        assert m.graph_2d, "capture fell back to eager"
+        for e, g in zip(eager, graphed):
+            for k in e:
+                err = ((e[k] - g[k]).abs().max() / e[k].abs().max()).item()
+                assert err < 5e-4, (k, err)              # same kernels; MIOpen's Winograd differs run to run by ~2e-4
+        assert not torch.equal(graphed[0]["ssc_logit"], graphed[1]["ssc_logit"])
+        err = ((again["ssc_logit"] - graphed[0]["ssc_logit"]).abs().max() / again["ssc_logit"].abs().max()).item()
+        assert err < 5e-4
+    finally:
+        m.batch_views, m.graph_2d = saved
+        m._graphs = {}
