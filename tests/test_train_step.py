@@ -78,7 +78,10 @@ def check(cfg_name, m, loss, metric, rel, grad_norm_rel=None, grad_elem=None):
                                                                 rel=grad_norm_rel or rel * 10), k
     print(cfg_name, "worst |dgrad| / rms(grad) over", len(keys), "parameters:", worst)
     assert worst < (grad_elem or rel * 50)
-    assert np.array_equal(metric.tps, g[f"{cfg_name}.metric.tps"])
+    if grad_elem is None:
+        assert np.array_equal(metric.tps, g[f"{cfg_name}.metric.tps"])
+    else:                                           # GPU run: an arg-max near a tie may flip with MIOpen's round-off
+        assert np.abs(metric.tps - g[f"{cfg_name}.metric.tps"]).sum() <= 0.005 * g[f"{cfg_name}.metric.tps"].sum() + 2
 
 
 @pytest.mark.parametrize("cfg_name", CFGS)
@@ -129,7 +132,7 @@ def test_hip_conv_functions_match_aten_backward_gpu(hip_lib):
             worst = max(worst, e)
             if k.startswith("net_3d_decoder."):
                 worst3d = max(worst3d, e)
-            assert float(a.norm()) == pytest.approx(float(b.norm()), rel=5e-3), k
+            assert float(a.norm()) == pytest.approx(float(b.norm()), rel=2e-2), k
     print("HIP vs ATen 3-D convolutions, worst |dgrad| / rms(grad): 3-D stack", worst3d, " all parameters", worst)
     # The 3-D stack's own parameters sit right behind the loss.  The 2-D encoder weights are ~100 layers further
     # down the backward pass of a random-init network: there a 1e-6 perturbation (and MIOpen's atomically
