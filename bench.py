@@ -94,6 +94,20 @@ def cpu_baseline(model, cfg, batch, seed, budget_s=45.0):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON).  Native libraries write banners to fd 1 (RCCL prints its version
+    # block at the first communicator, MIOpen its warnings): park fd 1 on stderr until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _main(real_stdout)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _main(real_stdout):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -109,7 +123,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("OCCDEPTH_FORCE_DIST") == "1":     # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
@@ -217,7 +231,8 @@ def main():
                                        "sample": f"failed: {e!r}"}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
