@@ -228,12 +228,14 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
  *   input : x (B, Cin, H, W) -> V (16, T, Cin),  V[4i+j] = (B^T d B)[i][j] of the 4x4 patch at (2ty-1, 2tx-1), zero padded
  *   (caller): M[xi] (T, Cout) = V[xi] (T, Cin) . U[xi] (Cin, Cout),  U[4i+j][ci][co] = (G g[co][ci] G^T)[i][j]
  *   output: M (16, T, Cout) -> y (B, Cout, H, W) = act(scale[c] * (A^T M A) + shift[c]) (+ res before or after act;
- *           act codes of occd_affine_act_nchw).                                                                   */
+ *           act codes of occd_affine_act_nchw).
+ * A call covers the STRIP of tile rows [ty0, ty0 + ths) of every image (ths = ceil(H/2), ty0 = 0: the whole image):
+ * T = B * ths * tw, row (b*ths + ty - ty0)*tw + tx.  Strips keep V / M of the high-resolution levels cache-sized.  */
 int occd_wino_input_transform_nchw(const float* x, float* V, int32_t batch, int32_t Cin, int32_t H, int32_t W,
-                                   void* stream);
+                                   int32_t ty0, int32_t ths, void* stream);
 int occd_wino_output_transform_nchw(const float* M, const float* scale, const float* shift, const float* res,
-                                    float* y, int32_t batch, int32_t Cout, int32_t H, int32_t W, int32_t act,
-                                    float slope, int32_t res_first, void* stream);
+                                    float* y, int32_t batch, int32_t Cout, int32_t H, int32_t W, int32_t ty0,
+                                    int32_t ths, int32_t act, float slope, int32_t res_first, void* stream);
 
 /* SURVEY 8(f) row N4 (first step): out[row] = lut[argmax_c x[row][coff + c]] (first maximum wins; lut may
  * be NULL) as uint16 -- replaces the host softmax + numpy argmax of scripts/generate_output.py:94-95 and the

@@ -29,12 +29,13 @@ __device__ __forceinline__ float act_apply2(float v, int act, float slope) {
 }
 
 // grid: (ceil(tw / 32), th, B * ceil(Cin / 32)); 256 threads
+// (ty0, ths): the tile rows [ty0, ty0 + ths) of every image form the T = B * ths * tw rows of this call's V (a strip)
 __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
-                                                         int Cin, int H, int W, int th, int tw) {
+                                                         int Cin, int H, int W, int ths, int tw, int ty0) {
     __shared__ float tile[kCh][4 * kCols + 1];            // [channel][row * kCols + col], odd stride: conflict-free
     const int cblocks = (Cin + kCh - 1) / kCh;
     const int b = blockIdx.z / cblocks, c0 = (blockIdx.z - b * cblocks) * kCh;
-    const int ty = blockIdx.y, tx0 = blockIdx.x * kTilesX;
+    const int tys = blockIdx.y, ty = ty0 + tys, tx0 = blockIdx.x * kTilesX;
     const int y0 = 2 * ty - 1, x0 = 2 * tx0 - 1;
     // stage 32 channels x 4 rows x 66 columns (zero outside the image = the convolution's padding)
     for (int i = threadIdx.x; i < kCh * 4 * kCols; i += 256) {
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
     }
     __syncthreads();
     const int c = threadIdx.x & 31;
-    const size_t T = (size_t)B * th * tw;
+    const size_t T = (size_t)B * ths * tw;
     for (int t = threadIdx.x >> 5; t < kTilesX; t += 8) {
         const int tx = tx0 + t;
         if (tx >= tw || c0 + c >= Cin) continue;
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
             w[2][j] = d[2][j] - d[1][j];
             w[3][j] = d[1][j] - d[3][j];
         }
-        const size_t tidx = ((size_t)b * th + ty) * tw + tx;
+        const size_t tidx = ((size_t)b * ths + tys) * tw + tx;
         float* o = V + tidx * Cin + c0 + c;
         const size_t xs = T * Cin;                            // stride between Winograd positions
 #pragma unroll
@@ -81,20 +82,20 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const float* __restrict
 // grid: (ceil(tw / 32), th, B * ceil(Cout / 32)); 256 threads
 __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ res,
-                                                          float* __restrict__ y, int B, int Cout, int H, int W, int th,
-                                                          int tw, int act, float slope, int res_first) {
+                                                          float* __restrict__ y, int B, int Cout, int H, int W, int ths,
+                                                          int tw, int ty0, int act, float slope, int res_first) {
     __shared__ float tile[kCh][2 * 2 * kTilesX + 1];      // [channel][row * 64 + col]
     const int cblocks = (Cout + kCh - 1) / kCh;
     const int b = blockIdx.z / cblocks, c0 = (blockIdx.z - b * cblocks) * kCh;
-    const int ty = blockIdx.y, tx0 = blockIdx.x * kTilesX;
+    const int tys = blockIdx.y, ty = ty0 + tys, tx0 = blockIdx.x * kTilesX;
     const int c = threadIdx.x & 31;
-    const size_t T = (size_t)B * th * tw;
+    const size_t T = (size_t)B * ths * tw;
     const size_t xs = T * Cout;
     for (int t = threadIdx.x >> 5; t < kTilesX; t += 8) {
         const int tx = tx0 + t;
         float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         if (tx < tw && c0 + c < Cout) {
-            const size_t tidx = ((size_t)b * th + ty) * tw + tx;
+            const size_t tidx = ((size_t)b * ths + tys) * tw + tx;
             const float* m = M + tidx * Cout + c0 + c;
             float v[4][4];
 #pragma unroll
@@ -142,30 +143,34 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const float* __restric
 extern "C" {
 
 int occd_wino_input_transform_nchw(const float* x, float* V, int32_t batch, int32_t Cin, int32_t H, int32_t W,
-                                   void* stream) {
+                                   int32_t ty0, int32_t ths, void* stream) {
     if (!x || !V || batch <= 0 || Cin <= 0 || H <= 0 || W <= 0) return OCCD_EINVAL;
-    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const int tw = (W + 1) / 2;
+    if (ty0 < 0 || ths < 1 || ty0 + ths > (H + 1) / 2) return OCCD_EINVAL;
+    const int th = ths;
     const long gz = (long)batch * ((Cin + kCh - 1) / kCh);
     if (gz > 65535 || th > 65535) return OCCD_EINVAL;
     const double T = (double)batch * th * tw;
     occd::ProfScope prof("wino_input", (hipStream_t)stream, 32.0 * T * Cin, 4.0 * ((double)batch * Cin * H * W + 16.0 * T * Cin));
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((tw + kTilesX - 1) / kTilesX), (unsigned)th, (unsigned)gz), dim3(256),
-                       0, (hipStream_t)stream, x, V, batch, Cin, H, W, th, tw);
+                       0, (hipStream_t)stream, x, V, batch, Cin, H, W, ths, tw, ty0);
     return occd::check_launch();
 }
 
 int occd_wino_output_transform_nchw(const float* M, const float* scale, const float* shift, const float* res, float* y,
-                                    int32_t batch, int32_t Cout, int32_t H, int32_t W, int32_t act, float slope,
-                                    int32_t res_first, void* stream) {
+                                    int32_t batch, int32_t Cout, int32_t H, int32_t W, int32_t ty0, int32_t ths,
+                                    int32_t act, float slope, int32_t res_first, void* stream) {
     if (!M || !y || batch <= 0 || Cout <= 0 || H <= 0 || W <= 0 || act < 0 || act > 3) return OCCD_EINVAL;
-    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const int tw = (W + 1) / 2;
+    if (ty0 < 0 || ths < 1 || ty0 + ths > (H + 1) / 2) return OCCD_EINVAL;
+    const int th = ths;
     const long gz = (long)batch * ((Cout + kCh - 1) / kCh);
     if (gz > 65535 || th > 65535) return OCCD_EINVAL;
     const double T = (double)batch * th * tw;
     occd::ProfScope prof("wino_output", (hipStream_t)stream, 24.0 * T * Cout,
                          4.0 * (16.0 * T * Cout + (double)batch * Cout * H * W * (1 + (res != nullptr))));
     hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((tw + kTilesX - 1) / kTilesX), (unsigned)th, (unsigned)gz), dim3(256),
-                       0, (hipStream_t)stream, M, scale, shift, res, y, batch, Cout, H, W, th, tw, act, slope, res_first);
+                       0, (hipStream_t)stream, M, scale, shift, res, y, batch, Cout, H, W, ths, tw, ty0, act, slope, res_first);
     return occd::check_launch();
 }
 

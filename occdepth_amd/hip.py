@@ -99,9 +99,10 @@ EXPORTS = {
                                        c_int32, c_float, c_int32, c_void_p]),
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
-    "occd_wino_input_transform_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "occd_wino_input_transform_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                 c_void_p]),
     "occd_wino_output_transform_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
-                                                  c_int32, c_int32, c_int32, c_float, c_int32, c_void_p]),
+                                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_void_p]),
     "occd_project_voxels": (c_int32, [c_void_p, c_void_p, c_void_p, c_double] + [c_int32] * 5
                             + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -438,36 +439,49 @@ def winograd_weights(w):
     return u.reshape(16, w.shape[1], w.shape[0]).float().contiguous()
 
 
-def wino_input_transform(x):
+def wino_input_transform(x, ty0=0, ths=None):
+    """x (B, C, H, W) -> V (16, B * ths * tw, C) for the tile rows [ty0, ty0 + ths) (default: all)."""
     B, C, H, W = x.shape
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    ths = (H + 1) // 2 - ty0 if ths is None else ths
+    T = B * ths * ((W + 1) // 2)
     V = torch.empty((16, T, C), device=x.device, dtype=torch.float32)
     xc = x if x.is_contiguous() else x.contiguous()
-    _check(load().occd_wino_input_transform_nchw(_f32(xc, "x"), V.data_ptr(), B, C, H, W, _stream()),
+    _check(load().occd_wino_input_transform_nchw(_f32(xc, "x"), V.data_ptr(), B, C, H, W, ty0, ths, _stream()),
            "occd_wino_input_transform_nchw")
     return V
 
 
-def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False):
+def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False, out=None,
+                          ty0=0, ths=None):
+    """M (16, B * ths * tw, C) -> rows [2 ty0, 2 (ty0 + ths)) of y (B, C, H, W) (allocated unless `out` is given)."""
     B, C, H, W = shape
-    y = torch.empty(shape, device=M.device, dtype=torch.float32)
+    ths = (H + 1) // 2 - ty0 if ths is None else ths
+    y = torch.empty(shape, device=M.device, dtype=torch.float32) if out is None else out
     if res is not None and not res.is_contiguous():
         res = res.contiguous()
     _check(load().occd_wino_output_transform_nchw(_f32(M, "M"), _f32(scale, "scale") if scale is not None else None,
                                                   _f32(shift, "shift") if shift is not None else None,
-                                                  _f32(res, "res") if res is not None else None, y.data_ptr(), B, C, H, W,
-                                                  ACT2D[act], float(slope), 1 if res_first else 0, _stream()),
+                                                  _f32(res, "res") if res is not None else None, _f32(y, "y"), B, C, H, W,
+                                                  ty0, ths, ACT2D[act], float(slope), 1 if res_first else 0, _stream()),
            "occd_wino_output_transform_nchw")
     return y
 
 
-def conv2d_3x3_winograd(x, U, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False):
+def conv2d_3x3_winograd(x, U, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False, strip_rows=None):
     """act(scale * conv3x3(x, g, pad 1) + shift) (+res) with U = winograd_weights(g): HIP transforms around 16 batched
-    fp32 GEMMs on the MFMA pipe (rocBLAS)."""
+    fp32 GEMMs on the MFMA pipe (hipBLASLt).  `strip_rows` tile rows per pass keep V / M cache-sized on big images."""
     B, Cin, H, W = x.shape
-    V = wino_input_transform(x)
-    M = torch.bmm(V, U)
-    return wino_output_transform(M, (B, U.shape[2], H, W), scale, shift, act, slope, res, res_first)
+    th = (H + 1) // 2
+    if strip_rows is None or strip_rows >= th:
+        V = wino_input_transform(x)
+        return wino_output_transform(torch.bmm(V, U), (B, U.shape[2], H, W), scale, shift, act, slope, res, res_first)
+    y = torch.empty((B, U.shape[2], H, W), device=x.device, dtype=torch.float32)
+    xc = x if x.is_contiguous() else x.contiguous()
+    for ty0 in range(0, th, strip_rows):
+        ths = min(strip_rows, th - ty0)
+        M = torch.bmm(wino_input_transform(xc, ty0, ths), U)
+        wino_output_transform(M, tuple(y.shape), scale, shift, act, slope, res, res_first, out=y, ty0=ty0, ths=ths)
+    return y
 
 
 def dwconv2d_same(x, w, scale, shift, stride, act=None):

@@ -58,11 +58,21 @@ class UpSampleBN(nn.Module):
             cache[id(conv)] = hit
         return hit[1:]
 
+    # experimental: the high-resolution levels in strips of tile rows sized so that V + M of one strip stay cache-resident
+    WINOGRAD_HIRES_PIXELS = int(os.environ.get("OCCDEPTH_WINOGRAD_HIRES_PIXELS", "0"))
+    WINOGRAD_HIRES_MIN_CIN = int(os.environ.get("OCCDEPTH_WINOGRAD_HIRES_MIN_CIN", "64"))
+    WINOGRAD_STRIP_MB = float(os.environ.get("OCCDEPTH_WINOGRAD_STRIP_MB", "96"))
+
     def _conv_bn_act(self, f, conv, bn, act):
         B, C, H, W = f.shape
         if self.WINOGRAD and C >= self.WINOGRAD_MIN_CIN and B * H * W <= self.WINOGRAD_MAX_PIXELS:
             U, scale, shift = self._wino_operands(conv, bn)
             return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope)
+        if self.WINOGRAD and C >= self.WINOGRAD_HIRES_MIN_CIN and B * H * W <= self.WINOGRAD_HIRES_PIXELS:
+            U, scale, shift = self._wino_operands(conv, bn)
+            per_row = 16.0 * B * ((W + 1) // 2) * (C + U.shape[2]) * 4
+            rows = max(1, int(self.WINOGRAD_STRIP_MB * 2 ** 20 / per_row))
+            return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope, strip_rows=rows)
         return hip.affine_act(conv(f), *bn_affine_cached(bn), "leaky", slope=act.negative_slope)
 
     def forward(self, x, concat_with):

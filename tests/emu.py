@@ -169,35 +169,43 @@ _BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0.,
 _AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]], dtype=torch.float64)
 
 
-def wino_input_transform(x):
+def wino_input_transform(x, ty0=0, ths=None):
     B, C, H, W = x.shape
     th, tw = (H + 1) // 2, (W + 1) // 2
+    ths = th - ty0 if ths is None else ths
     xp = F.pad(x.double(), (1, 2 * tw + 1 - W, 1, 2 * th + 1 - H))
-    d = F.unfold(xp, kernel_size=4, stride=2).reshape(B, C, 4, 4, th * tw)            # patches at (2ty-1, 2tx-1)
-    v = torch.einsum("ia,bcakt,jk->ijbtc", _BT, d, _BT)
-    return v.reshape(16, B * th * tw, C).float()
+    d = F.unfold(xp, kernel_size=4, stride=2).reshape(B, C, 4, 4, th, tw)[:, :, :, :, ty0:ty0 + ths]   # patches at (2ty-1, 2tx-1)
+    v = torch.einsum("ia,bcakyx,jk->ijbyxc", _BT, d, _BT)
+    return v.reshape(16, B * ths * tw, C).float()
 
 
-def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False):
+def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False, out=None,
+                          ty0=0, ths=None):
     B, C, H, W = shape
     th, tw = (H + 1) // 2, (W + 1) // 2
-    m = M.double().reshape(4, 4, B, th, tw, C)
-    y = torch.einsum("ri,ijbyxc,sj->bcyrxs", _AT, m, _AT).reshape(B, C, 2 * th, 2 * tw)[:, :, :H, :W]
+    ths = th - ty0 if ths is None else ths
+    r0, r1 = 2 * ty0, min(2 * (ty0 + ths), H)
+    m = M.double().reshape(4, 4, B, ths, tw, C)
+    y = torch.einsum("ri,ijbyxc,sj->bcyrxs", _AT, m, _AT).reshape(B, C, 2 * ths, 2 * tw)[:, :, :r1 - r0, :W]
     if scale is not None:
         y = y * scale.double().view(1, -1, 1, 1)
     if shift is not None:
         y = y + shift.double().view(1, -1, 1, 1)
-    if res is not None and res_first:
-        y = y + res.double()
+    rs = res.double()[:, :, r0:r1] if res is not None else None
+    if rs is not None and res_first:
+        y = y + rs
     if act == "relu":
         y = F.relu(y)
     elif act == "leaky":
         y = F.leaky_relu(y, slope)
     elif act == "swish":
         y = y * torch.sigmoid(y)
-    if res is not None and not res_first:
-        y = y + res.double()
-    return y.float()
+    if rs is not None and not res_first:
+        y = y + rs
+    if out is None:
+        out = torch.empty(shape)
+    out[:, :, r0:r1] = y.float()
+    return out
 
 
 def _softmax_and_target(logits, target, map_occ):

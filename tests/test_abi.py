@@ -115,10 +115,11 @@ def test_training_entry_points_validate_arguments(hip_lib):
 
 
 def test_winograd_entry_points_validate_arguments(hip_lib):
-    assert hip_lib.occd_wino_input_transform_nchw(None, None, 1, 8, 4, 4, None) == -1
-    assert hip_lib.occd_wino_output_transform_nchw(None, None, None, None, None, 1, 8, 4, 4, 0, 0.0, 0, None) == -1
+    assert hip_lib.occd_wino_input_transform_nchw(None, None, 1, 8, 4, 4, 0, 2, None) == -1
+    assert hip_lib.occd_wino_output_transform_nchw(None, None, None, None, None, 1, 8, 4, 4, 0, 2, 0, 0.0, 0, None) == -1
     import ctypes
     one = ctypes.c_float(0.0)
     ptr = ctypes.addressof(one)
-    assert hip_lib.occd_wino_input_transform_nchw(ptr, ptr, 0, 8, 4, 4, None) == -1
-    assert hip_lib.occd_wino_output_transform_nchw(ptr, None, None, None, ptr, 1, 8, 4, 4, 7, 0.0, 0, None) == -1     # act code
+    assert hip_lib.occd_wino_input_transform_nchw(ptr, ptr, 0, 8, 4, 4, 0, 2, None) == -1
+    assert hip_lib.occd_wino_input_transform_nchw(ptr, ptr, 1, 8, 4, 4, 1, 2, None) == -1                            # strip past the image
+    assert hip_lib.occd_wino_output_transform_nchw(ptr, None, None, None, ptr, 1, 8, 4, 4, 0, 2, 7, 0.0, 0, None) == -1     # act code

@@ -15,7 +15,7 @@ CASES = [(2, 40, 24, 12, 39, "leaky", False),      # the 1/16 level's odd width
          (1, 8, 8, 2, 130, "leaky", False)]        # more than one workgroup along x
 
 
-def run(case, device, tol):
+def run(case, device, tol, strip_rows=None):
     from occdepth_amd import hip
     B, cin, cout, H, W, act, with_res = case
     g = torch.Generator().manual_seed(B * 1000 + cin + H)
@@ -31,7 +31,7 @@ def run(case, device, tol):
     with (emu.patched() if device == "cpu" else contextlib.nullcontext()):
         U = hip.winograd_weights(w.to(dev))
         y = hip.conv2d_3x3_winograd(x.to(dev), U, scale.to(dev), shift.to(dev), act, 0.01,
-                                    res.to(dev) if with_res else None, res_first=True)
+                                    res.to(dev) if with_res else None, res_first=True, strip_rows=strip_rows)
     err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
     assert y.shape == ref.shape and err < tol, (case, err)
 
@@ -39,6 +39,7 @@ def run(case, device, tol):
 @pytest.mark.parametrize("case", CASES)
 def test_winograd_host_logic_cpu(case):
     run(case, "cpu", 2e-6)
+    run(case, "cpu", 2e-6, strip_rows=3)          # strips of 3 tile rows (ragged last strip)
 
 
 @pytest.mark.gpu
@@ -46,6 +47,7 @@ def test_winograd_host_logic_cpu(case):
 def test_winograd_kernels_gpu(case, hip_lib):
     torch.backends.cuda.matmul.allow_tf32 = False
     run(case, "cuda", 2e-5)
+    run(case, "cuda", 2e-5, strip_rows=3)
 
 
 @pytest.mark.gpu
