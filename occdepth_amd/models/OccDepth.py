@@ -2,12 +2,14 @@
 
 Constructor signature, config attributes read, sub-module names (`net_rgb`, `projects`,
 `flosp_depth`, `net_3d_decoder`) and the `forward(batch) -> dict` contract are the reference's.
-Eval-mode forward:
-    2-D UNet per view (PyTorch-ROCm / MIOpen, both views in one batch)
+Forward without autograd (eval under torch.no_grad()):
+    2-D UNet per view (PyTorch-ROCm / MIOpen + HIP helpers; both views in one batch, optionally replayed as a hipGraph)
  -> K1a FLoSP-Depth frustum sample + K1b fused multi-scale Stereo-SFA lift   (HIP, HBM-bound)
  -> channels-last 3-D UNet + CRP + cascade head on fp32-MFMA implicit GEMM     (HIP, MFMA-bound)
-Training mode keeps the reference's per-sample / per-scale structure on ATen autograd; the
-Lightning `*_step` hooks (losses, metrics, optimiser) are SURVEY 8(f) row N1 and not built yet.
+With autograd (training, or eval with gradients enabled) the reference's per-sample / per-scale structure runs on ATen
+autograd, with the 3-D convolutions on the HIP forward / dgrad / wgrad kernels (autograd3d.py).  `step` and the
+Lightning `*_step` hooks assemble the reference's losses from one statistics pass (loss/ssc_loss.py) and keep the
+SSC metrics on the GPU.
 """
 import torch
 import torch.nn as nn

@@ -1,8 +1,9 @@
 """2-D UNet: EfficientNet encoder + AdaBins-style BN decoder (mirror of occdepth/models/unet2d.py).
 
-Stays on PyTorch-ROCm / MIOpen (north_star); the HIP work starts at its output dict
-{"1_1","1_2","1_4","1_8","1_16"}.  Faithful quirks: the decoder taps encoder features
-[4, 5, 6, 8, 11] (conv_head output BEFORE bn2), `conv2` is a 1x1 conv with padding=1 (grows the
+Convolutions run in PyTorch-ROCm / MIOpen (north_star) except the 3x3 convolutions of the three low-resolution decoder
+levels, which take the Winograd-domain MFMA path (csrc/wino2d.hip + batched GEMMs); BatchNorm + activation, bilinear
+upsample + concat and the depthwise convolutions are fused HIP passes in eval mode.  Faithful quirks: the decoder taps
+encoder features [4, 5, 6, 8, 11] (conv_head output BEFORE bn2), `conv2` is a 1x1 conv with padding=1 (grows the
 1/32 map by 2), and `up1` concatenates the raw image.
 """
 import os

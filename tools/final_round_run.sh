@@ -30,5 +30,23 @@ for c, mul in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open("$O/pmc_lift_%s.csv" % c)) if r["Counter_Name"] == c]
     print("lift %s: %.1f MB per launch (KB counter%s)" % (c, sum(v) / len(v) * mul / 1e6, ", doubled per the gfx950 correction" if mul > 1024 else ""))
 PY
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d /tmp/pmc_sq -- python $R/tools/pmc_head.py > /tmp/pmc_sq.log 2>&1
+g=$(ls /tmp/pmc_sq/*/*counter_collection.csv | head -1)
+grep "Counter_Name\|conv3d_c32" $g > $O/pmc_head_sq.csv
+python - <<PY
+import csv, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open("$O/pmc_head_sq.csv")):
+    d = r["Kernel_Name"].split("<")[1][0]
+    acc[d][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    acc[d]["ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+for d, c in sorted(acc.items()):
+    m = {k: sum(v) / len(v) for k, v in c.items()}
+    cyc = m["GRBM_GUI_ACTIVE"] / 8.0                     # summed over the 8 XCDs
+    print("head conv d=%s: %.3f ms under the profiler, %.2f GHz, MFMA pipe busy %.1f %% of SIMD-cycles, waves: wait %.0f %% / issue-stall %.0f %% / active %.0f %%, LDS bank-conflict cycles %.2f %% of wave cycles"
+          % (d, m["ns"] / 1e6, cyc / m["ns"], 100 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),
+             100 * m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 100 * m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
+             100 * m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], 100 * m["SQ_LDS_BANK_CONFLICT"] / (4 * m["SQ_WAVE_CYCLES"])))
+PY
 cd $R
 timeout 300 python tools/bench_kernels.py head stack wgrad loss > $O/bench_kernels.txt 2>&1; grep "^conv\|^wgrad\|^loss\|UNet3D\|sfa_lift" $O/bench_kernels.txt
