@@ -1,4 +1,5 @@
-from .flosp_depth_conf_kitti import flosp_depth_conf as flosp_depth_conf_kitti
-from .flosp_depth_conf_nyu import flosp_depth_conf as flosp_depth_conf_nyu
+"""Dataset name -> FLoSP-Depth geometry table (same lookup the reference exposes as `flosp_depth_conf_map`)."""
+from . import flosp_depth_conf_kitti as _kitti
+from . import flosp_depth_conf_nyu as _nyu
 
-flosp_depth_conf_map = {"NYU": flosp_depth_conf_nyu, "kitti": flosp_depth_conf_kitti}
+flosp_depth_conf_map = {"kitti": _kitti.flosp_depth_conf, "NYU": _nyu.flosp_depth_conf}
