@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2   # 2: training entry points (loss statistics, wgrad), Winograd transforms with strip arguments
 
 _c_float_p = POINTER(c_float)
 
