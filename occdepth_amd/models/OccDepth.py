@@ -365,5 +365,8 @@ class OccDepth(_Base):
 
     def configure_optimizers(self):
         from torch.optim.lr_scheduler import MultiStepLR
-        opt = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        params = list(self.parameters())
+        # same AdamW as scripts/train.py's; the fused (multi-tensor, single-launch) implementation when on the GPU
+        opt = torch.optim.AdamW(params, lr=self.lr, weight_decay=self.weight_decay,
+                                fused=bool(params) and all(p.is_cuda for p in params))
         return [opt], [MultiStepLR(opt, milestones=[18, 24], gamma=0.4)]

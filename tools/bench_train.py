@@ -36,7 +36,7 @@ def main(steps=3, cfg_name="kitti_a100", amp=None):
     masks = torch.stack([fid == f for f in range(nf)], 0)
     batch.update(target=target, frustums_masks=[masks], frustums_class_dists=[torch.rand(nf, C, device=dev)],
                  gt_depth=torch.rand(1, 1, 370, 1220, device=dev) * 50.0)
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    opt = model.configure_optimizers()[0][0]               # AdamW (fused on the GPU) + the reference's MultiStepLR
     metric = SSCMetrics(C)
     times = []
     for it in range(steps + 1):
