@@ -67,8 +67,9 @@ class SFA(nn.Module):
         cnt = fov_mask.sum(-1)                                              # (V, N)
         feats, vis = [], []
         for v in range(V):
-            # index_select: its backward is an atomic index_add_ (the advanced-indexing form sorts: 1.8 ms per scale)
-            g = torch.index_select(flat[v], 1, idx[v].reshape(-1)).reshape(C, idx.shape[1], idx.shape[2]).sum(-1)
+            # advanced indexing: its backward sorts the indices (1.8 ms per scale); index_select's atomic index_add_
+            # was measured slower here (many voxels hit the same pixel column: +20 ms per step)
+            g = flat[v][:, idx[v].reshape(-1)].reshape(C, idx.shape[1], idx.shape[2]).sum(-1)
             seen = cnt[v] > 0
             feats.append(torch.where(seen, g / cnt[v].clamp(min=1), torch.zeros_like(g)))
             vis.append(seen.to(x2d.dtype))
