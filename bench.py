@@ -2,21 +2,34 @@
 """Headline benchmark: frames/s of OccDepth.forward, SemanticKITTI stereo 1220x370 -> 256x256x32 voxels
 (BASELINE.json configs[1]: EfficientNet-B7, feature 64, FLoSP-Depth + CRP + cascade head, batch 1 per GPU).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, frames sharded over ranks -- the forward
-     path has no data-path collective, so scaling is "weak": one frame per rank per step.)
+    python bench.py --gpus N --steps K --warmup W [--train [--bf16]]
 
-A step = one forward of one synthetic stereo frame per rank, inputs already resident in HBM, random-init
-weights of the named architecture, eval mode, fp32 (the 3-D stack runs on exact-fp32 MFMA).
+N > 1: one rank per GPU over RCCL.  Under `torch.distributed.run` (WORLD_SIZE set) the ranks are the launcher's;
+a bare `python bench.py --gpus N` re-executes itself through `torch.distributed.run` on 127.0.0.1, so the printed
+`n_gpus` is always the number of ranks that really ran (asserted against --gpus).  Frames are sharded over the ranks:
+the forward path has no data-path collective, so scaling is "weak" (one frame per rank per step).
+
+Default (forward): a step = one forward of one synthetic stereo frame per rank, inputs already resident in HBM,
+random-init weights of the named architecture, eval mode, fp32 (the 3-D stack runs on exact-fp32 MFMA).
+`--train` (BASELINE configs[2]/[3]): a step = forward + losses + backward + gradient exchange (shard.prepare_for_ddp:
+SyncBatchNorm + bucketed RCCL all-reduce, as the reference's DDP run) + AdamW on one frame per rank; `--bf16` runs it
+under bf16 autocast (configs[3]).
+
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : dominant kernel (3x3x3 32->32 head convolution, 115.96 GFLOP per launch) timed live with HIP
-                 events on the launch stream, against the fp32-MFMA peak (157.3 TF/s);
-  cpu_baseline : the CPU oracle (oracle/occdepth_oracle.py, a port of the reference's PyTorch path) timed on
-                 this box's host cores on ONE frame of the same workload (N=1 only).
+  roofline       : dominant kernel (3x3x3 32->32 head convolution, 115.96 GFLOP per launch) timed live with HIP
+                   events on the launch stream, against the fp32-MFMA peak (157.3 TF/s);
+  cpu_baseline   : the CPU oracle (oracle/occdepth_oracle.py, a port of the reference's PyTorch path) timed on
+                   this box's host cores on ONE frame of the same workload (N=1 only);
+  parity_rel_err : the SAME configuration flags as the timed model (batch_views, graph_2d, in-repo 2-D kernels), run once
+                   untimed on the golden frame with the golden weights and compared with the real reference's
+                   outputs (tests/golden/occdepth_kitti_a100.npz); max |delta| / max |ref| per output.
+The oracle / golden machinery is used by the `cpu_baseline` and `parity_rel_err` legs only, as the checker.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +49,12 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(device):
+def model_flags():
+    bv = os.environ.get("OCCDEPTH_BATCH_VIEWS", "1") == "1"
+    return bv, bv and os.environ.get("OCCDEPTH_GRAPH_2D", "1") == "1"
+
+
+def build_model(device, train=False):
     from occdepth_amd import configs
     from occdepth_amd.models.OccDepth import OccDepth
     cfg = configs.kitti_a100.clone()
@@ -47,22 +65,44 @@ def build_model(device):
         m = OccDepth(class_names=[str(i) for i in range(cfg.n_classes)], class_weights=torch.ones(cfg.n_classes),
                      class_weights_occ=torch.ones(2), full_scene_size=tuple(cfg.full_scene_size),
                      project_res=configs.PROJECT_RES, config=cfg)
-    m.batch_views = os.environ.get("OCCDEPTH_BATCH_VIEWS", "1") == "1"
-    m.graph_2d = m.batch_views and os.environ.get("OCCDEPTH_GRAPH_2D", "1") == "1"
+    if train:
+        return m.to(device).train(), cfg
+    m.batch_views, m.graph_2d = model_flags()
     return m.to(device).eval(), cfg
 
 
-def to_dev(batch, device):
-    out = {}
-    for k, v in batch.items():
-        out[k] = [t.to(device) for t in v] if isinstance(v, list) else v.to(device)
-    return out
+def parity_check(device):
+    """The benched configuration against the real reference: golden weights + golden frame through a second model
+    instance carrying the same flags as the timed one (untimed; rank 0 only)."""
+    import contextlib
+    import io
+    import golden_cases as gc
+    import numpy as np
+    from test_oracle_vs_golden import build_product
+    with contextlib.redirect_stdout(io.StringIO()):
+        m, cfg, _ = build_product("kitti_a100")
+    m = m.to(device).eval()
+    m.batch_views, m.graph_2d = model_flags()
+    batch = {k: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device))
+             for k, v in gc.occdepth_batch("kitti_a100").items()}
+    g = np.load(os.path.join(ROOT, "tests", "golden", "occdepth_kitti_a100.npz"))
+    with torch.no_grad():
+        m(batch)                                           # capture pass
+        out = m(batch)                                     # replay (what the timed loop runs)
+    errs = {}
+    for k, v in out.items():
+        ref = torch.from_numpy(g[k])
+        got = gc.subsample(v.cpu().contiguous())
+        errs[k] = float((got - ref).abs().max() / ref.abs().max())
+    return {"ssc_logit": errs["ssc_logit"], "occ_logit": errs["occ_logit"], "worst_of_all_outputs": max(errs.values()),
+            "batch_views": bool(m.batch_views), "graph_2d": bool(m.graph_2d),
+            "reference": "tests/golden/occdepth_kitti_a100.npz (real reference, CPU fp32)", "bar": 1e-3}
 
 
 def cpu_baseline(model, cfg, batch, seed, budget_s=45.0):
     """The CPU oracle on the host cores, same weights / inputs as the GPU run (reported, not a target).
-    This leg is the only place bench.py touches oracle/: the oracle builds its own batch from the same seed
-    (numpy restatement of the dataloader's vox2pix) and it must equal the GPU-projected one bit for bit."""
+    The oracle builds its own batch from the same seed (numpy restatement of the dataloader's vox2pix) and it must
+    equal the GPU-projected one bit for bit."""
     import copy
     from oracle import inputs
     from oracle import occdepth_oracle as orc
@@ -93,31 +133,57 @@ def cpu_baseline(model, cfg, batch, seed, budget_s=45.0):
                       f"best {best:.2f} s/frame"}
 
 
+def respawn(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks through torch.distributed.run and relay their output
+    (rank 0 prints the JSON line)."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--train", action="store_true", help="training step (configs[2]/[3]) instead of the forward")
+    ap.add_argument("--bf16", action="store_true", help="with --train: bf16 autocast (configs[3])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 5 if args.train else 20
+    if args.warmup is None:
+        args.warmup = 2 if args.train else 5
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn(args)
     # stdout carries exactly ONE line (the JSON).  Native libraries write banners to fd 1 (RCCL prints its version
     # block at the first communicator, MIOpen its warnings): park fd 1 on stderr until the result is ready.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        _main(real_stdout)
+        _main(args, real_stdout)
     finally:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         os.close(real_stdout)
 
 
-def _main(real_stdout):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+def _setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP kernels have no CPU path)")
     torch.cuda.set_device(local)
@@ -126,20 +192,36 @@ def _main(real_stdout):
     if world > 1 or os.environ.get("OCCDEPTH_FORCE_DIST") == "1":     # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     # MIOpen exhaustive find costs minutes of untimed warm-up on a fresh box; opt in with OCCDEPTH_MIOPEN_FIND=1
     torch.backends.cudnn.benchmark = os.environ.get("OCCDEPTH_MIOPEN_FIND", "0") == "1"
-
     from occdepth_amd import build, hip
     if rank == 0:
         build.build(verbose=False)
     if dist is not None:
         dist.barrier()
     hip.load()
+    return world, rank, device, dist
 
-    from occdepth_amd import synthetic
+
+def _main(args, real_stdout):
+    world, rank, device, dist = _setup(args)
+    res = _train(args, world, rank, device, dist) if args.train else _forward(args, world, rank, device, dist)
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _forward(args, world, rank, device, dist):
+    from occdepth_amd import hip, shard, synthetic
     model, cfg = build_model(device)
     # one stereo frame per rank; the voxel->pixel tables come from the product's GPU projection (dataloader work,
     # done once, outside the timed region -- exactly what the reference's dataloader hands to the model)
@@ -150,19 +232,14 @@ def _main(real_stdout):
         with torch.no_grad():
             return model(batch)
 
-    from occdepth_amd import shard
-
-    def fence():
-        shard.fence(dist)
-
     for _ in range(args.warmup):
         step()
-    fence()
+    shard.fence(dist)
     with hip.profile() as prof:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
-        fence()
+        shard.fence(dist)
         elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, device)
     assert out["ssc_logit"].shape == (1, 20, 256, 256, 32)
@@ -188,54 +265,113 @@ def _main(real_stdout):
     torch.cuda.synchronize()
     model.process_rgbs, model._forward_2d_to_3d, model.net_3d_decoder.forward = orig
     stages = {k: e0.elapsed_time(e1) for k, (e0, e1) in stages.items()}
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        fps = world * args.steps / elapsed
-        head = [(k, v) for k, v in prof.rows.items() if HEAD_CONV_TAG in k and k.startswith("conv3d")]
-        n_launch = sum(v["launches"] for _, v in head)
-        ms = sum(v["ms"] for _, v in head)
-        flops = sum(v["flops"] for _, v in head)
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("conv3d_")) / args.steps
-        lift_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("sfa_lift")) / args.steps
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "head_conv_hbm_bytes.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch")
-        res = {
-            "metric": "frames/sec forward, SemanticKITTI stereo->256x256x32 voxels",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SemanticKITTI stereo 370x1220, tf_efficientnet_b7_ns, "
-                                   "feature 64, flosp_depth + CRP + cascade head, 256x256x32 voxels, batch 1/GPU",
-                       "frames_per_step": world, "parallelism": f"dp{world} (frames sharded, no collective)",
-                       "batch_views": bool(model.batch_views), "graph_2d": bool(model.graph_2d)},
-            "roofline": {"bound": "mfma", "kernel": "conv3d_c32_slide_kernel: 3x3x3 32->32 @256x256x32 (v_mfma_f32_32x32x2_f32)",
-                         "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "launches": int(n_launch), "avg_launch_ms": ms / max(n_launch, 1),
-                         "gflop_per_launch": flops / max(n_launch, 1) / 1e9},
-            "stack3d": {"ms_per_frame": conv_ms, "tflops": STACK3D_GFLOP / conv_ms if conv_ms else 0.0,
-                        "frac_of_fp32_mfma_peak": STACK3D_GFLOP / conv_ms / FP32_MFMA_PEAK_TFLOPS if conv_ms else 0.0},
-            "stages_ms": stages,
-            "lift": {"ms_per_frame": lift_ms, "gbps": LIFT_MBYTES / lift_ms if lift_ms else 0.0,
-                     "frac_of_8TBps": LIFT_MBYTES / lift_ms / 8000.0 if lift_ms else 0.0},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                res["cpu_baseline"] = cpu_baseline(model, cfg, batch, rank)
-            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
-                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
+    fps = world * args.steps / elapsed
+    head = [(k, v) for k, v in prof.rows.items() if HEAD_CONV_TAG in k and k.startswith("conv3d")]
+    n_launch = sum(v["launches"] for _, v in head)
+    ms = sum(v["ms"] for _, v in head)
+    flops = sum(v["flops"] for _, v in head)
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("conv3d_")) / args.steps
+    lift_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("sfa_lift")) / args.steps
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "head_conv_hbm_bytes.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("bytes_per_launch")
+        traffic_src = "profiles/head_conv_hbm_bytes.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command)"
+    res = {
+        "metric": "frames/sec forward, SemanticKITTI stereo->256x256x32 voxels",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: SemanticKITTI stereo 370x1220, tf_efficientnet_b7_ns, "
+                               "feature 64, flosp_depth + CRP + cascade head, 256x256x32 voxels, batch 1/GPU",
+                   "frames_per_step": world, "parallelism": f"dp{world} (frames sharded, no collective)",
+                   "ranks": dist.get_world_size() if dist is not None else 1,
+                   "batch_views": bool(model.batch_views), "graph_2d": bool(model.graph_2d)},
+        "roofline": {"bound": "mfma", "kernel": "conv3d_c32_slide_kernel: 3x3x3 32->32 @256x256x32 (v_mfma_f32_32x32x2_f32)",
+                     "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "launches": int(n_launch), "avg_launch_ms": ms / max(n_launch, 1),
+                     "gflop_per_launch": flops / max(n_launch, 1) / 1e9},
+        "stack3d": {"ms_per_frame": conv_ms, "tflops": STACK3D_GFLOP / conv_ms if conv_ms else 0.0,
+                    "frac_of_fp32_mfma_peak": STACK3D_GFLOP / conv_ms / FP32_MFMA_PEAK_TFLOPS if conv_ms else 0.0},
+        "stages_ms": stages,
+        "lift": {"ms_per_frame": lift_ms, "gbps": LIFT_MBYTES / lift_ms if lift_ms else 0.0,
+                 "frac_of_8TBps": LIFT_MBYTES / lift_ms / 8000.0 if lift_ms else 0.0},
+    }
+    if getattr(model, "graph_2d_error", None):
+        res["config"]["graph_2d_error"] = model.graph_2d_error
+    if not args.no_parity:
+        try:
+            res["parity_rel_err"] = parity_check(device)
+        except Exception as e:  # a report, never a reason to lose the measurement
+            res["parity_rel_err"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(model, cfg, batch, rank)
+        except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+            res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    else:
+        res["cpu_baseline"] = None
+    return res
+
+
+def _train(args, world, rank, device, dist):
+    """BASELINE configs[2] (fp32) / configs[3] (--bf16): one frame per rank, the reference's full `training_step`
+    (forward, every loss term, backward), the gradient exchange of its DDP run, AdamW."""
+    from occdepth_amd import hip, shard, synthetic
+    model, cfg = build_model(device, train=True)
+    with torch.no_grad():
+        batch = synthetic.attach_projection(model, synthetic.to_device(synthetic.kitti_frame(seed=rank), device))
+    synthetic.attach_training_targets(model, batch, cfg, seed=1 + rank)
+    model, buckets = shard.prepare_for_ddp(model, dist)
+    opt = model.configure_optimizers()[0][0]
+
+    def step():
+        if buckets is not None:
+            buckets.zero_grad()
         else:
-            res["cpu_baseline"] = None
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(res) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
+            loss = model.training_step(batch, 0)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    shard.fence(dist)
+    with hip.profile() as prof:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        shard.fence(dist)
+        elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, dist, device)
+    if rank != 0:
+        return None
+    rows = sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:8]
+    return {
+        "metric": "frames/sec trained (fwd + losses + bwd + gradient exchange + AdamW), SemanticKITTI stereo->256x256x32 voxels",
+        "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16 autocast (3-D convolutions and loss statistics fp32)" if args.bf16 else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{3 if args.bf16 else 2}]: training step, SemanticKITTI stereo 370x1220, "
+                               "tf_efficientnet_b7_ns, feature 64, flosp_depth + CRP + cascade head, batch 1/GPU",
+                   "global_batch": world, "ranks": dist.get_world_size() if dist is not None else 1,
+                   "parallelism": f"dp{world}: SyncBatchNorm (packed all-reduce per layer) + "
+                                  f"{len(buckets.buckets) if buckets else 0} gradient buckets ({buckets.algo if buckets else 'none'})"},
+        "loss": float(loss.detach()), "max_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "hip_kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in rows},
+    }
 
 
 if __name__ == "__main__":

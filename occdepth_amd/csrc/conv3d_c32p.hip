@@ -17,6 +17,7 @@
 //
 // Reference semantics replaced: occdepth/models/modules.py:158-175 (conv0, conv1.*, conv2.*, conv_classes).
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <cstdlib>
 #include "common.h"
@@ -455,29 +456,56 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     }
 }
 
-int* g_counter = nullptr;
+// Per-DEVICE launch state (work-list counters live in that device's memory, CU count and the large-LDS function
+// attribute belong to it): a process that drives several GPUs gets one of these per device, looked up from the
+// current device at every launch.
+constexpr int kMaxDevices = 64;
+struct DevState {
+    std::mutex mu;
+    int* counter = nullptr;
+    int num_cu = 0;
+    bool slide_attr[4] = {};
+    bool attr_done[4] = {};
+};
+DevState g_dev[kMaxDevices];
 std::atomic<unsigned> g_slot{0};
-bool g_slide_attr[4] = {};
+
+DevState* dev_state() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    DevState* s = &g_dev[dev];
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (s->num_cu == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        s->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return s;
+}
 
 template <int D>
-int launch_slide(const PersistP& base, hipStream_t st, int num_cu) {
+int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
     constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D), RS4 = 16 / 4 + 1;
     const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * RS4 * 16 + 16 + 128;
-    if (!g_slide_attr[D]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return OCCD_ELAUNCH;
-        g_slide_attr[D] = true;
-    }
+    const int num_cu = ds->num_cu;
     // a ring of self re-arming counter pairs: launches in flight on different streams never share one
     constexpr int kSlots = 256;
-    if (g_counter == nullptr) {
-        if (hipMalloc(&g_counter, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
-        if (hipMemset(g_counter, 0, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
+    {
+        std::lock_guard<std::mutex> lock(ds->mu);
+        if (!ds->slide_attr[D]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return OCCD_ELAUNCH;
+            ds->slide_attr[D] = true;
+        }
+        if (ds->counter == nullptr) {
+            if (hipMalloc(&ds->counter, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
+            if (hipMemset(ds->counter, 0, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
+        }
     }
     SlideP sp;
     sp.base = base;
-    sp.counter = g_counter + 2 * (g_slot.fetch_add(1) % kSlots);
+    sp.counter = ds->counter + 2 * (g_slot.fetch_add(1) % kSlots);
     // ranges per column: k rounds over the grid; a range of L planes costs L + 2 stagings per run (D > 1: up to two
     // runs).  Few long ranges amortise the two extra planes, but the list must fill whole rounds.
     const int cols = base.batch * base.ytiles;
@@ -501,26 +529,20 @@ int launch_slide(const PersistP& base, hipStream_t st, int num_cu) {
     return occd::check_launch();
 }
 
-bool g_attr_done[4] = {};
-int g_num_cu = 0;
-
 template <int D>
-int launch(const PersistP& p, hipStream_t st) {
+int launch(const PersistP& p, hipStream_t st, DevState* ds) {
     constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D);
     const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * 5 * 16;
-    if (!g_attr_done[D]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_persist_kernel<D>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return OCCD_ELAUNCH;
-        g_attr_done[D] = true;
+    {
+        std::lock_guard<std::mutex> lock(ds->mu);
+        if (!ds->attr_done[D]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_persist_kernel<D>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return OCCD_ELAUNCH;
+            ds->attr_done[D] = true;
+        }
     }
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCCD_ELAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    int grid = g_num_cu;
+    int grid = ds->num_cu;
     if (grid > p.tiles_total) grid = p.tiles_total;
     hipLaunchKernelGGL(conv3d_c32_persist_kernel<D>, dim3((unsigned)grid), dim3(512), lds, st, p);
     return occd::check_launch();
@@ -559,18 +581,14 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
                                 27.0 * a->cin * a->cout);
     ProfScope prof("conv3d_c32p", stream, flops, bytes);
     static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
+    DevState* ds = dev_state();
+    if (ds == nullptr) return OCCD_ELAUNCH;
     int rc;
     if (tiled) {
-        rc = d == 1 ? launch<1>(p, stream) : d == 2 ? launch<2>(p, stream) : launch<3>(p, stream);
+        rc = d == 1 ? launch<1>(p, stream, ds) : d == 2 ? launch<2>(p, stream, ds) : launch<3>(p, stream, ds);
     } else {
-        if (g_num_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OCCD_ELAUNCH;
-            g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
-        rc = d == 1 ? launch_slide<1>(p, stream, g_num_cu) : d == 2 ? launch_slide<2>(p, stream, g_num_cu)
-                                                                  : launch_slide<3>(p, stream, g_num_cu);
+        rc = d == 1 ? launch_slide<1>(p, stream, ds) : d == 2 ? launch_slide<2>(p, stream, ds)
+                                                              : launch_slide<3>(p, stream, ds);
     }
     return rc == OCCD_OK ? 1 : rc;
 }

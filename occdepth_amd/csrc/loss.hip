@@ -232,6 +232,9 @@ int grid_for(long total) {
 int check_stats(const float* logits, const uint8_t* target, int64_t batch, int32_t C, int64_t S, int32_t F) {
     if (logits == nullptr || target == nullptr) return OCCD_EINVAL;
     if (batch < 1 || S < 1 || S > 0x7fffffff || C < 1 || C > kMaxC || F < 0 || F > 1024) return OCCD_EINVAL;
+    // the per-workgroup copy of the statistics lives in dynamic LDS (64-bit sums): it must fit the 64 KiB a kernel
+    // may request without the large-LDS attribute, e.g. C = 20 -> F <= 406 (the reference uses 64 frustums)
+    if ((3 * (int64_t)C + 3 + (int64_t)F * C) * (int64_t)sizeof(u64) > 64 * 1024) return OCCD_EINVAL;
     return OCCD_OK;
 }
 

@@ -562,13 +562,21 @@ SSC_Q32 = 4294967296.0
 SSC_Q24 = 16777216.0
 
 
+_ssc_scale_cache = {}
+
+
 def ssc_stats_scale(C, F, device):
-    """Multipliers that turn the fixed-point int64 statistics of occd_ssc_loss_stats_fwd into real sums."""
-    sc = torch.ones(3 * C + 3 + F * C, dtype=torch.float64)
-    sc[:2 * C] = 1.0 / SSC_Q32
-    sc[3 * C + 1:3 * C + 3] = 1.0 / SSC_Q24
-    sc[3 * C + 3:] = 1.0 / SSC_Q32
-    return sc.to(device)
+    """Multipliers that turn the fixed-point int64 statistics of occd_ssc_loss_stats_fwd into real sums
+    (built once per (C, F, device): no host-to-device copy on the loss path after the first step)."""
+    key = (int(C), int(F), str(device))
+    sc = _ssc_scale_cache.get(key)
+    if sc is None:
+        sc = torch.ones(3 * C + 3 + F * C, dtype=torch.float64)
+        sc[:2 * C] = 1.0 / SSC_Q32
+        sc[3 * C + 1:3 * C + 3] = 1.0 / SSC_Q24
+        sc[3 * C + 3:] = 1.0 / SSC_Q32
+        sc = _ssc_scale_cache[key] = sc.to(device)
+    return sc
 
 
 def _loss_operands(logits, target, masks, weights):

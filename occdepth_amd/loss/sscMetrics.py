@@ -14,34 +14,49 @@ from .. import hip
 
 
 class SSCMetrics:
-    def __init__(self, n_classes, device="cuda"):
+    def __init__(self, n_classes, device=None):
         self.n_classes = n_classes
-        self.device = torch.device(device)
+        self.device = torch.device(device) if device is not None else None   # None: wherever the first batch lives
         self.reset()
 
     def reset(self):
-        self.hist = torch.zeros(self.n_classes, self.n_classes, dtype=torch.int64, device=self.device)
+        self.hist = None                       # allocated with the first batch (the model is built before .to(device))
         self.count = 1e-8
 
-    def _u8(self, a):
+    def _alloc(self, device):
+        if self.hist is None:
+            self.hist = torch.zeros(self.n_classes, self.n_classes, dtype=torch.int64,
+                                    device=self.device if self.device is not None else device)
+        return self.hist
+
+    def _u8(self, a, device):
         t = torch.as_tensor(a)
-        return t.to(device=self.device, dtype=torch.uint8).contiguous()
+        return t.to(device=device, dtype=torch.uint8).contiguous()
 
     def add_batch(self, y_pred, y_true, nonempty=None, nonsurface=None):
         """y_pred / y_true: (B, X, Y, Z) class volumes (numpy or torch), 255 = unlabelled in y_true."""
         if nonempty is not None or nonsurface is not None:
             raise NotImplementedError("nonempty / nonsurface masks are not used by the reference's step")
         self.count += 1
-        hip.ssc_confusion(self.hist, self._u8(y_true), labels=self._u8(y_pred))
+        dev = self.device
+        if dev is None:
+            dev = y_true.device if torch.is_tensor(y_true) and y_true.is_cuda else \
+                torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        hist = self._alloc(dev)
+        hip.ssc_confusion(hist, self._u8(y_true, hist.device), labels=self._u8(y_pred, hist.device))
 
     def add_batch_logits(self, ssc_logit, y_true):
         """Fused variant of the step's `np.argmax(ssc_pred) -> add_batch`: logits (B, C, X, Y, Z) on the GPU."""
         self.count += 1
-        hip.ssc_confusion(self.hist, self._u8(y_true), logits=ssc_logit.detach().float().contiguous())
+        hist = self._alloc(ssc_logit.device)
+        hip.ssc_confusion(hist, self._u8(y_true, hist.device), logits=ssc_logit.detach().float().contiguous())
 
     # -- host-side views (synchronise) ----------------------------------------------------------------------
     def _counts(self):
-        h = self.hist.cpu().numpy().astype(np.float64)
+        if self.hist is None:
+            h = np.zeros((self.n_classes, self.n_classes), dtype=np.float64)
+        else:
+            h = self.hist.cpu().numpy().astype(np.float64)
         tps = np.diag(h).copy()
         return h, tps, h.sum(0) - tps, h.sum(1) - tps
 
@@ -72,5 +87,5 @@ class SSCMetrics:
 
     def merge_(self, other_hist):
         """Add another rank's confusion matrix (after an all-reduce / gather)."""
-        self.hist += other_hist.to(self.hist.device)
+        self._alloc(other_hist.device).add_(other_hist.to(self.hist.device))
         return self

@@ -78,6 +78,11 @@ class OccDepth(_Base):
                                     backbone_2d_name=config.backbone_2d_name,
                                     return_up_feats=config.return_up_feats)
         self.save_hyperparameters()
+        from ..loss.sscMetrics import SSCMetrics
+        self.train_metrics = SSCMetrics(self.n_classes)      # reference :131-133 (confusion matrices live on the GPU here)
+        self.val_metrics = SSCMetrics(self.n_classes)
+        self.test_metrics = SSCMetrics(self.n_classes)
+        self.metrics_allreduce = False    # opt-in: sum the confusion matrices over ranks before the epoch statistics
         self.init_2d_to_3d_trans(config)
         print("INFO: Use step decay loss: {}".format(self.sem_step_decay_loss))
         batch_size = config.batch_size_per_gpu * config.n_gpus
@@ -115,14 +120,45 @@ class OccDepth(_Base):
                 self.depth_loss_fn = DepthClsLoss(downsample_factor=conf["downsample_factor"], d_bound=conf["d_bound"])
 
     # ---------------------------------------------------------------- 2-D side
+    def _net_rgb_stamp(self):
+        """Cheap fingerprint of every tensor the captured 2-D graph bakes pointers / folded copies of: in-place updates
+        (optimizer.step, load_state_dict) bump `_version`; replaced storage changes `data_ptr`."""
+        ts = self.__dict__.get("_net_rgb_tensors")
+        if ts is None:
+            ts = list(self.net_rgb.parameters()) + list(self.net_rgb.buffers())
+            self.__dict__["_net_rgb_tensors"] = ts
+        return (len(ts), sum(t._version for t in ts), sum(t.data_ptr() for t in ts))
+
+    def _drop_graphs(self):
+        self._graphs.clear()
+        self.__dict__.pop("_net_rgb_tensors", None)
+
+    def train(self, mode=True):
+        self._drop_graphs()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_graphs()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._drop_graphs()
+        return super().load_state_dict(*a, **k)
+
     def _net_rgb_graphed(self, x):
         """The 2-D network is ~1200 launches of mostly 5-40 us kernels: with `graph_2d` (opt-in, eval only) it is
         captured once per input shape into a hipGraph and replayed, so the host never gates the GPU there.  The 3-D
-        stack stays outside (its launches are few, long, and individually timed by bench.py)."""
+        stack stays outside (its launches are few, long, and individually timed by bench.py).  A captured graph holds
+        pointers to the weights AND to tensors derived from them (folded BatchNorm, packed / Winograd-domain weights);
+        every entry therefore carries a stamp of the network's tensors and is re-captured when it no longer matches
+        (train(), load_state_dict() and device / dtype moves drop the cache outright)."""
         if not self.graph_2d or not x.is_cuda:
             return self.net_rgb(x)
         key = (tuple(x.shape), x.device)
+        stamp = self._net_rgb_stamp()
         entry = self._graphs.get(key)
+        if entry is not None and entry[3] != stamp:
+            entry = None
         if entry is None:
             static_in = x.clone()
             try:
@@ -135,14 +171,16 @@ class OccDepth(_Base):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     static_out = self.net_rgb(static_in)
-                entry = (graph, static_in, static_out)
-            except Exception as e:                             # capture is an optimisation, never a requirement
+                entry = (graph, static_in, static_out, stamp)
+            except (RuntimeError, torch.AcceleratorError) as e:   # capture is an optimisation, never a requirement
                 import warnings
                 warnings.warn(f"occdepth_amd: hipGraph capture of the 2-D network failed ({e!r}); running eagerly")
                 self.graph_2d = False
+                self.graph_2d_error = repr(e)
+                torch.cuda.synchronize(x.device)
                 return self.net_rgb(x)
             self._graphs[key] = entry
-        graph, static_in, static_out = entry
+        graph, static_in, static_out, _ = entry
         static_in.copy_(x)
         graph.replay()
         return static_out
@@ -345,28 +383,66 @@ class OccDepth(_Base):
         self._log(step_type + "/loss", loss)
         return loss
 
-    def _metrics(self, name):
-        from ..loss.sscMetrics import SSCMetrics
-        if not hasattr(self, "_metric_objs"):
-            self._metric_objs = {}
-        if name not in self._metric_objs:
-            self._metric_objs[name] = SSCMetrics(self.n_classes)
-        return self._metric_objs[name]
-
     def training_step(self, batch, batch_idx):
         self.cur_batch += 1
-        return self.step(batch, "train", self._metrics("train"))
+        return self.step(batch, "train", self.train_metrics)
 
     def validation_step(self, batch, batch_idx):
-        return self.step(batch, "val", self._metrics("val"))
+        self.step(batch, "val", self.val_metrics)
+
+    def _epoch_stats(self, metric):
+        """`SSCMetrics.get_stats()` of this rank's counts -- the reference's semantics: each rank logs the statistics of
+        its own confusion matrix and Lightning averages them (`sync_dist=True`).  With `metrics_allreduce` the
+        confusion matrices are summed over the ranks first (the statistically exact variant)."""
+        if self.metrics_allreduce:
+            from .. import shard
+            shard.allreduce_confusion(metric)
+        return metric.get_stats()
+
+    def validation_epoch_end(self, outputs):
+        """Reference :542-557: per-class IoU, mIoU, IoU, Precision, Recall of the train and val metrics, then reset."""
+        for prefix, metric in (("train", self.train_metrics), ("val", self.val_metrics)):
+            stats = self._epoch_stats(metric)
+            for i, class_name in enumerate(self.class_names):
+                self.log("{}_SemIoU/{}".format(prefix, class_name), stats["iou_ssc"][i], sync_dist=True)
+            self.log("{}/mIoU".format(prefix), stats["iou_ssc_mean"], sync_dist=True)
+            self.log("{}/IoU".format(prefix), stats["iou"], sync_dist=True)
+            self.log("{}/Precision".format(prefix), stats["precision"], sync_dist=True)
+            self.log("{}/Recall".format(prefix), stats["recall"], sync_dist=True)
+            metric.reset()
 
     def test_step(self, batch, batch_idx):
-        return self.step(batch, "test", self._metrics("test"))
+        self.step(batch, "test", self.test_metrics)
+
+    def test_epoch_end(self, outputs):
+        """Reference :562-580: the printed evaluation report of scripts/eval.py."""
+        classes = self.class_names
+        for prefix, metric in (("test", self.test_metrics),):
+            print("{}======".format(prefix))
+            stats = self._epoch_stats(metric)
+            print("Precision={:.4f}, Recall={:.4f}, IoU={:.4f}".format(
+                stats["precision"] * 100, stats["recall"] * 100, stats["iou"] * 100))
+            print("class IoU: {}, ".format(classes))
+            print(" ".join(["{:.4f}, "] * len(classes)).format(*(stats["iou_ssc"] * 100).tolist()))
+            print("mIoU={:.4f}".format(stats["iou_ssc_mean"] * 100))
+            metric.reset()
 
     def configure_optimizers(self):
+        """Reference :582-600: AdamW + MultiStepLR, schedule by dataset."""
         from torch.optim.lr_scheduler import MultiStepLR
+        if self.dataset in ("NYU", "kitti"):
+            milestones, gamma = [18, 24], 0.4
+        elif self.dataset == "tartanair":
+            milestones, gamma = [20], 0.1
+        else:
+            raise NotImplementedError("dataset is not supported: {}".format(self.dataset))
         params = list(self.parameters())
-        # same AdamW as scripts/train.py's; the fused (multi-tensor, single-launch) implementation when on the GPU
-        opt = torch.optim.AdamW(params, lr=self.lr, weight_decay=self.weight_decay,
-                                fused=bool(params) and all(p.is_cuda for p in params))
-        return [opt], [MultiStepLR(opt, milestones=[18, 24], gamma=0.4)]
+        opt = None
+        if params and all(p.is_cuda and p.is_floating_point() for p in params):
+            try:        # the fused (multi-tensor, single-launch) implementation of the same AdamW update
+                opt = torch.optim.AdamW(params, lr=self.lr, weight_decay=self.weight_decay, fused=True)
+            except (RuntimeError, ValueError):
+                opt = None
+        if opt is None:
+            opt = torch.optim.AdamW(params, lr=self.lr, weight_decay=self.weight_decay)
+        return [opt], [MultiStepLR(opt, milestones=milestones, gamma=gamma)]

@@ -93,7 +93,7 @@ class DepthNet(nn.Module):
             scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
                                                        sync_free=sweep_intrins.is_cuda and not needs_autograd(self))
         x = self.reduce_conv(x)
-        x = self.se(x, self.mlp(scaled_pixel_size)[..., None, None])
+        x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
         return self.depth_pred(self.depth_conv(x))
 
 
@@ -235,6 +235,7 @@ class FlospDepth(nn.Module):
         for i in range(n_cams):
             grid = grids[i] if mats is None else self.frustum_grid(mats[0][:, i], mats[1][:, i], mats[2][:, i])
             vol = depth[:, i].unsqueeze(1)
+            grid = grid.to(vol.dtype)              # geometry is float32 by definition; the volume may be bf16 / float64
             feats.append(F.grid_sample(vol, grid, mode="bilinear", padding_mode="zeros", align_corners=False))
             masks.append(F.grid_sample(torch.ones_like(vol), grid, mode="bilinear", padding_mode="zeros",
                                        align_corners=False))

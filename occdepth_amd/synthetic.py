@@ -47,3 +47,37 @@ def attach_projection(model, batch):
     batch[f"projected_pix_{s}"] = [p for p in pix]
     batch[f"fov_mask_{s}"] = [m for m in fov]
     return batch
+
+
+def attach_training_targets(model, batch, cfg, seed=1):
+    """Training-only entries of the reference's collate schema for a synthetic frame already on the GPU
+    (semantic_kitti/collate.py:62-83): `target` uint8 with 255 = unlabelled, `frustums_masks` / `frustums_class_dists`
+    for frustum_size^2 image-plane frustums, `CP_mega_matrices` shaped after the model's relation logits, sparse
+    `gt_depth`.  Values are random (there is no dataset here); shapes, dtypes and sparsity patterns are the real ones."""
+    dev = batch["img"].device
+    bs = batch["img"].shape[0]
+    C = cfg.n_classes
+    dims = tuple(cfg.full_scene_size)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    target = torch.randint(0, C, (bs, *dims), device=dev, generator=g).to(torch.uint8)
+    target[torch.rand(bs, *dims, device=dev, generator=g) < 0.5] = 0
+    target[torch.rand(bs, *dims, device=dev, generator=g) < 0.2] = 255
+    fs = cfg.frustum_size
+    nf = fs * fs
+    fid = (torch.arange(dims[0], device=dev).view(-1, 1, 1) * fs // dims[0]) * fs + \
+        (torch.arange(dims[1], device=dev).view(1, -1, 1) * fs // dims[1]) + \
+        torch.zeros(1, 1, dims[2], device=dev, dtype=torch.long)
+    masks = torch.stack([fid == f for f in range(nf)], 0)
+    batch["target"] = target
+    batch["frustums_masks"] = [masks for _ in range(bs)]
+    batch["frustums_class_dists"] = [torch.rand(nf, C, device=dev, generator=g) for _ in range(bs)]
+    H, W = batch["img"].shape[-2:]
+    gt = torch.rand(bs, 1, H, W, device=dev, generator=g) * 50.0
+    gt[torch.rand(bs, 1, H, W, device=dev, generator=g) < 0.7] = 0.0
+    batch["gt_depth"] = gt
+    if cfg.context_prior:
+        X, Y, Z = (d // 8 for d in dims)               # relation logits: (B, R, mega voxels at 1/16, voxels at 1/8)
+        n, m = X * Y * Z, (X // 2) * (Y // 2) * (Z // 2)
+        batch["CP_mega_matrices"] = [(torch.rand(cfg.n_relations, n, m, device=dev, generator=g) < 0.3).float()
+                                     for _ in range(bs)]
+    return batch

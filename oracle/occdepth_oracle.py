@@ -245,7 +245,7 @@ def depth_net(sd, p, x, intrins, scaled_pixel_size=None):
         size = torch.norm(torch.stack([inv[..., 0, 0], inv[..., 1, 1]], dim=-1), dim=-1).reshape(-1, 1)
         scaled_pixel_size = size * 1000.0
     x = F.relu(bn(sd, p + ".reduce_conv.1", conv2d(sd, p + ".reduce_conv.0", x, 1, 1)))
-    se = F.linear(F.relu(F.linear(scaled_pixel_size, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])),
+    se = F.linear(F.relu(F.linear(scaled_pixel_size.to(x.dtype), sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])),
                   sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])[..., None, None]
     gate = conv2d(sd, p + ".se.conv_expand", F.relu(conv2d(sd, p + ".se.conv_reduce", se)))
     x = x * torch.sigmoid(gate)
@@ -312,6 +312,7 @@ def flosp_depth(sd, p, img_feat, cam_k, T_velo_2_cam, ida_mats, conf, voxel_num,
         grid = frustum_grid(t_v2c[:, i], intr[:, i, :3, :], ida[:, i], voxel_num, pc_range, d_bound, nb,
                             conf["final_dim"])
         vol = depth[:, i].unsqueeze(1)
+        grid = grid.to(vol.dtype)                  # no-op in float32; lets tests run the NETWORK arithmetic in float64
         feats.append(F.grid_sample(vol, grid, mode="bilinear", padding_mode="zeros", align_corners=False))
         masks.append(F.grid_sample(torch.ones_like(vol), grid, mode="bilinear", padding_mode="zeros",
                                    align_corners=False))

@@ -135,6 +135,30 @@ def case_unet3d():
     _save("unet3d", arrays)
 
 
+def case_unet3d_512():
+    """BASELINE configs[4]: the reference UNet3D(kitti) alone on the synthetic 512x512x64 grid (lift volume
+    256x256x32, feature 64; 9.3 TFLOP, ~1-2 min per forward on these host cores).  Stored: BatchNorm statistics
+    calibrated on the same input, sub-sampled outputs, and each full output's |max| and sum."""
+    spec = gc.UNET3D_512
+    arrays = {}
+    m = ref_u3k.UNet3D(spec["classes"], BN3, spec["scene"], spec["feature"], spec["ps"], context_prior=True,
+                       cascade_cls=True)
+    x = gc.randn(spec["x"], "unet3d_512")
+    t0 = time.time()
+    m = _load_filled(m, gc.SEED, lambda mm: mm({"x3d": x}), "unet3d_512", arrays)
+    print(f"calibration forward {time.time() - t0:.0f} s")
+    t0 = time.time()
+    with torch.no_grad():
+        out = m({"x3d": x})
+    print(f"reference forward {time.time() - t0:.0f} s")
+    for k, v in out.items():
+        arrays[f"unet3d_512.{k}"] = _np(gc.subsample_512(v))
+        arrays[f"unet3d_512.{k}.absmax"] = np.float64(v.abs().max())
+        arrays[f"unet3d_512.{k}.sum"] = np.float64(v.double().sum())
+        print(k, tuple(v.shape), float(v.abs().max()))
+    _save("unet3d_512", arrays)
+
+
 def case_flosp():
     arrays = {}
     for name, spec in gc.FLOSP_CASES.items():
@@ -330,7 +354,8 @@ def case_train_step():
     _save("train_step_small", arrays)
 
 
-CASES = {"sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "flosp": case_flosp,
+CASES = {"sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "unet3d_512": case_unet3d_512,
+         "flosp": case_flosp,
          "decoder2d": case_decoder2d, "occdepth_small": case_occdepth_small, "occdepth_full": case_occdepth_full,
          "occdepth_nyu": case_occdepth_nyu, "losses": case_losses, "train_step": case_train_step}
 

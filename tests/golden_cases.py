@@ -135,6 +135,18 @@ def subsample(t):
     return t
 
 
+UNET3D_512 = dict(classes=20, scene=(512, 512, 64), feature=64, ps=2, x=(1, 64, 256, 256, 32))   # BASELINE configs[4]
+
+
+def subsample_512(t):
+    """Coarser deterministic sample for the configs[4] fixture (outputs up to 2.1 GB each)."""
+    if t.dim() == 5:
+        return t[:, :, 3::13, 2::13, 1::9].contiguous() if t.shape[2] > 64 else t[:, :, 1::3, 2::3, 1::2].contiguous()
+    if t.dim() == 4:
+        return t[:, :, 5::61, 3::47].contiguous()
+    return t
+
+
 def maybe_subsample(a, limit=60000):
     """numpy / torch array -> itself when small, else subsample()d (same rule on both sides of a test)."""
     t = torch.as_tensor(a)

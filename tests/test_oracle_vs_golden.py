@@ -263,3 +263,34 @@ def test_occdepth_forward_small(cfg_name):
     assert len(keys) == len([v for v in out.values() if v is not None])
     for k, v in out.items():
         close(gc.maybe_subsample(v), g[f"{cfg_name}.{k}"], tol=5e-6, what=f"{cfg_name}.{k}")
+
+
+def oracle_float64(cfg_name):
+    """The same function with the NETWORK arithmetic in float64 (geometry / pixel indices keep the reference's float32
+    and int64 semantics): the round-off-free value the float32 results scatter around.  -> dict of float64 outputs."""
+    import copy
+    m, cfg, sd = build_product(cfg_name)
+    as64 = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t
+    sd64 = {k: as64(v) for k, v in sd.items()}
+    b64 = {k: ([as64(t) for t in v] if isinstance(v, list) else as64(v)) for k, v in gc.occdepth_batch(cfg_name).items()}
+    with torch.no_grad():
+        out = orc.occdepth_forward(sd64, oracle_cfg(m, cfg), b64, copy.deepcopy(m.net_rgb.encoder.original_model).double())
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def rel_err(got, ref):
+    got, ref = torch.as_tensor(got).double(), torch.as_tensor(ref).double()
+    return float((got - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])
+def test_reference_float32_roundoff_on_small_configs(cfg_name):
+    """How far the REAL reference's float32 CPU result (the golden) sits from the float64 value of the same function:
+    1.5e-4 .. 9e-4 on the logits of these random-init reduced configs.  That is the conditioning of the function, not
+    an implementation error; the GPU parity test (test_parity_gpu.py::test_occdepth_small_vs_golden) bounds the HIP
+    path against the float64 value at 1e-3 and against the golden at 1e-3 + this number."""
+    g = gold("occdepth_small")
+    truth = oracle_float64(cfg_name)
+    errs = {k: rel_err(g[f"{cfg_name}.{k}"], gc.maybe_subsample(v)) for k, v in truth.items()}
+    print(cfg_name, "golden (reference float32) vs float64:", {k: f"{e:.1e}" for k, e in errs.items()})
+    assert 2e-5 < errs["ssc_logit"] < 1.5e-3, errs

@@ -118,26 +118,37 @@ def test_flosp_kernel_vs_oracle_same_depth(name):
 
 @pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small", "kitti_flosp_small"])
 def test_occdepth_small_vs_golden(cfg_name):
+    """Reduced configs end to end.  Two references: the golden (the REAL reference's float32 CPU run) and the float64
+    value of the same function (oracle with float64 network arithmetic, computed here).  These random-init reduced
+    networks are ill-conditioned: the reference's own float32 result sits 1.5e-4 .. 9e-4 from the float64 value
+    (tests/test_oracle_vs_golden.py::test_reference_float32_roundoff_on_small_configs).  So the 1e-3 bar is applied
+    against the float64 value, and the bound against the golden is the derived one, 1e-3 + (golden vs float64)."""
+    from test_oracle_vs_golden import oracle_float64, rel_err
     m, cfg, sd = build_product(cfg_name)
     m = m.to(DEV).eval()
     g = gold("occdepth_small")
     with torch.no_grad():
         out = m(to_dev(gc.occdepth_batch(cfg_name)))
     assert len([v for v in out.values() if v is not None]) == len([k for k in g.files if k.startswith(cfg_name + ".")])
-    errs = {}
+    truth = oracle_float64(cfg_name)
+    errs, errs64, gold64 = {}, {}, {}
     for k, v in out.items():
         ref = torch.from_numpy(g[f"{cfg_name}.{k}"])
         got = gc.maybe_subsample(v.cpu().contiguous())
         assert got.shape == ref.shape, k
-        errs[k] = ((got - ref).abs().max() / ref.abs().max()).item()
-    print(cfg_name, "end-to-end relative errors vs reference:", {k: f"{e:.1e}" for k, e in errs.items()})
-    # the voxel logits carry the 1e-3 bar; intermediates downstream of the MIOpen 2-D nets and the depth
-    # softmax are un-normalised sums (|x| ~ 4e3) and get a looser sanity bound
-    # End-to-end on these REDUCED configs the error is dominated by MIOpen-vs-CPU round-off inside the
-    # EfficientNet-B3 2-D net (not by the HIP kernels: see test_lift_and_3d_stack_vs_oracle_same_features,
-    # 2e-4, and test_config2_vs_reference_golden, where the full-size logits meet the 1e-3 bar).
-    assert errs["ssc_logit"] < 3e-3 and errs.get("occ_logit", 0.0) < 3e-3, errs
-    assert max(errs.values()) < 5e-3, errs
+        errs[k] = rel_err(got, ref)
+        errs64[k] = rel_err(v.cpu(), truth[k])
+        gold64[k] = rel_err(ref, gc.maybe_subsample(truth[k]))
+    fmt = lambda d: {k: f"{e:.1e}" for k, e in d.items()}
+    print(cfg_name, "HIP vs reference golden:", fmt(errs))
+    print(cfg_name, "HIP vs float64 value   :", fmt(errs64))
+    print(cfg_name, "golden vs float64 value:", fmt(gold64))
+    for k in ("ssc_logit", "occ_logit"):
+        if k in errs:
+            assert errs64[k] < 1e-3, (k, errs64)
+            assert errs[k] < 1e-3 + gold64[k], (k, errs, gold64)
+    # intermediates downstream of the 2-D nets and the depth softmax are un-normalised sums (|x| ~ 4e3): sanity bound
+    assert max(errs64.values()) < 5e-3, errs64
 
 
 def test_lift_and_3d_stack_vs_oracle_same_features():
@@ -201,6 +212,43 @@ def test_config2_vs_reference_golden(config2):
     assert max(worst.values()) < 5e-3, worst
 
 
+def config2_errors(out):
+    g = gold("occdepth_kitti_a100")
+    worst = {}
+    for k, v in out.items():
+        ref = torch.from_numpy(g[k])
+        got = gc.subsample(v.cpu().contiguous())
+        assert got.shape == ref.shape, k
+        worst[k] = ((got - ref).abs().max() / ref.abs().max()).item()
+    return worst
+
+
+def test_config2_benched_flags_vs_reference_golden():
+    """EXACTLY the configuration bench.py times (`batch_views=True`, `graph_2d=True`: both views through the 2-D
+    network as one batch, replayed from a captured hipGraph; in-repo 2-D kernels on) against the real reference's
+    config-2 golden, on the capture pass and on two replays with the input buffer refreshed in between."""
+    m, cfg, sd = build_product("kitti_a100")
+    m = m.to(DEV).eval()
+    m.batch_views, m.graph_2d = True, True
+    batch = to_dev(gc.occdepth_batch("kitti_a100"))
+    other = dict(batch, img=torch.randn_like(batch["img"]))
+    with torch.no_grad():
+        runs = [m(batch)]                 # captures
+        m(other)                          # replay on different pixels (the static input buffer must be refreshed)
+        runs.append(m(batch))             # replay
+        runs.append(m(batch))
+    assert m.graph_2d, "hipGraph capture fell back to eager: the benched configuration did not run"
+    assert len(m._graphs) == 1
+    for i, out in enumerate(runs):
+        worst = config2_errors(out)
+        print(f"config-2, benched flags, pass {i}: relative errors vs reference:", {k: f"{e:.2e}" for k, e in worst.items()})
+        assert worst["ssc_logit"] < 1e-3 and worst["occ_logit"] < 1e-3, (i, worst)
+        assert max(worst.values()) < 5e-3, (i, worst)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/config2_parity_benched_flags.txt", "w") as f:
+        f.write(repr(config2_errors(runs[-1])) + "\n")
+
+
 def test_config2_properties(config2):
     """Size-independent properties at full size."""
     m, cfg, batch, out = config2
@@ -255,21 +303,37 @@ def test_nyu_config1_vs_reference_golden():
 
 
 def test_config5_synthetic_512_grid():
-    """BASELINE configs[4]: UNet3D(kitti) alone on a 512x512x64 grid (lift volume 256x256x32, feature 64; CRP
-    with N = 32768 voxels / M = 4096 mega voxels, P_logits 2.1 GB).  No reference output exists at this size
-    (9.3 TFLOP); checked through size-independent properties: shapes, finiteness, determinism, and one
-    full-resolution head convolution (Z = 64, generic kernel) against ATen."""
+    """BASELINE configs[4]: UNet3D(kitti) alone on a 512x512x64 grid (lift volume 256x256x32, feature 64; CRP with
+    N = 32768 voxels / M = 4096 mega voxels, P_logits 2.1 GB, 9.3 TFLOP) against the REAL reference's CPU run of the
+    same seeded weights and input (tests/golden/unet3d_512.npz: sub-sampled outputs, |max| and sum of every full
+    output), plus determinism and one full-resolution head convolution (Z = 64, generic kernel) against ATen."""
     import torch.nn as nn
     import torch.nn.functional as F
     from occdepth_amd import hip
     from occdepth_amd.models.unet3d_kitti import UNet3D
-    torch.manual_seed(0)
-    m = UNet3D(20, nn.BatchNorm3d, (512, 512, 64), 64, 2, context_prior=True, cascade_cls=True).to(DEV).eval()
-    x = hip.Vox(torch.randn(1, 256, 256, 32, 64, device=DEV), 64)
+    from test_oracle_vs_golden import sd_for
+    spec = gc.UNET3D_512
+    m = UNet3D(spec["classes"], nn.BatchNorm3d, spec["scene"], spec["feature"], spec["ps"], context_prior=True,
+               cascade_cls=True)
+    m.load_state_dict(sd_for(m, "unet3d_512", "unet3d_512"))
+    m = m.to(DEV).eval()
+    g = gold("unet3d_512")
+    x = hip.Vox.from_ncdhw(gc.randn(spec["x"], "unet3d_512").to(DEV))
     with torch.no_grad():
         out = m({"x3d": x})
         assert out["ssc_logit"].shape == (1, 20, 512, 512, 64) and out["P_logits"].shape == (1, 4, 4096, 32768)
-        assert torch.isfinite(out["ssc_logit"]).all()
+        errs = {}
+        for k, v in out.items():
+            ref = torch.from_numpy(g[f"unet3d_512.{k}"]).to(DEV)
+            got = gc.subsample_512(v)
+            assert got.shape == ref.shape, k
+            scale = float(g[f"unet3d_512.{k}.absmax"])
+            errs[k] = ((got - ref).abs().max() / scale).item()
+            assert float(v.abs().max()) == pytest.approx(scale, rel=3e-4), k
+            total, want = float(v.double().sum()), float(g[f"unet3d_512.{k}.sum"])
+            assert abs(total - want) <= 3e-4 * scale * v.numel() ** 0.5 + 1e-5 * abs(want), (k, total, want)
+        print("config-5 (512x512x64) relative errors vs reference:", {k: f"{e:.2e}" for k, e in errs.items()})
+        assert max(errs.values()) < 3e-4, errs
         first = out["ssc_logit"][0, :, ::37, ::41, ::7].clone()
         del out
         again = m({"x3d": x})["ssc_logit"][0, :, ::37, ::41, ::7]
@@ -316,20 +380,32 @@ def test_project_voxels_bit_exact(geom):
 
 def test_forward_without_projection_inputs(config2):
     """N2 end to end: dropping `projected_pix_2` / `fov_mask_2` from the batch makes the model project the voxels
-    on the GPU from (cam_k, T_velo_2_cam); the batch carries float32 extrinsics (the dataloader used float64), so
-    individual pixels may move by one in rare rounding ties -- the logits stay within 1e-3."""
+    on the GPU from (cam_k, T_velo_2_cam).
+    (1) With the dataloader's float64 extrinsics (`T_velo_2_cam_f64`) the tables are bit-identical, so the logits meet
+        the same 1e-3 bar as any repeated forward.
+    (2) The reference batch only carries a float32 copy of the extrinsics: a few pixels move by one in rounding ties
+        (< 1e-4 of the table).  That is a different INPUT for those voxels, not round-off, so the check is that the
+        change stays local: fewer than 1e-3 of the voxels see any logit move by more than 1e-3."""
     m, cfg, batch, out = config2
     b = {k: v for k, v in batch.items() if not (k.startswith("projected_pix") or k.startswith("fov_mask"))}
+    ref_pix = torch.stack(batch["projected_pix_2"])
+    ref_fov = torch.stack(batch["fov_mask_2"])
+    scale = out["ssc_logit"].abs().max()
+    from occdepth_amd import synthetic                  # same calibration constants, float64 extrinsics included
+    b64 = dict(b, T_velo_2_cam_f64=[t.to(DEV) for t in synthetic.kitti_frame(seed=gc.SEED)["T_velo_2_cam_f64"]])
+    with torch.no_grad():
+        pix, fov = m.project_voxels_on_gpu(b64, batch["img"])
+        o64 = m(b64)
+    assert torch.equal(pix, ref_pix) and torch.equal(fov, ref_fov)
+    assert ((o64["ssc_logit"] - out["ssc_logit"]).abs().max() / scale).item() < 1e-3
     with torch.no_grad():
         pix, fov = m.project_voxels_on_gpu(b, batch["img"])
         o = m(b)
-    ref_pix = torch.stack(batch["projected_pix_2"])
-    ref_fov = torch.stack(batch["fov_mask_2"])
     assert (fov != ref_fov).float().mean().item() < 1e-4
     both = fov & ref_fov
     assert ((pix != ref_pix).any(-1) & both).float().mean().item() < 1e-4
-    e = ((o["ssc_logit"] - out["ssc_logit"]).abs().max() / out["ssc_logit"].abs().max()).item()
-    assert e < 2e-3, e
+    moved = ((o["ssc_logit"] - out["ssc_logit"]).abs().amax(1) / scale) > 1e-3
+    assert moved.float().mean().item() < 1e-3, moved.float().mean().item()
 
 
 def test_argmax_labels(config2):

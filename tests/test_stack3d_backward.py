@@ -1,0 +1,205 @@
+"""Backward of the 3-D stack ALONE: one fixed, seeded lift volume `x3d` and fixed targets go
+through `net_3d_decoder` + the scene-completion losses; the gradients of every parameter of the stack (and of x3d)
+are compared with an ATen float64 run of the same modules on the CPU.  No 2-D network, no MIOpen, no atomics: the
+comparison is deterministic, so the bound is tight (elements within 1e-3 of the gradient's rms, norms within 1e-4).
+
+The network is piecewise linear in its ReLUs and a float32 forward may land on the other side of a kink than the
+float64 one (measured on `kitti_ps2`: ONE of 2.6 M ReLU inputs, |x| = 5e-7, flips between ATen float32 and ATen float64
+and moves 3 % of the decoder's weight-gradient elements by up to 3e-2 rms -- the same signature as the 4 % the old
+whole-model test showed).  That is a property of the function, not of a kernel, so the float64 reference is evaluated
+ON THE PRODUCT'S LINEAR PIECE: the product run records every ReLU mask, the reference replays them, and the test
+asserts that replayed masks differ from the reference's own only where |x| is at round-off level.
+
+  * CPU (`not gpu`): the autograd3d Function classes (forward / phase-decomposed data gradient / weight gradient) on
+    the test-only emulation of the C ABI, against ATen float64 -- pins the host logic.
+  * `-m gpu`: the same Function classes on the HIP kernels (K2 / K2s forward + dgrad, K8 wgrad, K5 / K6 losses).
+
+The reference path is occdepth/models/OccDepth.py:378-533 restricted to its 3-D half (unet3d_*.py, loss/ssc_loss.py).
+"""
+import contextlib
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import emu
+import golden_cases as gc
+from test_oracle_vs_golden import sd_for
+
+CASES = ["nyu_odd", "kitti_ps2"]
+ELEM_TOL = 1e-3      # max |dgrad| / rms(grad) per parameter
+NORM_TOL = 1e-4      # relative error of every gradient norm
+
+
+def build_stack(name):
+    """The UNet3D of tests/golden/unet3d.npz (seeded weights, calibrated BatchNorm statistics), classifier
+    convolutions scaled down so the logits are O(1) (a saturated softmax would make the gradient a handful of voxels)."""
+    import torch.nn as nn
+    spec = gc.UNET3D_CASES[name]
+    if spec["kind"] == "kitti":
+        from occdepth_amd.models.unet3d_kitti import UNet3D
+        m = UNet3D(spec["classes"], nn.BatchNorm3d, full_scene_size=spec["scene"], feature=spec["feature"],
+                   project_scale=spec["ps"], context_prior=True, cascade_cls=True, occluded_cls=spec["occluded"])
+    else:
+        from occdepth_amd.models.unet3d_nyu import UNet3D
+        m = UNet3D(spec["classes"], nn.BatchNorm3d, n_relations=spec["n_relations"], feature=spec["feature"],
+                   full_scene_size=spec["scene"], context_prior=True)
+    sd = sd_for(m, "unet3d", name)
+    for k in sd:
+        if gc.is_classifier_param(k):
+            sd[k] = sd[k] * gc.CLASSIFIER_SCALE
+    m.load_state_dict(sd)
+    return m.eval(), spec            # BatchNorm on running statistics; autograd still on => differentiable path
+
+
+def targets(name, spec, dims):
+    g = torch.Generator().manual_seed(gc.SEED + 31 + len(name))
+    c = spec["classes"]
+    t = torch.randint(0, c, (1, *dims), generator=g)
+    t[torch.rand(1, *dims, generator=g) < 0.5] = 0
+    t[torch.rand(1, *dims, generator=g) < 0.15] = 255
+    w = 0.5 + torch.rand(c, generator=g) * 2.0
+    return t.to(torch.uint8), w
+
+
+def loss_float64(out, target, w):
+    """CE + sem_scal + geo_scal (+ cascade occupancy CE) exactly as loss/ssc_loss.py states them, in differentiable
+    float64 torch (reference: occdepth/loss/ssc_loss.py:17-103, models/OccDepth.py:398-418)."""
+    from occdepth_amd.loss import ssc_loss as S
+
+    def stats(logits, tgt, weights):
+        B, C = logits.shape[:2]
+        p = torch.softmax(logits.double().reshape(B, C, -1), 1)
+        t = tgt.reshape(B, -1).long()
+        lab = t != 255
+        onehot = torch.zeros_like(p).scatter_(1, t.clamp(max=C - 1).unsqueeze(1), 1.0) * lab.unsqueeze(1)
+        logp = torch.log_softmax(logits.double().reshape(B, C, -1), 1)
+        wt = (onehot * weights.double().view(1, C, 1)).sum(1)
+        return torch.cat([(p * lab.unsqueeze(1)).sum((0, 2)), (p * onehot).sum((0, 2)), onehot.sum((0, 2)),
+                          lab.sum().double().view(1), (-(logp * onehot).sum(1) * wt).sum().view(1), wt.sum().view(1)])
+
+    C = out["ssc_logit"].shape[1]
+    st = stats(out["ssc_logit"], target, w)
+    loss = S.ce_from_stats(st, C) + S.sem_scal_from_stats(st, C) + S.geo_scal_from_stats(st, C)
+    if "occ_logit" in out:
+        occ_t = target.clone()
+        occ_t[(target > 0) & (target != 255)] = 1
+        loss = loss + S.ce_from_stats(stats(out["occ_logit"], occ_t, torch.tensor([0.7, 1.9])), 2)
+    return loss
+
+
+def loss_product(out, target, w):
+    from occdepth_amd.loss import ssc_loss as S
+    terms = S.ssc_losses(out["ssc_logit"], target, w.to(out["ssc_logit"].device))
+    loss = terms["loss_ssc"].double() + terms["loss_sem_scal"].double() + terms["loss_geo_scal"].double()
+    if "occ_logit" in out:
+        loss = loss + S.occ_ce_loss(out["occ_logit"], target,
+                                    torch.tensor([0.7, 1.9], device=target.device)).double()
+    return loss
+
+
+@contextlib.contextmanager
+def relu_masks(record=None, replay=None, flips=None):
+    """Route every ReLU of the model code (F.relu and nn.ReLU) through a recorder (product run: keeps x > 0 per call,
+    in call order) or a replayer (reference run: y = x * recorded mask)."""
+    import torch.nn as nn
+    real_f, real_m = F.relu, nn.ReLU.forward
+    it = iter(replay) if replay is not None else None
+
+    def relu(x, inplace=False):
+        if record is not None:
+            record.append((x.detach() > 0).cpu())
+            return real_f(x)
+        mask = next(it)
+        own = x.detach() > 0
+        diff = own != mask
+        if diff.any():
+            flips.append((int(diff.sum()), float(x.detach()[diff].abs().max() / x.detach().abs().max())))
+        return x * mask.to(x.dtype)
+
+    F.relu = relu
+    nn.ReLU.forward = lambda self, x: relu(x)
+    try:
+        yield
+    finally:
+        F.relu, nn.ReLU.forward = real_f, real_m
+    if it is not None:
+        assert next(it, None) is None, "the reference ran fewer ReLUs than the product"
+
+
+def run(name, device):
+    """-> (loss, {param name: grad}, dx3d) with the HIP Function classes (emulated on the CPU), and the ATen
+    float64 CPU reference of the same modules on the same ReLU masks."""
+    from occdepth_amd import autograd3d
+    m, spec = build_stack(name)
+    x = gc.randn(spec["x"], ("stack3d_bwd", name))
+    ref = copy.deepcopy(m).double()
+    saved = autograd3d._hip_ok
+
+    m = m.to(device)
+    xp = x.clone().to(device).requires_grad_(True)
+    cpu = device == "cpu"
+    if cpu:                                                   # drive the Function classes through the emulation
+        autograd3d._hip_ok = lambda mod, t: mod.groups == 1
+    masks, flips = [], []
+    try:
+        with (emu.patched() if cpu else contextlib.nullcontext()), relu_masks(record=masks):
+            out = m({"x3d": xp})
+            dims = tuple(out["ssc_logit"].shape[2:])
+            target, w = targets(name, spec, dims)
+            loss = loss_product(out, target.to(device), w)
+            loss.backward()
+    finally:
+        autograd3d._hip_ok = saved
+
+    xr = x.detach().double().requires_grad_(True)
+    autograd3d._hip_ok = lambda mod, t: False
+    try:
+        with relu_masks(replay=masks, flips=flips):
+            out_r = ref({"x3d": xr})
+            loss_r = loss_float64(out_r, target, w)
+            loss_r.backward()
+    finally:
+        autograd3d._hip_ok = saved
+    n_relu = sum(int(k.numel()) for k in masks)
+    print(f"{name}: {len(masks)} ReLU calls, {n_relu} inputs, mask flips float32-product vs float64: {flips}")
+    assert sum(n for n, _ in flips) <= 1e-5 * n_relu + 2 and all(r < 1e-5 for _, r in flips), flips
+    return (loss, dict(m.named_parameters()), xp.grad), (loss_r, dict(ref.named_parameters()), xr.grad)
+
+
+def compare(name, got, want):
+    (loss, params, dx), (loss_r, params_r, dx_r) = got, want
+    assert float(loss.detach()) == pytest.approx(float(loss_r.detach()), rel=2e-5)
+    rows = []
+    items = [(k, p.grad, params_r[k].grad) for k, p in params.items()] + [("x3d", dx, dx_r)]
+    for k, g, r in items:
+        if r is None or float(r.norm()) == 0.0:
+            assert g is None or float(g.norm()) == 0.0, k
+            continue
+        assert g is not None, k
+        g = g.detach().double().cpu()
+        rms = float(r.norm()) / np.sqrt(r.numel())
+        rows.append((float((g - r).abs().max()) / rms, abs(float(g.norm()) / float(r.norm()) - 1.0), k))
+    rows.sort(reverse=True)
+    print(f"{name}: worst |dgrad|/rms(grad) = {rows[0][0]:.2e} ({rows[0][2]}); worst norm error = "
+          f"{max(r[1] for r in rows):.2e}; {len(rows)} tensors")
+    for e, n, k in rows[:5]:
+        print(f"   {k}: elem {e:.2e} norm {n:.2e}")
+    bad = [(k, e, n) for e, n, k in rows if e > ELEM_TOL or n > NORM_TOL]
+    assert not bad, bad[:10]
+    assert len(rows) > 100
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_stack3d_backward_through_conv_functions_cpu(name):
+    compare(name, *run(name, "cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_stack3d_backward_hip_vs_aten_float64_gpu(name, hip_lib):
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    compare(name, *run(name, "cuda"))

@@ -105,37 +105,12 @@ def test_train_step_matches_reference_gpu(cfg_name, hip_lib):
     torch.backends.cuda.matmul.allow_tf32 = False
     m, loss, metric = run_step(cfg_name, "cuda")
     # MIOpen-vs-CPU round-off of the 2-D networks dominates (cf. test_occdepth_small_vs_golden: 3e-3 on logits)
-    # gradients: norms within 5 %, elements within ~1 rms -- a wiring check only (see the HIP-vs-ATen test below for
-    # why a random-init network amplifies round-off this much); the kernels are pinned at 2e-5 in test_conv_grad.py
+    # gradients: norms within 5 %, elements within ~1 rms -- a wiring check only: a float32 forward that lands on the
+    # other side of ONE ReLU kink moves percent-level gradient mass in a random-init network (measured and explained in
+    # tests/test_stack3d_backward.py, which pins the 3-D stack's backward at 1e-3 rms on fixed ReLU masks); the
+    # kernels themselves are pinned at 2e-5 in test_conv_grad.py
     check(cfg_name, m, loss, metric, rel=3e-3, grad_norm_rel=5e-2, grad_elem=1.0)
 
 
-@pytest.mark.gpu
-def test_hip_conv_functions_match_aten_backward_gpu(hip_lib):
-    """Same GPU, same MIOpen 2-D networks, 3-D convolutions through the HIP Function classes vs through ATen:
-    isolates the HIP forward / dgrad / wgrad kernels from the MIOpen-vs-CPU round-off of the 2-D side."""
-    torch.backends.cudnn.allow_tf32 = False
-    torch.backends.cuda.matmul.allow_tf32 = False
-    m1, loss1, _ = run_step("nyu_small", "cuda")
-    m2, loss2, _ = run_step("nyu_small", "cuda", force_hip_functions="aten")
-    assert float(loss1.detach()) == pytest.approx(float(loss2.detach()), rel=1e-5)
-    g2 = dict(m2.named_parameters())
-    worst3d = worst = 0.0
-    for k, p in m1.named_parameters():
-        if p.grad is None:
-            assert g2[k].grad is None, k
-            continue
-        a, b = p.grad.double(), g2[k].grad.double()
-        rms = float(b.norm()) / np.sqrt(b.numel())
-        if rms > 0:
-            e = float((a - b).abs().max()) / rms
-            worst = max(worst, e)
-            if k.startswith("net_3d_decoder."):
-                worst3d = max(worst3d, e)
-            assert float(a.norm()) == pytest.approx(float(b.norm()), rel=2e-2), k
-    print("HIP vs ATen 3-D convolutions, worst |dgrad| / rms(grad): 3-D stack", worst3d, " all parameters", worst)
-    # The 3-D stack's own parameters sit right behind the loss.  The 2-D encoder weights are ~100 layers further
-    # down the backward pass of a random-init network: there a 1e-6 perturbation (and MIOpen's atomically
-    # accumulated 2-D weight gradients) is amplified to ~0.1 rms element-wise while the norms still agree to 1e-3;
-    # the kernels themselves are pinned at 2e-5 in tests/test_conv_grad.py.
-    assert worst3d < 0.1 and worst < 0.5
+# The HIP-vs-ATen comparison of the 3-D stack's backward lives in tests/test_stack3d_backward.py: the stack alone,
+# fixed inputs, ATen float64 reference on the same ReLU masks, elements within 1e-3 rms and norms within 1e-4.
