@@ -237,6 +237,30 @@ int occd_wino_output_transform_nchw(const float* M, const float* scale, const fl
                                     float* y, int32_t batch, int32_t Cout, int32_t H, int32_t W, int32_t ty0,
                                     int32_t ths, int32_t act, float slope, int32_t res_first, void* stream);
 
+/* K10: FUSED Winograd F(2x2, 3x3) convolution on the fp32 matrix pipe -- replaces
+ * nn.Conv2d(k=3, s=1, p=1) + BatchNorm2d (eval) + activation of the 2-D decoder (occdepth/models/unet2d.py:24-46)
+ * and the 3x3 convolutions of DepthNet / BasicBlock (occdepth/models/flosp_depth/flosp_depth.py:201-257):
+ *   y = act( conv3x3(x, g * scale[co], pad 1) + shift[co] ) (+ res before or after act), x / y / res NCHW float32.
+ * V = B^T d B is formed in registers from LDS-staged input patches, M stays in the MFMA accumulators, the output
+ * transform runs in the epilogue: neither exists in memory (cf. the unfused transforms above).
+ * upk: occd_wino_pack_weights(g (Cout, Cin, 3, 3), scale or NULL) -> occd_wino_packed_floats(Cout, Cin) floats,
+ *      U = G g G^T * scale in MFMA A-fragment order [ceil(Cin/8)][16][ceil(Cout/32)][64 lanes][4].
+ * shift: Cout floats or NULL.  act: codes of occd_affine_act_nchw (0 none, 1 relu, 2 swish, 3 leaky(slope)).
+ * tile_hint: 0 = choose; 16 / 32 = tiles per wave along x (wave = 2 x 16 or 1 x 32 tiles).                     */
+typedef struct occd_wino_args {
+    const float* x;
+    const float* upk;
+    const float* shift;
+    const float* res;
+    float* y;
+    int32_t batch, cin, cout, H, W;
+    int32_t act, res_first, tile_hint;
+    float slope;
+} occd_wino_args;
+int64_t occd_wino_packed_floats(int32_t cout, int32_t cin);
+int occd_wino_pack_weights(const float* w, const float* scale, float* upk, int32_t cout, int32_t cin, void* stream);
+int occd_wino_conv3x3_fwd(const occd_wino_args* a, void* stream);
+
 /* SURVEY 8(f) row N4 (first step): out[row] = lut[argmax_c x[row][coff + c]] (first maximum wins; lut may
  * be NULL) as uint16 -- replaces the host softmax + numpy argmax of scripts/generate_output.py:94-95 and the
  * learning_map_inv lookup of scripts/generate_kitti_submission.py:74-85.                               */

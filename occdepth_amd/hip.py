@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 2   # 2: training entry points (loss statistics, wgrad), Winograd transforms with strip arguments
+ABI_VERSION = 3   # 3: fused Winograd convolution (K10); 2: training entry points, Winograd transforms with strips
 
 _c_float_p = POINTER(c_float)
 
@@ -77,6 +77,11 @@ class LiftArgs(Structure):
     ]
 
 
+class WinoArgs(Structure):
+    _fields_ = [("x", c_void_p), ("upk", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("y", c_void_p)] + \
+        [(n, c_int32) for n in ("batch", "cin", "cout", "H", "W", "act", "res_first", "tile_hint")] + [("slope", c_float)]
+
+
 class ProfRow(Structure):
     _fields_ = [("tag", c_char * 64), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
                 ("bytes", c_double)]
@@ -103,6 +108,9 @@ EXPORTS = {
                                                  c_void_p]),
     "occd_wino_output_transform_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, c_void_p]),
+    "occd_wino_packed_floats": (c_int64, [c_int32, c_int32]),
+    "occd_wino_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "occd_wino_conv3x3_fwd": (c_int32, [POINTER(WinoArgs), c_void_p]),
     "occd_project_voxels": (c_int32, [c_void_p, c_void_p, c_void_p, c_double] + [c_int32] * 5
                             + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -481,6 +489,44 @@ def conv2d_3x3_winograd(x, U, scale=None, shift=None, act=None, slope=0.01, res=
         ths = min(strip_rows, th - ty0)
         M = torch.bmm(wino_input_transform(xc, ty0, ths), U)
         wino_output_transform(M, tuple(y.shape), scale, shift, act, slope, res, res_first, out=y, ty0=ty0, ths=ths)
+    return y
+
+
+def wino_pack_weights(w, scale=None):
+    """(Cout, Cin, 3, 3) conv weight (+ per-cout scale, e.g. a folded BatchNorm) -> packed Winograd-domain operand of K10."""
+    cout, cin = w.shape[0], w.shape[1]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise RuntimeError("wino_pack_weights needs a (Cout, Cin, 3, 3) weight")
+    n = load().occd_wino_packed_floats(cout, cin)
+    if n <= 0:
+        raise RuntimeError("occd_wino_packed_floats: bad shape")
+    wc = w.detach().float().contiguous()
+    upk = torch.empty(n, device=w.device, dtype=torch.float32)
+    sc = scale.detach().float().contiguous() if scale is not None else None
+    _check(load().occd_wino_pack_weights(_f32(wc, "w"), _f32(sc, "scale") if sc is not None else None,
+                                         _f32(upk, "upk"), cout, cin, _stream()), "occd_wino_pack_weights")
+    return upk
+
+
+def conv2d_3x3_fused(x, upk, cout, shift=None, act=None, slope=0.01, res=None, res_first=False, tile_hint=0, out=None):
+    """K10: act(conv3x3(x, g * scale, pad 1) + shift) (+ res) in one launch (upk = wino_pack_weights(g, scale))."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, cin, H, W = x.shape
+    y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32) if out is None else out
+    if res is not None and not res.is_contiguous():
+        res = res.contiguous()
+    a = WinoArgs()
+    a.x, a.upk, a.y = _f32(x, "x"), _f32(upk, "upk"), _f32(y, "y")
+    a.shift = _f32(shift, "shift") if shift is not None else None
+    a.res = _f32(res, "res") if res is not None else None
+    a.batch, a.cin, a.cout, a.H, a.W = B, cin, cout, H, W
+    a.act, a.res_first, a.tile_hint, a.slope = ACT2D[act], 1 if res_first else 0, int(tile_hint), float(slope)
+    if upk.numel() != load().occd_wino_packed_floats(cout, cin):
+        raise RuntimeError("packed Winograd weights do not match (cout, cin)")
+    if _PROFILING:
+        set_tag("%d>%d @%dx%dx%d" % (cin, cout, B, H, W))
+    _check(load().occd_wino_conv3x3_fwd(ctypes.byref(a), _stream()), "occd_wino_conv3x3_fwd")
     return y
 
 

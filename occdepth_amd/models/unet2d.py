@@ -64,8 +64,28 @@ class UpSampleBN(nn.Module):
     WINOGRAD_HIRES_MIN_CIN = int(os.environ.get("OCCDEPTH_WINOGRAD_HIRES_MIN_CIN", "64"))
     WINOGRAD_STRIP_MB = float(os.environ.get("OCCDEPTH_WINOGRAD_STRIP_MB", "96"))
 
+    # K10, the fused Winograd kernel (V in registers, M in the accumulators): levels with at least this many pixels
+    # (B * H * W); below, the unfused transforms + batched GEMMs above keep their large-K efficiency
+    FUSED_MIN_PIXELS = int(os.environ.get("OCCDEPTH_WINO_FUSED_MIN_PIXELS", "80001"))
+    FUSED = os.environ.get("OCCDEPTH_WINO_FUSED", "1") == "1"
+
+    def _fused_operands(self, conv, bn):
+        key = _stamp(conv, bn)
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            scale, shift = bn_affine_cached(bn)
+            if conv.bias is not None:
+                shift = shift + scale * conv.bias.detach().float()
+            hit = (key, hip.wino_pack_weights(conv.weight, scale), shift.contiguous())
+            cache[id(conv)] = hit
+        return hit[1:]
+
     def _conv_bn_act(self, f, conv, bn, act):
         B, C, H, W = f.shape
+        if self.FUSED and B * H * W >= self.FUSED_MIN_PIXELS:
+            upk, shift = self._fused_operands(conv, bn)
+            return hip.conv2d_3x3_fused(f, upk, conv.out_channels, shift, "leaky", act.negative_slope)
         if self.WINOGRAD and C >= self.WINOGRAD_MIN_CIN and B * H * W <= self.WINOGRAD_MAX_PIXELS:
             U, scale, shift = self._wino_operands(conv, bn)
             return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope)

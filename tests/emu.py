@@ -208,6 +208,40 @@ def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01
     return out
 
 
+class _PackedWino:
+    def __init__(self, w):
+        self.w = w
+
+    def numel(self):
+        return -1
+
+
+def wino_pack_weights(w, scale=None):
+    w = w.detach().double()
+    return _PackedWino(w * scale.double().view(-1, 1, 1, 1) if scale is not None else w)
+
+
+def conv2d_3x3_fused(x, upk, cout, shift=None, act=None, slope=0.01, res=None, res_first=False, tile_hint=0, out=None):
+    """K10 semantics: act(conv3x3(x, g * scale, pad 1) + shift) (+ res)."""
+    y = F.conv2d(x.double(), upk.w, None, padding=1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    if res is not None and res_first:
+        y = y + res.double()
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "leaky":
+        y = F.leaky_relu(y, slope)
+    elif act == "swish":
+        y = y * torch.sigmoid(y)
+    if res is not None and not res_first:
+        y = y + res.double()
+    if out is not None:
+        out.copy_(y.float())
+        return out
+    return y.float()
+
+
 def _softmax_and_target(logits, target, map_occ):
     B, C = logits.shape[:2]
     p = F.softmax(logits.detach().double().reshape(B, C, -1), 1)        # (B, C, S)
@@ -274,7 +308,9 @@ def ssc_confusion(hist, target, logits=None, labels=None):
 def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
-                                          "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform")}
+                                          "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
+                                          "wino_pack_weights", "conv2d_3x3_fused")}
+    hip.wino_pack_weights, hip.conv2d_3x3_fused = wino_pack_weights, conv2d_3x3_fused
     hip.conv3d_wgrad = conv3d_wgrad
     hip.wino_input_transform, hip.wino_output_transform = wino_input_transform, wino_output_transform
     hip.ssc_loss_stats, hip.ssc_loss_grad, hip.ssc_confusion = ssc_loss_stats, ssc_loss_grad, ssc_confusion

@@ -226,8 +226,10 @@ def test_two_rank_real_model_syncbn_and_buckets_match_batch_of_two():
     procs = [ctx.Process(target=_real_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    # meanwhile: the single-process statement of the same step
-    torch.set_num_threads(4)
+    # meanwhile: the single-process statement of the same step (thread count restored below: other tests' float32
+    # reduction order, hence their round-off, depends on it)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(4, n_threads)))
     m, cfg = _real_model()
     frames = [_real_frame(i, m, cfg) for i in range(world)]
     from occdepth_amd.loss.sscMetrics import SSCMetrics
@@ -243,6 +245,7 @@ def test_two_rank_real_model_syncbn_and_buckets_match_batch_of_two():
         finally:
             m.forward = real_forward
         total.backward()
+    torch.set_num_threads(n_threads)
     want = dict(m.named_parameters())
     want_sd = m.state_dict()
     got = {}

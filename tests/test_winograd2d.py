@@ -64,3 +64,73 @@ def test_transform_kernels_match_emulation(hip_lib):
         y = hip.wino_output_transform(M.cuda(), (2, 50, 13, 71), sc.cuda(), sh.cuda(), "leaky", 0.2, res.cuda(), rf)
         assert torch.allclose(y.cpu(), emu.wino_output_transform(M, (2, 50, 13, 71), sc, sh, "leaky", 0.2, res, rf),
                               rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K10: the fused kernel (csrc/wino_conv2d.hip) -- V in registers, M in the MFMA accumulators, output transform in the
+# epilogue.  Reference: ATen float64 conv2d + affine + activation (+ residual) on the CPU.
+# (B, Cin, Cout, H, W, act, residual, res_first, tile_hint)
+FUSED_CASES = [
+    (2, 40, 24, 12, 39, "leaky", False, False, 0),       # odd width, cout < 32, cin = 5 chunks
+    (1, 33, 70, 7, 5, None, False, False, 0),            # ragged channels (cin % 8 != 0, 3 cout blocks), tiny image
+    (2, 64, 64, 24, 77, "relu", True, True, 16),         # BasicBlock: relu(bn(conv) + x), narrow waves
+    (2, 64, 64, 24, 77, "relu", True, False, 32),        # residual after the activation, wide waves
+    (1, 8, 8, 2, 130, "leaky", False, False, 0),         # several workgroups along x, one tile row
+    (1, 19, 40, 37, 68, "leaky", False, False, 16),      # even width (paired stores), several workgroups along y
+    (1, 19, 40, 37, 68, "swish", False, False, 32),
+    (2, 163, 80, 50, 131, "leaky", False, False, 0),     # the up1 channel counts on a crop
+]
+
+
+def run_fused(case, device, tol):
+    from occdepth_amd import hip
+    B, cin, cout, H, W, act, with_res, res_first, hint = case
+    g = torch.Generator().manual_seed(B * 1000 + cin + H + hint)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g) if with_res else None
+    ref = F.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if with_res and res_first:
+        ref = ref + res.double()
+    ref = {"leaky": lambda t: F.leaky_relu(t, 0.01), "relu": F.relu, "swish": lambda t: t * torch.sigmoid(t),
+           None: lambda t: t}[act](ref)
+    if with_res and not res_first:
+        ref = ref + res.double()
+    dev = torch.device(device)
+    with (emu.patched() if device == "cpu" else contextlib.nullcontext()):
+        upk = hip.wino_pack_weights(w.to(dev), scale.to(dev))
+        y = hip.conv2d_3x3_fused(x.to(dev), upk, cout, shift.to(dev), act, 0.01, res.to(dev) if with_res else None,
+                                 res_first=res_first, tile_hint=hint)
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert y.shape == ref.shape and err < tol, (case, err)
+    return err
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_winograd_host_logic_cpu(case):
+    run_fused(case, "cpu", 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_winograd_kernel_gpu(case, hip_lib):
+    err = run_fused(case, "cuda", 2e-5)
+    print(case, f"rel err vs float64 {err:.2e}")
+
+
+@pytest.mark.gpu
+def test_fused_winograd_is_deterministic_and_ignores_garbage_outside(hip_lib):
+    """Same launch twice = same bits; pixels outside the image never leak in (the staged patch is zero padded)."""
+    from occdepth_amd import hip
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 24, 9, 35, generator=g).cuda()
+    w = (torch.randn(32, 24, 3, 3, generator=g) * 0.1).cuda()
+    upk = hip.wino_pack_weights(w)
+    a = hip.conv2d_3x3_fused(x, upk, 32)
+    b = hip.conv2d_3x3_fused(x, upk, 32)
+    assert torch.equal(a, b)
+    big = torch.full((1, 24, 11, 37), float("nan"), device="cuda")     # the same image inside a NaN frame ...
+    big[:, :, 1:10, 1:36] = x
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    assert float((a.double() - ref).abs().max() / ref.abs().max()) < 2e-5

@@ -48,3 +48,31 @@ for (H, W), cin, cout in LEVELS:
     print(f"{cin:5d}->{cout:4d} @{H}x{W}: MIOpen conv {tc:.3f} ms ({fl / tc / 1e9:5.1f} TF/s direct-equiv) | "
           f"bmm 16x({T}x{cin}x{cout}) {tg:.3f} ms ({flg / tg / 1e9:5.1f} TF/s) | transform traffic {gb:.2f} GB", flush=True)
 print(f"total: MIOpen {tot_c:.2f} ms, batched GEMMs {tot_g:.2f} ms")
+
+# ---- K10: the fused kernel per level (both wave shapes) against the two paths above
+from occdepth_amd import hip  # noqa: E402
+
+hip.load()
+print("\nK10 fused Winograd kernel (csrc/wino_conv2d.hip), batch 2:")
+tot = {"miopen": 0.0, "unfused": 0.0, "fused": 0.0}
+for (H, W), cin, cout in LEVELS:
+    x = torch.randn(2, cin, H, W, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.02
+    sc, sh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+    upk = hip.wino_pack_weights(w, sc)
+    U = hip.winograd_weights(w)
+    y = torch.empty(2, cout, H, W, device="cuda")
+    tm = t(lambda: hip.affine_act(F.conv2d(x, w, padding=1), sc, sh, "leaky"))
+    tu = t(lambda: hip.conv2d_3x3_winograd(x, U, sc, sh, "leaky"))
+    tf = {h: t(lambda: hip.conv2d_3x3_fused(x, upk, cout, sh, "leaky", tile_hint=h, out=y)) for h in (16, 32)}
+    ref = hip.affine_act(F.conv2d(x, w, padding=1), sc, sh, "leaky")
+    err = float((hip.conv2d_3x3_fused(x, upk, cout, sh, "leaky") - ref).abs().max() / ref.abs().max())
+    fl = 2.0 * 2 * H * W * 9 * cin * cout
+    best = min(tf.values())
+    tot["miopen"] += tm
+    tot["unfused"] += tu
+    tot["fused"] += best
+    print(f"{cin:5d}->{cout:4d} @{H}x{W}: MIOpen+BN/act {tm:.3f} ms | unfused wino {tu:.3f} ms | fused 2x16 {tf[16]:.3f} "
+          f"1x32 {tf[32]:.3f} ms ({fl / best / 1e9:5.1f} TF/s direct-equiv, {fl / 2.25 / best / 1e9:5.1f} TF/s MFMA) "
+          f"| vs MIOpen err {err:.1e}", flush=True)
+print("totals (ms):", {k: round(v, 3) for k, v in tot.items()})
