@@ -261,6 +261,30 @@ int64_t occd_wino_packed_floats(int32_t cout, int32_t cin);
 int occd_wino_pack_weights(const float* w, const float* scale, float* upk, int32_t cout, int32_t cin, void* stream);
 int occd_wino_conv3x3_fwd(const occd_wino_args* a, void* stream);
 
+/* K11: pointwise (1x1) convolution on NCHW maps as a GEMM on the fp32 matrix pipe with the
+ * EfficientNet / decoder epilogue fused -- replaces conv1x1 + BatchNorm2d (eval) + Swish (+ squeeze-excite gate on the
+ * input, + MBConv skip add) of the geffnet blocks behind occdepth/models/unet2d.py:175-190, the `resize_output_1_s`
+ * convolutions of DecoderBN (unet2d.py:137-165) and DepthNet.depth_pred (flosp_depth/flosp_depth.py:225-227):
+ *   y[b][co][n] = act( sum_ci (w[co][ci] * scale[co]) * (x[b][ci][n] * gate[b][ci]) + shift[co] ) (+ res[b][co][n])
+ * x (B, Cin, N), y / res (B, Cout, N), N = H*W; gate (B, Cin) or NULL; shift (Cout) or NULL; act codes as above.
+ * wpk: occd_pw_pack_weights(w (Cout, Cin), scale or NULL) -> occd_pw_packed_floats(Cout, Cin) floats in MFMA
+ *      A-fragment order [ceil(Cin/8)][ceil(Cout/32)][64 lanes][4].  tile_hint: 0 = choose, 1..6 = fixed variant.   */
+typedef struct occd_pw_args {
+    const float* x;
+    const float* wpk;
+    const float* shift;
+    const float* gate;
+    const float* res;
+    float* y;
+    int64_t N;
+    int32_t batch, cin, cout;
+    int32_t act, tile_hint;
+    float slope;
+} occd_pw_args;
+int64_t occd_pw_packed_floats(int32_t cout, int32_t cin);
+int occd_pw_pack_weights(const float* w, const float* scale, float* wpk, int32_t cout, int32_t cin, void* stream);
+int occd_pw_conv_fwd(const occd_pw_args* a, void* stream);
+
 /* SURVEY 8(f) row N4 (first step): out[row] = lut[argmax_c x[row][coff + c]] (first maximum wins; lut may
  * be NULL) as uint16 -- replaces the host softmax + numpy argmax of scripts/generate_output.py:94-95 and the
  * learning_map_inv lookup of scripts/generate_kitti_submission.py:74-85.                               */

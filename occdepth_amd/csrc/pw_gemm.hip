@@ -1,0 +1,227 @@
+// K11 -- pointwise (1x1) convolution on NCHW feature maps as a GEMM on the fp32 matrix pipe, with the whole
+// EfficientNet / decoder epilogue fused:
+//
+//   y[b][co][n] = act( sum_ci (w[co][ci] * scale[co]) * (x[b][ci][n] * gate[b][ci]) + shift[co] ) (+ res[b][co][n])
+//
+// i.e. conv1x1 + BatchNorm(eval) + Swish / none (+ the MBConv skip add), with the squeeze-excite gate of the
+// PRECEDING depthwise stage applied to the input channels on the fly (x * sigmoid(...) never exists in memory).
+// GEMM view per image: C (Cout x N) = W (Cout x Cin) . X (Cin x N), N = H*W pixels -- NCHW is already the row-major
+// B operand, so nothing is transposed.  Instruction: v_mfma_f32_32x32x2_f32 (exact fp32).
+//   * D rows = couts, D columns = pixels: a lane owns ONE pixel column (lane & 31) and 16 couts, so every store
+//     instruction writes 32 consecutive pixels (128 B) of a cout row and residual reads are the same shape;
+//   * A (weights): pre-packed per layer in fragment order [k/8][cout/32][lane][4] (BatchNorm scale folded in): one
+//     global_load_dwordx4 per lane per 8-channel step, L2 resident;
+//   * B (activations): read straight from global memory -- the K index is permuted so lane half h owns channels
+//     8c + 4h .. 8c + 4h + 3, and for each of them the half-wave reads 32 consecutive pixels (128 B).  A wave's B
+//     fragment is reused by its MT cout blocks and its A fragment by its NT pixel blocks; nothing is shared between
+//     waves, so there is no LDS and no barrier: a wave is an independent (MT*32) x (NT*32) register-blocked GEMM and
+//     the 4 waves of a workgroup sit side by side (WM along couts x WN along pixels) only for L1 locality;
+//   * fragments of step c+1 are loaded before the MFMAs of step c.
+// Most of these layers are HBM-bound (algorithmic bytes 4 * B * N * (Cin + Cout (+ Cout for the residual))); the
+// wide ones (Cin, Cout >= 640) are MFMA-bound (2 * B * N * Cin8 * Cout32 FLOP).
+//
+// Reference semantics replaced: the conv_pw / conv_pwl / conv_head 1x1 convolutions + BatchNorm + Swish + SE gate
+// + skip of the geffnet EfficientNet blocks behind occdepth/models/unet2d.py:175-190, and the `resize_output_1_s`
+// 1x1 convolutions of DecoderBN (unet2d.py:137-165), DepthNet.depth_pred (flosp_depth.py:225-227).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct PwP {
+    const float* x;
+    const float* wpk;
+    const float* shift;
+    const float* gate;
+    const float* res;
+    float* y;
+    int Cin, Cout, kchunks, mblocks;
+    long N;
+    int act;
+    float slope;
+    int ntiles, mtiles;
+};
+
+__device__ __forceinline__ float pw_act(float v, int act, float slope) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v / (1.f + expf(-v));
+    if (act == 3) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// (second launch bound = workgroups per CU = waves per SIMD: 128 accumulator registers leave room for 2, 64 for 3)
+template <int MT, int NT, int WM, int WN>
+__global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(const PwP p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.z;
+    // consecutive workgroups walk the cout tiles of one pixel tile first: they re-read the same X columns from L2
+    const int mt_wg = blockIdx.x % p.mtiles, nt_wg = blockIdx.x / p.mtiles;
+    const int mb0 = (mt_wg * WM + wm) * MT;                       // first 32-cout block of this wave
+    const long n0 = ((long)nt_wg * WN + wn) * NT * 32;            // first pixel of this wave
+    if (mb0 >= p.mblocks || n0 >= p.N) return;                    // (no barriers in this kernel)
+
+    const float* const xb = p.x + (size_t)b * p.Cin * p.N;
+    const float* const gb = p.gate != nullptr ? p.gate + (size_t)b * p.Cin : nullptr;
+
+    // pixel columns of this lane and their validity; A-fragment offsets of the owned cout blocks
+    long col[NT];
+    bool colok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        col[nt] = n0 + nt * 32 + li;
+        colok[nt] = col[nt] < p.N;
+        col[nt] = colok[nt] ? col[nt] : p.N - 1;
+    }
+    int wofs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wofs[mt] = min(mb0 + mt, p.mblocks - 1) * 256 + lane * 4;
+    const size_t w_step = (size_t)p.mblocks * 256;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    auto load_a = [&](int c, f32x4* a) {
+        const float* wp = p.wpk + (size_t)c * w_step;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(wp + wofs[mt]);
+    };
+    auto load_b = [&](int c, f32x4* bf) {
+        const int k0 = c * 8 + kk * 4;
+        f32x4 g = {1.f, 1.f, 1.f, 1.f};
+        bool kok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kok[q] = k0 + q < p.Cin;
+        if (gb != nullptr) {                                       // (uniform branch; the loads inside are unconditional)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = gb[min(k0 + q, p.Cin - 1)];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kok[q] ? k0 + q : p.Cin - 1;
+                const float v = xb[(size_t)k * p.N + col[nt]];
+                bf[nt][q] = kok[q] ? v * g[q] : 0.f;
+            }
+    };
+
+    f32x4 a_cur[MT], b_cur[NT];
+    load_a(0, a_cur);
+    load_b(0, b_cur);
+    for (int c = 0; c < p.kchunks; ++c) {
+        f32x4 a_nxt[MT], b_nxt[NT];
+        const int cn = c + 1 < p.kchunks ? c + 1 : c;              // (the last step re-reads itself: no branch)
+        load_a(cn, a_nxt);
+        load_b(cn, b_nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+    }
+
+    // ---------------- epilogue: register r of tile (mt, nt) is cout 32 (mb0 + mt) + 8 (r >> 2) + 4 kk + (r & 3)
+    // at pixel n0 + 32 nt + li.
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mb0 + mt >= p.mblocks) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (mb0 + mt) * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
+            if (co >= p.Cout) continue;
+            const float sh = p.shift != nullptr ? p.shift[co] : 0.f;
+            const size_t row = ((size_t)b * p.Cout + co) * p.N;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (!colok[nt]) continue;
+                float v = pw_act(acc[mt][nt][r] + sh, p.act, p.slope);
+                if (p.res != nullptr) v += p.res[row + col[nt]];
+                p.y[row + col[nt]] = v;
+            }
+        }
+    }
+}
+
+// wpk[k/8][cout/32][lane][4]: cout = blk*32 + (lane & 31), cin = chunk*8 + (lane >> 5)*4 + q, value w[cout][cin] * scale[cout]
+__global__ void pw_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ wpk,
+                               int cout, int cin, int mblocks, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = i & 3, lane = (i >> 2) & 63;
+    const long t = i >> 8;
+    const int blk = t % mblocks, chunk = (int)(t / mblocks);
+    const int co = blk * 32 + (lane & 31), ci = chunk * 8 + (lane >> 5) * 4 + q;
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[(size_t)co * cin + ci] * (scale != nullptr ? scale[co] : 1.f);
+    wpk[i] = v;
+}
+
+template <int MT, int NT, int WM, int WN>
+int launch_pw(PwP& p, int batch, hipStream_t st) {
+    p.mtiles = (p.mblocks + MT * WM - 1) / (MT * WM);
+    p.ntiles = (int)((p.N + (long)NT * WN * 32 - 1) / ((long)NT * WN * 32));
+    const long gx = (long)p.mtiles * p.ntiles;
+    if (gx > 0x7fffffffL || batch > 65535) return OCCD_EINVAL;
+    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN>), dim3((unsigned)gx, 1, (unsigned)batch), dim3(256), 0, st, p);
+    return occd::check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t occd_pw_packed_floats(int32_t cout, int32_t cin) {
+    if (cout < 1 || cin < 1) return OCCD_EINVAL;
+    return (int64_t)((cin + 7) / 8) * ((cout + 31) / 32) * 256;
+}
+
+int occd_pw_pack_weights(const float* w, const float* scale, float* wpk, int32_t cout, int32_t cin, void* stream) {
+    if (w == nullptr || wpk == nullptr || cout < 1 || cin < 1) return OCCD_EINVAL;
+    const long total = occd_pw_packed_floats(cout, cin);
+    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale,
+                       wpk, cout, cin, (cout + 31) / 32, total);
+    return occd::check_launch();
+}
+
+int occd_pw_conv_fwd(const occd_pw_args* a, void* stream) {
+    if (a == nullptr || a->x == nullptr || a->wpk == nullptr || a->y == nullptr) return OCCD_EINVAL;
+    if (a->batch < 1 || a->cin < 1 || a->cout < 1 || a->N < 1 || a->act < 0 || a->act > 3) return OCCD_EINVAL;
+    PwP p{};
+    p.x = a->x; p.wpk = a->wpk; p.shift = a->shift; p.gate = a->gate; p.res = a->res; p.y = a->y;
+    p.Cin = a->cin; p.Cout = a->cout; p.N = a->N; p.act = a->act; p.slope = a->slope;
+    p.kchunks = (a->cin + 7) / 8;
+    p.mblocks = (a->cout + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    occd::ProfScope prof("pw_conv", st, 2.0 * a->batch * (double)a->N * p.kchunks * 8 * p.mblocks * 32,
+                         4.0 * a->batch * (double)a->N * (a->cin + a->cout * (a->res != nullptr ? 2.0 : 1.0)));
+    // wave tile: as many cout blocks as the layer has (<= 4) so X is read once; wide layers take 128 x 64 per wave and
+    // put the 4 waves along the couts when that still leaves >= 2 workgroups per CU, else along the pixels
+    const int mb = p.mblocks;
+    const int hint = a->tile_hint;
+    const long n = a->N;
+    if (hint == 1 || (hint == 0 && mb == 1)) return launch_pw<1, 4, 1, 4>(p, a->batch, st);
+    if (hint == 2 || (hint == 0 && mb == 2)) return launch_pw<2, 4, 1, 4>(p, a->batch, st);
+    if (hint == 3 || (hint == 0 && mb <= 4)) return launch_pw<4, 2, 1, 4>(p, a->batch, st);
+    if (hint == 4 || (hint == 0 && mb <= 8 && n * a->batch >= 16384)) return launch_pw<4, 2, 2, 2>(p, a->batch, st);
+    if (hint == 5 || (hint == 0 && n * a->batch >= 4096)) return launch_pw<4, 2, 4, 1>(p, a->batch, st);
+    return launch_pw<2, 2, 4, 1>(p, a->batch, st);      // hint 6: few pixels (the 1/32 level): smaller tiles, more workgroups
+}
+
+}  // extern "C"

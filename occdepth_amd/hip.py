@@ -82,6 +82,12 @@ class WinoArgs(Structure):
         [(n, c_int32) for n in ("batch", "cin", "cout", "H", "W", "act", "res_first", "tile_hint")] + [("slope", c_float)]
 
 
+class PwArgs(Structure):
+    _fields_ = [("x", c_void_p), ("wpk", c_void_p), ("shift", c_void_p), ("gate", c_void_p), ("res", c_void_p),
+                ("y", c_void_p), ("N", c_int64), ("batch", c_int32), ("cin", c_int32), ("cout", c_int32),
+                ("act", c_int32), ("tile_hint", c_int32), ("slope", c_float)]
+
+
 class ProfRow(Structure):
     _fields_ = [("tag", c_char * 64), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
                 ("bytes", c_double)]
@@ -111,6 +117,9 @@ EXPORTS = {
     "occd_wino_packed_floats": (c_int64, [c_int32, c_int32]),
     "occd_wino_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "occd_wino_conv3x3_fwd": (c_int32, [POINTER(WinoArgs), c_void_p]),
+    "occd_pw_packed_floats": (c_int64, [c_int32, c_int32]),
+    "occd_pw_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "occd_pw_conv_fwd": (c_int32, [POINTER(PwArgs), c_void_p]),
     "occd_project_voxels": (c_int32, [c_void_p, c_void_p, c_void_p, c_double] + [c_int32] * 5
                             + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "occd_argmax_channels": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -527,6 +536,51 @@ def conv2d_3x3_fused(x, upk, cout, shift=None, act=None, slope=0.01, res=None, r
     if _PROFILING:
         set_tag("%d>%d @%dx%dx%d" % (cin, cout, B, H, W))
     _check(load().occd_wino_conv3x3_fwd(ctypes.byref(a), _stream()), "occd_wino_conv3x3_fwd")
+    return y
+
+
+def pw_pack_weights(w, scale=None):
+    """(Cout, Cin[, 1, 1]) 1x1-conv weight (+ per-cout scale) -> packed A operand of K11."""
+    cout, cin = w.shape[0], w.shape[1]
+    n = load().occd_pw_packed_floats(cout, cin)
+    if n <= 0 or w.numel() != cout * cin:
+        raise RuntimeError("pw_pack_weights needs a (Cout, Cin[, 1, 1]) weight")
+    wc = w.detach().float().reshape(cout, cin).contiguous()
+    wpk = torch.empty(n, device=w.device, dtype=torch.float32)
+    sc = scale.detach().float().contiguous() if scale is not None else None
+    _check(load().occd_pw_pack_weights(_f32(wc, "w"), _f32(sc, "scale") if sc is not None else None, _f32(wpk, "wpk"),
+                                       cout, cin, _stream()), "occd_pw_pack_weights")
+    return wpk
+
+
+def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None, tile_hint=0, out=None):
+    """K11: act(conv1x1(x * gate, w * scale) + shift) (+ res) on (B, Cin, *spatial) float32, one launch."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, cin = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    N = 1
+    for d in sp:
+        N *= d
+    y = torch.empty((B, cout) + sp, device=x.device, dtype=torch.float32) if out is None else out
+    if res is not None and not res.is_contiguous():
+        res = res.contiguous()
+    if gate is not None:
+        gate = gate.reshape(B, cin)
+        if not gate.is_contiguous():
+            gate = gate.contiguous()
+    if wpk.numel() != load().occd_pw_packed_floats(cout, cin):
+        raise RuntimeError("packed 1x1 weights do not match (cout, cin)")
+    a = PwArgs()
+    a.x, a.wpk, a.y = _f32(x, "x"), _f32(wpk, "wpk"), _f32(y, "y")
+    a.shift = _f32(shift, "shift") if shift is not None else None
+    a.gate = _f32(gate, "gate") if gate is not None else None
+    a.res = _f32(res, "res") if res is not None else None
+    a.N, a.batch, a.cin, a.cout = N, B, cin, cout
+    a.act, a.tile_hint, a.slope = ACT2D[act], int(tile_hint), float(slope)
+    if _PROFILING:
+        set_tag("%d>%d @%dx%d" % (cin, cout, B, N))
+    _check(load().occd_pw_conv_fwd(ctypes.byref(a), _stream()), "occd_pw_conv_fwd")
     return y
 
 

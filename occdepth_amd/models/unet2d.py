@@ -66,7 +66,7 @@ class UpSampleBN(nn.Module):
 
     # K10, the fused Winograd kernel (V in registers, M in the accumulators): levels with at least this many pixels
     # (B * H * W); below, the unfused transforms + batched GEMMs above keep their large-K efficiency
-    FUSED_MIN_PIXELS = int(os.environ.get("OCCDEPTH_WINO_FUSED_MIN_PIXELS", "80001"))
+    FUSED_MIN_PIXELS = int(os.environ.get("OCCDEPTH_WINO_FUSED_MIN_PIXELS", "50000"))
     FUSED = os.environ.get("OCCDEPTH_WINO_FUSED", "1") == "1"
 
     def _fused_operands(self, conv, bn):

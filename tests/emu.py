@@ -242,6 +242,33 @@ def conv2d_3x3_fused(x, upk, cout, shift=None, act=None, slope=0.01, res=None, r
     return y.float()
 
 
+def pw_pack_weights(w, scale=None):
+    w = w.detach().double().reshape(w.shape[0], w.shape[1])
+    return _PackedWino(w * scale.double().view(-1, 1) if scale is not None else w)
+
+
+def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None, tile_hint=0, out=None):
+    """K11 semantics: act(conv1x1(x * gate, w * scale) + shift) (+ res)."""
+    xd = x.double()
+    if gate is not None:
+        xd = xd * gate.double().reshape(x.shape[0], x.shape[1], *([1] * (x.dim() - 2)))
+    y = torch.einsum("oc,bc...->bo...", wpk.w, xd)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, *([1] * (x.dim() - 2)))
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "leaky":
+        y = F.leaky_relu(y, slope)
+    elif act == "swish":
+        y = y * torch.sigmoid(y)
+    if res is not None:
+        y = y + res.double()
+    if out is not None:
+        out.copy_(y.float())
+        return out
+    return y.float()
+
+
 def _softmax_and_target(logits, target, map_occ):
     B, C = logits.shape[:2]
     p = F.softmax(logits.detach().double().reshape(B, C, -1), 1)        # (B, C, S)
@@ -309,8 +336,9 @@ def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
-                                          "wino_pack_weights", "conv2d_3x3_fused")}
+                                          "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1")}
     hip.wino_pack_weights, hip.conv2d_3x3_fused = wino_pack_weights, conv2d_3x3_fused
+    hip.pw_pack_weights, hip.conv1x1 = pw_pack_weights, conv1x1
     hip.conv3d_wgrad = conv3d_wgrad
     hip.wino_input_transform, hip.wino_output_transform = wino_input_transform, wino_output_transform
     hip.ssc_loss_stats, hip.ssc_loss_grad, hip.ssc_confusion = ssc_loss_stats, ssc_loss_grad, ssc_confusion
