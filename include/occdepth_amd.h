@@ -261,6 +261,20 @@ int64_t occd_wino_packed_floats(int32_t cout, int32_t cin);
 int occd_wino_pack_weights(const float* w, const float* scale, float* upk, int32_t cout, int32_t cin, void* stream);
 int occd_wino_conv3x3_fwd(const occd_wino_args* a, void* stream);
 
+/* Depthwise convolution as above that ALSO leaves the squeeze-excite pooling behind: pool_part
+ * (B*C, occd_dwconv2d_pool_blocks(Ho, Wo)) holds each workgroup's share of sum_{y,x} y[b][c] (fixed summation order).
+ * occd_se_gate turns the partials into the gate  sigmoid(W_e swish(W_r mean + b_r) + b_e)  (B, C) of geffnet's
+ * SqueezeExcite (conv_reduce (Cr, C), conv_expand (C, Cr)); r_scratch: B * Cr floats.  The gate is consumed by
+ * occd_pw_conv_fwd's `gate` operand: x * gate never exists in memory.                                            */
+int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo);
+int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                            float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
+                            int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
+                            int32_t act, void* stream);
+int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_reduce, const float* w_expand,
+                 const float* b_expand, float* r_scratch, float* gate, int32_t batch, int32_t C, int32_t Cr,
+                 int32_t nblk, int64_t S, void* stream);
+
 /* K11: pointwise (1x1) convolution on NCHW maps as a GEMM on the fp32 matrix pipe with the
  * EfficientNet / decoder epilogue fused -- replaces conv1x1 + BatchNorm2d (eval) + Swish (+ squeeze-excite gate on the
  * input, + MBConv skip add) of the geffnet blocks behind occdepth/models/unet2d.py:175-190, the `resize_output_1_s`

@@ -61,13 +61,16 @@ template <int K, int STRIDE>
 __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
-                                                       int pad_t, int pad_l, int act) {
+                                                       int pad_t, int pad_l, int act, float* __restrict__ pool_part) {
     constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K;
+    __shared__ float wsum[4];
     const int plane = blockIdx.y;
     const int c = plane % C;
     const int wq = (Wo + NX - 1) / NX;
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= Ho * wq) return;
+    const int item_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool live = item_raw < Ho * wq;
+    if (!live && pool_part == nullptr) return;
+    const int item = live ? item_raw : 0;                  // (dead lanes of the last block still join the reduction)
     const int oy = item / wq, ox0 = (item - oy * wq) * NX;
     const float* xp = x + (size_t)plane * H * W;
     float wr[K * K];
@@ -93,9 +96,23 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
     }
     const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
     float* yp = y + ((size_t)plane * Ho + oy) * Wo + ox0;
+    float part = 0.f;
 #pragma unroll
     for (int o = 0; o < NX; ++o)
-        if (ox0 + o < Wo) yp[o] = act_apply(acc[o] * s + t, act, 0.f);
+        if (live && ox0 + o < Wo) {
+            const float v = act_apply(acc[o] * s + t, act, 0.f);
+            yp[o] = v;
+            part += v;
+        }
+    if (pool_part != nullptr) {
+        // squeeze-excite pooling: this workgroup's share of sum_{y,x} y[b][c] in a FIXED order (wave tree, then 4
+        // partials), one float per (plane, workgroup); occd_se_gate sums the partials in index order: deterministic
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) pool_part[(size_t)plane * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
 }
 
 __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restrict__ x, const float* __restrict__ skip,
@@ -141,10 +158,9 @@ extern "C" int occd_affine_act_nchw(const float* x, const float* res, float* y, 
     return occd::check_launch();
 }
 
-extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
-                                  int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride,
-                                  int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act,
-                                  void* stream) {
+static int dwconv_launch(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                         int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride, int32_t pad_top,
+                         int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act, float* pool_part, void* stream) {
     if (!x || !w || !y || batch <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0)
         return OCCD_EINVAL;
     if ((k != 3 && k != 5) || act < 0 || act > 2 || (long)batch * C > 65535) return OCCD_EINVAL;
@@ -156,13 +172,30 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
     hipStream_t st = (hipStream_t)stream;
 #define OCCD_DW(KK, SS)                                                                                          \
     hipLaunchKernelGGL((dwconv2d_kernel<KK, SS>), grid, dim3(256), 0, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
-                       pad_top, pad_left, act)
+                       pad_top, pad_left, act, pool_part)
     if (k == 3 && stride == 1) OCCD_DW(3, 1);
     else if (k == 3) OCCD_DW(3, 2);
     else if (stride == 1) OCCD_DW(5, 1);
     else OCCD_DW(5, 2);
 #undef OCCD_DW
     return occd::check_launch();
+}
+
+extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                  int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride,
+                                  int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act,
+                                  void* stream) {
+    return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, nullptr, stream);
+}
+
+extern "C" int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo) { return (Ho * ((Wo + 3) / 4) + 255) / 256; }
+
+extern "C" int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                       float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
+                                       int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
+                                       int32_t act, void* stream) {
+    if (pool_part == nullptr) return OCCD_EINVAL;
+    return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, pool_part, stream);
 }
 
 extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* out, int32_t batch, int32_t C,

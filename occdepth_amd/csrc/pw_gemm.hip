@@ -52,7 +52,7 @@ __device__ __forceinline__ float pw_act(float v, int act, float slope) {
 }
 
 // (second launch bound = workgroups per CU = waves per SIMD: 128 accumulator registers leave room for 2, 64 for 3)
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, bool GATE>
 __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(const PwP p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     const int lane = threadIdx.x & 63;
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(con
     if (mb0 >= p.mblocks || n0 >= p.N) return;                    // (no barriers in this kernel)
 
     const float* const xb = p.x + (size_t)b * p.Cin * p.N;
-    const float* const gb = p.gate != nullptr ? p.gate + (size_t)b * p.Cin : nullptr;
+    const float* const gb = GATE ? p.gate + (size_t)b * p.Cin : nullptr;
 
     // pixel columns of this lane and their validity; A-fragment offsets of the owned cout blocks
     long col[NT];
@@ -96,34 +96,46 @@ __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(con
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(wp + wofs[mt]);
     };
-    auto load_b = [&](int c, f32x4* bf) {
+    // Every load is unconditional (clamped address); the channel tail is zeroed by a bit mask on the loaded value (a load
+    // guarded by a runtime condition makes hipcc branch around it and wait for each one separately).  Loads and their
+    // post-processing (gate multiply, tail mask) are separate steps so that the raw loads of step c+1 can be issued
+    // ABOVE the MFMAs of step c and touched only below them (sched_barrier pins both sides).
+    auto load_b = [&](int c, f32x4* braw, f32x4& g) {
         const int k0 = c * 8 + kk * 4;
-        f32x4 g = {1.f, 1.f, 1.f, 1.f};
-        bool kok[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) kok[q] = k0 + q < p.Cin;
-        if (gb != nullptr) {                                       // (uniform branch; the loads inside are unconditional)
+        if (GATE) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = gb[min(k0 + q, p.Cin - 1)];
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int q = 0; q < 4; ++q) {
+            const float* row = xb + (size_t)min(k0 + q, p.Cin - 1) * p.N;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = kok[q] ? k0 + q : p.Cin - 1;
-                const float v = xb[(size_t)k * p.N + col[nt]];
-                bf[nt][q] = kok[q] ? v * g[q] : 0.f;
+            for (int nt = 0; nt < NT; ++nt) braw[nt][q] = row[col[nt]];
+        }
+    };
+    auto finish_b = [&](int c, const f32x4* braw, const f32x4& g, f32x4* bf) {
+        const int k0 = c * 8 + kk * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t keep = 0u - (uint32_t)(k0 + q < p.Cin);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float v = GATE ? braw[nt][q] * g[q] : braw[nt][q];
+                bf[nt][q] = __uint_as_float(__float_as_uint(v) & keep);
             }
+        }
     };
 
-    f32x4 a_cur[MT], b_cur[NT];
+    f32x4 a_cur[MT], b_cur[NT], b_raw[NT], g_raw = {1.f, 1.f, 1.f, 1.f};
     load_a(0, a_cur);
-    load_b(0, b_cur);
+    load_b(0, b_raw, g_raw);
+    finish_b(0, b_raw, g_raw, b_cur);
     for (int c = 0; c < p.kchunks; ++c) {
-        f32x4 a_nxt[MT], b_nxt[NT];
+        f32x4 a_nxt[MT];
         const int cn = c + 1 < p.kchunks ? c + 1 : c;              // (the last step re-reads itself: no branch)
         load_a(cn, a_nxt);
-        load_b(cn, b_nxt);
+        load_b(cn, b_raw, g_raw);
+        __builtin_amdgcn_sched_barrier(0);                         // the next step's loads stay ABOVE this step's MFMAs
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -131,10 +143,10 @@ __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(con
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+        finish_b(cn, b_raw, g_raw, b_cur);
     }
 
     // ---------------- epilogue: register r of tile (mt, nt) is cout 32 (mb0 + mt) + 8 (r >> 2) + 4 kk + (r & 3)
@@ -175,11 +187,13 @@ __global__ void pw_pack_kernel(const float* __restrict__ w, const float* __restr
 
 template <int MT, int NT, int WM, int WN>
 int launch_pw(PwP& p, int batch, hipStream_t st) {
+    const bool gate = p.gate != nullptr;
     p.mtiles = (p.mblocks + MT * WM - 1) / (MT * WM);
     p.ntiles = (int)((p.N + (long)NT * WN * 32 - 1) / ((long)NT * WN * 32));
     const long gx = (long)p.mtiles * p.ntiles;
     if (gx > 0x7fffffffL || batch > 65535) return OCCD_EINVAL;
-    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN>), dim3((unsigned)gx, 1, (unsigned)batch), dim3(256), 0, st, p);
+    if (gate) hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, true>), dim3((unsigned)gx, 1, (unsigned)batch), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, false>), dim3((unsigned)gx, 1, (unsigned)batch), dim3(256), 0, st, p);
     return occd::check_launch();
 }
 
@@ -211,17 +225,22 @@ int occd_pw_conv_fwd(const occd_pw_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     occd::ProfScope prof("pw_conv", st, 2.0 * a->batch * (double)a->N * p.kchunks * 8 * p.mblocks * 32,
                          4.0 * a->batch * (double)a->N * (a->cin + a->cout * (a->res != nullptr ? 2.0 : 1.0)));
-    // wave tile: as many cout blocks as the layer has (<= 4) so X is read once; wide layers take 128 x 64 per wave and
-    // put the 4 waves along the couts when that still leaves >= 2 workgroups per CU, else along the pixels
+    // Variant table (tile_hint 1..6 = <MT, NT, WM, WN>); the automatic choice follows tools/bench_pw.py on the B7 / decoder
+    // shapes at two views (profiles/r02_pw_gemm_layers.txt): narrow layers take one cout block per wave and 128 pixels
+    // (X is re-read once per cout block, from L2, but the grid is large); layers with a long K and few couts take the
+    // 64 x 64 wave tile with the 4 waves along the couts.
     const int mb = p.mblocks;
-    const int hint = a->tile_hint;
-    const long n = a->N;
-    if (hint == 1 || (hint == 0 && mb == 1)) return launch_pw<1, 4, 1, 4>(p, a->batch, st);
-    if (hint == 2 || (hint == 0 && mb == 2)) return launch_pw<2, 4, 1, 4>(p, a->batch, st);
-    if (hint == 3 || (hint == 0 && mb <= 4)) return launch_pw<4, 2, 1, 4>(p, a->batch, st);
-    if (hint == 4 || (hint == 0 && mb <= 8 && n * a->batch >= 16384)) return launch_pw<4, 2, 2, 2>(p, a->batch, st);
-    if (hint == 5 || (hint == 0 && n * a->batch >= 4096)) return launch_pw<4, 2, 4, 1>(p, a->batch, st);
-    return launch_pw<2, 2, 4, 1>(p, a->batch, st);      // hint 6: few pixels (the 1/32 level): smaller tiles, more workgroups
+    int hint = a->tile_hint;
+    if (hint == 0) hint = mb == 1 ? 1 : mb == 2 ? (a->cin >= 192 ? 6 : 2) : mb == 3 ? 6 : (a->cin <= 256 ? 1 : 6);
+    switch (hint) {
+    case 1: return launch_pw<1, 4, 1, 4>(p, a->batch, st);
+    case 2: return launch_pw<2, 4, 1, 4>(p, a->batch, st);
+    case 3: return launch_pw<4, 2, 1, 4>(p, a->batch, st);
+    case 4: return launch_pw<4, 2, 2, 2>(p, a->batch, st);
+    case 5: return launch_pw<4, 2, 4, 1>(p, a->batch, st);
+    case 6: return launch_pw<2, 2, 4, 1>(p, a->batch, st);
+    default: return OCCD_EINVAL;
+    }
 }
 
 }  // extern "C"

@@ -117,6 +117,9 @@ EXPORTS = {
     "occd_wino_packed_floats": (c_int64, [c_int32, c_int32]),
     "occd_wino_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "occd_wino_conv3x3_fwd": (c_int32, [POINTER(WinoArgs), c_void_p]),
+    "occd_dwconv2d_pool_blocks": (c_int32, [c_int32, c_int32]),
+    "occd_dwconv2d_pool_nchw": (c_int32, [c_void_p] * 6 + [c_int32] * 11 + [c_void_p]),
+    "occd_se_gate": (c_int32, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "occd_pw_packed_floats": (c_int64, [c_int32, c_int32]),
     "occd_pw_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "occd_pw_conv_fwd": (c_int32, [POINTER(PwArgs), c_void_p]),
@@ -600,6 +603,40 @@ def dwconv2d_same(x, w, scale, shift, stride, act=None):
                                      stride, pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
            "occd_dwconv2d_nchw")
     return y
+
+
+def dwconv2d_same_pool(x, w, scale, shift, stride, act=None):
+    """dwconv2d_same that also returns the squeeze-excite pooling partials (B*C, nblk) and the plane size Ho*Wo."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, C, H, W = x.shape
+    k = w.shape[-1]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    pad_h = max((Ho - 1) * stride + k - H, 0)
+    pad_w = max((Wo - 1) * stride + k - W, 0)
+    y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32)
+    nblk = load().occd_dwconv2d_pool_blocks(Ho, Wo)
+    part = torch.empty((B * C, nblk), device=x.device, dtype=torch.float32)
+    wc = w if w.is_contiguous() else w.contiguous()
+    _check(load().occd_dwconv2d_pool_nchw(_f32(x, "x"), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
+                                          _f32(shift, "shift") if shift is not None else None, _f32(y, "y"),
+                                          _f32(part, "pool_part"), B, C, H, W, k, stride, pad_h // 2, pad_w // 2, Ho, Wo,
+                                          ACT2D[act], _stream()), "occd_dwconv2d_pool_nchw")
+    return y, part, Ho * Wo
+
+
+def se_gate(part, plane_size, batch, w_reduce, b_reduce, w_expand, b_expand):
+    """Squeeze-excite gate (B, C) from the pooling partials of dwconv2d_same_pool (two small launches)."""
+    C = part.shape[0] // batch
+    Cr = w_reduce.shape[0]
+    wr = w_reduce.detach().reshape(Cr, C).contiguous()
+    we = w_expand.detach().reshape(C, Cr).contiguous()
+    r = torch.empty((batch, Cr), device=part.device, dtype=torch.float32)
+    gate = torch.empty((batch, C), device=part.device, dtype=torch.float32)
+    _check(load().occd_se_gate(_f32(part, "pool_part"), _f32(wr, "w_reduce"), _f32(b_reduce.detach().contiguous(), "b_reduce"),
+                               _f32(we, "w_expand"), _f32(b_expand.detach().contiguous(), "b_expand"), _f32(r, "r"),
+                               _f32(gate, "gate"), batch, C, Cr, part.shape[1], int(plane_size), _stream()), "occd_se_gate")
+    return gate
 
 
 def upsample_bilinear_cat(x, skip):

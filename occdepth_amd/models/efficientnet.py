@@ -14,8 +14,39 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from .. import hip
-from ..fused import bn_affine_cached, needs_autograd
+from ..fused import _stamp, bn_affine_cached, needs_autograd
+
+# K11 / SE-fusion path of the eval forward (OCCDEPTH_PW_FUSED=0 restores the MIOpen / rocBLAS 1x1 convolutions for A/B)
+PW_FUSED = os.environ.get("OCCDEPTH_PW_FUSED", "1") == "1"
+# K11 streams X from HBM with no split-K: it wins where pixels are many and K is short (tools/bench_pw.py: 2-3 TB/s
+# against rocBLAS' 1.4 on the 1/2 ... 1/8 levels); the 1/16 and 1/32 levels (K up to 3840, < 2000 pixels per view) stay
+# on rocBLAS / hipBLASLt
+PW_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_MIN_PIXELS", "14000"))      # B * H * W
+
+
+def pw_wins(x):
+    return PW_FUSED and x.shape[0] * x.shape[2] * x.shape[3] >= PW_MIN_PIXELS
+
+
+def pw_operands(owner, conv, bn=None):
+    """(packed K11 weights with the BatchNorm scale folded in, shift) of a 1x1 convolution (+ BatchNorm), cached on
+    `owner` until a source tensor changes (load_state_dict, optimizer step: (data_ptr, _version) stamp)."""
+    key = _stamp(conv, bn)
+    cache = owner.__dict__.setdefault("_pw_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        scale = shift = None
+        if bn is not None:
+            scale, shift = bn_affine_cached(bn)
+        if conv.bias is not None:
+            b = conv.bias.detach().float()
+            shift = b * scale + shift if bn is not None else b
+        hit = (key, hip.pw_pack_weights(conv.weight, scale), shift.contiguous() if shift is not None else None)
+        cache[id(conv)] = hit
+    return hit[1], hit[2]
 
 
 def _fast(x, module):
@@ -41,6 +72,9 @@ class Conv2dSame(nn.Conv2d):
     """TensorFlow 'SAME' padding: output = ceil(input / stride), extra pad goes right/bottom."""
 
     def forward(self, x):
+        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and _fast(x, self) and pw_wins(x)):
+            wpk, shift = pw_operands(self, self)            # e.g. conv_head: plain 1x1 convolution on the MFMA GEMM (K11)
+            return hip.conv1x1(x, wpk, self.out_channels, shift)
         pads = []
         for size, k, s, d in zip(x.shape[-2:], self.kernel_size, self.stride, self.dilation):
             total = max((math.ceil(size / s) - 1) * s + (k - 1) * d + 1 - size, 0)
@@ -68,6 +102,11 @@ class SqueezeExcite(nn.Module):
         g = self.conv_expand(self.act1(self.conv_reduce(x.mean((2, 3), keepdim=True))))
         return x * torch.sigmoid(g)
 
+    def gate_from_pool(self, part, plane_size, batch):
+        """The gate (B, C) from the pooling partials the depthwise kernel left behind (two small HIP launches)."""
+        return hip.se_gate(part, plane_size, batch, self.conv_reduce.weight, self.conv_reduce.bias,
+                           self.conv_expand.weight, self.conv_expand.bias)
+
 
 def _bn(ch):
     return nn.BatchNorm2d(ch, eps=_BN_EPS)
@@ -86,6 +125,13 @@ class DepthwiseSeparableConv(nn.Module):
         self.act2 = nn.Identity()
 
     def forward(self, x):
+        if _fast(x, self) and pw_wins(x):
+            # 3 launches: depthwise + BN + swish (+ SE pooling), SE gate, project GEMM with gate / BN / skip fused
+            y, part, plane = hip.dwconv2d_same_pool(x, self.conv_dw.weight, *bn_affine_cached(self.bn1),
+                                                    self.conv_dw.stride[0], "swish")
+            gate = self.se.gate_from_pool(part, plane, x.shape[0])
+            wpk, shift = pw_operands(self, self.conv_pw, self.bn2)
+            return hip.conv1x1(y, wpk, self.conv_pw.out_channels, shift, None, gate=gate, res=x if self.skip else None)
         if _fast(x, self):
             y = hip.dwconv2d_same(x, self.conv_dw.weight, *bn_affine_cached(self.bn1), self.conv_dw.stride[0], "swish")
             y = F.conv2d(self.se(y), self.conv_pw.weight)
@@ -111,6 +157,16 @@ class InvertedResidual(nn.Module):
         self.bn3 = _bn(cout)
 
     def forward(self, x):
+        if _fast(x, self) and pw_wins(x):
+            # 4 launches instead of 11: expand GEMM + BN + swish, depthwise + BN + swish + SE pooling, SE gate,
+            # project GEMM with the gate on its input channels + BN + skip
+            wpk, shift = pw_operands(self, self.conv_pw, self.bn1)
+            y = hip.conv1x1(x, wpk, self.conv_pw.out_channels, shift, "swish")
+            y, part, plane = hip.dwconv2d_same_pool(y, self.conv_dw.weight, *bn_affine_cached(self.bn2),
+                                                    self.conv_dw.stride[0], "swish")
+            gate = self.se.gate_from_pool(part, plane, x.shape[0])
+            wpk, shift = pw_operands(self, self.conv_pwl, self.bn3)
+            return hip.conv1x1(y, wpk, self.conv_pwl.out_channels, shift, None, gate=gate, res=x if self.skip else None)
         if _fast(x, self):
             y = hip.affine_act(F.conv2d(x, self.conv_pw.weight), *bn_affine_cached(self.bn1), "swish")
             y = hip.dwconv2d_same(y, self.conv_dw.weight, *bn_affine_cached(self.bn2), self.conv_dw.stride[0], "swish")

@@ -94,7 +94,13 @@ class DepthNet(nn.Module):
                                                        sync_free=sweep_intrins.is_cuda and not needs_autograd(self))
         x = self.reduce_conv(x)
         x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
-        return self.depth_pred(self.depth_conv(x))
+        x = self.depth_conv(x)
+        if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+            from ..efficientnet import pw_operands, pw_wins
+            if pw_wins(x):                                    # 1x1 convolution + bias on the MFMA GEMM (K11)
+                wpk, shift = pw_operands(self, self.depth_pred)
+                return hip.conv1x1(x, wpk, self.depth_pred.out_channels, shift)
+        return self.depth_pred(x)
 
 
 def _bounds_buffers(x_bound, y_bound, z_bound, project_scale):

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from .. import hip
 from ..fused import _stamp, bn_affine_cached, needs_autograd
-from .efficientnet import EfficientNet
+from .efficientnet import EfficientNet, pw_operands, pw_wins
 
 MODEL_NAME = "tf_efficientnet_b3_ns"
 MODEL_CHANNELS = {
@@ -148,7 +148,12 @@ class DecoderBN(nn.Module):
             if self.return_up_feats > s:
                 continue
             x = getattr(self, f"up{s}")(x, taps[s])
-            res[f"1_{s}"] = getattr(self, f"resize_output_1_{s}")(x)
+            head = getattr(self, f"resize_output_1_{s}")
+            if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32 and pw_wins(x):
+                wpk, shift = pw_operands(self, head)         # 1x1 convolution + bias on the MFMA GEMM (K11)
+                res[f"1_{s}"] = hip.conv1x1(x, wpk, head.out_channels, shift)
+            else:
+                res[f"1_{s}"] = head(x)
         return res
 
 

@@ -242,6 +242,31 @@ def conv2d_3x3_fused(x, upk, cout, shift=None, act=None, slope=0.01, res=None, r
     return y.float()
 
 
+def dwconv2d_same_pool(x, w, scale, shift, stride, act=None):
+    B, C, H, W = x.shape
+    k = w.shape[-1]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw_ = max((Ho - 1) * stride + k - H, 0), max((Wo - 1) * stride + k - W, 0)
+    xp = F.pad(x.double(), [pw_ // 2, pw_ - pw_ // 2, ph // 2, ph - ph // 2])
+    y = F.conv2d(xp, w.double(), None, stride, 0, 1, C)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if act == "swish":
+        y = y * torch.sigmoid(y)
+    elif act == "relu":
+        y = F.relu(y)
+    y = y.float()
+    return y, y.double().sum((2, 3)).reshape(B * C, 1).float(), Ho * Wo
+
+
+def se_gate(part, plane_size, batch, w_reduce, b_reduce, w_expand, b_expand):
+    C = part.shape[0] // batch
+    mean = part.double().sum(1).reshape(batch, C) / plane_size
+    r = mean @ w_reduce.double().reshape(-1, C).t() + b_reduce.double()
+    r = r * torch.sigmoid(r)
+    return torch.sigmoid(r @ w_expand.double().reshape(C, -1).t() + b_expand.double()).float()
+
+
 def pw_pack_weights(w, scale=None):
     w = w.detach().double().reshape(w.shape[0], w.shape[1])
     return _PackedWino(w * scale.double().view(-1, 1) if scale is not None else w)
@@ -336,7 +361,9 @@ def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
-                                          "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1")}
+                                          "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
+                                          "dwconv2d_same_pool", "se_gate")}
+    hip.dwconv2d_same_pool, hip.se_gate = dwconv2d_same_pool, se_gate
     hip.wino_pack_weights, hip.conv2d_3x3_fused = wino_pack_weights, conv2d_3x3_fused
     hip.pw_pack_weights, hip.conv1x1 = pw_pack_weights, conv1x1
     hip.conv3d_wgrad = conv3d_wgrad

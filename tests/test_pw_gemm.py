@@ -1,0 +1,122 @@
+"""K11 (csrc/pw_gemm.hip): pointwise convolution + folded BatchNorm + activation (+ squeeze-excite gate on the input,
++ skip add) as one MFMA GEMM launch on NCHW maps.  Reference: float64 einsum on the CPU.
+CPU: host-side wrapper logic through the test-only emulation; `-m gpu`: the kernel, every tile variant."""
+import contextlib
+
+import pytest
+import torch
+
+import emu
+
+# (B, Cin, Cout, spatial, act, gate, residual)
+CASES = [
+    (2, 32, 192, (25, 41), "swish", False, False),      # expand conv of an MBConv block, ragged pixel count
+    (1, 288, 48, (31, 30), None, True, True),           # project conv: SE gate on the input + skip add
+    (2, 3840, 640, (12, 39), None, True, False),        # widest project conv of B7, few pixels
+    (2, 640, 2560, (12, 39), None, False, False),       # conv_head
+    (1, 83, 64, (50, 100), None, False, False),         # resize_output-like: ragged cin (tail chunk), bias via shift
+    (3, 20, 10, (7,), "leaky", True, True),             # tiny everything, 1-D spatial
+    (1, 128, 104, (47, 153), None, False, False),       # DepthNet.depth_pred
+]
+
+
+def run(case, device, tol, hints=(0,)):
+    from occdepth_amd import hip
+    B, cin, cout, sp, act, with_gate, with_res = case
+    g = torch.Generator().manual_seed(B * 100 + cin + cout)
+    x = torch.randn(B, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    gate = torch.rand(B, cin, 1, 1, generator=g) if with_gate else None
+    res = torch.randn(B, cout, *sp, generator=g) if with_res else None
+    xd = x.double() * (gate.double().reshape(B, cin, *([1] * len(sp))) if with_gate else 1.0)
+    ref = torch.einsum("oc,bc...->bo...", w.double().reshape(cout, cin) * scale.double().view(-1, 1), xd)
+    ref = ref + shift.double().view(1, -1, *([1] * len(sp)))
+    ref = {"leaky": lambda t: torch.nn.functional.leaky_relu(t, 0.01), "swish": lambda t: t * torch.sigmoid(t),
+           None: lambda t: t}[act](ref)
+    if with_res:
+        ref = ref + res.double()
+    dev = torch.device(device)
+    worst = 0.0
+    with (emu.patched() if device == "cpu" else contextlib.nullcontext()):
+        wpk = hip.pw_pack_weights(w.to(dev), scale.to(dev))
+        for h in hints:
+            y = hip.conv1x1(x.to(dev), wpk, cout, shift.to(dev), act, 0.01, gate.to(dev) if with_gate else None,
+                            res.to(dev) if with_res else None, tile_hint=h)
+            err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert y.shape == ref.shape and err < tol, (case, h, err)
+            worst = max(worst, err)
+    return worst
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_pointwise_conv_host_logic_cpu(case):
+    run(case, "cpu", 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_pointwise_conv_kernel_gpu(case, hip_lib):
+    err = run(case, "cuda", 2e-5, hints=(0, 1, 2, 3, 4, 5, 6))
+    print(case, f"worst rel err vs float64 over the tile variants {err:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# depthwise + SE pooling, SE gate, and whole EfficientNet blocks on the fused path
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 24, 37, 53, 3, 1), (1, 40, 30, 41, 5, 2), (2, 7, 9, 300, 5, 1)])
+def test_dwconv_pool_and_se_gate_gpu(shape, hip_lib):
+    from occdepth_amd import hip
+    B, C, H, W, k, stride = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    y, part, plane = hip.dwconv2d_same_pool(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), stride, "swish")
+    y_ref, part_ref, plane_ref = emu.dwconv2d_same_pool(x, w, sc, sh, stride, "swish")
+    assert plane == plane_ref and torch.allclose(y.cpu(), y_ref, rtol=1e-5, atol=1e-5)
+    y2 = hip.dwconv2d_same(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), stride, "swish")
+    assert torch.equal(y, y2)                                   # same kernel, pooling on / off
+    assert torch.allclose(part.double().sum(1).cpu(), part_ref.double().sum(1), rtol=1e-5, atol=1e-4)
+    y3, part3, _ = hip.dwconv2d_same_pool(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), stride, "swish")
+    assert torch.equal(part, part3)                             # fixed summation order: bit-reproducible
+    Cr = max(1, C // 4)
+    wr, br = torch.randn(Cr, C, 1, 1, generator=g) * 0.3, torch.randn(Cr, generator=g) * 0.1
+    we, be = torch.randn(C, Cr, 1, 1, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    gate = hip.se_gate(part, plane, B, wr.cuda(), br.cuda(), we.cuda(), be.cuda())
+    ref = emu.se_gate(part_ref, plane_ref, B, wr, br, we, be)
+    assert gate.shape == (B, C) and torch.allclose(gate.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ir_skip", "ir_stride2", "ds_skip"])
+def test_efficientnet_block_fused_path_gpu(kind, hip_lib):
+    """A whole MBConv / depthwise-separable block on the fused path (4 / 3 launches) against the module's own
+    float64 CPU forward (the generic nn path)."""
+    import copy
+    from occdepth_amd.models import efficientnet as E
+    torch.manual_seed(5)
+    m = {"ir_skip": lambda: E.InvertedResidual(24, 24, 5, 1, 6), "ir_stride2": lambda: E.InvertedResidual(24, 40, 3, 2, 6),
+         "ds_skip": lambda: E.DepthwiseSeparableConv(32, 32, 3, 1)}[kind]()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    m.eval()
+    x = torch.randn(2, m.conv_dw.in_channels if kind == "ds_skip" else m.conv_pw.in_channels, 37, 61)
+    saved = E.PW_MIN_PIXELS
+    E.PW_MIN_PIXELS = 0                                        # (the product only takes this path on large maps)
+    try:
+        with torch.no_grad():
+            ref = copy.deepcopy(m).double()(x.double())
+            assert E.PW_FUSED and E.pw_wins(x)
+            from occdepth_amd import hip
+            with hip.profile() as prof:
+                got = m.cuda()(x.cuda())
+        assert any(k.startswith("pw_conv") for k in prof.rows) and any(k.startswith("se_gate") for k in prof.rows)
+    finally:
+        E.PW_MIN_PIXELS = saved
+    err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert got.shape == ref.shape and err < 2e-5, (kind, err)
