@@ -159,6 +159,14 @@ typedef struct occd_lift_args {
     float* out;                           /* (B, rows, out_cs)                 */
     int64_t out_rows;                     /* rows per batch item               */
     int32_t out_cs;                       /* pads [C, out_cs) are zero-filled  */
+    /* batch stride (floats) of feat[s][v]; 0 = dense (feat_h * feat_w * feat_cs).  Lets a view of a tensor that
+     * interleaves the views (B, V, H, W, cs) be gathered in place.                                             */
+    int64_t feat_bstride[OCCD_MAX_SCALES][OCCD_MAX_VIEWS];
+    /* workgroup -> XCD placement of the single-pattern-point kernel (speed only, any value is correct):
+     * 0 = dispatch order (columns of voxels dealt round-robin to the 8 XCDs), 1 = every XCD a contiguous range of the
+     * flat voxel index, 2 = every XCD a contiguous (b, c) range inside every a-slab (needs dimB*dimC*LPV % 2048 == 0,
+     * else falls back to 0).                                                                                    */
+    int32_t xcd_mode;
 } occd_lift_args;
 
 int occd_lift_fwd(const occd_lift_args* a, void* stream);
@@ -211,6 +219,9 @@ int occd_cascade_tail_fwd(const float* part, const float* wn, float* out, int32_
 int occd_affine_act_nchw(const float* x, const float* res, float* y, const float* scale,
                          const float* shift, int32_t batch, int32_t C, int64_t S, int32_t act,
                          float slope, int32_t res_first, void* stream);
+/* y = softmax(x, dim=1) of a (B, C, S) map (S = H*W): the depth-bin softmax of FlospDepth.forward
+ * (occdepth/models/flosp_depth/flosp_depth.py:548).                                         */
+int occd_softmax_nchw(const float* x, float* y, int32_t batch, int32_t C, int64_t S, void* stream);
 /* depthwise k x k (k = 3 or 5) convolution, x (B, C, H, W), w (C, 1, k, k), explicit top/left
  * zero padding (TensorFlow SAME), y (B, C, Ho, Wo) = act(conv * scale[c] + shift[c]).   */
 int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const float* shift,
@@ -282,7 +293,10 @@ int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_r
  *   y[b][co][n] = act( sum_ci (w[co][ci] * scale[co]) * (x[b][ci][n] * gate[b][ci]) + shift[co] ) (+ res[b][co][n])
  * x (B, Cin, N), y / res (B, Cout, N), N = H*W; gate (B, Cin) or NULL; shift (Cout) or NULL; act codes as above.
  * wpk: occd_pw_pack_weights(w (Cout, Cin), scale or NULL) -> occd_pw_packed_floats(Cout, Cin) floats in MFMA
- *      A-fragment order [ceil(Cin/8)][ceil(Cout/32)][64 lanes][4].  tile_hint: 0 = choose, 1..6 = fixed variant.   */
+ *      A-fragment order [ceil(Cin/8)][ceil(Cout/32)][64 lanes][4].  tile_hint: 0 = choose, 1..6 = fixed variant.
+ * out_nhwc_cs != 0: y is written pixel-major, y[b][n][co] in rows of out_nhwc_cs >= Cout floats (pad written as zeros)
+ *      -- the layout occd_lift_fwd gathers from, so the decoder's 1x1 heads feed the lift without a transpose pass
+ *      (no gate / res in this mode).                                                                              */
 typedef struct occd_pw_args {
     const float* x;
     const float* wpk;
@@ -294,6 +308,7 @@ typedef struct occd_pw_args {
     int32_t batch, cin, cout;
     int32_t act, tile_hint;
     float slope;
+    int32_t out_nhwc_cs;
 } occd_pw_args;
 int64_t occd_pw_packed_floats(int32_t cout, int32_t cin);
 int occd_pw_pack_weights(const float* w, const float* scale, float* wpk, int32_t cout, int32_t cin, void* stream);

@@ -84,36 +84,55 @@ __global__ void __launch_bounds__(256) lift_p1_kernel(const LiftP pp) {
     const occd_lift_args& a = pp.a;
     const int tid = threadIdx.x;
     const int sub = tid % LPV;
-    const long n = ((long)blockIdx.x * 256 + tid) / LPV;
+    // Workgroup -> XCD placement (the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its
+    // own L2).  A pixel row is re-read by the y / z neighbours of a voxel at the coarse scales and by the voxels further
+    // along the same camera ray; which voxels share an L2 decides the HBM fetch (PMC numbers in DESIGN.md).
+    uint32_t bid = blockIdx.x;
+    if (a.xcd_mode == 1) {
+        const uint32_t nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    } else if (a.xcd_mode == 2) {
+        const uint32_t wps = (uint32_t)((long)a.dimB * a.dimC * LPV / 256);      // workgroups per a-slab (multiple of 8)
+        const uint32_t per = wps >> 3, xcd = bid & 7, idx = bid >> 3;
+        bid = (idx / per) * wps + xcd * per + idx % per;
+    }
+    const long n = ((long)bid * 256 + tid) / LPV;
     const int b = blockIdx.y;
     const bool vox_ok = n < a.N;
     const long nn = vox_ok ? n : (long)a.N - 1;
     const int c = sub * 4;
     const bool ch_ok = c < a.C;
+    const int cc = ch_ok ? c : 0;
     const int64_t* pix = a.pix + ((size_t)b * V) * a.N * 2;
     const uint8_t* fov = a.fov + ((size_t)b * V) * a.N;
 
+    // Every load below is UNCONDITIONAL (clamped address) and masked afterwards: a load guarded by a runtime condition
+    // makes hipcc branch around it and wait for each one separately, which serialises the V*S gathers of a voxel.
     int px[V], py[V];
+    uint32_t keep[V];
     float m[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const size_t pi = (size_t)v * a.N + nn;
         const bool in = fov[pi] != 0;
-        px[v] = in ? (int)pix[pi * 2] : 0;       // in-FOV pixels are non-negative image coordinates
-        py[v] = in ? (int)pix[pi * 2 + 1] : 0;
+        const int64_t x64 = pix[pi * 2], y64 = pix[pi * 2 + 1];
+        px[v] = in ? (int)x64 : 0;               // in-FOV pixels are non-negative image coordinates
+        py[v] = in ? (int)y64 : 0;
         m[v] = in ? 1.f : 0.f;
+        keep[v] = in && ch_ok ? 0xFFFFFFFFu : 0u;
     }
     f32x4 g[OCCD_MAX_SCALES][V];
 #pragma unroll
     for (int s = 0; s < OCCD_MAX_SCALES; ++s)
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            g[s][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (s < a.n_scales && m[v] != 0.f && ch_ok) {
-                const int dv = a.scale_div[s], w = a.feat_w[s], cs = a.feat_cs[s];
-                const int idx = (py[v] / dv) * w + (px[v] / dv);
-                g[s][v] = *(const f32x4*)(a.feat[s][v] + ((size_t)b * a.feat_h[s] * w + idx) * cs + c);
-            }
+            const int ss = s < a.n_scales ? s : 0;                       // (absent scales re-read scale 0: discarded)
+            const int dv = a.scale_div[ss], w = a.feat_w[ss], cs = a.feat_cs[ss];
+            const int idx = (py[v] / dv) * w + (px[v] / dv);
+            const f32x4 t = *(const f32x4*)(a.feat[ss][v] + (size_t)b * a.feat_bstride[ss][v] + (size_t)idx * cs + cc);
+            const uint32_t k = s < a.n_scales ? keep[v] : 0u;
+            g[s][v] = f32x4{__uint_as_float(__float_as_uint(t.x) & k), __uint_as_float(__float_as_uint(t.y) & k),
+                            __uint_as_float(__float_as_uint(t.z) & k), __uint_as_float(__float_as_uint(t.w) & k)};
         }
     f32x4 total = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -145,13 +164,12 @@ __global__ void __launch_bounds__(256) lift_any_kernel(const LiftP pp) {
     f32x4 total = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < a.n_scales; ++s) {
         const int div = a.scale_div[s], w = a.feat_w[s], cs = a.feat_cs[s];
-        const size_t bstride = (size_t)a.feat_h[s] * w * cs;
         f32x4 f[V];
         float m[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             f[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* fm = a.feat[s][v] + (size_t)b * bstride + c;
+            const float* fm = a.feat[s][v] + (size_t)b * a.feat_bstride[s][v] + c;
             int cnt = 0;
             for (int q = 0; q < P; ++q) {          // pattern points accumulate in index order (SFA.py:28-30)
                 const size_t pi = ((size_t)v * a.N + nn) * P + q;
@@ -367,7 +385,13 @@ extern "C" int occd_lift_fwd(const occd_lift_args* a, void* stream) {
     p.a = *a;
     const int need = a->out_cs / 4;  // lanes that must exist per voxel
     const int lpv = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+    for (int s = 0; s < a->n_scales; ++s)
+        for (int v = 0; v < a->n_views; ++v)
+            if (p.a.feat_bstride[s][v] == 0) p.a.feat_bstride[s][v] = (int64_t)a->feat_h[s] * a->feat_w[s] * a->feat_cs[s];
+    if (p.a.xcd_mode < 0 || p.a.xcd_mode > 2) return OCCD_EINVAL;
+    if (p.a.xcd_mode == 2 && ((long)a->dimB * a->dimC * lpv) % 2048 != 0) p.a.xcd_mode = 0;
     const long threads = (long)a->N * lpv;
+    if (p.a.xcd_mode == 2 && threads % 256 != 0) p.a.xcd_mode = 0;
     const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)a->batch);
     // algorithmic bytes: output rows + one gathered pixel row per view/scale + indices
     const double bytes = (double)a->batch * a->N *

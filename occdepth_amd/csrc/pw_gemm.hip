@@ -42,6 +42,7 @@ struct PwP {
     int act;
     float slope;
     int ntiles, mtiles;
+    int out_cs;                 // NHWC output: floats per pixel row
 };
 
 __device__ __forceinline__ float pw_act(float v, int act, float slope) {
@@ -52,7 +53,10 @@ __device__ __forceinline__ float pw_act(float v, int act, float slope) {
 }
 
 // (second launch bound = workgroups per CU = waves per SIMD: 128 accumulator registers leave room for 2, 64 for 3)
-template <int MT, int NT, int WM, int WN, bool GATE>
+// NHWC: the output is written pixel-major, y[b][n][co] (rows of out_cs floats) -- what the 2D->3D lift gathers from.
+// The MFMA operands are swapped for it (D rows = pixels, D columns = couts), so a store instruction still writes 32
+// consecutive floats (128 B): 32 couts of one pixel instead of 32 pixels of one cout.
+template <int MT, int NT, int WM, int WN, bool GATE, bool NHWC>
 __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(const PwP p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     const int lane = threadIdx.x & 63;
@@ -142,13 +146,34 @@ __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(con
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = NHWC ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nt][q], a_cur[mt][q], acc[mt][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
         finish_b(cn, b_raw, g_raw, b_cur);
     }
 
+    if (NHWC) {
+        // register r of tile (mt, nt) is pixel n0 + 32 nt + 8 (r >> 2) + 4 kk + (r & 3) at cout 32 (mb0 + mt) + li
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mb0 + mt) * 32 + li;
+            if (mb0 + mt >= p.mblocks || co >= p.out_cs) continue;
+            const bool real = co < p.Cout;
+            const float sh = real && p.shift != nullptr ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long n = n0 + nt * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
+                    if (n >= p.N) continue;
+                    const float v = pw_act(acc[mt][nt][r] + sh, p.act, p.slope);
+                    p.y[((size_t)b * p.N + n) * p.out_cs + co] = real ? v : 0.f;     // (channel pad written as zeros)
+                }
+        }
+        return;
+    }
     // ---------------- epilogue: register r of tile (mt, nt) is cout 32 (mb0 + mt) + 8 (r >> 2) + 4 kk + (r & 3)
     // at pixel n0 + 32 nt + li.
 #pragma unroll
@@ -192,8 +217,10 @@ int launch_pw(PwP& p, int batch, hipStream_t st) {
     p.ntiles = (int)((p.N + (long)NT * WN * 32 - 1) / ((long)NT * WN * 32));
     const long gx = (long)p.mtiles * p.ntiles;
     if (gx > 0x7fffffffL || batch > 65535) return OCCD_EINVAL;
-    if (gate) hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, true>), dim3((unsigned)gx, 1, (unsigned)batch), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, false>), dim3((unsigned)gx, 1, (unsigned)batch), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)gx, 1, (unsigned)batch);
+    if (p.out_cs > 0) hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, false, true>), grid, dim3(256), 0, st, p);
+    else if (gate) hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, true, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, false, false>), grid, dim3(256), 0, st, p);
     return occd::check_launch();
 }
 
@@ -217,7 +244,9 @@ int occd_pw_pack_weights(const float* w, const float* scale, float* wpk, int32_t
 int occd_pw_conv_fwd(const occd_pw_args* a, void* stream) {
     if (a == nullptr || a->x == nullptr || a->wpk == nullptr || a->y == nullptr) return OCCD_EINVAL;
     if (a->batch < 1 || a->cin < 1 || a->cout < 1 || a->N < 1 || a->act < 0 || a->act > 3) return OCCD_EINVAL;
+    if (a->out_nhwc_cs != 0 && (a->out_nhwc_cs < a->cout || a->gate != nullptr || a->res != nullptr)) return OCCD_EINVAL;
     PwP p{};
+    p.out_cs = a->out_nhwc_cs;
     p.x = a->x; p.wpk = a->wpk; p.shift = a->shift; p.gate = a->gate; p.res = a->res; p.y = a->y;
     p.Cin = a->cin; p.Cout = a->cout; p.N = a->N; p.act = a->act; p.slope = a->slope;
     p.kchunks = (a->cin + 7) / 8;

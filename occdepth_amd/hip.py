@@ -74,6 +74,7 @@ class LiftArgs(Structure):
         ("dimA", c_int32), ("dimB", c_int32), ("dimC", c_int32),
         ("row_a", c_int64), ("row_b", c_int64), ("row_c", c_int64),
         ("out", c_void_p), ("out_rows", c_int64), ("out_cs", c_int32),
+        ("feat_bstride", (c_int64 * MAX_VIEWS) * MAX_SCALES), ("xcd_mode", c_int32),
     ]
 
 
@@ -85,7 +86,7 @@ class WinoArgs(Structure):
 class PwArgs(Structure):
     _fields_ = [("x", c_void_p), ("wpk", c_void_p), ("shift", c_void_p), ("gate", c_void_p), ("res", c_void_p),
                 ("y", c_void_p), ("N", c_int64), ("batch", c_int32), ("cin", c_int32), ("cout", c_int32),
-                ("act", c_int32), ("tile_hint", c_int32), ("slope", c_float)]
+                ("act", c_int32), ("tile_hint", c_int32), ("slope", c_float), ("out_nhwc_cs", c_int32)]
 
 
 class ProfRow(Structure):
@@ -117,6 +118,7 @@ EXPORTS = {
     "occd_wino_packed_floats": (c_int64, [c_int32, c_int32]),
     "occd_wino_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "occd_wino_conv3x3_fwd": (c_int32, [POINTER(WinoArgs), c_void_p]),
+    "occd_softmax_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "occd_dwconv2d_pool_blocks": (c_int32, [c_int32, c_int32]),
     "occd_dwconv2d_pool_nchw": (c_int32, [c_void_p] * 6 + [c_int32] * 11 + [c_void_p]),
     "occd_se_gate": (c_int32, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
@@ -359,8 +361,14 @@ def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, me
     return out
 
 
-def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0):
-    """feats[s][v]: (B, H_s, W_s, cs) channels-last maps; pix (B, V, N, P, 2) int64; fov (B, V, N, P) bool.
+# workgroup -> XCD placement of the lift (profiles/r02_lift_xcd_modes.txt): 2 = y-blocks per XCD, the HBM fetch of the
+# config-2 lift drops from 282 MB (dispatch order) to 174 MB = the distinct bytes
+LIFT_XCD_MODE = int(os.environ.get("OCCDEPTH_LIFT_XCD", "2"))
+
+
+def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0, xcd_mode=None):
+    """feats[s][v]: (B, H_s, W_s, cs) channels-last maps (dense per image; the batch stride is free); pix (B, V, N, P, 2)
+    int64; fov (B, V, N, P) bool.
 
     Writes out.buf rows (channels-last voxel grid); n -> (a,b,c) over n_dims, row = a*ra + b*rb + c*rc."""
     a = LiftArgs()
@@ -368,7 +376,13 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     B = feats[0][0].shape[0]
     for s in range(S):
         for v in range(V):
-            a.feat[s][v] = _f32(feats[s][v], "feat")
+            f = feats[s][v]
+            if f.dtype != torch.float32 or not f.is_cuda:
+                raise RuntimeError("feature rows must be float32 GPU tensors")
+            if not f[0].is_contiguous():
+                raise RuntimeError("every image of a feature-row tensor must be dense (H, W, cs)")
+            a.feat[s][v] = f.data_ptr()
+            a.feat_bstride[s][v] = f.stride(0) if f.shape[0] > 1 else 0
         a.feat_h[s], a.feat_w[s] = feats[s][0].shape[1], feats[s][0].shape[2]
         a.feat_cs[s] = feats[s][0].shape[3]
         a.scale_div[s] = int(scale_divs[s])
@@ -390,6 +404,7 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     a.out = _f32(out.buf, "out")
     a.out_rows = out.dims[0] * out.dims[1] * out.dims[2]
     a.out_cs = out.cs
+    a.xcd_mode = LIFT_XCD_MODE if xcd_mode is None else int(xcd_mode)
     if out.coff != 0:
         raise RuntimeError("lift output must start at channel 0")
     _check(load().occd_lift_fwd(ctypes.byref(a), _stream()), "occd_lift_fwd")
@@ -556,8 +571,10 @@ def pw_pack_weights(w, scale=None):
     return wpk
 
 
-def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None, tile_hint=0, out=None):
-    """K11: act(conv1x1(x * gate, w * scale) + shift) (+ res) on (B, Cin, *spatial) float32, one launch."""
+def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None, tile_hint=0, out=None, nhwc=False):
+    """K11: act(conv1x1(x * gate, w * scale) + shift) (+ res) on (B, Cin, *spatial) float32, one launch.
+    nhwc=True: the result is stored pixel-major (B, *spatial, ceil4(Cout)) and returned as its logical (B, Cout, *spatial)
+    view (channels-last strides): what the 2D->3D lift gathers from."""
     if not x.is_contiguous():
         x = x.contiguous()
     B, cin = x.shape[0], x.shape[1]
@@ -565,7 +582,11 @@ def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None,
     N = 1
     for d in sp:
         N *= d
-    y = torch.empty((B, cout) + sp, device=x.device, dtype=torch.float32) if out is None else out
+    ocs = round_up(cout, 4) if nhwc else 0
+    if nhwc:
+        y = torch.empty((B,) + sp + (ocs,), device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty((B, cout) + sp, device=x.device, dtype=torch.float32) if out is None else out
     if res is not None and not res.is_contiguous():
         res = res.contiguous()
     if gate is not None:
@@ -580,10 +601,13 @@ def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None,
     a.gate = _f32(gate, "gate") if gate is not None else None
     a.res = _f32(res, "res") if res is not None else None
     a.N, a.batch, a.cin, a.cout = N, B, cin, cout
-    a.act, a.tile_hint, a.slope = ACT2D[act], int(tile_hint), float(slope)
+    a.act, a.tile_hint, a.slope, a.out_nhwc_cs = ACT2D[act], int(tile_hint), float(slope), ocs
     if _PROFILING:
         set_tag("%d>%d @%dx%d" % (cin, cout, B, N))
     _check(load().occd_pw_conv_fwd(ctypes.byref(a), _stream()), "occd_pw_conv_fwd")
+    if nhwc:
+        nd = len(sp)
+        return y[..., :cout].permute(0, nd + 1, *range(1, nd + 1))
     return y
 
 
@@ -602,6 +626,16 @@ def dwconv2d_same(x, w, scale, shift, stride, act=None):
                                      _f32(shift, "shift") if shift is not None else None, _f32(y, "y"), B, C, H, W, k,
                                      stride, pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
            "occd_dwconv2d_nchw")
+    return y
+
+
+def softmax_nchw(x):
+    """softmax over dim 1 of a contiguous float32 (B, C, *spatial) GPU tensor (one HIP launch)."""
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    _check(load().occd_softmax_nchw(_f32(x, "x"), _f32(y, "y"), B, C, x.numel() // (B * C), _stream()), "occd_softmax_nchw")
     return y
 
 

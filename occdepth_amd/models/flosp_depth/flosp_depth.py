@@ -181,7 +181,10 @@ class FlospDepth(nn.Module):
             intrins[:, :, :3, :3] = k3
             intrins[:, :, 3, 3] = 1
             logits = self.depth_net[0](x=feat, sweep_intrins=intrins, scaled_pixel_size=None)
-        depth = logits.softmax(1).reshape(bs, n_cams, self.depth_channels, h, w)
+        if logits.is_cuda and not needs_autograd(self) and logits.dtype == torch.float32:
+            depth = hip.softmax_nchw(logits).reshape(bs, n_cams, self.depth_channels, h, w)
+        else:
+            depth = logits.softmax(1).reshape(bs, n_cams, self.depth_channels, h, w)
 
         if needs_autograd(self):
             vox = self._sample_autograd(depth, None if self.infer_mode else (t_v2c, intrins, ida), grids)

@@ -150,8 +150,10 @@ class DecoderBN(nn.Module):
             x = getattr(self, f"up{s}")(x, taps[s])
             head = getattr(self, f"resize_output_1_{s}")
             if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32 and pw_wins(x):
-                wpk, shift = pw_operands(self, head)         # 1x1 convolution + bias on the MFMA GEMM (K11)
-                res[f"1_{s}"] = hip.conv1x1(x, wpk, head.out_channels, shift)
+                # 1x1 convolution + bias on the MFMA GEMM (K11), written pixel-major: the 2D->3D lift gathers pixel rows,
+                # so the (B, C, H, W) result is returned as a channels-last view and no transpose pass exists
+                wpk, shift = pw_operands(self, head)
+                res[f"1_{s}"] = hip.conv1x1(x, wpk, head.out_channels, shift, nhwc=True)
             else:
                 res[f"1_{s}"] = head(x)
         return res

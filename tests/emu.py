@@ -125,7 +125,7 @@ def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, me
     return feat.reshape(B, -1)
 
 
-def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0):
+def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0, xcd_mode=None):
     from oracle.occdepth_oracle import sfa
     B = pix.shape[0]
     C = out.C
@@ -272,7 +272,7 @@ def pw_pack_weights(w, scale=None):
     return _PackedWino(w * scale.double().view(-1, 1) if scale is not None else w)
 
 
-def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None, tile_hint=0, out=None):
+def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None, tile_hint=0, out=None, nhwc=False):
     """K11 semantics: act(conv1x1(x * gate, w * scale) + shift) (+ res)."""
     xd = x.double()
     if gate is not None:
@@ -291,6 +291,8 @@ def conv1x1(x, wpk, cout, shift=None, act=None, slope=0.01, gate=None, res=None,
     if out is not None:
         out.copy_(y.float())
         return out
+    if nhwc:
+        return y.float().contiguous(memory_format=torch.channels_last) if y.dim() == 4 else y.float()
     return y.float()
 
 

@@ -46,7 +46,8 @@ def test_argument_validation_without_gpu(hip_lib):
 def test_ctypes_structs_match_c_layout(tmp_path):
     from occdepth_amd import hip
     structs = {"occd_conv3d_args": hip.Conv3dArgs, "occd_flosp_args": hip.FlospArgs, "occd_lift_args": hip.LiftArgs,
-               "occd_prof_row": hip.ProfRow, "occd_conv3d_wgrad_args": hip.WgradArgs}
+               "occd_prof_row": hip.ProfRow, "occd_conv3d_wgrad_args": hip.WgradArgs, "occd_wino_args": hip.WinoArgs,
+               "occd_pw_args": hip.PwArgs}
     rename = {"inp": "in"}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
@@ -123,3 +124,33 @@ def test_winograd_entry_points_validate_arguments(hip_lib):
     assert hip_lib.occd_wino_input_transform_nchw(ptr, ptr, 0, 8, 4, 4, 0, 2, None) == -1
     assert hip_lib.occd_wino_input_transform_nchw(ptr, ptr, 1, 8, 4, 4, 1, 2, None) == -1                            # strip past the image
     assert hip_lib.occd_wino_output_transform_nchw(ptr, None, None, None, ptr, 1, 8, 4, 4, 0, 2, 7, 0.0, 0, None) == -1     # act code
+
+
+def test_round2_2d_entry_points_validate_arguments(hip_lib):
+    """K10 / K11 / SE-gate / pooled depthwise entry points: argument checks happen before any launch."""
+    import ctypes
+    from occdepth_amd import hip
+    assert hip_lib.occd_wino_packed_floats(80, 163) == 21 * 16 * 3 * 256
+    assert hip_lib.occd_wino_packed_floats(0, 8) < 0
+    assert hip_lib.occd_wino_conv3x3_fwd(None, None) == -1
+    w = hip.WinoArgs()
+    assert hip_lib.occd_wino_conv3x3_fwd(ctypes.byref(w), None) == -1
+    one = ctypes.c_float(0.0)
+    ptr = ctypes.addressof(one)
+    w.x = w.upk = w.y = ptr
+    w.batch, w.cin, w.cout, w.H, w.W, w.act = 1, 8, 8, 4, 4, 9
+    assert hip_lib.occd_wino_conv3x3_fwd(ctypes.byref(w), None) == -1                  # act code
+    assert hip_lib.occd_wino_pack_weights(None, None, None, 8, 8, None) == -1
+    assert hip_lib.occd_pw_packed_floats(48, 288) == 36 * 2 * 256
+    assert hip_lib.occd_pw_pack_weights(None, None, None, 8, 8, None) == -1
+    a = hip.PwArgs()
+    assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1
+    a.x = a.wpk = a.y = ptr
+    a.batch, a.cin, a.cout, a.N = 1, 8, 8, 16
+    a.tile_hint = 9
+    assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1                       # unknown variant
+    a.tile_hint, a.out_nhwc_cs = 0, 4
+    assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1                       # NHWC row shorter than Cout
+    assert hip_lib.occd_dwconv2d_pool_blocks(185, 610) == (185 * 153 + 255) // 256
+    assert hip_lib.occd_dwconv2d_pool_nchw(ptr, ptr, None, None, ptr, None, 1, 1, 4, 4, 3, 1, 1, 1, 4, 4, 0, None) == -1
+    assert hip_lib.occd_se_gate(None, None, None, None, None, None, None, 1, 8, 2, 1, 16, None) == -1

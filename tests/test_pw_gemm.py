@@ -120,3 +120,37 @@ def test_efficientnet_block_fused_path_gpu(kind, hip_lib):
         E.PW_MIN_PIXELS = saved
     err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
     assert got.shape == ref.shape and err < 2e-5, (kind, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 80, 64, 37, 61), (1, 163, 30, 9, 70)])
+def test_pointwise_conv_nhwc_output_feeds_the_lift_without_a_transpose(shape, hip_lib):
+    """K11's pixel-major mode: same numbers as the NCHW mode, returned as a channels-last view whose pixel rows
+    `lift_scales` consumes in place."""
+    from occdepth_amd import hip
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(B, cin, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).cuda()
+    shift = torch.randn(cout, generator=g).cuda()
+    wpk = hip.pw_pack_weights(w)
+    for hint in (0, 1, 2, 6):
+        a = hip.conv1x1(x, wpk, cout, shift, tile_hint=hint)
+        b = hip.conv1x1(x, wpk, cout, shift, tile_hint=hint, nhwc=True)
+        assert b.shape == a.shape and b.permute(0, 2, 3, 1).stride(3) == 1
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+        rows = b.permute(0, 2, 3, 1)
+        cs = rows.stride(2)
+        assert cs % 4 == 0 and cs >= cout
+        if cs > cout:                                        # the channel pad of every pixel row is zero
+            full = rows.as_strided((B, H, W, cs), rows.stride()[:3] + (1,))
+            assert float(full[..., cout:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_softmax_nchw_gpu(hip_lib):
+    from occdepth_amd import hip
+    x = torch.randn(2, 104, 47, 153, generator=torch.Generator().manual_seed(1)) * 5
+    y = hip.softmax_nchw(x.cuda())
+    ref = torch.softmax(x.double(), 1)
+    assert float((y.double().cpu() - ref).abs().max()) < 1e-6

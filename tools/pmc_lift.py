@@ -1,5 +1,5 @@
-"""Run the config-2 lift (K1b) a few times, for rocprofv3 --pmc passes (HBM bytes of the gather kernel):
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python tools/pmc_lift.py"""
+"""Run the config-2 lift (K1b) a few times per XCD placement, for rocprofv3 --pmc passes (HBM bytes of the gather kernel):
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python tools/pmc_lift.py [modes...]"""
 import os
 import sys
 
@@ -20,7 +20,16 @@ rows = [[torch.randn(1, h, w, 64, device="cuda") for _ in range(2)] for h, w in 
 n_dims, out_dims, strides = voxel_layout((256, 256, 32), 2, "kitti")
 out = hip.Vox.empty(1, out_dims, 64, "cuda")
 depth = torch.rand(1, 262144, device="cuda")
-for _ in range(5):
-    hip.lift(rows, [1, 2, 4, 8], pix, fov, n_dims, strides, out, depth_scale=depth)
-torch.cuda.synchronize()
+modes = [int(m) for m in sys.argv[1:]] or [0]
+for m in modes:
+    for _ in range(4):
+        hip.lift(rows, [1, 2, 4, 8], pix, fov, n_dims, strides, out, depth_scale=depth, xcd_mode=m)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        hip.lift(rows, [1, 2, 4, 8], pix, fov, n_dims, strides, out, depth_scale=depth, xcd_mode=m)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"xcd_mode {m}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
 print("done")
