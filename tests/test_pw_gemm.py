@@ -153,4 +153,4 @@ def test_softmax_nchw_gpu(hip_lib):
     x = torch.randn(2, 104, 47, 153, generator=torch.Generator().manual_seed(1)) * 5
     y = hip.softmax_nchw(x.cuda())
     ref = torch.softmax(x.double(), 1)
-    assert float((y.double().cpu() - ref).abs().max()) < 1e-6
+    assert float((y.double().cpu() - ref).abs().max()) < 5e-6      # float32 exp + a 104-term sum against float64
