@@ -171,6 +171,19 @@ typedef struct occd_lift_args {
 
 int occd_lift_fwd(const occd_lift_args* a, void* stream);
 
+/* Backward of occd_lift_fwd for single-point patterns (P = 1): what autograd computes through
+ * SFA.forward x 4 scales and the `* depth * 100` of occdepth/models/OccDepth.py:266-298,339 in training_step.
+ * gout (B, out_rows, out_cs) = d loss / d out, same rows as the forward output.  gfeat[s][v]: gradient maps with the
+ * layout (and batch stride) of fwd.feat[s][v], ZEROED by the caller, accumulated with float atomics (summation order,
+ * hence the last bits, vary from run to run).  gdepth (B, N) = d loss / d depth_scale, or NULL.                   */
+typedef struct occd_lift_bwd_args {
+    occd_lift_args fwd;
+    const float* gout;
+    float* gfeat[OCCD_MAX_SCALES][OCCD_MAX_VIEWS];
+    float* gdepth;
+} occd_lift_bwd_args;
+int occd_lift_bwd(const occd_lift_bwd_args* a, void* stream);
+
 /* voxel centroid -> pixel projection on the GPU instead of the dataloader's numba
  * `vox2pix` (occdepth/data/utils/helpers.py:94-169, fusion.py:203-217,336-337,518-522), pattern_id 0.
  * cam_E (4x4 row-major), cam_k (3x3), vox_origin (3) are small HOST arrays of doubles; outputs are device

@@ -51,11 +51,12 @@ __device__ __forceinline__ f32x4 sfa_fuse(const f32x4 (&f)[V], const float (&m)[
             // torch.cosine_similarity: normalise each vector by max(||.||, eps) first
             float ni = f[i].x * f[i].x + f[i].y * f[i].y + f[i].z * f[i].z + f[i].w * f[i].w;
             float nj = f[j].x * f[j].x + f[j].y * f[j].y + f[j].z * f[j].z + f[j].w * f[j].w;
-            ni = fmaxf(sqrtf(group_sum<LPV>(ni)), 1e-8f);
-            nj = fmaxf(sqrtf(group_sum<LPV>(nj)), 1e-8f);
-            // x / max(||x||, eps) as x * (1 / max(||x||, eps)): one division instead of four per vector (an IEEE
-            // float division is ~10 VALU instructions and this kernel is latency / issue bound, not HBM bound)
-            const float ri = 1.f / ni, rj = 1.f / nj;
+            // x / max(||x||, eps) as x * rcp(max(sqrt(||x||^2), eps)) on the hardware sqrt / rcp instructions (1 ulp each):
+            // the IEEE-exact sequences are ~10 VALU instructions apiece, four divisions per vector on top, and this
+            // kernel is VALU / latency bound, not HBM bound (profiles/r02_lift_xcd_modes.txt)
+            ni = fmaxf(__builtin_amdgcn_sqrtf(group_sum<LPV>(ni)), 1e-8f);
+            nj = fmaxf(__builtin_amdgcn_sqrtf(group_sum<LPV>(nj)), 1e-8f);
+            const float ri = __builtin_amdgcn_rcpf(ni), rj = __builtin_amdgcn_rcpf(nj);
             const f32x4 xi = f[i] * ri, xj = f[j] * rj;
             float d = xi.x * xj.x + xi.y * xj.y + xi.z * xj.z + xi.w * xj.w;
             d = group_sum<LPV>(d) * (m[i] * m[j]);
@@ -145,6 +146,127 @@ __global__ void __launch_bounds__(256) lift_p1_kernel(const LiftP pp) {
         }
     if (a.depth_scale != nullptr) total = total * a.depth_scale[(size_t)b * a.N + nn] * a.scale_const;
     if (vox_ok && c < a.out_cs) store_voxel_row(a, b, n, c, ch_ok, total);
+}
+
+// ---------------------------------------------------------------- backward of the single-pattern-point lift (N1)
+// y = scale_const * depth_scale[n] * sum_s fuse_s(f_s,0 .. f_s,V-1): given gy (channels-last voxel rows) this kernel
+// recomputes the gathers and the fusion weights, and scatters d loss / d f_s,v into per-scale, per-view gradient maps
+// with hardware float atomics (pixel rows of the coarse scales receive many voxels), plus d loss / d depth_scale.
+// For a pair (a, b) = (f_i, f_j) with masks m:   c = m_i m_j (a^.b^),  a^ = a / max(|a|, eps)
+//     out = [(c + [m_i > m_j]) a + (c + [m_j > m_i]) b] / (V (V - 1))
+//     d out . g / d a = (c + [m_i > m_j]) g + (g.a + g.b) m_i m_j (b^ - (a^.b^) a^) / |a|        (and symmetrically for b)
+// Reference: autograd through occdepth/models/SFA.py:12-106 and OccDepth.py:266-298,339 (training_step).
+struct LiftBwdP {
+    occd_lift_args a;
+    const float* gout;
+    float* gfeat[OCCD_MAX_SCALES][OCCD_MAX_VIEWS];
+    float* gdepth;
+};
+
+template <int LPV, int V>
+__global__ void __launch_bounds__(256) lift_p1_bwd_kernel(const LiftBwdP pp) {
+    const occd_lift_args& a = pp.a;
+    const int tid = threadIdx.x;
+    const int sub = tid % LPV;
+    const long n = ((long)blockIdx.x * 256 + tid) / LPV;
+    const int b = blockIdx.y;
+    const bool vox_ok = n < a.N;
+    const long nn = vox_ok ? n : (long)a.N - 1;
+    const int c = sub * 4;
+    const bool ch_ok = c < a.C;
+    const int cc = ch_ok ? c : 0;
+    const int64_t* pix = a.pix + ((size_t)b * V) * a.N * 2;
+    const uint8_t* fov = a.fov + ((size_t)b * V) * a.N;
+
+    int px[V], py[V];
+    uint32_t keep[V];
+    float m[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const size_t pi = (size_t)v * a.N + nn;
+        const bool in = fov[pi] != 0 && vox_ok;
+        const int64_t x64 = pix[pi * 2], y64 = pix[pi * 2 + 1];
+        px[v] = in ? (int)x64 : 0;
+        py[v] = in ? (int)y64 : 0;
+        m[v] = in ? 1.f : 0.f;
+        keep[v] = in && ch_ok ? 0xFFFFFFFFu : 0u;
+    }
+    // upstream gradient row of this voxel (same row mapping as the forward store)
+    f32x4 g;
+    {
+        const long bc = a.dimB * (long)a.dimC;
+        const long ia = nn / bc, rem = nn - ia * bc;
+        const long ib = rem / a.dimC, ic = rem - ib * a.dimC;
+        const long row = ia * a.row_a + ib * a.row_b + ic * a.row_c;
+        const f32x4 t = *(const f32x4*)(pp.gout + ((size_t)b * a.out_rows + row) * a.out_cs + cc);
+        const uint32_t k = vox_ok && ch_ok ? 0xFFFFFFFFu : 0u;
+        g = f32x4{__uint_as_float(__float_as_uint(t.x) & k), __uint_as_float(__float_as_uint(t.y) & k),
+                  __uint_as_float(__float_as_uint(t.z) & k), __uint_as_float(__float_as_uint(t.w) & k)};
+    }
+    // (the forward applies depth_scale * scale_const only when a depth volume is given)
+    const float dsc = a.depth_scale != nullptr ? a.depth_scale[(size_t)b * a.N + nn] * a.scale_const : 1.f;
+    const f32x4 gt = g * dsc;                                    // d loss / d (sum over scales)
+    const float inv_den = V > 1 ? 1.f / (float)(V * (V - 1)) : 1.f;
+    float g_dot_total = 0.f;                                     // g . sum_s out_s  (for d loss / d depth_scale)
+
+#pragma unroll
+    for (int s = 0; s < OCCD_MAX_SCALES; ++s) {
+        if (s >= a.n_scales) break;                              // (uniform)
+        const int dv = a.scale_div[s], w = a.feat_w[s], cs = a.feat_cs[s];
+        f32x4 f[V];
+        size_t off[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int idx = (py[v] / dv) * w + (px[v] / dv);
+            off[v] = (size_t)b * a.feat_bstride[s][v] + (size_t)idx * cs + cc;
+            const f32x4 t = *(const f32x4*)(a.feat[s][v] + off[v]);
+            const uint32_t k = keep[v];
+            f[v] = f32x4{__uint_as_float(__float_as_uint(t.x) & k), __uint_as_float(__float_as_uint(t.y) & k),
+                         __uint_as_float(__float_as_uint(t.z) & k), __uint_as_float(__float_as_uint(t.w) & k)};
+        }
+        f32x4 gf[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) gf[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (V == 1) {
+            gf[0] = gt;
+            g_dot_total += g.x * f[0].x + g.y * f[0].y + g.z * f[0].z + g.w * f[0].w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+#pragma unroll
+                for (int j = i + 1; j < V; ++j) {
+                    auto dot = [](const f32x4& p, const f32x4& q) { return p.x * q.x + p.y * q.y + p.z * q.z + p.w * q.w; };
+                    const float aa = group_sum<LPV>(dot(f[i], f[i])), bb = group_sum<LPV>(dot(f[j], f[j]));
+                    const float na = fmaxf(sqrtf(aa), 1e-8f), nb = fmaxf(sqrtf(bb), 1e-8f);
+                    const float mm = m[i] * m[j];
+                    const float cosab = group_sum<LPV>(dot(f[i], f[j])) / (na * nb);
+                    const float cw = cosab * mm;
+                    const float wi = cw + (m[i] > m[j] ? 1.f : 0.f), wj = cw + (m[j] > m[i] ? 1.f : 0.f);
+                    const float ga = group_sum<LPV>(dot(gt, f[i])), gb = group_sum<LPV>(dot(gt, f[j]));
+                    const float S = (ga + gb) * mm * inv_den;
+                    // d c / d a = (b^ - cos a^) / |a|   (|a| > eps; below it a^ = a / eps and the projection term vanishes)
+                    const f32x4 ah = f[i] * (1.f / na), bh = f[j] * (1.f / nb);
+                    const float pa = sqrtf(aa) > 1e-8f ? cosab : 0.f, pb = sqrtf(bb) > 1e-8f ? cosab : 0.f;
+                    gf[i] += gt * (wi * inv_den) + (bh - ah * pa) * (S / na);
+                    gf[j] += gt * (wj * inv_den) + (ah - bh * pb) * (S / nb);
+                    const f32x4 o = (f[i] * wi + f[j] * wj) * inv_den;
+                    g_dot_total += dot(g, o);
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (keep[v] != 0u) {                                  // in the field of view, real channel
+                float* dst = pp.gfeat[s][v] + off[v];
+                unsafeAtomicAdd(dst + 0, gf[v].x);
+                unsafeAtomicAdd(dst + 1, gf[v].y);
+                unsafeAtomicAdd(dst + 2, gf[v].z);
+                unsafeAtomicAdd(dst + 3, gf[v].w);
+            }
+    }
+    if (pp.gdepth != nullptr) {
+        const float t = group_sum<LPV>(g_dot_total) * a.scale_const;
+        if (vox_ok && sub == 0) pp.gdepth[(size_t)b * a.N + n] = t;
+    }
 }
 
 // General path: any pattern size P (DSO patterns up to 25 points), V views.
@@ -407,6 +529,47 @@ extern "C" int occd_lift_fwd(const occd_lift_args* a, void* stream) {
         case 32: launch_lift<32>(p, grid, st); break;
         default: launch_lift<64>(p, grid, st); break;
     }
+    return occd::check_launch();
+}
+
+extern "C" int occd_lift_bwd(const occd_lift_bwd_args* q, void* stream) {
+    if (!q || !q->gout) return OCCD_EINVAL;
+    const occd_lift_args* a = &q->fwd;
+    if (!a->pix || !a->fov) return OCCD_EINVAL;
+    if (a->n_scales < 1 || a->n_scales > OCCD_MAX_SCALES || a->n_views < 1 || a->n_views > OCCD_MAX_VIEWS) return OCCD_EINVAL;
+    if (a->P != 1) return OCCD_EINVAL;                        // pattern_id 0 only (every shipped config)
+    if (a->C <= 0 || (a->C & 3) || a->C > 256 || (a->out_cs & 3) || a->out_cs < a->C || a->out_cs > 256) return OCCD_EINVAL;
+    if (a->N <= 0 || a->batch <= 0 || (long)a->dimA * a->dimB * a->dimC != (long)a->N) return OCCD_EINVAL;
+    LiftBwdP p;
+    p.a = *a;
+    p.gout = q->gout;
+    p.gdepth = q->gdepth;
+    for (int s = 0; s < a->n_scales; ++s) {
+        if (a->scale_div[s] <= 0 || (a->feat_cs[s] & 3) || a->feat_cs[s] < a->C) return OCCD_EINVAL;
+        for (int v = 0; v < a->n_views; ++v) {
+            if (!a->feat[s][v] || !q->gfeat[s][v]) return OCCD_EINVAL;
+            p.gfeat[s][v] = q->gfeat[s][v];
+            if (p.a.feat_bstride[s][v] == 0) p.a.feat_bstride[s][v] = (int64_t)a->feat_h[s] * a->feat_w[s] * a->feat_cs[s];
+        }
+    }
+    const int need = a->out_cs / 4;
+    const int lpv = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+    const long threads = (long)a->N * lpv;
+    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)a->batch);
+    hipStream_t st = (hipStream_t)stream;
+    occd::ProfScope prof("sfa_lift_bwd", st, 0.0,
+                         (double)a->batch * a->N * 4.0 * a->C * (1 + 3.0 * a->n_views * a->n_scales));
+#define OCCD_LB(L, VV) hipLaunchKernelGGL((lift_p1_bwd_kernel<L, VV>), grid, dim3(256), 0, st, p)
+#define OCCD_LBV(L) \
+    switch (a->n_views) { case 1: OCCD_LB(L, 1); break; case 2: OCCD_LB(L, 2); break; case 3: OCCD_LB(L, 3); break; default: OCCD_LB(L, 4); }
+    switch (lpv) {
+        case 8: OCCD_LBV(8); break;
+        case 16: OCCD_LBV(16); break;
+        case 32: OCCD_LBV(32); break;
+        default: OCCD_LBV(64); break;
+    }
+#undef OCCD_LBV
+#undef OCCD_LB
     return occd::check_launch();
 }
 

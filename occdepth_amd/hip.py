@@ -89,6 +89,10 @@ class PwArgs(Structure):
                 ("act", c_int32), ("tile_hint", c_int32), ("slope", c_float), ("out_nhwc_cs", c_int32)]
 
 
+class LiftBwdArgs(Structure):
+    _fields_ = [("fwd", LiftArgs), ("gout", c_void_p), ("gfeat", (c_void_p * MAX_VIEWS) * MAX_SCALES), ("gdepth", c_void_p)]
+
+
 class ProfRow(Structure):
     _fields_ = [("tag", c_char * 64), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
                 ("bytes", c_double)]
@@ -103,6 +107,7 @@ EXPORTS = {
                                     c_int32, c_void_p]),
     "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
     "occd_lift_fwd": (c_int32, [POINTER(LiftArgs), c_void_p]),
+    "occd_lift_bwd": (c_int32, [POINTER(LiftBwdArgs), c_void_p]),
     "occd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p]),
     "occd_nhwc_to_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p]),
     "occd_softmax_channels": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -366,12 +371,7 @@ def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, me
 LIFT_XCD_MODE = int(os.environ.get("OCCDEPTH_LIFT_XCD", "2"))
 
 
-def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0, xcd_mode=None):
-    """feats[s][v]: (B, H_s, W_s, cs) channels-last maps (dense per image; the batch stride is free); pix (B, V, N, P, 2)
-    int64; fov (B, V, N, P) bool.
-
-    Writes out.buf rows (channels-last voxel grid); n -> (a,b,c) over n_dims, row = a*ra + b*rb + c*rc."""
-    a = LiftArgs()
+def _lift_args(a, feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale, scale_const, xcd_mode):
     S, V = len(feats), len(feats[0])
     B = feats[0][0].shape[0]
     for s in range(S):
@@ -407,8 +407,41 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     a.xcd_mode = LIFT_XCD_MODE if xcd_mode is None else int(xcd_mode)
     if out.coff != 0:
         raise RuntimeError("lift output must start at channel 0")
+
+
+def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None, scale_const=100.0, xcd_mode=None):
+    """feats[s][v]: (B, H_s, W_s, cs) channels-last maps (dense per image; the batch stride is free); pix (B, V, N, P, 2)
+    int64; fov (B, V, N, P) bool.
+
+    Writes out.buf rows (channels-last voxel grid); n -> (a,b,c) over n_dims, row = a*ra + b*rb + c*rc."""
+    a = LiftArgs()
+    _lift_args(a, feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale, scale_const, xcd_mode)
     _check(load().occd_lift_fwd(ctypes.byref(a), _stream()), "occd_lift_fwd")
     return out
+
+
+def lift_backward(feats, scale_divs, pix, fov, n_dims, row_strides, out_like, gout, depth_scale=None, scale_const=100.0):
+    """Backward of `lift` (single-point patterns): gout (B, X, Y, Z, cs) channels-last d loss / d out ->
+    ([[d loss / d feats[s][v] (same shape, channels-last rows)]], d loss / d depth_scale (B, N) or None)."""
+    q = LiftBwdArgs()
+    _lift_args(q.fwd, feats, scale_divs, pix, fov, n_dims, row_strides, out_like, depth_scale, scale_const, 0)
+    q.gout = _f32(gout, "gout")
+    grads = []
+    for s, per_scale in enumerate(feats):
+        row = []
+        for v, f in enumerate(per_scale):
+            g = torch.zeros_like(f)
+            if g.stride() != f.stride():
+                raise RuntimeError("gradient map layout differs from the feature map's")
+            q.gfeat[s][v] = g.data_ptr()
+            row.append(g)
+        grads.append(row)
+    gd = None
+    if depth_scale is not None:
+        gd = torch.empty_like(depth_scale)
+        q.gdepth = gd.data_ptr()
+    _check(load().occd_lift_bwd(ctypes.byref(q), _stream()), "occd_lift_bwd")
+    return grads, gd
 
 
 # ----------------------------------------------------------------------------- helpers

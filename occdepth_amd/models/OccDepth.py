@@ -58,6 +58,7 @@ class OccDepth(_Base):
         self.batch_views = False  # eval: run all views through net_rgb as one batch (faster, not bit-equal)
         self.graph_2d = False     # eval + batch_views: replay the 2-D network as one captured hipGraph
         self._graphs = {}
+        self.fused_lift = True    # training on the GPU: HIP lift + one-launch backward (lift_autograd.py) where it applies
         if infer_mode:
             self.context_prior = False
         assert not (config.use_stereo_depth_gt and config.use_lidar_depth_gt), "only with one depth data supported."
@@ -256,9 +257,20 @@ class OccDepth(_Base):
             vox = lift_scales(feats, scales, pix, fov, self.projects[str(scales[0])].scene_size,
                               self.project_scale, self.dataset, depth_scale=flat, scale_const=100.0)
             return vox, depth_pred
+        from .. import lift_autograd
+        pix_all = torch.stack([p.to(device) for p in batch[key]])
+        fov_all = torch.stack([m.to(device) for m in batch[mkey]])
+        feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
+        if self.fused_lift and lift_autograd.usable(feats, pix_all) and self.dataset == "kitti":
+            # training on the GPU, single-point patterns: the fused HIP lift with its one-launch backward
+            # (the reference's per-sample / per-scale SFA calls and the `* depth * 100` in one differentiable op)
+            x3ds = lift_autograd.lift_scales_autograd(feats, scales, pix_all, fov_all,
+                                                      self.projects[str(scales[0])].scene_size, self.project_scale,
+                                                      self.dataset, depth_scale=depth_vol, scale_const=100.0)
+            return x3ds, depth_pred
         x3ds = []
         for i in range(bs):
-            pix, fov = batch[key][i].to(device), batch[mkey][i].to(device)
+            pix, fov = pix_all[i], fov_all[i]
             x3d = None
             for s in scales:
                 stack = torch.stack([x_rgb[j]["1_" + str(s)] for j in range(len(x_rgb))], 1).to(device)

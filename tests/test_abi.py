@@ -47,7 +47,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     from occdepth_amd import hip
     structs = {"occd_conv3d_args": hip.Conv3dArgs, "occd_flosp_args": hip.FlospArgs, "occd_lift_args": hip.LiftArgs,
                "occd_prof_row": hip.ProfRow, "occd_conv3d_wgrad_args": hip.WgradArgs, "occd_wino_args": hip.WinoArgs,
-               "occd_pw_args": hip.PwArgs}
+               "occd_pw_args": hip.PwArgs, "occd_lift_bwd_args": hip.LiftBwdArgs}
     rename = {"inp": "in"}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
@@ -154,3 +154,7 @@ def test_round2_2d_entry_points_validate_arguments(hip_lib):
     assert hip_lib.occd_dwconv2d_pool_blocks(185, 610) == (185 * 153 + 255) // 256
     assert hip_lib.occd_dwconv2d_pool_nchw(ptr, ptr, None, None, ptr, None, 1, 1, 4, 4, 3, 1, 1, 1, 4, 4, 0, None) == -1
     assert hip_lib.occd_se_gate(None, None, None, None, None, None, None, 1, 8, 2, 1, 16, None) == -1
+    assert hip_lib.occd_lift_bwd(None, None) == -1
+    q = hip.LiftBwdArgs()
+    assert hip_lib.occd_lift_bwd(ctypes.byref(q), None) == -1
+    assert hip_lib.occd_softmax_nchw(None, None, 1, 4, 8, None) == -1
