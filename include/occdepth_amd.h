@@ -285,6 +285,17 @@ int64_t occd_wino_packed_floats(int32_t cout, int32_t cin);
 int occd_wino_pack_weights(const float* w, const float* scale, float* upk, int32_t cout, int32_t cin, void* stream);
 int occd_wino_conv3x3_fwd(const occd_wino_args* a, void* stream);
 
+/* Backward of the depthwise convolution (autograd of the geffnet conv_dw layers in training_step):
+ *   data  : dx (B, C, H, W) from gy (B, C, Ho, Wo) and w (C, 1, k, k), same geometry arguments as the forward;
+ *   weight: dw (C, 1, k, k) from x and gy; workspace: occd_dwconv2d_bwd_weight_workspace_floats(...) floats
+ *           (per-workgroup partial sums, reduced in index order: deterministic).                                    */
+int occd_dwconv2d_bwd_data_nchw(const float* gy, const float* w, float* dx, int32_t batch, int32_t C, int32_t H,
+                                int32_t W, int32_t k, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho,
+                                int32_t Wo, void* stream);
+int64_t occd_dwconv2d_bwd_weight_workspace_floats(int32_t batch, int32_t C, int32_t k, int32_t Ho, int32_t Wo);
+int occd_dwconv2d_bwd_weight_nchw(const float* x, const float* gy, float* dw, float* workspace, int32_t batch, int32_t C,
+                                  int32_t H, int32_t W, int32_t k, int32_t stride, int32_t pad_top, int32_t pad_left,
+                                  int32_t Ho, int32_t Wo, void* stream);
 /* Depthwise convolution as above that ALSO leaves the squeeze-excite pooling behind: pool_part
  * (B*C, occd_dwconv2d_pool_blocks(Ho, Wo)) holds each workgroup's share of sum_{y,x} y[b][c] (fixed summation order).
  * occd_se_gate turns the partials into the gate  sigmoid(W_e swish(W_r mean + b_r) + b_e)  (B, C) of geffnet's

@@ -124,6 +124,9 @@ EXPORTS = {
     "occd_wino_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "occd_wino_conv3x3_fwd": (c_int32, [POINTER(WinoArgs), c_void_p]),
     "occd_softmax_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
+    "occd_dwconv2d_bwd_data_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p]),
+    "occd_dwconv2d_bwd_weight_workspace_floats": (c_int64, [c_int32] * 5),
+    "occd_dwconv2d_bwd_weight_nchw": (c_int32, [c_void_p] * 4 + [c_int32] * 10 + [c_void_p]),
     "occd_dwconv2d_pool_blocks": (c_int32, [c_int32, c_int32]),
     "occd_dwconv2d_pool_nchw": (c_int32, [c_void_p] * 6 + [c_int32] * 11 + [c_void_p]),
     "occd_se_gate": (c_int32, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
@@ -660,6 +663,56 @@ def dwconv2d_same(x, w, scale, shift, stride, act=None):
                                      stride, pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
            "occd_dwconv2d_nchw")
     return y
+
+
+def _same_geometry(H, W, k, stride):
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    pad_h = max((Ho - 1) * stride + k - H, 0)
+    pad_w = max((Wo - 1) * stride + k - W, 0)
+    return Ho, Wo, pad_h // 2, pad_w // 2
+
+
+class _DwConvSameFn(torch.autograd.Function):
+    """Depthwise convolution with TensorFlow SAME padding, forward / data gradient / weight gradient on the HIP kernels
+    (csrc/nchw2d.hip); under autocast it computes in float32 (HBM-bound either way)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w, stride):
+        x = x.contiguous()
+        y = dwconv2d_same(x, w.detach(), None, None, stride, None)
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride = ctx.stride
+        B, C, H, W = x.shape
+        k = w.shape[-1]
+        Ho, Wo, pt, pl = _same_geometry(H, W, k, stride)
+        gy = gy.float().contiguous()
+        wc = w.detach().float().contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _check(load().occd_dwconv2d_bwd_data_nchw(_f32(gy, "gy"), _f32(wc, "w"), _f32(dx, "dx"), B, C, H, W, k, stride,
+                                                      pt, pl, Ho, Wo, _stream()), "occd_dwconv2d_bwd_data_nchw")
+        if ctx.needs_input_grad[1]:
+            n = load().occd_dwconv2d_bwd_weight_workspace_floats(B, C, k, Ho, Wo)
+            ws = torch.empty(n, device=x.device, dtype=torch.float32)
+            dw = torch.empty_like(wc)
+            _check(load().occd_dwconv2d_bwd_weight_nchw(_f32(x, "x"), _f32(gy, "gy"), _f32(dw, "dw"), _f32(ws, "ws"), B, C,
+                                                        H, W, k, stride, pt, pl, Ho, Wo, _stream()),
+                   "occd_dwconv2d_bwd_weight_nchw")
+        return dx, dw, None
+
+
+def dwconv2d_same_autograd(x, w, stride):
+    """Differentiable depthwise SAME convolution (training path of the EfficientNet blocks)."""
+    return _DwConvSameFn.apply(x, w, int(stride))
 
 
 def softmax_nchw(x):

@@ -75,6 +75,13 @@ class Conv2dSame(nn.Conv2d):
         if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and _fast(x, self) and pw_wins(x)):
             wpk, shift = pw_operands(self, self)            # e.g. conv_head: plain 1x1 convolution on the MFMA GEMM (K11)
             return hip.conv1x1(x, wpk, self.out_channels, shift)
+        if (self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda and needs_autograd(self)
+                and self.kernel_size in ((3, 3), (5, 5)) and self.stride in ((1, 1), (2, 2)) and self.bias is None
+                and self.dilation == (1, 1) and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                and x.shape[0] * x.shape[1] <= 65535):
+            # training: depthwise forward / data gradient / weight gradient on the HIP kernels (MIOpen's fp32 depthwise
+            # path is the naive fallback: 17.5 ms of a config-2 step)
+            return hip.dwconv2d_same_autograd(x, self.weight, self.stride[0])
         pads = []
         for size, k, s, d in zip(x.shape[-2:], self.kernel_size, self.stride, self.dilation):
             total = max((math.ceil(size / s) - 1) * s + (k - 1) * d + 1 - size, 0)

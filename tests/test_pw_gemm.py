@@ -154,3 +154,27 @@ def test_softmax_nchw_gpu(hip_lib):
     y = hip.softmax_nchw(x.cuda())
     ref = torch.softmax(x.double(), 1)
     assert float((y.double().cpu() - ref).abs().max()) < 5e-6      # float32 exp + a 104-term sum against float64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 24, 37, 53, 3, 1), (1, 40, 30, 41, 5, 2), (2, 7, 9, 300, 5, 1), (1, 16, 24, 77, 3, 2)])
+def test_depthwise_autograd_gpu(shape, hip_lib):
+    """Depthwise SAME convolution: HIP forward / data gradient / weight gradient against ATen float64 on the CPU."""
+    import torch.nn.functional as F
+    from occdepth_amd import hip
+    B, C, H, W, k, stride = shape
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    R = torch.randn(B, C, Ho, Wo, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ph, pw_ = max((Ho - 1) * stride + k - H, 0), max((Wo - 1) * stride + k - W, 0)
+    ref = F.conv2d(F.pad(xd, [pw_ // 2, pw_ - pw_ // 2, ph // 2, ph - ph // 2]), wd, None, stride, 0, 1, C)
+    (ref * R.double()).sum().backward()
+    xc, wc = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = hip.dwconv2d_same_autograd(xc, wc, stride)
+    (y * R.cuda()).sum().backward()
+    for got, want in ((y, ref), (xc.grad, xd.grad), (wc.grad, wd.grad)):
+        assert got.shape == want.shape
+        assert float((got.double().cpu() - want.detach()).abs().max() / want.detach().abs().max()) < 2e-5
