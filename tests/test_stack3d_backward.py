@@ -4,7 +4,7 @@ are compared with an ATen float64 run of the same modules on the CPU.  No 2-D ne
 comparison is deterministic, so the bound is tight (elements within 1e-3 of the gradient's rms, norms within 1e-4).
 
 The network is piecewise linear in its ReLUs and a float32 forward may land on the other side of a kink than the
-float64 one (measured on `kitti_ps2`: ONE of 2.6 M ReLU inputs, |x| = 5e-7, flips between ATen float32 and ATen float64
+float64 one (measured on `kitti_ps2`: ONE of ~4 M ReLU inputs, |x| = 5e-7, flips between ATen float32 and ATen float64
 and moves 3 % of the decoder's weight-gradient elements by up to 3e-2 rms -- the same signature as the 4 % the old
 whole-model test showed).  That is a property of the function, not of a kernel, so the float64 reference is evaluated
 ON THE PRODUCT'S LINEAR PIECE: the product run records every ReLU mask, the reference replays them, and the test
