@@ -317,7 +317,8 @@ int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_r
  *   y[b][co][n] = act( sum_ci (w[co][ci] * scale[co]) * (x[b][ci][n] * gate[b][ci]) + shift[co] ) (+ res[b][co][n])
  * x (B, Cin, N), y / res (B, Cout, N), N = H*W; gate (B, Cin) or NULL; shift (Cout) or NULL; act codes as above.
  * wpk: occd_pw_pack_weights(w (Cout, Cin), scale or NULL) -> occd_pw_packed_floats(Cout, Cin) floats in MFMA
- *      A-fragment order [ceil(Cin/8)][ceil(Cout/32)][64 lanes][4].  tile_hint: 0 = choose, 1..6 = fixed variant.
+ *      A-fragment order [ceil(Cin/8)][ceil(Cout/32)][64 lanes][4].  tile_hint: 0 = choose, 1..6 = fixed streaming
+ *      variant, 7..12 = fixed split-K variant (K11s: the waves of a workgroup split Cin, for maps of few pixels).
  * out_nhwc_cs != 0: y is written pixel-major, y[b][n][co] in rows of out_nhwc_cs >= Cout floats (pad written as zeros)
  *      -- the layout occd_lift_fwd gathers from, so the decoder's 1x1 heads feed the lift without a transpose pass
  *      (no gate / res in this mode).                                                                              */

@@ -78,22 +78,32 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
     for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)c * K * K + i];
     float acc[NX] = {0.f, 0.f, 0.f, 0.f};
     const int ix0 = ox0 * STRIDE - pad_l;
+    // Every load is unconditional (clamped address) and the padding is a bit mask on the loaded value: a load guarded by
+    // a runtime condition makes hipcc branch around it and wait for each one separately, which serialised the K * SPAN
+    // loads of a thread (the kernel ran at a quarter of what its bytes allow).
+    int cix[SPAN];
+    uint32_t cm[SPAN];
+#pragma unroll
+    for (int j = 0; j < SPAN; ++j) {
+        const int ix = ix0 + j;
+        cm[j] = 0u - (uint32_t)((unsigned)ix < (unsigned)W);
+        cix[j] = min(max(ix, 0), W - 1);
+    }
+    float v[K][SPAN];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         const int iy = oy * STRIDE - pad_t + ky;
-        if ((unsigned)iy >= (unsigned)H) continue;
-        const float* row = xp + (size_t)iy * W;
-        float v[SPAN];
+        const uint32_t rm = 0u - (uint32_t)((unsigned)iy < (unsigned)H);
+        const float* row = xp + (size_t)min(max(iy, 0), H - 1) * W;
 #pragma unroll
-        for (int j = 0; j < SPAN; ++j) {
-            const int ix = ix0 + j;
-            v[j] = (unsigned)ix < (unsigned)W ? row[ix] : 0.f;
-        }
+        for (int j = 0; j < SPAN; ++j) v[ky][j] = __uint_as_float(__float_as_uint(row[cix[j]]) & (rm & cm[j]));
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
 #pragma unroll
         for (int o = 0; o < NX; ++o)
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) acc[o] += v[o * STRIDE + kx] * wr[ky * K + kx];
-    }
+            for (int kx = 0; kx < K; ++kx) acc[o] += v[ky][o * STRIDE + kx] * wr[ky * K + kx];
     const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
     float* yp = y + ((size_t)plane * Ho + oy) * Wo + ox0;
     float part = 0.f;
@@ -135,18 +145,47 @@ __global__ void __launch_bounds__(256) dwconv2d_bwd_data_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)c * K * K + i];
     float acc[NX] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (STRIDE == 1) {
+        // correlation with the flipped kernel: output o, tap kx reads gy column ix0 + o + pad_l - kx = j0 + (o + K - 1 - kx);
+        // one span of NX + K - 1 values per row, all loads unconditional (clamped address, bit-mask zero fill)
+        constexpr int SP = NX + K - 1;
+        const int j0 = ix0 + pad_l - (K - 1);
+        int cj[SP];
+        uint32_t cm[SP];
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        const int ty = iy + pad_t - ky;
-        if (ty < 0 || ty % STRIDE != 0 || ty / STRIDE >= Ho) continue;
-        const float* row = gp + (size_t)(ty / STRIDE) * Wo;
+        for (int j = 0; j < SP; ++j) {
+            cm[j] = 0u - (uint32_t)((unsigned)(j0 + j) < (unsigned)Wo);
+            cj[j] = min(max(j0 + j, 0), Wo - 1);
+        }
+        float v[K][SP];
 #pragma unroll
-        for (int o = 0; o < NX; ++o)
+        for (int ky = 0; ky < K; ++ky) {
+            const int ty = iy + pad_t - ky;
+            const uint32_t rm = 0u - (uint32_t)((unsigned)ty < (unsigned)Ho);
+            const float* row = gp + (size_t)min(max(ty, 0), Ho - 1) * Wo;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int tx = ix0 + o + pad_l - kx;
-                if (tx >= 0 && tx % STRIDE == 0 && tx / STRIDE < Wo) acc[o] += row[tx / STRIDE] * wr[ky * K + kx];
-            }
+            for (int j = 0; j < SP; ++j) v[ky][j] = __uint_as_float(__float_as_uint(row[cj[j]]) & (rm & cm[j]));
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int o = 0; o < NX; ++o)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[o] += v[ky][o + K - 1 - kx] * wr[ky * K + kx];
+    } else {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int ty = iy + pad_t - ky;
+            if (ty < 0 || ty % STRIDE != 0 || ty / STRIDE >= Ho) continue;
+            const float* row = gp + (size_t)(ty / STRIDE) * Wo;
+#pragma unroll
+            for (int o = 0; o < NX; ++o)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int tx = ix0 + o + pad_l - kx;
+                    if (tx >= 0 && tx % STRIDE == 0 && tx / STRIDE < Wo) acc[o] += row[tx / STRIDE] * wr[ky * K + kx];
+                }
+        }
     }
     float* xp = dx + ((size_t)plane * H + iy) * W + ix0;
 #pragma unroll
@@ -163,27 +202,47 @@ __global__ void __launch_bounds__(256) dwconv2d_bwd_weight_kernel(const float* _
                                                                   float* __restrict__ part, int B, int C, int H, int W,
                                                                   int Ho, int Wo, int pad_t, int pad_l) {
     __shared__ float red[4][K * K];
+    constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K;
     const int c = blockIdx.y;
-    const long total = (long)B * Ho * Wo;
+    const int wq = (Wo + NX - 1) / NX;
+    const long total = (long)B * Ho * wq;                    // items of NX horizontally adjacent outputs
     float acc[K * K];
 #pragma unroll
     for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int b = (int)(i / ((long)Ho * Wo));
-        const int r = (int)(i - (long)b * Ho * Wo);
-        const int oy = r / Wo, ox = r - oy * Wo;
-        const float g = gy[((size_t)b * C + c) * Ho * Wo + r];
+        const int b = (int)(i / ((long)Ho * wq));
+        const int r = (int)(i - (long)b * Ho * wq);
+        const int oy = r / wq, ox0 = (r - oy * wq) * NX;
+        const float* gp = gy + (((size_t)b * C + c) * Ho + oy) * Wo;
         const float* xp = x + ((size_t)b * C + c) * H * W;
+        // all loads unconditional (clamped address), padding / ragged tail as bit masks on the loaded values
+        float g[NX];
+#pragma unroll
+        for (int o = 0; o < NX; ++o)
+            g[o] = __uint_as_float(__float_as_uint(gp[min(ox0 + o, Wo - 1)]) & (0u - (uint32_t)(ox0 + o < Wo)));
+        const int ix0 = ox0 * STRIDE - pad_l;
+        int cix[SPAN];
+        uint32_t cm[SPAN];
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j) {
+            cm[j] = 0u - (uint32_t)((unsigned)(ix0 + j) < (unsigned)W);
+            cix[j] = min(max(ix0 + j, 0), W - 1);
+        }
+        float v[K][SPAN];
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
             const int iy = oy * STRIDE - pad_t + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
+            const uint32_t rm = 0u - (uint32_t)((unsigned)iy < (unsigned)H);
+            const float* row = xp + (size_t)min(max(iy, 0), H - 1) * W;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const int ix = ox * STRIDE - pad_l + kx;
-                if ((unsigned)ix < (unsigned)W) acc[ky * K + kx] += g * xp[(size_t)iy * W + ix];
-            }
+            for (int j = 0; j < SPAN; ++j) v[ky][j] = __uint_as_float(__float_as_uint(row[cix[j]]) & (rm & cm[j]));
         }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int o = 0; o < NX; ++o) acc[ky * K + kx] += g[o] * v[ky][o * STRIDE + kx];
     }
 #pragma unroll
     for (int i = 0; i < K * K; ++i) {

@@ -30,6 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+constexpr long kSplitKBelowWgs = 400;    // the split-K variants (K11s) take over when K11 would launch fewer workgroups
+
 struct PwP {
     const float* x;
     const float* wpk;
@@ -196,6 +198,147 @@ __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(con
     }
 }
 
+// K11s -- the same GEMM for the low-resolution EfficientNet stages (1/16 and 1/32: < 2000 pixels per view, K up to 3840,
+// up to 3840 couts).  There are too few pixel tiles to fill 256 CUs and a wave walking K = 3840 alone is a 50 us serial
+// chain, so the KS waves of a workgroup share ONE (MT*32) x (NT*32) output tile and split K between them (wave w takes the
+// 8-channel chunks w, w + KS, ...); the partial accumulators meet in LDS once, after the loop, and the reduction doubles
+// as a redistribution: wave w sums accumulator registers w, w + KS, ... of all KS partials (fixed order: deterministic)
+// and runs the epilogue for them, so the stores are spread over all waves and are the same 128-byte rows as above.
+template <int MT, int NT, int KS, bool GATE, bool NHWC>
+__global__ void __launch_bounds__(KS * 64) pw_gemm_splitk_kernel(const PwP p) {
+    __shared__ float red[KS * MT * NT * 16 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.z;
+    const int mt_wg = blockIdx.x % p.mtiles, nt_wg = blockIdx.x / p.mtiles;
+    const int mb0 = mt_wg * MT;
+    const long n0 = (long)nt_wg * NT * 32;
+
+    const float* const xb = p.x + (size_t)b * p.Cin * p.N;
+    const float* const gb = GATE ? p.gate + (size_t)b * p.Cin : nullptr;
+
+    long col[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) col[nt] = min(n0 + nt * 32 + li, p.N - 1);
+    int wofs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wofs[mt] = min(mb0 + mt, p.mblocks - 1) * 256 + lane * 4;
+    const size_t w_step = (size_t)p.mblocks * 256;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    auto load_a = [&](int c, f32x4* a) {
+        const float* wp = p.wpk + (size_t)c * w_step;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(wp + wofs[mt]);
+    };
+    auto load_b = [&](int c, f32x4* braw, f32x4& g) {
+        const int k0 = c * 8 + kk * 4;
+        if (GATE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = gb[min(k0 + q, p.Cin - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* row = xb + (size_t)min(k0 + q, p.Cin - 1) * p.N;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) braw[nt][q] = row[col[nt]];
+        }
+    };
+    auto finish_b = [&](int c, const f32x4* braw, const f32x4& g, f32x4* bf) {
+        const int k0 = c * 8 + kk * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t keep = 0u - (uint32_t)(k0 + q < p.Cin);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float v = GATE ? braw[nt][q] * g[q] : braw[nt][q];
+                bf[nt][q] = __uint_as_float(__float_as_uint(v) & keep);
+            }
+        }
+    };
+
+    // Software pipeline of depth PF: the raw loads of step j + PF are issued above the MFMAs of step j (a step is only
+    // 4 * MT * NT MFMAs, far shorter than an L2 round trip).  Steps past the wave's last chunk load a clamped address
+    // and are zeroed by finish_b's channel mask (chunk index >= kchunks), so the loop body is branch-free.
+    {
+        constexpr int PF = 3;
+        f32x4 a_r[PF][MT], b_r[PF][NT], g_r[PF];
+        const int last = p.kchunks - 1;
+        const int nsteps = p.kchunks > wave ? (p.kchunks - wave + KS - 1) / KS : 0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            g_r[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+            load_a(min(wave + u * KS, last), a_r[u]);
+            load_b(min(wave + u * KS, last), b_r[u], g_r[u]);
+        }
+        for (int j0 = 0; j0 < nsteps; j0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int c = wave + (j0 + u) * KS;                 // (unclamped: finish_b zeroes chunks >= kchunks)
+                f32x4 a_cur[MT], b_cur[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_r[u][mt];
+                finish_b(c, b_r[u], g_r[u], b_cur);
+                load_a(min(c + PF * KS, last), a_r[u]);
+                load_b(min(c + PF * KS, last), b_r[u], g_r[u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = NHWC ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nt][q], a_cur[mt][q], acc[mt][nt], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // partials -> LDS: red[wave][slice = (mt * NT + nt) * 16 + r][lane]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[((wave * MT * NT + mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+    __syncthreads();
+    // slice s = register r of tile (mt, nt): cout 32 (mb0 + mt) + 8 (r >> 2) + 4 kk + (r & 3) at pixel n0 + 32 nt + li
+    // (NHWC, operands swapped: pixel n0 + 32 nt + 8 (r >> 2) + 4 kk + (r & 3) at cout 32 (mb0 + mt) + li)
+    for (int s = wave; s < MT * NT * 16; s += KS) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += red[(w * MT * NT * 16 + s) * 64 + lane];
+        const int r = s & 15, t = s >> 4, mt = t / NT, nt = t - mt * NT;
+        const int sub = 8 * (r >> 2) + 4 * kk + (r & 3);
+        if (NHWC) {
+            const int co = (mb0 + mt) * 32 + li;
+            const long n = n0 + nt * 32 + sub;
+            if (mb0 + mt >= p.mblocks || co >= p.out_cs || n >= p.N) continue;
+            const bool real = co < p.Cout;
+            v = pw_act(v + (real && p.shift != nullptr ? p.shift[co] : 0.f), p.act, p.slope);
+            p.y[((size_t)b * p.N + n) * p.out_cs + co] = real ? v : 0.f;             // (channel pad written as zeros)
+        } else {
+            const int co = (mb0 + mt) * 32 + sub;
+            const long n = n0 + nt * 32 + li;
+            if (mb0 + mt >= p.mblocks || co >= p.Cout || n >= p.N) continue;
+            const size_t o = ((size_t)b * p.Cout + co) * p.N + n;
+            v = pw_act(v + (p.shift != nullptr ? p.shift[co] : 0.f), p.act, p.slope);
+            if (p.res != nullptr) v += p.res[o];
+            p.y[o] = v;
+        }
+    }
+}
+
 // wpk[k/8][cout/32][lane][4]: cout = blk*32 + (lane & 31), cin = chunk*8 + (lane >> 5)*4 + q, value w[cout][cin] * scale[cout]
 __global__ void pw_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ wpk,
                                int cout, int cin, int mblocks, long total) {
@@ -221,6 +364,19 @@ int launch_pw(PwP& p, int batch, hipStream_t st) {
     if (p.out_cs > 0) hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, false, true>), grid, dim3(256), 0, st, p);
     else if (gate) hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, true, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, WM, WN, false, false>), grid, dim3(256), 0, st, p);
+    return occd::check_launch();
+}
+
+template <int MT, int NT, int KS>
+int launch_pw_splitk(PwP& p, int batch, hipStream_t st) {
+    p.mtiles = (p.mblocks + MT - 1) / MT;
+    p.ntiles = (int)((p.N + (long)NT * 32 - 1) / ((long)NT * 32));
+    const long gx = (long)p.mtiles * p.ntiles;
+    if (gx > 0x7fffffffL || batch > 65535) return OCCD_EINVAL;
+    const dim3 grid((unsigned)gx, 1, (unsigned)batch);
+    if (p.out_cs > 0) hipLaunchKernelGGL((pw_gemm_splitk_kernel<MT, NT, KS, false, true>), grid, dim3(KS * 64), 0, st, p);
+    else if (p.gate != nullptr) hipLaunchKernelGGL((pw_gemm_splitk_kernel<MT, NT, KS, true, false>), grid, dim3(KS * 64), 0, st, p);
+    else hipLaunchKernelGGL((pw_gemm_splitk_kernel<MT, NT, KS, false, false>), grid, dim3(KS * 64), 0, st, p);
     return occd::check_launch();
 }
 
@@ -260,8 +416,25 @@ int occd_pw_conv_fwd(const occd_pw_args* a, void* stream) {
     // 64 x 64 wave tile with the 4 waves along the couts.
     const int mb = p.mblocks;
     int hint = a->tile_hint;
-    if (hint == 0) hint = mb == 1 ? 1 : mb == 2 ? (a->cin >= 192 ? 6 : 2) : mb == 3 ? 6 : (a->cin <= 256 ? 1 : 6);
+    if (hint == 0) {
+        hint = mb == 1 ? 1 : mb == 2 ? (a->cin >= 192 ? 6 : 2) : mb == 3 ? 6 : (a->cin <= 256 ? 1 : 6);
+        // K11s (hints 7..12 = <MT, NT, KS>) when the streaming variant would leave CUs without a workgroup and K is long
+        // enough to split: the largest register tile that still gives every CU a workgroup
+        static const int wg_m[7] = {0, 1, 2, 4, 8, 16, 8}, wg_n[7] = {0, 512, 512, 256, 128, 64, 64};   // couts/32, pixels per WG
+        const long wgs = (long)((mb + wg_m[hint] - 1) / wg_m[hint]) * ((a->N + wg_n[hint] - 1) / wg_n[hint]) * a->batch;
+        if (wgs < kSplitKBelowWgs && p.kchunks >= 16) {
+            auto tiles = [&](int mt, int nt) { return (long)((mb + mt - 1) / mt) * ((a->N + 32 * nt - 1) / (32 * nt)) * a->batch; };
+            const bool longk = p.kchunks >= 48;
+            hint = tiles(2, 2) >= 256 ? 11 : tiles(2, 1) >= 256 ? (longk ? 9 : 12) : (longk ? 8 : 7);
+        }
+    }
     switch (hint) {
+    case 7: return launch_pw_splitk<1, 1, 4>(p, a->batch, st);
+    case 8: return launch_pw_splitk<1, 1, 8>(p, a->batch, st);
+    case 9: return launch_pw_splitk<2, 1, 8>(p, a->batch, st);
+    case 10: return launch_pw_splitk<1, 2, 8>(p, a->batch, st);
+    case 11: return launch_pw_splitk<2, 2, 4>(p, a->batch, st);
+    case 12: return launch_pw_splitk<2, 1, 4>(p, a->batch, st);
     case 1: return launch_pw<1, 4, 1, 4>(p, a->batch, st);
     case 2: return launch_pw<2, 4, 1, 4>(p, a->batch, st);
     case 3: return launch_pw<4, 2, 1, 4>(p, a->batch, st);

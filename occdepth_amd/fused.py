@@ -67,6 +67,21 @@ def bn_affine_cached(bn):
     return cached[1], cached[2]
 
 
+def wino_fused_operands(owner, conv, bn):
+    """(packed Winograd-domain weights of K10 with the BatchNorm scale folded in, shift) of a 3x3 convolution + BatchNorm,
+    cached on `owner` until a source tensor changes ((data_ptr, _version) stamp)."""
+    key = _stamp(conv, bn)
+    cache = owner.__dict__.setdefault("_fused_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        scale, shift = bn_affine_cached(bn)
+        if conv.bias is not None:
+            shift = shift + scale * conv.bias.detach().float()
+        hit = (key, hip.wino_pack_weights(conv.weight, scale), shift.contiguous())
+        cache[id(conv)] = hit
+    return hit[1:]
+
+
 def _pad_bias(bias, cout):
     out = torch.zeros(hip.round_up(cout, 32), device=bias.device, dtype=torch.float32)
     out[:cout] = bias

@@ -21,10 +21,10 @@ from ..fused import _stamp, bn_affine_cached, needs_autograd
 
 # K11 / SE-fusion path of the eval forward (OCCDEPTH_PW_FUSED=0 restores the MIOpen / rocBLAS 1x1 convolutions for A/B)
 PW_FUSED = os.environ.get("OCCDEPTH_PW_FUSED", "1") == "1"
-# K11 streams X from HBM with no split-K: it wins where pixels are many and K is short (tools/bench_pw.py: 2-3 TB/s
-# against rocBLAS' 1.4 on the 1/2 ... 1/8 levels); the 1/16 and 1/32 levels (K up to 3840, < 2000 pixels per view) stay
-# on rocBLAS / hipBLASLt
-PW_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_MIN_PIXELS", "14000"))      # B * H * W
+# Below this many pixels (B * H * W) the blocks fall back to rocBLAS / ATen glue.  0 = never: the library picks the
+# streaming K11 variants where pixels are many and the split-K ones (K11s) on the 1/16 and 1/32 levels (K up to 3840,
+# < 2000 pixels per view), so every MBConv block of the eval path is 4 launches.  Kept as an A/B switch.
+PW_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_MIN_PIXELS", "0"))          # B * H * W
 
 
 def pw_wins(x):

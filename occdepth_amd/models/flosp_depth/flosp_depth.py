@@ -17,7 +17,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import hip
-from ...fused import bn_affine_cached, needs_autograd
+import os
+
+from ...fused import bn_affine_cached, needs_autograd, wino_fused_operands
+
+# DepthNet's 3x3 convolutions on K10 (fused Winograd MFMA kernel, BatchNorm / ReLU / identity skip in its epilogue) instead
+# of MIOpen + a BatchNorm pass; OCCDEPTH_DEPTHNET_K10=0 restores MIOpen for A/B
+DEPTHNET_K10 = os.environ.get("OCCDEPTH_DEPTHNET_K10", "1") == "1"
 
 
 class BasicBlock(nn.Module):
@@ -30,6 +36,11 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+            if DEPTHNET_K10:                                   # 2 launches per block
+                upk, shift = wino_fused_operands(self, self.conv1, self.bn1)
+                y = hip.conv2d_3x3_fused(x, upk, self.conv1.out_channels, shift, "relu")
+                upk, shift = wino_fused_operands(self, self.conv2, self.bn2)
+                return hip.conv2d_3x3_fused(y, upk, self.conv2.out_channels, shift, "relu", res=x, res_first=True)
             y = hip.affine_act(self.conv1(x), *bn_affine_cached(self.bn1), "relu")
             return hip.affine_act(self.conv2(y), *bn_affine_cached(self.bn2), "relu", res=x, res_first=True)
         out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
@@ -92,7 +103,11 @@ class DepthNet(nn.Module):
         if not self.infer_mode:
             scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
                                                        sync_free=sweep_intrins.is_cuda and not needs_autograd(self))
-        x = self.reduce_conv(x)
+        if DEPTHNET_K10 and x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+            upk, shift = wino_fused_operands(self, self.reduce_conv[0], self.reduce_conv[1])
+            x = hip.conv2d_3x3_fused(x, upk, self.reduce_conv[0].out_channels, shift, "relu")
+        else:
+            x = self.reduce_conv(x)
         x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
         x = self.depth_conv(x)
         if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:

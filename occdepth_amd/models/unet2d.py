@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
-from ..fused import _stamp, bn_affine_cached, needs_autograd
+from ..fused import _stamp, bn_affine_cached, needs_autograd, wino_fused_operands
 from .efficientnet import EfficientNet, pw_operands, pw_wins
 
 MODEL_NAME = "tf_efficientnet_b3_ns"
@@ -70,16 +70,7 @@ class UpSampleBN(nn.Module):
     FUSED = os.environ.get("OCCDEPTH_WINO_FUSED", "1") == "1"
 
     def _fused_operands(self, conv, bn):
-        key = _stamp(conv, bn)
-        cache = self.__dict__.setdefault("_fused_cache", {})
-        hit = cache.get(id(conv))
-        if hit is None or hit[0] != key:
-            scale, shift = bn_affine_cached(bn)
-            if conv.bias is not None:
-                shift = shift + scale * conv.bias.detach().float()
-            hit = (key, hip.wino_pack_weights(conv.weight, scale), shift.contiguous())
-            cache[id(conv)] = hit
-        return hit[1:]
+        return wino_fused_operands(self, conv, bn)
 
     def _conv_bn_act(self, f, conv, bn, act):
         B, C, H, W = f.shape
@@ -137,7 +128,17 @@ class DecoderBN(nn.Module):
 
     def forward(self, features):
         taps = {16: features[8], 8: features[6], 4: features[5], 2: features[4], 1: features[0]}
-        x = self.conv2(features[11])
+        f = features[11]
+        if (f.is_cuda and not needs_autograd(self) and f.dtype == torch.float32 and pw_wins(f)
+                and self.conv2.kernel_size == (1, 1) and self.conv2.padding == (1, 1)):
+            # the reference's 1x1 convolution with padding=1 (unet2d.py:65-67): bias on the one-pixel frame, the GEMM
+            # (K11s: 2560 -> 2560 on < 1000 pixels) inside it
+            wpk, shift = pw_operands(self, self.conv2)
+            B, _, H, W = f.shape
+            x = shift.view(1, -1, 1, 1).expand(B, self.conv2.out_channels, H + 2, W + 2).contiguous()
+            x[:, :, 1:-1, 1:-1] = hip.conv1x1(f, wpk, self.conv2.out_channels, shift)
+        else:
+            x = self.conv2(f)
         if not self.use_decoder:
             bs = features[4].shape[0]
             return {"1_1": self.resize_output_1_1(features[0]), "1_2": self.resize_output_1_2(features[4]),

@@ -147,8 +147,8 @@ def test_round2_2d_entry_points_validate_arguments(hip_lib):
     assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1
     a.x = a.wpk = a.y = ptr
     a.batch, a.cin, a.cout, a.N = 1, 8, 8, 16
-    a.tile_hint = 9
-    assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1                       # unknown variant
+    a.tile_hint = 13
+    assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1                       # unknown variant (1..6 K11, 7..12 K11s)
     a.tile_hint, a.out_nhwc_cs = 0, 4
     assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1                       # NHWC row shorter than Cout
     assert hip_lib.occd_dwconv2d_pool_blocks(185, 610) == (185 * 153 + 255) // 256

@@ -17,6 +17,9 @@ CASES = [
     (1, 83, 64, (50, 100), None, False, False),         # resize_output-like: ragged cin (tail chunk), bias via shift
     (3, 20, 10, (7,), "leaky", True, True),             # tiny everything, 1-D spatial
     (1, 128, 104, (47, 153), None, False, False),       # DepthNet.depth_pred
+    (2, 2304, 384, (12, 39), None, True, True),         # stage-6 project conv (split-K variants by default)
+    (2, 160, 960, (24, 77), "swish", False, False),     # stage-4 expand conv
+    (1, 1344, 224, (5, 9), None, True, True),           # fewer pixels than one tile, K not a multiple of the wave split
 ]
 
 
@@ -57,8 +60,31 @@ def test_pointwise_conv_host_logic_cpu(case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_pointwise_conv_kernel_gpu(case, hip_lib):
-    err = run(case, "cuda", 2e-5, hints=(0, 1, 2, 3, 4, 5, 6))
+    err = run(case, "cuda", 2e-5, hints=tuple(range(0, 13)))          # 1..6 = K11, 7..12 = K11s (split-K)
     print(case, f"worst rel err vs float64 over the tile variants {err:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 1280, 64, (24, 77)), (1, 83, 61, (50, 100)), (2, 160, 64, (9, 300))])
+def test_pointwise_conv_pixel_major_gpu(case, hip_lib):
+    """nhwc=True (what the decoder heads hand to the 2D->3D lift): every K11 / K11s variant writes pixel-major rows of
+    ceil4(Cout) floats with a zero channel pad, and returns the logical (B, Cout, H, W) view of them."""
+    from occdepth_amd import hip
+    B, cin, cout, sp = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+    shift = torch.randn(cout, generator=g)
+    ref = torch.einsum("oc,bchw->bohw", w.double().reshape(cout, cin), x.double()) + shift.double().view(1, -1, 1, 1)
+    wpk = hip.pw_pack_weights(w.cuda())
+    for h in range(0, 13):
+        y = hip.conv1x1(x.cuda(), wpk, cout, shift.cuda(), nhwc=True, tile_hint=h)
+        assert y.shape == ref.shape and y.stride(1) == 1, (h, y.shape, y.stride())
+        err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, (case, h, err)
+        rows = y.permute(0, 2, 3, 1)                               # the storage: (B, H, W, ceil4(Cout)) rows
+        base = torch.as_strided(rows, (B, sp[0], sp[1], (cout + 3) // 4 * 4), rows.stride())
+        assert float(base[..., cout:].abs().max()) == 0.0 if cout % 4 else True
 
 
 # ---------------------------------------------------------------------------------------------------------------

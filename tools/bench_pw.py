@@ -30,7 +30,7 @@ for cin, cout, H, W, n in SHAPES:
     tr = t(lambda: F.conv2d(x, w))
     best, bh = 1e9, 0
     row = []
-    for h in range(0, 7):
+    for h in range(0, 13):
         try:
             ms = t(lambda: hip.conv1x1(x, wpk, cout, tile_hint=h, out=y))
         except RuntimeError:
