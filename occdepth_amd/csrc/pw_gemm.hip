@@ -422,10 +422,11 @@ int occd_pw_conv_fwd(const occd_pw_args* a, void* stream) {
         // enough to split: the largest register tile that still gives every CU a workgroup
         static const int wg_m[7] = {0, 1, 2, 4, 8, 16, 8}, wg_n[7] = {0, 512, 512, 256, 128, 64, 64};   // couts/32, pixels per WG
         const long wgs = (long)((mb + wg_m[hint] - 1) / wg_m[hint]) * ((a->N + wg_n[hint] - 1) / wg_n[hint]) * a->batch;
-        if (wgs < kSplitKBelowWgs && p.kchunks >= 16) {
+        if (wgs < kSplitKBelowWgs && p.kchunks >= 36) {
+            // measured on the B7 project convolutions (profiles/r02_pw_gemm_layers.txt): the 64 x 64 tile wins down to
+            // ~100 workgroups (operand re-reads from L2 cost more than idle CUs), then 64 x 32 and 32 x 32 with 8 waves on K
             auto tiles = [&](int mt, int nt) { return (long)((mb + mt - 1) / mt) * ((a->N + 32 * nt - 1) / (32 * nt)) * a->batch; };
-            const bool longk = p.kchunks >= 48;
-            hint = tiles(2, 2) >= 256 ? 11 : tiles(2, 1) >= 256 ? (longk ? 9 : 12) : (longk ? 8 : 7);
+            hint = tiles(2, 2) >= 128 ? 11 : tiles(2, 1) >= 128 ? 9 : 8;
         }
     }
     switch (hint) {

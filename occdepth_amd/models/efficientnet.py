@@ -31,6 +31,16 @@ def pw_wins(x):
     return PW_FUSED and x.shape[0] * x.shape[2] * x.shape[3] >= PW_MIN_PIXELS
 
 
+# Expand convolutions (short K, up to 3840 couts, no gate) on maps of fewer pixels than this go to the library GEMM + one
+# BN / swish pass: rocBLAS' LDS-tiled kernels run them at 70-90 TF/s where K11 / K11s reach 40-50
+# (profiles/r02_pw_gemm_layers.txt); the project convolutions (long K, SE gate + BN + skip fused) stay on K11s.
+PW_EXPAND_LIB_BELOW = int(os.environ.get("OCCDEPTH_PW_EXPAND_LIB_BELOW", "14000"))
+
+
+def expand_on_library(x):
+    return x.shape[0] * x.shape[2] * x.shape[3] < PW_EXPAND_LIB_BELOW
+
+
 def pw_operands(owner, conv, bn=None):
     """(packed K11 weights with the BatchNorm scale folded in, shift) of a 1x1 convolution (+ BatchNorm), cached on
     `owner` until a source tensor changes (load_state_dict, optimizer step: (data_ptr, _version) stamp)."""
@@ -72,7 +82,8 @@ class Conv2dSame(nn.Conv2d):
     """TensorFlow 'SAME' padding: output = ceil(input / stride), extra pad goes right/bottom."""
 
     def forward(self, x):
-        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and _fast(x, self) and pw_wins(x)):
+        if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and _fast(x, self) and pw_wins(x)
+                and not expand_on_library(x)):
             wpk, shift = pw_operands(self, self)            # e.g. conv_head: plain 1x1 convolution on the MFMA GEMM (K11)
             return hip.conv1x1(x, wpk, self.out_channels, shift)
         if (self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda and needs_autograd(self)
@@ -167,8 +178,11 @@ class InvertedResidual(nn.Module):
         if _fast(x, self) and pw_wins(x):
             # 4 launches instead of 11: expand GEMM + BN + swish, depthwise + BN + swish + SE pooling, SE gate,
             # project GEMM with the gate on its input channels + BN + skip
-            wpk, shift = pw_operands(self, self.conv_pw, self.bn1)
-            y = hip.conv1x1(x, wpk, self.conv_pw.out_channels, shift, "swish")
+            if expand_on_library(x):
+                y = hip.affine_act(F.conv2d(x, self.conv_pw.weight), *bn_affine_cached(self.bn1), "swish")
+            else:
+                wpk, shift = pw_operands(self, self.conv_pw, self.bn1)
+                y = hip.conv1x1(x, wpk, self.conv_pw.out_channels, shift, "swish")
             y, part, plane = hip.dwconv2d_same_pool(y, self.conv_dw.weight, *bn_affine_cached(self.bn2),
                                                     self.conv_dw.stride[0], "swish")
             gate = self.se.gate_from_pool(part, plane, x.shape[0])

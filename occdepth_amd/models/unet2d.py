@@ -126,19 +126,25 @@ class DecoderBN(nn.Module):
             setattr(self, f"up{s}", UpSampleBN(skip_input=prev + skip, output_features=width))
             prev = width
 
-    def forward(self, features):
+    def _conv2_merged(self, f, conv_head):
+        """conv2(conv_head(f)) as ONE convolution: both are 1x1 and nothing sits between them (the reference taps
+        features[11] = conv_head's raw output, unet2d.py:146,183), so W = W_conv2 . W_head (formed once in float64) and the
+        2560 -> 2560 GEMM on the 1/32 map disappears: 640 -> 2560 with conv2's bias and conv2's padding=1 frame."""
+        key = _stamp(self.conv2, conv_head)
+        hit = self.__dict__.get("_merged_head")
+        if hit is None or hit[0] != key:
+            w2 = self.conv2.weight.detach().double().flatten(1)
+            wh = conv_head.weight.detach().double().flatten(1)
+            hit = (key, (w2 @ wh).float().reshape(w2.shape[0], wh.shape[1], 1, 1).contiguous())
+            self.__dict__["_merged_head"] = hit
+        return F.conv2d(f, hit[1], self.conv2.bias, self.conv2.stride, self.conv2.padding)
+
+    def forward(self, features, merged_head=None):
         taps = {16: features[8], 8: features[6], 4: features[5], 2: features[4], 1: features[0]}
-        f = features[11]
-        if (f.is_cuda and not needs_autograd(self) and f.dtype == torch.float32 and pw_wins(f)
-                and self.conv2.kernel_size == (1, 1) and self.conv2.padding == (1, 1)):
-            # the reference's 1x1 convolution with padding=1 (unet2d.py:65-67): bias on the one-pixel frame, the GEMM
-            # (K11s: 2560 -> 2560 on < 1000 pixels) inside it
-            wpk, shift = pw_operands(self, self.conv2)
-            B, _, H, W = f.shape
-            x = shift.view(1, -1, 1, 1).expand(B, self.conv2.out_channels, H + 2, W + 2).contiguous()
-            x[:, :, 1:-1, 1:-1] = hip.conv1x1(f, wpk, self.conv2.out_channels, shift)
+        if merged_head is not None:
+            x = self._conv2_merged(features[10], merged_head)
         else:
-            x = self.conv2(f)
+            x = self.conv2(features[11])
         if not self.use_decoder:
             bs = features[4].shape[0]
             return {"1_1": self.resize_output_1_1(features[0]), "1_2": self.resize_output_1_2(features[4]),
@@ -165,12 +171,19 @@ class Encoder(nn.Module):
         super().__init__()
         self.original_model = backend
 
-    def forward(self, x):
+    HEAD = ("conv_head", "bn2", "act2", "global_pool", "classifier")
+
+    def forward(self, x, skip_head=False):
+        """The reference's feature list (unet2d.py:175-190).  skip_head: leave None in the slots of conv_head and of
+        the modules behind it -- the decoder only taps conv_head's output (features[11]) and, in the eval path, gets it
+        folded into its own first convolution (DecoderBN._conv2_merged); bn2 / act2 / pool / classifier are dead code."""
         features = [x]
         for name, mod in self.original_model._modules.items():
             if name == "blocks":
                 for stage in mod._modules.values():
                     features.append(stage(features[-1]))
+            elif skip_head and name in self.HEAD:
+                features.append(None)
             else:
                 features.append(mod(features[-1]))
         return features
@@ -186,7 +199,17 @@ class UNet2D(nn.Module):
                                  num_features=num_features, backbone_2d_name=backbone_2d_name,
                                  return_up_feats=return_up_feats)
 
+    # eval path: conv_head folded into the decoder's conv2 (OCCDEPTH_MERGE_HEAD=0 restores the two GEMMs for A/B)
+    MERGE_HEAD = os.environ.get("OCCDEPTH_MERGE_HEAD", "1") == "1"
+
     def forward(self, x, **kwargs):
+        head = getattr(self.encoder.original_model, "conv_head", None)
+        if (self.MERGE_HEAD and self.use_decoder and x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32
+                and isinstance(head, nn.Conv2d) and head.kernel_size == (1, 1) and head.stride == (1, 1)
+                and head.bias is None and head.groups == 1 and self.decoder.conv2.kernel_size == (1, 1)
+                and list(self.encoder.original_model._modules)[:5] == ["conv_stem", "bn1", "act1", "blocks", "conv_head"]
+                and len(self.encoder.original_model.blocks) == 7):      # i.e. features[10] feeds conv_head, features[11] conv2
+            return self.decoder(self.encoder(x, skip_head=True), merged_head=head, **kwargs)
         return self.decoder(self.encoder(x), **kwargs)
 
     def get_encoder_params(self):

@@ -493,3 +493,39 @@ def test_graph_replay_of_2d_network_matches_eager(config2):
     finally:
         m.batch_views, m.graph_2d = saved
         m._graphs = {}
+
+
+def test_graph_capture_failure_falls_back_to_eager(monkeypatch):
+    """`graph_2d` is an optimisation, never a requirement: when hipGraph capture raises, the model warns, records the
+    reason (`graph_2d_error`, which bench.py copies into its JSON line), switches the flag off and returns the eager
+    result of the same kernels."""
+    m, cfg, sd = build_product("kitti_small")
+    m = m.to(DEV).eval()
+    batch = to_dev(gc.occdepth_batch("kitti_small"))
+    m.batch_views = True
+    with torch.no_grad():
+        m.graph_2d = False
+        eager = {k: v.clone() for k, v in m(batch).items() if v is not None}
+
+    class Boom:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError("capture refused (test)")
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "graph", Boom)
+    m.graph_2d = True
+    m._graphs = {}
+    with torch.no_grad(), pytest.warns(UserWarning, match="hipGraph capture"):
+        out = m(batch)
+    assert m.graph_2d is False and "capture refused" in m.graph_2d_error and not m._graphs
+    for k, v in eager.items():
+        err = ((out[k] - v).abs().max() / v.abs().max().clamp_min(1e-30)).item()
+        assert err < 5e-4, (k, err)
+    with torch.no_grad():
+        again = m(batch)                                    # stays eager, no second warning path
+    assert torch.isfinite(again["ssc_logit"]).all()

@@ -204,3 +204,33 @@ def test_depthwise_autograd_gpu(shape, hip_lib):
     for got, want in ((y, ref), (xc.grad, xd.grad), (wc.grad, wd.grad)):
         assert got.shape == want.shape
         assert float((got.double().cpu() - want.detach()).abs().max() / want.detach().abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_merged_head_matches_two_gemms_gpu(hip_lib):
+    """Eval path: conv_head (encoder) folded into the decoder's conv2 -- one 1x1 convolution with W = W_conv2 . W_head,
+    conv2's bias and its padding=1 frame -- against the unmerged module path of the same network."""
+    from occdepth_amd.models.unet2d import UNet2D
+    torch.manual_seed(3)
+    m = UNet2D.build(out_feature=16, use_decoder=True, backbone_2d_name="tf_efficientnet_b3_ns", return_up_feats=1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.7, 1.3)
+    m = m.cuda().eval()
+    x = torch.randn(2, 3, 70, 122, device="cuda")
+    saved = UNet2D.MERGE_HEAD
+    try:
+        with torch.no_grad():
+            UNet2D.MERGE_HEAD = False
+            ref = m(x)
+            UNet2D.MERGE_HEAD = True
+            feats = m.encoder(x, skip_head=True)
+            assert feats[11] is None and feats[12] is None and feats[10] is not None
+            got = m(x)
+    finally:
+        UNet2D.MERGE_HEAD = saved
+    assert set(got) == set(ref)
+    for k in ref:
+        err = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        assert got[k].shape == ref[k].shape and err < 1e-4, (k, err)
