@@ -12,6 +12,33 @@ import sys
 from collections import defaultdict
 
 
+def train_main(path, out):
+    """Training trace (tools/bench_train.py): one steady-state step = the kernels between the last two optimizer
+    updates (fused AdamW multi-tensor kernels mark the end of a step)."""
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"].lower()]
+    assert adam, "no optimizer kernels in the trace"
+    ends = [i for k, i in enumerate(adam) if k + 1 == len(adam) or adam[k + 1] - i > 50]    # last kernel of each update
+    assert len(ends) >= 2, "need two optimizer updates"
+    sel = rows[ends[-2] + 1:ends[-1] + 1]
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in sel:
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:120]
+        a = agg[n]
+        a[0] += 1
+        a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    tot = sum(v[1] for v in agg.values())
+    span = int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])
+    with open(out, "w") as f:
+        f.write(f"# one steady-state training step (between the last two AdamW updates): {len(sel)} launches, "
+                f"GPU busy {tot / 1e6:.2f} ms, wall span {span / 1e6:.2f} ms\n")
+        f.write("kernel,calls,ms,avg_us,percent\n")
+        for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"\"{n}\",{c},{t / 1e6:.3f},{t / 1e3 / c:.2f},{100 * t / tot:.2f}\n")
+    print(open(out).read()[:6000])
+
+
 def main(path, out, n_fwd=5):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -41,4 +68,7 @@ def main(path, out, n_fwd=5):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 5)
+    if len(sys.argv) > 3 and sys.argv[3] == "train":
+        train_main(sys.argv[1], sys.argv[2])
+    else:
+        main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 5)
