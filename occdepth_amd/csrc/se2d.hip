@@ -10,56 +10,57 @@
 
 namespace {
 
-constexpr int kROut = 4;     // reduce outputs per workgroup (1 per wave)
+constexpr int kWPre = 16;    // weight values a thread preloads (C <= 256 * kWPre = 4096; beyond, a plain loop)
 
-// Latency, not bandwidth, decides these kernels: a wave that sums 60 dependent global loads one after the other waits
-// 60 HBM round trips (the first version: 26 us on the 3840-channel stages).  So every loop below is unrolled into
-// independent accumulators (8 loads in flight per lane), and the sums keep a fixed order (deterministic).
+// Latency, not bandwidth, decides this kernel (the weights are cold every frame -- the network's parameters exceed the
+// Infinity Cache -- and every global load costs an HBM round trip): the first versions walked a weight row with one
+// wave, 36-60 dependent loads deep (20-26 us per launch, 1.1 ms per frame).  Now ONE WORKGROUP PER OUTPUT: its 256
+// threads issue their <= 16 weight loads first, then the pooling partials (tpc threads per channel, 4 independent
+// accumulators), and only then touch any of them: two round trips per launch.  All sums keep a fixed order.
 __global__ void __launch_bounds__(256) se_reduce_kernel(const float* __restrict__ part, const float* __restrict__ wr,
                                                         const float* __restrict__ br, float* __restrict__ r, int C,
-                                                        int Cr, int nblk, float inv_s) {
+                                                        int Cr, int nblk, float inv_s, int tpc) {
     extern __shared__ float mean[];                       // C floats
-    const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* pb = part + (size_t)b * C * nblk;
-    if (nblk <= 4) {
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float s = 0.f;
-            for (int j = 0; j < nblk; ++j) s += pb[(size_t)c * nblk + j];
-            mean[c] = s * inv_s;
-        }
-    } else {
-        // many partials per channel (high-resolution stages): a wave per channel, lanes across the partials
-        for (int c = wave; c < C; c += 4) {
-            const float* pc = pb + (size_t)c * nblk;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int j = lane;
-            for (; j + 192 < nblk; j += 256) {
-                s0 += pc[j]; s1 += pc[j + 64]; s2 += pc[j + 128]; s3 += pc[j + 192];
-            }
-            for (; j < nblk; j += 64) s0 += pc[j];
-            float s = (s0 + s1) + (s2 + s3);
+    __shared__ float wsum[4];
+    const int b = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+    const float* w = wr + (size_t)i * C;
+    float wv[kWPre];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0) mean[c] = s * inv_s;
+    for (int u = 0; u < kWPre; ++u) wv[u] = w[min(t + u * 256, C - 1)];        // (clamped; unused tail masked below)
+    // ---- pooled means: channel c = c0 + t / tpc, partials j = t % tpc, + tpc, ...
+    const float* pb = part + (size_t)b * C * nblk;
+    const int cl = t / tpc, jp = t - cl * tpc, cpp = 256 / tpc;
+    for (int c0 = 0; c0 < C; c0 += cpp) {
+        const int c = c0 + cl;
+        const float* pc = pb + (size_t)min(c, C - 1) * nblk;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int j = jp;
+        for (; j + 3 * tpc < nblk; j += 4 * tpc) {
+            s0 += pc[j]; s1 += pc[j + tpc]; s2 += pc[j + 2 * tpc]; s3 += pc[j + 3 * tpc];
         }
+        for (; j < nblk; j += tpc) s0 += pc[j];
+        float sum = (s0 + s1) + (s2 + s3);
+        for (int off = tpc >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);   // tpc divides 64: groups stay in a wave
+        if (jp == 0 && c < C) mean[c] = sum * inv_s;
     }
     __syncthreads();
-    const int i = blockIdx.x * kROut + wave;
-    if (i >= Cr) return;                                  // wave-uniform
-    const float* w = wr + (size_t)i * C;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int c = lane;
-    for (; c + 7 * 64 < C; c += 8 * 64) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += w[c + u * 64] * mean[c + u * 64];
+    for (int u = 0; u < kWPre; u += 4) {
+        const int c = t + u * 256;
+        if (c < C) a0 += wv[u] * mean[c];
+        if (c + 256 < C) a1 += wv[u + 1] * mean[c + 256];
+        if (c + 512 < C) a2 += wv[u + 2] * mean[c + 512];
+        if (c + 768 < C) a3 += wv[u + 3] * mean[c + 768];
     }
-    for (; c < C; c += 64) a[0] += w[c] * mean[c];
-    float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int c = t + kWPre * 256; c < C; c += 256) a0 += w[c] * mean[c];
+    float sum = (a0 + a1) + (a2 + a3);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) {
-        const float v = s + br[i];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = sum;
+    __syncthreads();
+    if (t == 0) {
+        const float v = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]) + br[i];
         r[(size_t)b * Cr + i] = v / (1.f + expf(-v));
     }
 }
@@ -93,9 +94,10 @@ extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const
     if (batch < 1 || batch > 65535 || C < 1 || C > 16384 || Cr < 1 || Cr > 4096 || nblk < 1 || S < 1) return OCCD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     occd::ProfScope prof("se_gate", st, 4.0 * batch * C * Cr, 8.0 * C * Cr + 4.0 * batch * C * nblk);
-    hipLaunchKernelGGL(se_reduce_kernel, dim3((unsigned)((Cr + kROut - 1) / kROut), (unsigned)batch), dim3(256),
-                       (size_t)C * sizeof(float), st, pool_part, w_reduce, b_reduce, r_scratch, C, Cr, nblk,
-                       (float)(1.0 / (double)S));
+    int tpc = 1;                                           // threads per channel in the pooling phase
+    while (tpc < 64 && (long)tpc * 2 * C <= 256 && tpc * 2 <= nblk) tpc *= 2;
+    hipLaunchKernelGGL(se_reduce_kernel, dim3((unsigned)Cr, (unsigned)batch), dim3(256), (size_t)C * sizeof(float), st,
+                       pool_part, w_reduce, b_reduce, r_scratch, C, Cr, nblk, (float)(1.0 / (double)S), tpc);
     hipLaunchKernelGGL(se_expand_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)batch), dim3(256),
                        (size_t)Cr * sizeof(float), st, r_scratch, w_expand, b_expand, gate, C, Cr);
     return occd::check_launch();

@@ -22,8 +22,9 @@ import os
 from ...fused import bn_affine_cached, needs_autograd, wino_fused_operands
 
 # DepthNet's 3x3 convolutions on K10 (fused Winograd MFMA kernel, BatchNorm / ReLU / identity skip in its epilogue) instead
-# of MIOpen + a BatchNorm pass; OCCDEPTH_DEPTHNET_K10=0 restores MIOpen for A/B
-DEPTHNET_K10 = os.environ.get("OCCDEPTH_DEPTHNET_K10", "1") == "1"
+# of MIOpen + a BatchNorm pass: opt-in (OCCDEPTH_DEPTHNET_K10=1).  Measured: 128 channels on a 47x153 map are 120
+# workgroups of K10 -- 62 us per convolution against MIOpen's 46 + 6 us, so MIOpen stays the default here
+DEPTHNET_K10 = os.environ.get("OCCDEPTH_DEPTHNET_K10", "0") == "1"
 
 
 class BasicBlock(nn.Module):
