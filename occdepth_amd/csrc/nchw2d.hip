@@ -55,11 +55,80 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const float* __restrict
     }
 }
 
-// Depthwise forward: each thread produces 4 horizontally adjacent outputs of one (b, c) plane, the K*K weights live in
-// registers.  The first version read its window straight from global memory with 4-byte loads whose lanes sit 16 bytes
-// apart: every load instruction touched 8 cache lines for 256 useful bytes and the K * SPAN loads of a thread re-touched
-// the same lines, so it was bound by the texture-address / L1 path at ~1/4 of what its bytes allow (measured: 41 us for
-// 40 MB at the 1/16 level).  Here a workgroup first stages the input rows of its tile in LDS
+// each thread produces 4 horizontally adjacent outputs of one (b, c) plane: a row of the window is loaded once
+// ((4-1)*stride + K values) and reused by the 4 outputs; the K*K weights live in registers.
+template <int K, int STRIDE>
+__global__ void __launch_bounds__(256) dwconv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
+                                                              int pad_t, int pad_l, int act, float* __restrict__ pool_part) {
+    constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K;
+    __shared__ float wsum[4];
+    const int plane = blockIdx.y;
+    const int c = plane % C;
+    const int wq = (Wo + NX - 1) / NX;
+    const int item_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool live = item_raw < Ho * wq;
+    if (!live && pool_part == nullptr) return;
+    const int item = live ? item_raw : 0;                  // (dead lanes of the last block still join the reduction)
+    const int oy = item / wq, ox0 = (item - oy * wq) * NX;
+    const float* xp = x + (size_t)plane * H * W;
+    float wr[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)c * K * K + i];
+    float acc[NX] = {0.f, 0.f, 0.f, 0.f};
+    const int ix0 = ox0 * STRIDE - pad_l;
+    // Every load is unconditional (clamped address) and the padding is a bit mask on the loaded value: a load guarded by
+    // a runtime condition makes hipcc branch around it and wait for each one separately, which serialised the K * SPAN
+    // loads of a thread (the kernel ran at a quarter of what its bytes allow).
+    int cix[SPAN];
+    uint32_t cm[SPAN];
+#pragma unroll
+    for (int j = 0; j < SPAN; ++j) {
+        const int ix = ix0 + j;
+        cm[j] = 0u - (uint32_t)((unsigned)ix < (unsigned)W);
+        cix[j] = min(max(ix, 0), W - 1);
+    }
+    float v[K][SPAN];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * STRIDE - pad_t + ky;
+        const uint32_t rm = 0u - (uint32_t)((unsigned)iy < (unsigned)H);
+        const float* row = xp + (size_t)min(max(iy, 0), H - 1) * W;
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j) v[ky][j] = __uint_as_float(__float_as_uint(row[cix[j]]) & (rm & cm[j]));
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int o = 0; o < NX; ++o)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[o] += v[ky][o * STRIDE + kx] * wr[ky * K + kx];
+    const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
+    float* yp = y + ((size_t)plane * Ho + oy) * Wo + ox0;
+    float part = 0.f;
+#pragma unroll
+    for (int o = 0; o < NX; ++o)
+        if (live && ox0 + o < Wo) {
+            const float v = act_apply(acc[o] * s + t, act, 0.f);
+            yp[o] = v;
+            part += v;
+        }
+    if (pool_part != nullptr) {
+        // squeeze-excite pooling: this workgroup's share of sum_{y,x} y[b][c] in a FIXED order (wave tree, then 4
+        // partials), one float per (plane, workgroup); occd_se_gate sums the partials in index order: deterministic
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) pool_part[(size_t)plane * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
+}
+
+// The forward kernel of the product.  The direct kernel above reads its window with 4-byte loads whose lanes sit 16
+// bytes apart: every load instruction touches 8 cache lines for 256 useful bytes and the K * SPAN loads of a thread
+// re-touch the same lines, so the kernel is bound by the texture-address / L1 path at ~1/4 of what its bytes allow
+// (measured: 41 us for 40 MB at the 1/16 level).  Here a workgroup first stages the input rows of its 256 items in LDS
 // with fully coalesced loads (lane = consecutive float; zero padding written into the tile, so the compute phase has no
 // bounds checks), then every thread reads its window rows as aligned 16-byte LDS vectors (column j of the tile is image
 // column j - pad_l, so the window of output quad q starts at j = 4 q STRIDE).
@@ -68,48 +137,39 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
                                                        int pad_t, int pad_l, int act, float* __restrict__ pool_part,
-                                                       int tq, int th, int tiles_x) {
+                                                       int wp) {
     constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K, SPAN4 = (SPAN + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [rows][wp]
     __shared__ float wsum[4];
     const int plane = blockIdx.y;
     const int c = plane % C;
-    // a workgroup = a tile of tq output quads x th output rows (tq * th <= 256): wide planes get 64-quad x 4-row tiles
-    // (2 halo rows on 4 instead of on 1.7), narrow planes one tile over their whole width
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int q0 = tx * tq, oy0 = ty * th;
-    const int wp = 4 * (tq - 1) * STRIDE + 4 * SPAN4;
-    const int nrows = (min(th, Ho - oy0) - 1) * STRIDE + K;
-    const int iy_first = oy0 * STRIDE - pad_t, ix_first = q0 * NX * STRIDE - pad_l;
+    const int wq = (Wo + NX - 1) / NX;
+    const int nitems = Ho * wq;
+    const int item0 = blockIdx.x * 256;
+    const int oy_first = item0 / wq;
+    const int oy_last = min(item0 + 255, nitems - 1) / wq;
+    const int iy_first = oy_first * STRIDE - pad_t;
+    const int nrows = (oy_last - oy_first) * STRIDE + K;
     const float* xp = x + (size_t)plane * H * W;
-    // ---- stage: unconditional clamped loads, padding as a bit mask on the loaded value; 4 loads in flight per thread
+    // ---- stage: unconditional clamped loads, padding as a bit mask on the loaded value
     const int total = nrows * wp;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * 256) {
-        float v[4];
-        uint32_t ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = min(e0 + u * 256, total - 1);
-            const int r = e / wp, j = e - r * wp;
-            const int iy = iy_first + r, ix = ix_first + j;
-            ok[u] = 0u - (uint32_t)(((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W));
-            v[u] = xp[(size_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e0 + u * 256 < total) tile[e0 + u * 256] = __uint_as_float(__float_as_uint(v[u]) & ok[u]);
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int r = e / wp, j = e - r * wp;
+        const int iy = iy_first + r, ix = j - pad_l;
+        const uint32_t ok = 0u - (uint32_t)(((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W));
+        const float v = xp[(size_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
+        tile[e] = __uint_as_float(__float_as_uint(v) & ok);
     }
     float wr[K * K];
 #pragma unroll
     for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)c * K * K + i];
     __syncthreads();
     // ---- compute
-    const int wq = (Wo + NX - 1) / NX;
-    const int ly = threadIdx.x / tq, lq = threadIdx.x - ly * tq;
-    const int oy = oy0 + ly, q = q0 + lq;
-    const bool live = ly < th && oy < Ho && q < wq;
-    const int ox0 = q * NX;
-    const float* trow = tile + (size_t)((live ? ly : 0) * STRIDE) * wp + (live ? lq : 0) * NX * STRIDE;
+    const int item_raw = item0 + threadIdx.x;
+    const bool live = item_raw < nitems;
+    const int item = live ? item_raw : item0;               // (dead lanes of the last block still join the reduction)
+    const int oy = item / wq, q = item - oy * wq, ox0 = q * NX;
+    const float* trow = tile + (size_t)((oy - oy_first) * STRIDE) * wp + q * NX * STRIDE;
     float acc[NX] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
@@ -125,7 +185,7 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
             for (int kx = 0; kx < K; ++kx) acc[o] += v[o * STRIDE + kx] * wr[ky * K + kx];
     }
     const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
-    float* yp = y + ((size_t)plane * Ho + (live ? oy : 0)) * Wo + ox0;
+    float* yp = y + ((size_t)plane * Ho + oy) * Wo + ox0;
     float part = 0.f;
 #pragma unroll
     for (int o = 0; o < NX; ++o)
@@ -355,18 +415,6 @@ extern "C" int occd_affine_act_nchw(const float* x, const float* res, float* y, 
     return occd::check_launch();
 }
 
-struct DwTiling { int tq, th, tiles_x, tiles_y; };
-static DwTiling dw_tiling(int Ho, int Wo) {
-    DwTiling t;
-    const int wq = (Wo + 3) / 4;
-    t.tq = wq < 64 ? wq : 64;
-    t.th = 256 / t.tq;
-    if (t.th > Ho) t.th = Ho;
-    t.tiles_x = (wq + t.tq - 1) / t.tq;
-    t.tiles_y = (Ho + t.th - 1) / t.th;
-    return t;
-}
-
 static int dwconv_launch(const float* x, const float* w, const float* scale, const float* shift, float* y,
                          int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride, int32_t pad_top,
                          int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act, float* pool_part, void* stream) {
@@ -374,19 +422,22 @@ static int dwconv_launch(const float* x, const float* w, const float* scale, con
         return OCCD_EINVAL;
     if ((k != 3 && k != 5) || act < 0 || act > 2 || (long)batch * C > 65535) return OCCD_EINVAL;
     if (stride != 1 && stride != 2) return OCCD_EINVAL;
+    const int items = Ho * ((Wo + 3) / 4);
+    const dim3 grid((unsigned)((items + 255) / 256), (unsigned)(batch * C));
     occd::ProfScope prof("dwconv2d_nchw", (hipStream_t)stream, 2.0 * batch * C * (double)Ho * Wo * k * k,
                          4.0 * batch * C * ((double)H * W + (double)Ho * Wo));
     hipStream_t st = (hipStream_t)stream;
-    // staged kernel: tiles of tq quads x th rows (see dwconv2d_kernel); LDS = rows x padded width of one tile
-    DwTiling tl = dw_tiling(Ho, Wo);
+    // LDS tile of the staged kernel: rows of one workgroup's 256 items x padded width (see dwconv2d_kernel)
+    const int wq = (Wo + 3) / 4;
     const int span4 = ((3 * stride + k) + 3) / 4;
-    const int wp = 4 * (tl.tq - 1) * stride + 4 * span4;
-    const size_t lds = (size_t)((tl.th - 1) * stride + k) * wp * sizeof(float);
+    const int wp = 4 * (wq - 1) * stride + 4 * span4;
+    int dmax = (255 + wq - 1) / wq;
+    if (dmax > Ho - 1) dmax = Ho - 1;
+    const size_t lds = (size_t)(dmax * stride + k) * wp * sizeof(float);
     if (lds <= 48 * 1024) {
-        const dim3 tgrid((unsigned)(tl.tiles_x * tl.tiles_y), (unsigned)(batch * C));
-#define OCCD_DW(KK, SS)                                                                                              \
-    hipLaunchKernelGGL((dwconv2d_kernel<KK, SS>), tgrid, dim3(256), lds, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
-                       pad_top, pad_left, act, pool_part, tl.tq, tl.th, tl.tiles_x)
+#define OCCD_DW(KK, SS)                                                                                             \
+    hipLaunchKernelGGL((dwconv2d_kernel<KK, SS>), grid, dim3(256), lds, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
+                       pad_top, pad_left, act, pool_part, wp)
         if (k == 3 && stride == 1) OCCD_DW(3, 1);
         else if (k == 3) OCCD_DW(3, 2);
         else if (stride == 1) OCCD_DW(5, 1);
@@ -394,7 +445,15 @@ static int dwconv_launch(const float* x, const float* w, const float* scale, con
 #undef OCCD_DW
         return occd::check_launch();
     }
-    return OCCD_EINVAL;                                    // (unreachable: a tile never exceeds 25 KB)
+#define OCCD_DW(KK, SS)                                                                                                 \
+    hipLaunchKernelGGL((dwconv2d_direct_kernel<KK, SS>), grid, dim3(256), 0, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
+                       pad_top, pad_left, act, pool_part)
+    if (k == 3 && stride == 1) OCCD_DW(3, 1);
+    else if (k == 3) OCCD_DW(3, 2);
+    else if (stride == 1) OCCD_DW(5, 1);
+    else OCCD_DW(5, 2);
+#undef OCCD_DW
+    return occd::check_launch();
 }
 
 extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
@@ -404,11 +463,7 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
     return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, nullptr, stream);
 }
 
-extern "C" int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo) {
-    if (Ho < 1 || Wo < 1) return OCCD_EINVAL;
-    const DwTiling t = dw_tiling(Ho, Wo);
-    return t.tiles_x * t.tiles_y;
-}
+extern "C" int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo) { return (Ho * ((Wo + 3) / 4) + 255) / 256; }
 
 extern "C" int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                        float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,

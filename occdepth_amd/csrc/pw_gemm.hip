@@ -16,7 +16,7 @@
 //     fragment is reused by its MT cout blocks and its A fragment by its NT pixel blocks; nothing is shared between
 //     waves, so there is no LDS and no barrier: a wave is an independent (MT*32) x (NT*32) register-blocked GEMM and
 //     the 4 waves of a workgroup sit side by side (WM along couts x WN along pixels) only for L1 locality;
-//   * fragments of steps c+1 .. c+3 are in flight under the MFMAs of step c (ring of raw operand registers).
+//   * fragments of step c+1 are loaded before the MFMAs of step c.
 // Most of these layers are HBM-bound (algorithmic bytes 4 * B * N * (Cin + Cout (+ Cout for the residual))); the
 // wide ones (Cin, Cout >= 640) are MFMA-bound (2 * B * N * Cin8 * Cout32 FLOP).
 //
@@ -132,44 +132,28 @@ __global__ void __launch_bounds__(256, (MT * NT > 4 ? 2 : 3)) pw_gemm_kernel(con
         }
     };
 
-    // Software pipeline of depth PF (ring of raw operand registers): the loads of step c + PF are issued above the MFMAs
-    // of step c.  One step is only 4 * MT * NT MFMAs (0.1-0.4 us), far less than an L2 / HBM round trip, and with 2-3
-    // waves per SIMD a one-step prefetch left the matrix pipe waiting on memory at every step.
-    {
-        // (the wide tiles have no registers for a third stage; the gate costs another 4 per stage)
-        constexpr int PF = GATE ? (MT * NT >= 8 && NT >= 4 ? 1 : 2) : (NT >= 4 || MT * NT > 4) ? 2 : 3;
-        f32x4 a_r[PF][MT], b_r[PF][NT], g_r[PF];
-        const int last = p.kchunks - 1;
+    f32x4 a_cur[MT], b_cur[NT], b_raw[NT], g_raw = {1.f, 1.f, 1.f, 1.f};
+    load_a(0, a_cur);
+    load_b(0, b_raw, g_raw);
+    finish_b(0, b_raw, g_raw, b_cur);
+    for (int c = 0; c < p.kchunks; ++c) {
+        f32x4 a_nxt[MT];
+        const int cn = c + 1 < p.kchunks ? c + 1 : c;              // (the last step re-reads itself: no branch)
+        load_a(cn, a_nxt);
+        load_b(cn, b_raw, g_raw);
+        __builtin_amdgcn_sched_barrier(0);                         // the next step's loads stay ABOVE this step's MFMAs
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            g_r[u] = f32x4{1.f, 1.f, 1.f, 1.f};
-            load_a(min(u, last), a_r[u]);
-            load_b(min(u, last), b_r[u], g_r[u]);
-        }
-        for (int c0 = 0; c0 < p.kchunks; c0 += PF) {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int c = c0 + u;
-                if (c < p.kchunks) {                               // (wave-uniform)
-                    f32x4 a_cur[MT], b_cur[NT];
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_r[u][mt];
-                    finish_b(c, b_r[u], g_r[u], b_cur);
-                    load_a(min(c + PF, last), a_r[u]);
-                    load_b(min(c + PF, last), b_r[u], g_r[u]);
-                    __builtin_amdgcn_sched_barrier(0);             // the later steps' loads stay ABOVE this step's MFMAs
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = NHWC ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nt][q], a_cur[mt][q], acc[mt][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = NHWC ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nt][q], a_cur[mt][q], acc[mt][nt], 0, 0, 0)
-                                                   : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][q], b_cur[nt][q], acc[mt][nt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+        finish_b(cn, b_raw, g_raw, b_cur);
     }
 
     if (NHWC) {
