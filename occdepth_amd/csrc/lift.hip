@@ -37,6 +37,11 @@ __device__ __forceinline__ float group_sum(float v) {
 
 struct LiftP {
     occd_lift_args a;
+    // power-of-two fast path of lift_p1_kernel (every shipped KITTI geometry): shifts instead of integer divisions --
+    // the generic form spends ~25 VALU instructions per 32-bit division (2 per gathered row) and ~100 per 64-bit one (2
+    // per stored row), in a kernel that is VALU / latency bound
+    int sshift[OCCD_MAX_SCALES];
+    int bc_shift, c_shift;
 };
 
 // Stereo-SFA fusion of the V per-view feature vectors of one voxel (SFA.py:46-89).
@@ -82,7 +87,7 @@ __device__ __forceinline__ void store_voxel_row(const occd_lift_args& a, int b, 
 // Fast path: one pattern point (every shipped config), V views.  The kernel is latency-bound, so the
 // projection indices are fetched first and then the gathers of ALL scales and views are put in flight
 // together (V*S independent 16-byte loads per lane) before any arithmetic.
-template <int LPV, int V>
+template <int LPV, int V, bool P2>
 __global__ void __launch_bounds__(256) lift_p1_kernel(const LiftP pp) {
     const occd_lift_args& a = pp.a;
     const int tid = threadIdx.x;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(256) lift_p1_kernel(const LiftP pp) {
         for (int v = 0; v < V; ++v) {
             const int ss = s < a.n_scales ? s : 0;                       // (absent scales re-read scale 0: discarded)
             const int dv = a.scale_div[ss], w = a.feat_w[ss], cs = a.feat_cs[ss];
-            const int idx = (py[v] / dv) * w + (px[v] / dv);
+            const int idx = P2 ? (py[v] >> pp.sshift[ss]) * w + (px[v] >> pp.sshift[ss]) : (py[v] / dv) * w + (px[v] / dv);
             const f32x4 t = *(const f32x4*)(a.feat[ss][v] + (size_t)b * a.feat_bstride[ss][v] + (size_t)idx * cs + cc);
             const uint32_t k = s < a.n_scales ? keep[v] : 0u;
             g[s][v] = f32x4{__uint_as_float(__float_as_uint(t.x) & k), __uint_as_float(__float_as_uint(t.y) & k),
@@ -145,7 +150,16 @@ __global__ void __launch_bounds__(256) lift_p1_kernel(const LiftP pp) {
             if (s == 0) total = o; else total += o;
         }
     if (a.depth_scale != nullptr) total = total * a.depth_scale[(size_t)b * a.N + nn] * a.scale_const;
-    if (vox_ok && c < a.out_cs) store_voxel_row(a, b, n, c, ch_ok, total);
+    if (P2) {
+        if (vox_ok && c < a.out_cs) {
+            const uint32_t n32 = (uint32_t)n;
+            const uint32_t ia = n32 >> pp.bc_shift, rem = n32 & ((1u << pp.bc_shift) - 1u);
+            const uint32_t ib = rem >> pp.c_shift, ic = rem & ((1u << pp.c_shift) - 1u);
+            const long row = (long)ia * a.row_a + (long)ib * a.row_b + (long)ic * a.row_c;
+            float* o = a.out + ((size_t)b * a.out_rows + row) * a.out_cs + c;
+            *(f32x4*)o = ch_ok ? total : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else if (vox_ok && c < a.out_cs) store_voxel_row(a, b, n, c, ch_ok, total);
 }
 
 // ---------------------------------------------------------------- backward of the single-pattern-point lift (N1)
@@ -320,9 +334,11 @@ template <int LPV>
 void launch_lift(const LiftP& p, dim3 grid, hipStream_t st) {
     const int V = p.a.n_views;
     const bool p1 = p.a.P == 1;
+    const bool p2 = p.bc_shift >= 0;
 #define OCCD_LIFT(VV)                                                                             \
     if (V == VV) {                                                                                \
-        if (p1) hipLaunchKernelGGL((lift_p1_kernel<LPV, VV>), grid, dim3(256), 0, st, p);         \
+        if (p1 && p2) hipLaunchKernelGGL((lift_p1_kernel<LPV, VV, true>), grid, dim3(256), 0, st, p);   \
+        else if (p1) hipLaunchKernelGGL((lift_p1_kernel<LPV, VV, false>), grid, dim3(256), 0, st, p);   \
         else hipLaunchKernelGGL((lift_any_kernel<LPV, VV>), grid, dim3(256), 0, st, p);           \
     }
     OCCD_LIFT(1) OCCD_LIFT(2) OCCD_LIFT(3) OCCD_LIFT(4)
@@ -509,6 +525,17 @@ extern "C" int occd_lift_fwd(const occd_lift_args* a, void* stream) {
     p.a = *a;
     const int need = a->out_cs / 4;  // lanes that must exist per voxel
     const int lpv = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+    {   // shift form of the index arithmetic when every divisor is a power of two (pixel coordinates are >= 0)
+        auto lg2 = [](long v) { int s = 0; while ((1L << s) < v) ++s; return (1L << s) == v ? s : -1; };
+        bool all = true;
+        for (int s = 0; s < OCCD_MAX_SCALES; ++s) {
+            p.sshift[s] = s < a->n_scales ? lg2(a->scale_div[s]) : 0;
+            all = all && p.sshift[s] >= 0;
+        }
+        p.bc_shift = lg2((long)a->dimB * a->dimC);
+        p.c_shift = lg2(a->dimC);
+        if (!all || p.bc_shift < 0 || p.c_shift < 0) p.bc_shift = p.c_shift = -1;
+    }
     for (int s = 0; s < a->n_scales; ++s)
         for (int v = 0; v < a->n_views; ++v)
             if (p.a.feat_bstride[s][v] == 0) p.a.feat_bstride[s][v] = (int64_t)a->feat_h[s] * a->feat_w[s] * a->feat_cs[s];

@@ -347,30 +347,48 @@ __global__ void dwconv2d_bwd_weight_reduce_kernel(const float* __restrict__ part
     dw[i] = s;
 }
 
+// bilinear upsampling (align_corners=True) of x (B, C, h, w) to (H, W) + concat with skip (B, Cs, H, W): each thread
+// writes FOUR horizontally adjacent output pixels of one plane with one 16-byte store (the first version stored 4 bytes
+// per lane: 2.1 TB/s on a pass that is almost pure writing); the vertical weights are shared by the four.
 __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restrict__ x, const float* __restrict__ skip,
                                                            float* __restrict__ out, int C, int Cs, int h, int w, int H,
                                                            int W, float rh, float rw) {
     const int plane = blockIdx.z;                 // b * (C + Cs) + channel
     const int ct = C + Cs;
     const int b = plane / ct, c = plane - b * ct;
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ox0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ox >= W || oy >= H) return;
-    float v;
+    if (ox0 >= W || oy >= H) return;
+    float v[4];
     if (c >= C) {
-        v = skip[(((size_t)b * Cs + (c - C)) * H + oy) * W + ox];
+        const float* sp = skip + (((size_t)b * Cs + (c - C)) * H + oy) * W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = sp[min(ox0 + i, W - 1)];
     } else {
         // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
-        const float sy = rh * oy, sx = rw * ox;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
-        const float ly = sy - y0, lx = sx - x0;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* p = x + ((size_t)b * C + c) * h * w;
-        v = hy * (hx * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1]) +
-            ly * (hx * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1]);
+        const float sy = rh * oy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < h - 1);
+        const float ly = sy - y0, hy = 1.f - ly;
+        const float* p0 = x + (((size_t)b * C + c) * h + y0) * w;
+        const float* p1 = x + (((size_t)b * C + c) * h + y1) * w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sx = rw * min(ox0 + i, W - 1);
+            const int x0 = (int)sx;
+            const int x1 = x0 + (x0 < w - 1);
+            const float lx = sx - x0, hx = 1.f - lx;
+            v[i] = hy * (hx * p0[x0] + lx * p0[x1]) + ly * (hx * p1[x0] + lx * p1[x1]);
+        }
     }
-    out[((size_t)plane * H + oy) * W + ox] = v;
+    float* op = out + ((size_t)plane * H + oy) * W + ox0;
+    if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ox0 + i < W) op[i] = v[i];
+    }
 }
 
 }  // namespace
@@ -482,7 +500,7 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
     // at::native::area_pixel_compute_scale<float>(in, out, align_corners=true)
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)(batch * (C + Cskip)));
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * (C + Cskip)));
     occd::ProfScope prof("upsample_cat_nchw", (hipStream_t)stream, 0.0,
                          4.0 * batch * ((double)C * h * w + 2.0 * Cskip * H * W + (double)C * H * W));
     hipLaunchKernelGGL(upsample_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, skip, out, C, Cskip, h, w, H, W,
@@ -568,6 +586,74 @@ __global__ void __launch_bounds__(256) cascade_tail_kernel(const float* __restri
     }
 }
 
+// Staged form (Z <= 64, i.e. every shipped head): a workgroup owns TY rows x Z voxels of one x plane.  The direct
+// kernel above reads the two occupancy logits of all 27 neighbours straight from the 128-byte voxel rows -- 54 wave
+// loads of 64 different cache lines each, so it is bound by the texture-address path (0.30 ms at config 2) -- here
+// the 3 x (TY + 2) x (Z + 2) neighbourhood is read ONCE per workgroup (4 row touches per voxel instead of 54), its
+// softmax is taken once per voxel instead of 27 times, and the taps run out of LDS.  Same arithmetic per tap, same
+// tap order as the direct kernel: results are bit-identical.
+template <int NG>
+__global__ void __launch_bounds__(256) cascade_tail_lds_kernel(const float* __restrict__ part, const float* __restrict__ wn,
+                                                               float* __restrict__ out, int X, int Y, int Z, int TY,
+                                                               int part_cs, int occ_off, int out_cs, int nbr) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * 2 * NG * 4];   // [tap][c][o]
+    extern __shared__ __attribute__((aligned(16))) float sm[];           // [3][TY + 2][Z + 2][2] softmax(occ), 0 outside
+    for (int i = threadIdx.x; i < 27 * 2 * NG * 4; i += 256) {
+        const int o = i % (NG * 4), c = (i / (NG * 4)) & 1, tap = i / (2 * NG * 4);
+        wl[i] = o < nbr ? wn[((size_t)o * 2 + c) * 27 + tap] : 0.f;
+    }
+    const int b = blockIdx.z, x = blockIdx.y, y0 = blockIdx.x * TY;
+    const int ZP = Z + 2, YP = TY + 2;
+    const int nhalo = 3 * YP * ZP;
+    for (int e = threadIdx.x; e < nhalo; e += 256) {
+        const int zi = e % ZP, r = e / ZP;
+        const int yi = r % YP, xi = r / YP;
+        const int xx = x + xi - 1, yy = y0 + yi - 1, zz = zi - 1;
+        const bool ok = (unsigned)xx < (unsigned)X && (unsigned)yy < (unsigned)Y && (unsigned)zz < (unsigned)Z;
+        const size_t v = (((size_t)b * X + (ok ? xx : x)) * Y + (ok ? yy : y0)) * Z + (ok ? zz : 0);
+        const float l0 = part[v * part_cs + occ_off], l1 = part[v * part_cs + occ_off + 1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        sm[2 * e] = ok ? e0 / (e0 + e1) : 0.f;
+        sm[2 * e + 1] = ok ? e1 / (e0 + e1) : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / Z, z = threadIdx.x - ly * Z;
+    const int y = y0 + ly;
+    if (ly >= TY || y >= Y) return;
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+            const float* row = sm + 2 * (((dx * YP) + ly + dy) * ZP + z);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float s0 = row[2 * k], s1 = row[2 * k + 1];
+                const f32x4* w0 = (const f32x4*)(wl + (((dx * 3 + dy) * 3 + k) * 2 + 0) * NG * 4);
+                const f32x4* w1 = (const f32x4*)(wl + (((dx * 3 + dy) * 3 + k) * 2 + 1) * NG * 4);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] += s0 * w0[g] + s1 * w1[g];
+            }
+        }
+    const size_t n = (((size_t)b * X + x) * Y + y) * Z + z;
+    const float* pr = part + n * part_cs;
+    float* po = out + n * out_cs;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 v = acc[g] + *(const f32x4*)(pr + g * 4);
+        if (g * 4 + 3 < nbr) {
+            *(f32x4*)(po + g * 4) = v;
+        } else {
+            if (g * 4 + 0 < nbr) po[g * 4 + 0] = v.x;
+            if (g * 4 + 1 < nbr) po[g * 4 + 1] = v.y;
+            if (g * 4 + 2 < nbr) po[g * 4 + 2] = v.z;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int occd_cascade_tail_fwd(const float* part, const float* wn, float* out, int32_t batch, int32_t X,
@@ -582,6 +668,19 @@ extern "C" int occd_cascade_tail_fwd(const float* part, const float* wn, float* 
     const dim3 grid((unsigned)((total + 255) / 256));
     const int ng = (nbr + 3) >> 2;
     hipStream_t st = (hipStream_t)stream;
+    if (Z <= 64 && X <= 65535 && batch <= 65535) {
+        const int TY = 256 / Z;
+        const dim3 tgrid((unsigned)((Y + TY - 1) / TY), (unsigned)X, (unsigned)batch);
+        const size_t lds = (size_t)3 * (TY + 2) * (Z + 2) * 2 * sizeof(float);
+#define OCCD_TAIL_LDS(NG)                                                                                            \
+    hipLaunchKernelGGL(cascade_tail_lds_kernel<NG>, tgrid, dim3(256), lds, st, part, wn, out, X, Y, Z, TY, part_cs, \
+                       occ_off, out_cs, nbr)
+        if (ng <= 3) OCCD_TAIL_LDS(3);
+        else if (ng <= 5) OCCD_TAIL_LDS(5);
+        else OCCD_TAIL_LDS(8);
+#undef OCCD_TAIL_LDS
+        return occd::check_launch();
+    }
 #define OCCD_TAIL(NG)                                                                                        \
     hipLaunchKernelGGL(cascade_tail_kernel<NG>, grid, dim3(256), 0, st, part, wn, out, batch, X, Y, Z, part_cs, \
                        occ_off, out_cs, nbr)
