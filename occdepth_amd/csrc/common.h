@@ -35,6 +35,13 @@ inline FastDiv make_fastdiv(uint32_t d) {
     return f;
 }
 
+// swish(v) = v * sigmoid(v) on the hardware exp2 / rcp instructions (1 ulp each): the libm expf + IEEE division pair is
+// ~25 VALU instructions per element, which in the epilogue of a short-K pointwise GEMM (64 accumulator values per lane)
+// costs as much as its MFMA loop.  Result within ~3 ulp of the exact form.
+__device__ __forceinline__ float swish_fast(float v) {
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
+
 }  // namespace occd
 
 __device__ __forceinline__ uint32_t occd_fastdiv(uint32_t n, occd::FastDiv f) {

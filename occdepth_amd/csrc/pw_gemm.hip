@@ -49,7 +49,7 @@ struct PwP {
 
 __device__ __forceinline__ float pw_act(float v, int act, float slope) {
     if (act == 1) return fmaxf(v, 0.f);
-    if (act == 2) return v / (1.f + expf(-v));
+    if (act == 2) return occd::swish_fast(v);
     if (act == 3) return v > 0.f ? v : v * slope;
     return v;
 }
