@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
                                                        int pad_t, int pad_l, int act, float* __restrict__ pool_part,
-                                                       int wp) {
+                                                       int wp, occd::FastDiv wpd) {
     constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K, SPAN4 = (SPAN + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [rows][wp]
     __shared__ float wsum[4];
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
     // ---- stage: unconditional clamped loads, padding as a bit mask on the loaded value
     const int total = nrows * wp;
     for (int e = threadIdx.x; e < total; e += 256) {
-        const int r = e / wp, j = e - r * wp;
+        const int r = (int)occd_fastdiv((uint32_t)e, wpd), j = e - r * wp;      // (one mul-hi instead of ~25 instructions)
         const int iy = iy_first + r, ix = j - pad_l;
         const uint32_t ok = 0u - (uint32_t)(((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W));
         const float v = xp[(size_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
@@ -347,11 +347,9 @@ __global__ void dwconv2d_bwd_weight_reduce_kernel(const float* __restrict__ part
     dw[i] = s;
 }
 
-// bilinear upsampling (align_corners=True) of x (B, C, h, w) to (H, W) + concat with skip (B, Cs, H, W): a thread
-// writes FOUR horizontally adjacent pixels (one 16-byte store) in each of kUpRows consecutive rows of one plane; the
-// horizontal source indices and weights are computed once per thread and shared by its rows (the one-pixel-per-thread
-// form spent ~100 VALU instructions per 4 bytes written and ran at 2.1 TB/s).
-constexpr int kUpRows = 4;
+// bilinear upsampling (align_corners=True) of x (B, C, h, w) to (H, W) + concat with skip (B, Cs, H, W): each thread
+// writes FOUR horizontally adjacent output pixels of one plane with one 16-byte store (the first version stored 4 bytes
+// per lane: 2.1 TB/s on a pass that is almost pure writing); the vertical weights are shared by the four.
 __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restrict__ x, const float* __restrict__ skip,
                                                            float* __restrict__ out, int C, int Cs, int h, int w, int H,
                                                            int W, float rh, float rw) {
@@ -359,61 +357,37 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restri
     const int ct = C + Cs;
     const int b = plane / ct, c = plane - b * ct;
     const int ox0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int oyb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kUpRows;
-    if (ox0 >= W || oyb >= H) return;
-    float* const ob = out + (size_t)plane * H * W + ox0;
-    // rows of a plane keep the 16-byte alignment of its first one iff W % 4 == 0
-    const bool vec = ox0 + 3 < W && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15) == 0;
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox0 >= W || oy >= H) return;
+    float v[4];
     if (c >= C) {
-        const float* sp = skip + ((size_t)b * Cs + (c - C)) * H * W + ox0;
+        const float* sp = skip + (((size_t)b * Cs + (c - C)) * H + oy) * W;
 #pragma unroll
-        for (int r = 0; r < kUpRows; ++r) {
-            const int oy = oyb + r;
-            if (oy >= H) break;
-            if (vec && (reinterpret_cast<uintptr_t>(sp) & 15) == 0) {
-                *(f32x4*)(ob + (size_t)oy * W) = *(const f32x4*)(sp + (size_t)oy * W);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ox0 + i < W) ob[(size_t)oy * W + i] = sp[(size_t)oy * W + i];
-            }
-        }
-        return;
-    }
-    // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
-    int x0[4], x1[4];
-    float lx[4], hx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float sx = rw * min(ox0 + i, W - 1);
-        x0[i] = (int)sx;
-        x1[i] = x0[i] + (x0[i] < w - 1);
-        lx[i] = sx - x0[i];
-        hx[i] = 1.f - lx[i];
-    }
-    const float* pb = x + ((size_t)b * C + c) * h * w;
-#pragma unroll
-    for (int r = 0; r < kUpRows; ++r) {
-        const int oy = oyb + r;
-        if (oy >= H) break;
+        for (int i = 0; i < 4; ++i) v[i] = sp[min(ox0 + i, W - 1)];
+    } else {
+        // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
         const float sy = rh * oy;
         const int y0 = (int)sy;
         const int y1 = y0 + (y0 < h - 1);
         const float ly = sy - y0, hy = 1.f - ly;
-        const float* p0 = pb + (size_t)y0 * w;
-        const float* p1 = pb + (size_t)y1 * w;
-        float v[4];
+        const float* p0 = x + (((size_t)b * C + c) * h + y0) * w;
+        const float* p1 = x + (((size_t)b * C + c) * h + y1) * w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sx = rw * min(ox0 + i, W - 1);
+            const int x0 = (int)sx;
+            const int x1 = x0 + (x0 < w - 1);
+            const float lx = sx - x0, hx = 1.f - lx;
+            v[i] = hy * (hx * p0[x0] + lx * p0[x1]) + ly * (hx * p1[x0] + lx * p1[x1]);
+        }
+    }
+    float* op = out + ((size_t)plane * H + oy) * W + ox0;
+    if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+        *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            v[i] = hy * (hx[i] * p0[x0[i]] + lx[i] * p0[x1[i]]) + ly * (hx[i] * p1[x0[i]] + lx[i] * p1[x1[i]]);
-        float* op = ob + (size_t)oy * W;
-        if (vec) {
-            *(f32x4*)op = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (ox0 + i < W) op[i] = v[i];
-        }
+            if (ox0 + i < W) op[i] = v[i];
     }
 }
 
@@ -481,7 +455,7 @@ static int dwconv_launch(const float* x, const float* w, const float* scale, con
     if (lds <= 48 * 1024) {
 #define OCCD_DW(KK, SS)                                                                                             \
     hipLaunchKernelGGL((dwconv2d_kernel<KK, SS>), grid, dim3(256), lds, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
-                       pad_top, pad_left, act, pool_part, wp)
+                       pad_top, pad_left, act, pool_part, wp, occd::make_fastdiv((uint32_t)wp))
         if (k == 3 && stride == 1) OCCD_DW(3, 1);
         else if (k == 3) OCCD_DW(3, 2);
         else if (stride == 1) OCCD_DW(5, 1);
@@ -526,7 +500,7 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
     // at::native::area_pixel_compute_scale<float>(in, out, align_corners=true)
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 4 * kUpRows - 1) / (4 * kUpRows)), (unsigned)(batch * (C + Cskip)));
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * (C + Cskip)));
     occd::ProfScope prof("upsample_cat_nchw", (hipStream_t)stream, 0.0,
                          4.0 * batch * ((double)C * h * w + 2.0 * Cskip * H * W + (double)C * H * W));
     hipLaunchKernelGGL(upsample_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, skip, out, C, Cskip, h, w, H, W,

@@ -715,6 +715,43 @@ def dwconv2d_same_autograd(x, w, stride):
     return _DwConvSameFn.apply(x, w, int(stride))
 
 
+class _Conv3x3Fn(torch.autograd.Function):
+    """Differentiable nn.Conv2d(3x3, stride 1, padding 1) on K10 (SURVEY 8(f) rows N1 + N3: the 2-D decoder in the training
+    step).  forward = K10; data gradient = K10 on dL/dy with the 180-degree rotated, channel-transposed kernel (a 3x3 / pad 1
+    convolution is its own transpose up to that); weight / bias gradient = the backend's wgrad (MIOpen implicit GEMM).
+    MIOpen's fp32 forward / data-gradient choice for these shapes is the VALU Winograd kernel: 32 ms of a config-2 step."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w, b):
+        y = conv2d_3x3_fused(x, wino_pack_weights(w.detach()), w.shape[0], b.detach() if b is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()          # (cin, cout, 3, 3), rotated
+            dx = conv2d_3x3_fused(gy, wino_pack_weights(wt), w.shape[1])
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            _, dw, db = torch.ops.aten.convolution_backward(gy, x, w.detach(), [w.shape[0]] if want_b else None, [1, 1], [1, 1],
+                                                            [1, 1], False, [0, 0], 1, [False, True, want_b])
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db
+
+
+def conv2d_3x3_autograd(x, w, b=None):
+    """Differentiable 3x3 / stride 1 / padding 1 convolution, (B, Cin, H, W) float32 CUDA tensors."""
+    return _Conv3x3Fn.apply(x, w, b)
+
+
 def softmax_nchw(x):
     """softmax over dim 1 of a contiguous float32 (B, C, *spatial) GPU tensor (one HIP launch)."""
     if not x.is_contiguous():

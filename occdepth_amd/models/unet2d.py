@@ -72,6 +72,8 @@ class UpSampleBN(nn.Module):
     def _fused_operands(self, conv, bn):
         return wino_fused_operands(self, conv, bn)
 
+    TRAIN_K10 = os.environ.get("OCCDEPTH_TRAIN_K10", "1") == "1"
+
     def _conv_bn_act(self, f, conv, bn, act):
         B, C, H, W = f.shape
         if self.FUSED and B * H * W >= self.FUSED_MIN_PIXELS:
@@ -96,7 +98,14 @@ class UpSampleBN(nn.Module):
             f = self._conv_bn_act(f, n[0], n[1], n[2])
             return self._conv_bn_act(f, n[3], n[4], n[5])
         up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
-        return self._net(torch.cat([up, concat_with], dim=1))
+        f = torch.cat([up, concat_with], dim=1)
+        if self.TRAIN_K10 and f.is_cuda and f.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            # training on the GPU: the two 3x3 convolutions (forward and data gradient) on K10, BatchNorm / LeakyReLU
+            # on ATen; OCCDEPTH_TRAIN_K10=0 restores MIOpen for A/B
+            n = self._net
+            f = n[2](n[1](hip.conv2d_3x3_autograd(f, n[0].weight, n[0].bias)))
+            return n[5](n[4](hip.conv2d_3x3_autograd(f, n[3].weight, n[3].bias)))
+        return self._net(f)
 
 
 class DecoderBN(nn.Module):
