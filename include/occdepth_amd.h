@@ -247,6 +247,14 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
                                     int32_t C, int32_t Cskip, int32_t h, int32_t w, int32_t H,
                                     int32_t W, void* stream);
 
+/* conv3x3(pad 1)(bilinear_up(x))  ==  sum_t shift_t(bilinear_up(W_t . x)): given z (B, 9 * Cout, h, w) = the nine per-tap
+ * channel mixings of the LOW-resolution map (one pointwise GEMM, tap t = ky * 3 + kx in channel block t), writes
+ * out (B, Cout, H, W) = sum_t [inside] bilinear_{align_corners=True}(z_t)(oy + ky - 1, ox + kx - 1).  Replaces the
+ * upsampled-channel part of the first convolution of a decoder level (occdepth/models/unet2d.py:24-46) -- the
+ * (Cup + Cskip)-channel upsample+concat tensor is never formed.                                                      */
+int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch, int32_t Cout, int32_t h, int32_t w,
+                            int32_t H, int32_t W, void* stream);
+
 /* Winograd F(2x2, 3x3) transforms for nn.Conv2d(k=3, s=1, p=1) of the 2-D decoder
  * (occdepth/models/unet2d.py:24-46).  T = B * ceil(H/2) * ceil(W/2) tiles, tile (b, ty, tx) -> row (b*th + ty)*tw + tx.
  *   input : x (B, Cin, H, W) -> V (16, T, Cin),  V[4i+j] = (B^T d B)[i][j] of the 4x4 patch at (2ty-1, 2tx-1), zero padded

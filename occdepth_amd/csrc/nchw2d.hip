@@ -391,6 +391,68 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restri
     }
 }
 
+// conv3x3(pad 1) applied to a bilinearly upsampled map, without ever forming the upsampled map (the
+// first convolution of every decoder level, occdepth/models/unet2d.py:24-46: conv(cat[up(x), skip])).  Upsampling, the
+// one-pixel tap shifts and the channel mixing are all linear and the channel mixing commutes with the two spatial ones:
+//     conv(up(x))[co][p] = sum_t (up(z_t))[co][p + d_t],     z_t = W_t . x   (t = ky * 3 + kx, d_t = (ky - 1, kx - 1)),
+// with up(z_t) := 0 outside the output grid (the convolution's zero padding).  The nine W_t . x are ONE pointwise GEMM at
+// the LOW resolution (Cup -> 9 Cout, a quarter of the pixels: 9 / 16 of the multiplies of the Winograd form at the high
+// resolution, and no (Cup + Cskip)-channel high-resolution tensor is written or re-read); this kernel is the rest:
+//     out[b][co][oy][ox] = sum_{ky, kx} [inside(oy + ky - 1, ox + kx - 1)] bilinear(z[b][(ky * 3 + kx) * Cout + co], that pixel)
+// with exactly upsample_cat_kernel's (= ATen's align_corners=True) source index arithmetic.  A thread owns 4 adjacent ox.
+__global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
+                                                            int h, int w, int H, int W, float rh, float rw) {
+    const int plane = blockIdx.z;                 // b * Cout + co
+    const int b = plane / Cout, co = plane - b * Cout;
+    const int ox0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox0 >= W || oy >= H) return;
+    // the 6 columns ox0 - 1 .. ox0 + 4 the 3 horizontal taps of the 4 outputs look at
+    int x0[6], x1[6];
+    float lx[6], cm[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int cx = ox0 - 1 + j;
+        cm[j] = (unsigned)cx < (unsigned)W ? 1.f : 0.f;
+        const float sx = rw * min(max(cx, 0), W - 1);
+        x0[j] = (int)sx;
+        x1[j] = x0[j] + (x0[j] < w - 1);
+        lx[j] = sx - x0[j];
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t tap_stride = (size_t)Cout * h * w;
+    const float* zb = z + ((size_t)b * 9 * Cout + co) * h * w;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ry = oy + ky - 1;
+        if ((unsigned)ry >= (unsigned)H) continue;                   // (uniform over the wave: one output row per wave)
+        const float sy = rh * ry;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < h - 1);
+        const float ly = sy - y0, hy = 1.f - ly;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* p0 = zb + (size_t)(ky * 3 + kx) * tap_stride + (size_t)y0 * w;
+            const float* p1 = zb + (size_t)(ky * 3 + kx) * tap_stride + (size_t)y1 * w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = i + kx;
+                const float hx = 1.f - lx[j];
+                const float v = hy * (hx * p0[x0[j]] + lx[j] * p0[x1[j]]) + ly * (hx * p1[x0[j]] + lx[j] * p1[x1[j]]);
+                acc[i] += cm[j] * v;
+            }
+        }
+    }
+    float* op = out + ((size_t)plane * H + oy) * W + ox0;
+    if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+        *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ox0 + i < W) op[i] = acc[i];
+    }
+}
+
 }  // namespace
 
 // softmax over the channel axis of an NCHW map: thread = pixel, channels strided by the plane (coalesced across the
@@ -505,6 +567,19 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
                          4.0 * batch * ((double)C * h * w + 2.0 * Cskip * H * W + (double)C * H * W));
     hipLaunchKernelGGL(upsample_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, skip, out, C, Cskip, h, w, H, W,
                        rh, rw);
+    return occd::check_launch();
+}
+
+extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch, int32_t Cout, int32_t h, int32_t w,
+                                       int32_t H, int32_t W, void* stream) {
+    if (!z || !out || batch <= 0 || Cout <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (long)batch * Cout > 65535)
+        return OCCD_EINVAL;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
+    occd::ProfScope prof("upconv_gather_nchw", (hipStream_t)stream, 2.0 * 36 * batch * Cout * (double)H * W,
+                         4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
+    hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw);
     return occd::check_launch();
 }
 

@@ -89,13 +89,49 @@ class UpSampleBN(nn.Module):
             return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope, strip_rows=rows)
         return hip.affine_act(conv(f), *bn_affine_cached(bn), "leaky", slope=act.negative_slope)
 
+    # The first convolution of a level as "nine tap GEMMs at the LOW resolution + upsample-shift-accumulate + a small
+    # convolution over the skip channels" (csrc/nchw2d.hip: upconv_gather_kernel): 9/16 of the Winograd-domain multiplies
+    # of the upsampled channels and no upsample+concat tensor.  OCCDEPTH_UPCONV=0 restores upsample+concat -> K10 / K9.
+    UPCONV = os.environ.get("OCCDEPTH_UPCONV", "1") == "1"
+    # the tap GEMM (Cup -> 9 Cout, short K, many couts) runs on K11 where pixels are many, on the library GEMM below
+    UPCONV_LIB_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_LIB_BELOW", "14000"))      # B * h * w
+
+    def _upconv_operands(self, conv, bn, cup):
+        key = (_stamp(conv, bn), cup)
+        hit = self.__dict__.get("_upconv_cache")
+        if hit is None or hit[0] != key:
+            scale, shift = bn_affine_cached(bn)
+            if conv.bias is not None:
+                shift = shift + scale * conv.bias.detach().float()
+            w = conv.weight.detach().float()
+            cout = w.shape[0]
+            # rows t * Cout + co (t = ky * 3 + kx) of the tap GEMM, BatchNorm scale folded in
+            w9 = (w[:, :cup] * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(9 * cout, cup).contiguous()
+            hit = (key, hip.pw_pack_weights(w9), w9.reshape(9 * cout, cup, 1, 1),
+                   hip.wino_pack_weights(w[:, cup:].contiguous(), scale), shift.contiguous())
+            self.__dict__["_upconv_cache"] = hit
+        return hit[1:]
+
+    def _first_conv_upconv(self, x, skip, conv, bn, act):
+        wpk9, w9, upk_skip, shift = self._upconv_operands(conv, bn, x.shape[1])
+        cout = conv.out_channels
+        if x.shape[0] * x.shape[2] * x.shape[3] < self.UPCONV_LIB_BELOW:
+            z = F.conv2d(x, w9)
+        else:
+            z = hip.conv1x1(x, wpk9, 9 * cout)
+        u = hip.upconv_gather(z, cout, skip.shape[2:])
+        return hip.conv2d_3x3_fused(skip, upk_skip, cout, shift, "leaky", act.negative_slope, res=u, res_first=True)
+
     def forward(self, x, concat_with):
         if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
-            # eval: bilinear-up + concat in one HIP pass; BatchNorm + LeakyReLU fused into the Winograd output transform
-            # or applied in one pass behind the MIOpen convolution
-            f = hip.upsample_bilinear_cat(x, concat_with)
             n = self._net
-            f = self._conv_bn_act(f, n[0], n[1], n[2])
+            if (self.UPCONV and self.FUSED and n[0].kernel_size == (3, 3) and n[0].padding == (1, 1)
+                    and n[0].stride == (1, 1) and x.shape[0] * n[0].out_channels <= 65535):
+                f = self._first_conv_upconv(x, concat_with, n[0], n[1], n[2])
+            else:
+                # bilinear-up + concat in one HIP pass; BatchNorm + LeakyReLU fused into the Winograd output transform
+                # or applied in one pass behind the MIOpen convolution
+                f = self._conv_bn_act(hip.upsample_bilinear_cat(x, concat_with), n[0], n[1], n[2])
             return self._conv_bn_act(f, n[3], n[4], n[5])
         up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
         f = torch.cat([up, concat_with], dim=1)

@@ -173,3 +173,67 @@ def test_conv3x3_autograd_gpu(case, hip_lib):
     err = _conv3x3_grads(case, "cuda")
     print(case, f"forward / dx / dw / db worst rel err vs float64 {err:.2e}")
     assert err < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv3x3(bilinear_up(x)) as nine low-resolution tap GEMMs + upsample-shift-accumulate (upconv_gather_kernel)
+def _upconv_reference(z, cout, size):
+    """sum_t shift_t(bilinear_up(z_t)) with zero padding, float64, by ATen ops."""
+    B = z.shape[0]
+    H, W = size
+    out = torch.zeros(B, cout, H, W, dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            t = ky * 3 + kx
+            up = F.interpolate(z[:, t * cout:(t + 1) * cout].double(), size=size, mode="bilinear", align_corners=True)
+            out += F.pad(up, (1, 1, 1, 1))[:, :, ky:ky + H, kx:kx + W]           # out[p] += up[p + (ky - 1, kx - 1)]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 5, 7, 11, 13, 22), (1, 3, 12, 39, 24, 77), (1, 2, 9, 8, 9, 8), (1, 4, 3, 5, 17, 130)])
+def test_upconv_gather_kernel_gpu(case, hip_lib):
+    from occdepth_amd import hip
+    B, cout, h, w, H, W = case
+    g = torch.Generator().manual_seed(h * 100 + W)
+    z = torch.randn(B, 9 * cout, h, w, generator=g)
+    got = hip.upconv_gather(z.cuda(), cout, (H, W)).cpu()
+    ref = _upconv_reference(z, cout, (H, W))
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert got.shape == ref.shape and err < 1e-5, (case, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 40, 9, 16, 7, 9, 13, 18), (1, 24, 3, 8, 6, 20, 12, 40)])
+def test_upsample_block_upconv_matches_module_gpu(case, hip_lib):
+    """A whole decoder level (UpSampleBN, eval): the tap-GEMM form of its first convolution against the module's own
+    float64 CPU forward (interpolate -> cat -> conv -> BN -> LeakyReLU, twice), and against the upsample+concat form."""
+    import copy
+    from occdepth_amd.models.unet2d import UpSampleBN
+    B, cup, cs, cout, h, w, H, W = case
+    torch.manual_seed(cup + cout)
+    m = UpSampleBN(cup + cs, cout)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    m.eval()
+    x, skip = torch.randn(B, cup, h, w), torch.randn(B, cs, H, W)
+    saved = (UpSampleBN.UPCONV, UpSampleBN.FUSED_MIN_PIXELS, UpSampleBN.UPCONV_LIB_BELOW)
+    try:
+        with torch.no_grad():
+            ref = copy.deepcopy(m).double()(x.double(), skip.double())
+            mc = m.cuda()
+            UpSampleBN.FUSED_MIN_PIXELS = 0
+            outs = {}
+            for name, on, lib_below in (("upconv_k11", True, 0), ("upconv_lib", True, 1 << 30), ("concat", False, 0)):
+                UpSampleBN.UPCONV, UpSampleBN.UPCONV_LIB_BELOW = on, lib_below
+                outs[name] = mc(x.cuda(), skip.cuda()).double().cpu()
+    finally:
+        UpSampleBN.UPCONV, UpSampleBN.FUSED_MIN_PIXELS, UpSampleBN.UPCONV_LIB_BELOW = saved
+    for name, got in outs.items():
+        err = float((got - ref).abs().max() / ref.abs().max())
+        print(case, name, f"{err:.2e}")
+        assert got.shape == ref.shape and err < 3e-5, (name, err)
