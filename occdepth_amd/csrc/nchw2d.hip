@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restri
 // resolution, and no (Cup + Cskip)-channel high-resolution tensor is written or re-read); this kernel is the rest:
 //     out[b][co][oy][ox] = sum_{ky, kx} [inside(oy + ky - 1, ox + kx - 1)] bilinear(z[b][(ky * 3 + kx) * Cout + co], that pixel)
 // with exactly upsample_cat_kernel's (= ATen's align_corners=True) source index arithmetic.  A thread owns 4 adjacent ox.
-__global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
+__global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
                                                             int h, int w, int H, int W, float rh, float rw) {
     const int plane = blockIdx.z;                 // b * Cout + co
     const int b = plane / Cout, co = plane - b * Cout;
@@ -441,6 +441,89 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
                 const float v = hy * (hx * p0[x0[j]] + lx[j] * p0[x1[j]]) + ly * (hx * p1[x0[j]] + lx[j] * p1[x1[j]]);
                 acc[i] += cm[j] * v;
             }
+        }
+    }
+    float* op = out + ((size_t)plane * H + oy) * W + ox0;
+    if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+        *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ox0 + i < W) op[i] = acc[i];
+    }
+}
+
+// Staged form of the kernel above (the product path).  The direct form issues 144 four-byte gathers per thread (9 taps x
+// 4 outputs x 4 bilinear corners) and is bound by the texture-address path (0.58 ms per decoder level).  Here the
+// workgroup (4 output rows x 256 output columns of one (b, co) plane) first builds, for every tap plane t and each of its
+// 4 output rows, the VERTICALLY interpolated low-resolution row segment its columns can touch -- coalesced loads along
+// the row, 2 per element, zero for rows outside the output grid -- in LDS: L[t][r][c] = hy z_t[y0][xlo + c] + ly z_t[y1][xlo + c]
+// for the output row oy0 + r + ky - 1.  A thread then needs 2 LDS reads per (tap, output): 72 instead of 144 global ones.
+// Same arithmetic as the direct form up to the order of the two interpolations (vertical first here).
+constexpr int kUpNC = 192;                                   // LDS row length: low-resolution columns a workgroup can touch
+__global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
+                                                            int h, int w, int H, int W, float rh, float rw) {
+    __shared__ float L[9 * 4 * kUpNC];
+    const int plane = blockIdx.z;                 // b * Cout + co
+    const int b = plane / Cout, co = plane - b * Cout;
+    const int X0 = blockIdx.x * 256, oy0 = blockIdx.y * 4;
+    // low-resolution column window of the hi-res columns X0 - 1 .. X0 + 256 (clamped): [xlo, xlo + nc)
+    const int xlo = (int)(rw * max(X0 - 1, 0));
+    const int xe = (int)(rw * min(X0 + 256, W - 1));
+    const int nc = min(xe + 1, w - 1) - xlo + 1;              // (the host guarantees nc <= kUpNC)
+    const size_t tap_stride = (size_t)Cout * h * w;
+    const float* zb = z + ((size_t)b * 9 * Cout + co) * h * w;
+    // thread c stages column xlo + c of all 36 (tap, row) segments: the row arithmetic is wave-uniform, the loads of a
+    // wave are consecutive floats, and 12 segments (24 loads) are in flight per thread before any is used
+    if ((int)threadIdx.x < nc) {
+        const float* pc = zb + xlo + threadIdx.x;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float a0[12], a1[12], wy[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int tr = g * 12 + u, t = tr >> 2, r = tr & 3;
+                const int ry = oy0 + r + t / 3 - 1;
+                const bool ok = (unsigned)ry < (unsigned)H;
+                const float sy = rh * (ok ? ry : 0);
+                const int y0 = (int)sy;
+                const int y1 = y0 + (y0 < h - 1);
+                wy[u] = ok ? sy - y0 : -1.f;                   // (-1 marks a row outside the output grid)
+                a0[u] = pc[(size_t)t * tap_stride + (size_t)y0 * w];
+                a1[u] = pc[(size_t)t * tap_stride + (size_t)y1 * w];
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const float ly = wy[u];
+                L[(g * 12 + u) * kUpNC + threadIdx.x] = ly >= 0.f ? (1.f - ly) * a0[u] + ly * a1[u] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 6;
+    const int ox0 = X0 + (threadIdx.x & 63) * 4, oy = oy0 + r;
+    if (ox0 >= W || oy >= H) return;
+    int x0[6], x1[6];
+    float lx[6], cm[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int cx = ox0 - 1 + j;
+        cm[j] = (unsigned)cx < (unsigned)W ? 1.f : 0.f;
+        const float sx = rw * min(max(cx, 0), W - 1);
+        const int xa = (int)sx;
+        x0[j] = xa - xlo;
+        x1[j] = xa + (xa < w - 1) - xlo;
+        lx[j] = sx - xa;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float* row = L + (t * 4 + r) * kUpNC;
+        const int kx = t % 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = i + kx;
+            acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
         }
     }
     float* op = out + ((size_t)plane * H + oy) * W + ox0;
@@ -579,7 +662,12 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
     occd::ProfScope prof("upconv_gather_nchw", (hipStream_t)stream, 2.0 * 36 * batch * Cout * (double)H * W,
                          4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
-    hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw);
+    // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
+    if (rw * 258.f + 3.f <= (float)kUpNC)
+        hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw);
+    else
+        hipLaunchKernelGGL(upconv_gather_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
+                           rh, rw);
     return occd::check_launch();
 }
 

@@ -93,8 +93,11 @@ class UpSampleBN(nn.Module):
     # convolution over the skip channels" (csrc/nchw2d.hip: upconv_gather_kernel): 9/16 of the Winograd-domain multiplies
     # of the upsampled channels and no upsample+concat tensor.  OCCDEPTH_UPCONV=0 restores upsample+concat -> K10 / K9.
     UPCONV = os.environ.get("OCCDEPTH_UPCONV", "1") == "1"
-    # the tap GEMM (Cup -> 9 Cout, short K, many couts) runs on K11 where pixels are many, on the library GEMM below
-    UPCONV_LIB_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_LIB_BELOW", "14000"))      # B * h * w
+    # The tap GEMM (Cup -> 9 Cout: 720 ... 11520 rows, K = 160 ... 2560) is a plain large GEMM: the library's LDS-tiled
+    # kernels (torch.matmul -> hipBLASLt / rocBLAS, ~100 TF/s) beat K11, whose per-wave register tiles re-read both
+    # operands from L2 (measured 28-35 TF/s on these shapes).  OCCDEPTH_UPCONV_LIB_BELOW = B * h * w below which the
+    # library is used (default: always) keeps K11 selectable for A/B.
+    UPCONV_LIB_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_LIB_BELOW", str(1 << 62)))
 
     def _upconv_operands(self, conv, bn, cup):
         key = (_stamp(conv, bn), cup)
@@ -107,7 +110,7 @@ class UpSampleBN(nn.Module):
             cout = w.shape[0]
             # rows t * Cout + co (t = ky * 3 + kx) of the tap GEMM, BatchNorm scale folded in
             w9 = (w[:, :cup] * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(9 * cout, cup).contiguous()
-            hit = (key, hip.pw_pack_weights(w9), w9.reshape(9 * cout, cup, 1, 1),
+            hit = (key, hip.pw_pack_weights(w9), w9,
                    hip.wino_pack_weights(w[:, cup:].contiguous(), scale), shift.contiguous())
             self.__dict__["_upconv_cache"] = hit
         return hit[1:]
@@ -115,8 +118,10 @@ class UpSampleBN(nn.Module):
     def _first_conv_upconv(self, x, skip, conv, bn, act):
         wpk9, w9, upk_skip, shift = self._upconv_operands(conv, bn, x.shape[1])
         cout = conv.out_channels
-        if x.shape[0] * x.shape[2] * x.shape[3] < self.UPCONV_LIB_BELOW:
-            z = F.conv2d(x, w9)
+        B, cup, h, w = x.shape
+        if B * h * w < self.UPCONV_LIB_BELOW:
+            xc = x if x.is_contiguous() else x.contiguous()
+            z = torch.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)
         else:
             z = hip.conv1x1(x, wpk9, 9 * cout)
         u = hip.upconv_gather(z, cout, skip.shape[2:])

@@ -228,7 +228,7 @@ def test_upsample_block_upconv_matches_module_gpu(case, hip_lib):
             mc = m.cuda()
             UpSampleBN.FUSED_MIN_PIXELS = 0
             outs = {}
-            for name, on, lib_below in (("upconv_k11", True, 0), ("upconv_lib", True, 1 << 30), ("concat", False, 0)):
+            for name, on, lib_below in (("upconv_k11", True, 0), ("upconv_lib", True, 1 << 62), ("concat", False, 0)):
                 UpSampleBN.UPCONV, UpSampleBN.UPCONV_LIB_BELOW = on, lib_below
                 outs[name] = mc(x.cuda(), skip.cuda()).double().cpu()
     finally:
