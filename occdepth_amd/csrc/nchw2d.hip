@@ -11,6 +11,7 @@
 //                        (F.interpolate + torch.cat of unet2d.py:38-46 in one pass)
 //
 // Reference semantics: occdepth/models/unet2d.py:24-46 and the geffnet EfficientNet blocks (third party).
+#include <cstdlib>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
         const float* pc = zb + xlo + threadIdx.x;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            float a0[12], a1[12], wy[12];
+            float a0[12], a1[12], wy[12], rowok[12];
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
                 const int tr = g * 12 + u, t = tr >> 2, r = tr & 3;
@@ -488,14 +489,15 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
                 const float sy = rh * (ok ? ry : 0);
                 const int y0 = (int)sy;
                 const int y1 = y0 + (y0 < h - 1);
-                wy[u] = ok ? sy - y0 : -1.f;                   // (-1 marks a row outside the output grid)
+                wy[u] = sy - y0;                               // (may round a hair below 0 when contracted into an fma:
+                rowok[u] = ok ? 1.f : 0.f;                     //  never use its sign as the "outside the grid" marker)
                 a0[u] = pc[(size_t)t * tap_stride + (size_t)y0 * w];
                 a1[u] = pc[(size_t)t * tap_stride + (size_t)y1 * w];
             }
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
                 const float ly = wy[u];
-                L[(g * 12 + u) * kUpNC + threadIdx.x] = ly >= 0.f ? (1.f - ly) * a0[u] + ly * a1[u] : 0.f;
+                L[(g * 12 + u) * kUpNC + threadIdx.x] = rowok[u] * ((1.f - ly) * a0[u] + ly * a1[u]);
             }
         }
     }
@@ -663,7 +665,8 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     occd::ProfScope prof("upconv_gather_nchw", (hipStream_t)stream, 2.0 * 36 * batch * Cout * (double)H * W,
                          4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
-    if (rw * 258.f + 3.f <= (float)kUpNC)
+    static const bool force_direct = getenv("OCCD_UPCONV_DIRECT") != nullptr;        // A/B switch
+    if (!force_direct && rw * 258.f + 3.f <= (float)kUpNC)
         hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw);
     else
         hipLaunchKernelGGL(upconv_gather_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,

@@ -191,7 +191,8 @@ def _upconv_reference(z, cout, size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 5, 7, 11, 13, 22), (1, 3, 12, 39, 24, 77), (1, 2, 9, 8, 9, 8), (1, 4, 3, 5, 17, 130)])
+@pytest.mark.parametrize("case", [(2, 5, 7, 11, 13, 22), (1, 3, 12, 39, 24, 77), (1, 2, 9, 8, 9, 8), (1, 4, 3, 5, 17, 130),
+                                  (1, 2, 15, 20, 30, 40), (1, 2, 30, 40, 60, 80), (1, 1, 93, 305, 185, 610)])
 def test_upconv_gather_kernel_gpu(case, hip_lib):
     from occdepth_amd import hip
     B, cout, h, w, H, W = case
