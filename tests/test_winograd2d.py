@@ -201,7 +201,9 @@ def test_upconv_gather_kernel_gpu(case, hip_lib):
     got = hip.upconv_gather(z.cuda(), cout, (H, W)).cpu()
     ref = _upconv_reference(z, cout, (H, W))
     err = float((got.double() - ref).abs().max() / ref.abs().max())
-    assert got.shape == ref.shape and err < 1e-5, (case, err)
+    # the source coordinates are float32 products (as in ATen's float32 kernel): at column 600 one ulp of the coordinate
+    # is 3e-5 of a pixel, which is the error of the interpolation weight against this float64 reference
+    assert got.shape == ref.shape and err < (1e-5 if W < 200 else 6e-5), (case, err)
 
 
 @pytest.mark.gpu
