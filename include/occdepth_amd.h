@@ -251,9 +251,10 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
  * channel mixings of the LOW-resolution map (one pointwise GEMM, tap t = ky * 3 + kx in channel block t), writes
  * out (B, Cout, H, W) = sum_t [inside] bilinear_{align_corners=True}(z_t)(oy + ky - 1, ox + kx - 1).  Replaces the
  * upsampled-channel part of the first convolution of a decoder level (occdepth/models/unet2d.py:24-46) -- the
- * (Cup + Cskip)-channel upsample+concat tensor is never formed.                                                      */
+ * (Cup + Cskip)-channel upsample+concat tensor is never formed.  z[b][ch][y][x] sits at b * z_batch_stride +
+ * ch * z_channel_stride + y * w + x floats (0 = dense NCHW); (h*w*B, h*w) is the layout of ONE GEMM over all images.  */
 int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch, int32_t Cout, int32_t h, int32_t w,
-                            int32_t H, int32_t W, void* stream);
+                            int32_t H, int32_t W, int64_t z_channel_stride, int64_t z_batch_stride, void* stream);
 
 /* Winograd F(2x2, 3x3) transforms for nn.Conv2d(k=3, s=1, p=1) of the 2-D decoder
  * (occdepth/models/unet2d.py:24-46).  T = B * ceil(H/2) * ceil(W/2) tiles, tile (b, ty, tx) -> row (b*th + ty)*tw + tx.

@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(256) upsample_cat_kernel(const float* __restri
 //     out[b][co][oy][ox] = sum_{ky, kx} [inside(oy + ky - 1, ox + kx - 1)] bilinear(z[b][(ky * 3 + kx) * Cout + co], that pixel)
 // with exactly upsample_cat_kernel's (= ATen's align_corners=True) source index arithmetic.  A thread owns 4 adjacent ox.
 __global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
-                                                            int h, int w, int H, int W, float rh, float rw) {
+                                                            int h, int w, int H, int W, float rh, float rw, long zcs,
+                                                            long zbs) {
     const int plane = blockIdx.z;                 // b * Cout + co
     const int b = plane / Cout, co = plane - b * Cout;
     const int ox0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
@@ -421,8 +422,8 @@ __global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* 
         lx[j] = sx - x0[j];
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const size_t tap_stride = (size_t)Cout * h * w;
-    const float* zb = z + ((size_t)b * 9 * Cout + co) * h * w;
+    const size_t tap_stride = (size_t)Cout * zcs;            // z[b][ch][y][x] at b * zbs + ch * zcs + y * w + x
+    const float* zb = z + (size_t)b * zbs + (size_t)co * zcs;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int ry = oy + ky - 1;
@@ -463,7 +464,8 @@ __global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* 
 // Same arithmetic as the direct form up to the order of the two interpolations (vertical first here).
 constexpr int kUpNC = 192;                                   // LDS row length: low-resolution columns a workgroup can touch
 __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
-                                                            int h, int w, int H, int W, float rh, float rw) {
+                                                            int h, int w, int H, int W, float rh, float rw, long zcs,
+                                                            long zbs) {
     __shared__ float L[9 * 4 * kUpNC];
     const int plane = blockIdx.z;                 // b * Cout + co
     const int b = plane / Cout, co = plane - b * Cout;
@@ -472,8 +474,8 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     const int xlo = (int)(rw * max(X0 - 1, 0));
     const int xe = (int)(rw * min(X0 + 256, W - 1));
     const int nc = min(xe + 1, w - 1) - xlo + 1;              // (the host guarantees nc <= kUpNC)
-    const size_t tap_stride = (size_t)Cout * h * w;
-    const float* zb = z + ((size_t)b * 9 * Cout + co) * h * w;
+    const size_t tap_stride = (size_t)Cout * zcs;            // z[b][ch][y][x] at b * zbs + ch * zcs + y * w + x
+    const float* zb = z + (size_t)b * zbs + (size_t)co * zcs;
     // thread c stages column xlo + c of all 36 (tap, row) segments: the row arithmetic is wave-uniform, the loads of a
     // wave are consecutive floats, and 12 segments (24 loads) are in flight per thread before any is used
     if ((int)threadIdx.x < nc) {
@@ -656,9 +658,13 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
 }
 
 extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch, int32_t Cout, int32_t h, int32_t w,
-                                       int32_t H, int32_t W, void* stream) {
+                                       int32_t H, int32_t W, int64_t z_channel_stride, int64_t z_batch_stride,
+                                       void* stream) {
     if (!z || !out || batch <= 0 || Cout <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (long)batch * Cout > 65535)
         return OCCD_EINVAL;
+    const long zcs = z_channel_stride > 0 ? z_channel_stride : (long)h * w;
+    const long zbs = z_batch_stride > 0 ? z_batch_stride : 9L * Cout * zcs;
+    if (zcs < (long)h * w) return OCCD_EINVAL;
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
@@ -667,10 +673,11 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
     static const bool force_direct = getenv("OCCD_UPCONV_DIRECT") != nullptr;        // A/B switch
     if (!force_direct && rw * 258.f + 3.f <= (float)kUpNC)
-        hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw);
+        hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw,
+                           zcs, zbs);
     else
         hipLaunchKernelGGL(upconv_gather_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
-                           rh, rw);
+                           rh, rw, zcs, zbs);
     return occd::check_launch();
 }
 

@@ -116,7 +116,7 @@ EXPORTS = {
                                        c_int32, c_float, c_int32, c_void_p]),
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
-    "occd_upconv_gather_nchw": (c_int32, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
+    "occd_upconv_gather_nchw": (c_int32, [c_void_p, c_void_p] + [c_int32] * 6 + [c_int64, c_int64, c_void_p]),
     "occd_wino_input_transform_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                  c_void_p]),
     "occd_wino_output_transform_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
@@ -811,17 +811,23 @@ def upsample_bilinear_cat(x, skip):
     return out
 
 
-def upconv_gather(z, cout, size):
+def upconv_gather(z, cout, size, batch_inner=False):
     """sum over the 9 taps of shift_t(bilinear_up(z_t)): z (B, 9 * cout, h, w) -> (B, cout, H, W), size = (H, W).
-    With z = conv1x1(x, W9) this is conv3x3(pad 1)(bilinear_up(x, align_corners=True)) (see occd_upconv_gather_nchw)."""
+    With z = conv1x1(x, W9) this is conv3x3(pad 1)(bilinear_up(x, align_corners=True)) (see occd_upconv_gather_nchw).
+    batch_inner: z is (9 * cout, B, h, w) -- the result of ONE GEMM over the pixels of all images."""
     if not z.is_contiguous():
         z = z.contiguous()
-    B, c9, h, w = z.shape
+    if batch_inner:
+        c9, B, h, w = z.shape
+        zcs, zbs = B * h * w, h * w
+    else:
+        B, c9, h, w = z.shape
+        zcs, zbs = 0, 0
     if c9 != 9 * cout:
         raise RuntimeError("upconv_gather: z must have 9 * cout channels")
     H, W = int(size[0]), int(size[1])
     out = torch.empty((B, cout, H, W), device=z.device, dtype=torch.float32)
-    _check(load().occd_upconv_gather_nchw(_f32(z, "z"), _f32(out, "out"), B, cout, h, w, H, W, _stream()),
+    _check(load().occd_upconv_gather_nchw(_f32(z, "z"), _f32(out, "out"), B, cout, h, w, H, W, zcs, zbs, _stream()),
            "occd_upconv_gather_nchw")
     return out
 

@@ -98,6 +98,7 @@ class UpSampleBN(nn.Module):
     # operands from L2 (measured 28-35 TF/s on these shapes).  OCCDEPTH_UPCONV_LIB_BELOW = B * h * w below which the
     # library is used (default: always) keeps K11 selectable for A/B.
     UPCONV_LIB_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_LIB_BELOW", str(1 << 62)))
+    UPCONV_FOLD_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_FOLD_BELOW", "0"))        # B * h * w (experiment)
 
     def _upconv_operands(self, conv, bn, cup):
         key = (_stamp(conv, bn), cup)
@@ -119,12 +120,17 @@ class UpSampleBN(nn.Module):
         wpk9, w9, upk_skip, shift = self._upconv_operands(conv, bn, x.shape[1])
         cout = conv.out_channels
         B, cup, h, w = x.shape
-        if B * h * w < self.UPCONV_LIB_BELOW:
-            xc = x if x.is_contiguous() else x.contiguous()
-            z = torch.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)
+        if B > 1 and B * h * w <= self.UPCONV_FOLD_BELOW:
+            # few pixels per image: ONE GEMM over the pixels of all images (the operand copy is small here)
+            z = torch.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w)).view(9 * cout, B, h, w)
+            u = hip.upconv_gather(z, cout, skip.shape[2:], batch_inner=True)
         else:
-            z = hip.conv1x1(x, wpk9, 9 * cout)
-        u = hip.upconv_gather(z, cout, skip.shape[2:])
+            if B * h * w < self.UPCONV_LIB_BELOW:
+                xc = x if x.is_contiguous() else x.contiguous()
+                z = torch.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)
+            else:
+                z = hip.conv1x1(x, wpk9, 9 * cout)
+            u = hip.upconv_gather(z, cout, skip.shape[2:])
         return hip.conv2d_3x3_fused(skip, upk_skip, cout, shift, "leaky", act.negative_slope, res=u, res_first=True)
 
     def forward(self, x, concat_with):

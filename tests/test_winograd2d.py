@@ -224,18 +224,19 @@ def test_upsample_block_upconv_matches_module_gpu(case, hip_lib):
             mod.bias.data.normal_(0, 0.2)
     m.eval()
     x, skip = torch.randn(B, cup, h, w), torch.randn(B, cs, H, W)
-    saved = (UpSampleBN.UPCONV, UpSampleBN.FUSED_MIN_PIXELS, UpSampleBN.UPCONV_LIB_BELOW)
+    saved = (UpSampleBN.UPCONV, UpSampleBN.FUSED_MIN_PIXELS, UpSampleBN.UPCONV_LIB_BELOW, UpSampleBN.UPCONV_FOLD_BELOW)
     try:
         with torch.no_grad():
             ref = copy.deepcopy(m).double()(x.double(), skip.double())
             mc = m.cuda()
             UpSampleBN.FUSED_MIN_PIXELS = 0
             outs = {}
-            for name, on, lib_below in (("upconv_k11", True, 0), ("upconv_lib", True, 1 << 62), ("concat", False, 0)):
-                UpSampleBN.UPCONV, UpSampleBN.UPCONV_LIB_BELOW = on, lib_below
+            for name, on, lib_below, fold in (("upconv_k11", True, 0, 0), ("upconv_lib", True, 1 << 62, 0),
+                                              ("upconv_fold", True, 1 << 62, 1 << 62), ("concat", False, 0, 0)):
+                UpSampleBN.UPCONV, UpSampleBN.UPCONV_LIB_BELOW, UpSampleBN.UPCONV_FOLD_BELOW = on, lib_below, fold
                 outs[name] = mc(x.cuda(), skip.cuda()).double().cpu()
     finally:
-        UpSampleBN.UPCONV, UpSampleBN.FUSED_MIN_PIXELS, UpSampleBN.UPCONV_LIB_BELOW = saved
+        UpSampleBN.UPCONV, UpSampleBN.FUSED_MIN_PIXELS, UpSampleBN.UPCONV_LIB_BELOW, UpSampleBN.UPCONV_FOLD_BELOW = saved
     for name, got in outs.items():
         err = float((got - ref).abs().max() / ref.abs().max())
         print(case, name, f"{err:.2e}")
