@@ -232,6 +232,11 @@ int occd_cascade_tail_fwd(const float* part, const float* wn, float* out, int32_
 int occd_affine_act_nchw(const float* x, const float* res, float* y, const float* scale,
                          const float* shift, int32_t batch, int32_t C, int64_t S, int32_t act,
                          float slope, int32_t res_first, void* stream);
+
+/* Backward of swish(x) = x * sigmoid(x) (the EfficientNet activation, geffnet behind occdepth/models/unet2d.py:175-190) in
+ * one pass: gx = gy * s * (1 + x * (1 - s)), s = sigmoid(x); n contiguous floats, 16-byte aligned pointers.  The forward
+ * is occd_affine_act_nchw with act = 2.                                                                             */
+int occd_swish_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
 /* y = softmax(x, dim=1) of a (B, C, S) map (S = H*W): the depth-bin softmax of FlospDepth.forward
  * (occdepth/models/flosp_depth/flosp_depth.py:548).                                         */
 int occd_softmax_nchw(const float* x, float* y, int32_t batch, int32_t C, int64_t S, void* stream);

@@ -116,6 +116,7 @@ EXPORTS = {
                                        c_int32, c_float, c_int32, c_void_p]),
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_swish_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "occd_upconv_gather_nchw": (c_int32, [c_void_p, c_void_p] + [c_int32] * 6 + [c_int64, c_int64, c_void_p]),
     "occd_wino_input_transform_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                  c_void_p]),
@@ -714,6 +715,61 @@ class _DwConvSameFn(torch.autograd.Function):
 def dwconv2d_same_autograd(x, w, stride):
     """Differentiable depthwise SAME convolution (training path of the EfficientNet blocks)."""
     return _DwConvSameFn.apply(x, w, int(stride))
+
+
+class _SwishFn(torch.autograd.Function):
+    """x * sigmoid(x) with a one-pass forward (affine_act) and a one-pass backward (occd_swish_bwd): 2 launches per
+    site instead of the 6 of the autograd graph of `x * torch.sigmoid(x)` (training path of the EfficientNet blocks)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.detach()
+        if not xc.is_contiguous():
+            xc = xc.contiguous()
+        ctx.save_for_backward(xc)
+        B, C = (xc.shape[0], xc.shape[1]) if xc.dim() >= 2 else (1, 1)
+        return affine_act(xc.reshape(1, 1, -1) if B * C > 65535 or xc.dim() < 2 else xc, None, None, "swish",
+                          out=torch.empty_like(xc)).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        g = gy.float().contiguous()
+        gx = torch.empty_like(x)
+        _check(load().occd_swish_bwd(_f32(x, "x"), _f32(g, "gy"), _f32(gx, "gx"), x.numel(), _stream()), "occd_swish_bwd")
+        return gx
+
+
+def swish_autograd(x):
+    """Differentiable swish on a float32 CUDA tensor (see _SwishFn)."""
+    return _SwishFn.apply(x)
+
+
+class _UpCatFn(torch.autograd.Function):
+    """cat([F.interpolate(x, skip's size, bilinear, align_corners=True), skip], 1) with the one-pass HIP forward
+    (upsample_cat_kernel) -- ATen needs an upsample pass (0.33 ms per call at the high-resolution levels) and a concat
+    copy -- and ATen's upsample backward on the matching gradient slice."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        ctx.x_shape = tuple(x.shape)
+        ctx.size = tuple(skip.shape[2:])
+        return upsample_bilinear_cat(x.detach().float(), skip.detach().float())
+
+    @staticmethod
+    def backward(ctx, g):
+        C = ctx.x_shape[1]
+        gx = gs = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.upsample_bilinear2d_backward(g[:, :C].contiguous(), list(ctx.size), list(ctx.x_shape), True,
+                                                             None, None)
+        if ctx.needs_input_grad[1]:
+            gs = g[:, C:]
+        return gx, gs
+
+
+def upsample_bilinear_cat_autograd(x, skip):
+    return _UpCatFn.apply(x, skip)
 
 
 class _Conv3x3Fn(torch.autograd.Function):

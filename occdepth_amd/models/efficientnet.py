@@ -102,10 +102,17 @@ class Conv2dSame(nn.Conv2d):
         return F.conv2d(x, self.weight, self.bias, self.stride, (0, 0), self.dilation, self.groups)
 
 
+# training on the GPU: swish as one forward + one backward launch (hip._SwishFn) instead of the six of the autograd graph
+# of x * sigmoid(x); OCCDEPTH_TRAIN_FUSED_ACT=0 restores ATen for A/B
+TRAIN_FUSED_ACT = os.environ.get("OCCDEPTH_TRAIN_FUSED_ACT", "1") == "1"
+
+
 class Swish(nn.Module):
     def forward(self, x):
         if _fast(x, self):
             return hip.affine_act(x, None, None, "swish", out=torch.empty_like(x))
+        if TRAIN_FUSED_ACT and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and x.numel() >= 4:
+            return hip.swish_autograd(x)
         return x * torch.sigmoid(x)
 
 

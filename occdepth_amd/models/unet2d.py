@@ -144,8 +144,11 @@ class UpSampleBN(nn.Module):
                 # or applied in one pass behind the MIOpen convolution
                 f = self._conv_bn_act(hip.upsample_bilinear_cat(x, concat_with), n[0], n[1], n[2])
             return self._conv_bn_act(f, n[3], n[4], n[5])
-        up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
-        f = torch.cat([up, concat_with], dim=1)
+        if self.TRAIN_K10 and x.is_cuda and x.dtype == torch.float32 and concat_with.dtype == torch.float32:
+            f = hip.upsample_bilinear_cat_autograd(x, concat_with)       # one pass instead of upsample + concat copy
+        else:
+            up = F.interpolate(x, size=concat_with.shape[2:], mode="bilinear", align_corners=True)
+            f = torch.cat([up, concat_with], dim=1)
         if self.TRAIN_K10 and f.is_cuda and f.dtype in (torch.float32, torch.bfloat16, torch.float16):
             # training on the GPU: the two 3x3 convolutions (forward and data gradient) on K10, BatchNorm / LeakyReLU
             # on ATen; OCCDEPTH_TRAIN_K10=0 restores MIOpen for A/B

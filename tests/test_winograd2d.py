@@ -241,3 +241,32 @@ def test_upsample_block_upconv_matches_module_gpu(case, hip_lib):
         err = float((got - ref).abs().max() / ref.abs().max())
         print(case, name, f"{err:.2e}")
         assert got.shape == ref.shape and err < 3e-5, (name, err)
+
+
+@pytest.mark.gpu
+def test_swish_and_upsample_cat_autograd_gpu(hip_lib):
+    """Training-path Functions: fused swish (forward + one-pass backward) and upsample+concat (HIP forward, ATen backward
+    on the gradient slice) against the autograd graphs they replace, in float64 on the CPU."""
+    from occdepth_amd import hip
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 7, 5, 9, generator=g) * 3
+    gy = torch.randn(2, 7, 5, 9, generator=g)
+    xr = x.double().requires_grad_(True)
+    (xr * torch.sigmoid(xr)).backward(gy.double())
+    xc = x.cuda().requires_grad_(True)
+    y = hip.swish_autograd(xc)
+    y.backward(gy.cuda())
+    ref_y = (x.double() * torch.sigmoid(x.double()))
+    assert float((y.detach().double().cpu() - ref_y).abs().max()) < 1e-5
+    assert float((xc.grad.double().cpu() - xr.grad).abs().max() / xr.grad.abs().max()) < 1e-5
+    a, s = torch.randn(2, 6, 4, 7, generator=g), torch.randn(2, 3, 9, 13, generator=g)
+    go = torch.randn(2, 9, 9, 13, generator=g)
+    ar, sr = a.double().requires_grad_(True), s.double().requires_grad_(True)
+    ref = torch.cat([F.interpolate(ar, size=(9, 13), mode="bilinear", align_corners=True), sr], 1)
+    ref.backward(go.double())
+    ac, sc = a.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    out = hip.upsample_bilinear_cat_autograd(ac, sc)
+    out.backward(go.cuda())
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max()) < 1e-5
+    assert float((ac.grad.double().cpu() - ar.grad).abs().max()) < 1e-5
+    assert torch.equal(sc.grad.cpu(), go[:, 6:])
