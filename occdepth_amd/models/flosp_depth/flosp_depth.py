@@ -103,7 +103,7 @@ class DepthNet(nn.Module):
     def forward(self, x=None, sweep_intrins=None, scaled_pixel_size=None, scale_depth_factor=1000.0):
         if not self.infer_mode:
             scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
-                                                       sync_free=sweep_intrins.is_cuda and not needs_autograd(self))
+                                                       sync_free=sweep_intrins.is_cuda)
         if DEPTHNET_K10 and x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
             upk, shift = wino_fused_operands(self, self.reduce_conv[0], self.reduce_conv[1])
             x = hip.conv2d_3x3_fused(x, upk, self.reduce_conv[0].out_channels, shift, "relu")
