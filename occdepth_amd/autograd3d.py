@@ -47,6 +47,19 @@ def _axis_phases(K, s, p, d):
     return out
 
 
+_TAPS = {}
+
+
+def _taps(ks, device):
+    """Tap index list -> cached device LongTensor (indexing with a Python list uploads it on every call: a host sync per
+    phase per layer, and illegal inside hipGraph capture of the training step)."""
+    key = (tuple(ks), str(device))
+    t = _TAPS.get(key)
+    if t is None:
+        t = _TAPS[key] = torch.tensor(list(ks), dtype=torch.long, device=device)
+    return t
+
+
 def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz)."""
     cout, cin = w.shape[:2]
@@ -59,7 +72,7 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     for (rx, tx, dx_, px), (ry, ty, dy_, py), (rz, tz, dz_, pz) in itertools.product(*axes):
         if not (tx and ty and tz):
             continue
-        sub = wt[:, :, tx][:, :, :, ty][:, :, :, :, tz].contiguous()
+        sub = wt.index_select(2, _taps(tx, wt.device)).index_select(3, _taps(ty, wt.device)).index_select(4, _taps(tz, wt.device))
         n_pos = tuple((in_dims[a] - r + stride[a] - 1) // stride[a] for a, r in enumerate((rx, ry, rz)))
         if min(n_pos) <= 0:
             continue

@@ -349,13 +349,13 @@ class OccDepth(_Base):
         if use_fp:
             masks = torch.stack(list(batch["frustums_masks"])).to(dev)
             dists = torch.stack(list(batch["frustums_class_dists"])).float().to(dev)
-        terms = ssc_loss.ssc_losses(ssc_pred, target, self.class_weights.to(dev).float(), masks, dists,
+        terms = ssc_loss.ssc_losses(ssc_pred, target, self._on_device("class_weights", dev), masks, dists,
                                     ce=self.CE_ssc_loss, sem_scal=self.sem_scal_loss, geo_scal=self.geo_scal_loss)
         if self.CE_ssc_loss:
             loss = loss + terms["loss_ssc"]
             self._log(step_type + "/loss_ssc", terms["loss_ssc"])
             if self.cascade_cls:
-                loss_occ = ssc_loss.occ_ce_loss(out_dict["occ_logit"], target, self.class_weights_occ.to(dev).float())
+                loss_occ = ssc_loss.occ_ce_loss(out_dict["occ_logit"], target, self._on_device("class_weights_occ", dev))
                 loss = loss + loss_occ
                 self._log(step_type + "/loss_occ", loss_occ)
             if self.occluded_cls and "occluded" in batch:
@@ -394,6 +394,17 @@ class OccDepth(_Base):
                 metric.add_batch(ssc_pred.detach().argmax(1).cpu().numpy(), target.cpu().numpy())
         self._log(step_type + "/loss", loss)
         return loss
+
+    def _on_device(self, name, dev):
+        """float32 device copy of a host-side attribute tensor (class weights), cached: `.to(dev)` per step is a host
+        sync on the loss path."""
+        src = getattr(self, name)
+        cache = self.__dict__.setdefault("_dev_attr", {})
+        hit = cache.get((name, str(dev)))
+        if hit is None or hit[0] is not src:
+            hit = (src, src.to(dev).float())
+            cache[(name, str(dev))] = hit
+        return hit[1]
 
     def training_step(self, batch, batch_idx):
         self.cur_batch += 1

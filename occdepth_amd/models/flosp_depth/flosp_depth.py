@@ -226,6 +226,15 @@ class FlospDepth(nn.Module):
         return vox
 
     # ---------------------------------------------------------------- ATen (training / autograd)
+    def _device_const(self, key, dev, make):
+        """Small host-built constants cached per device: an H2D copy per step is a host sync (and breaks hipGraph capture
+        of the training step)."""
+        cache = self.__dict__.setdefault("_dev_consts", {})
+        k = (key, str(dev))
+        if k not in cache:
+            cache[k] = make().to(dev)
+        return cache[k]
+
     def frustum_grid(self, t_v2c_cam, intrins_cam, ida_cam):
         """Normalised (B, X, Y, Z, 3) sampling grid of one camera, torch ops only."""
         A, Bd, C = self._grid_dims
@@ -239,7 +248,7 @@ class FlospDepth(nn.Module):
             scale = torch.where(wv.abs() > 1e-8, 1.0 / (wv + 1e-8), torch.ones_like(wv))
             return p[..., :-1] * scale
 
-        trans = t_v2c_cam @ _grid_to_lidar(self._pc_range, self._grid_dims).to(dev)
+        trans = t_v2c_cam @ self._device_const("g2l", dev, lambda: _grid_to_lidar(self._pc_range, self._grid_dims))
         cam = dehomog(pts @ trans.transpose(1, 2))
         img = torch.cat([cam, torch.ones_like(cam[..., :1])], -1) @ intrins_cam[:, :3, :].transpose(1, 2)
         uv = dehomog(img)
@@ -249,7 +258,8 @@ class FlospDepth(nn.Module):
         idx = -0.5 + 0.5 * torch.sqrt(1 + 8 * (dep - d0) / bin_size)
         fr = torch.cat([uv, idx.unsqueeze(-1), torch.ones_like(idx).unsqueeze(-1)], -1)
         fr = dehomog(fr @ ida_cam.transpose(1, 2))
-        shape = torch.tensor([self.final_dim[1], self.final_dim[0], nb], device=dev, dtype=torch.float32)
+        shape = self._device_const(("shape", nb), dev, lambda: torch.tensor([self.final_dim[1], self.final_dim[0], nb],
+                                                                             dtype=torch.float32))
         fr = fr / (shape - 1) * 2 - 1
         fr = torch.where(torch.isfinite(fr), fr, torch.full_like(fr, -2.0))
         return fr.reshape(-1, A, Bd, C, 3)
