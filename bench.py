@@ -331,6 +331,10 @@ def _train(args, world, rank, device, dist):
     synthetic.attach_training_targets(model, batch, cfg, seed=1 + rank)
     model, buckets = shard.prepare_for_ddp(model, dist)
     opt = model.configure_optimizers()[0][0]
+    use_graph = buckets is None and os.environ.get("OCCDEPTH_TRAIN_GRAPH", "1") == "1"
+    if use_graph:
+        from occdepth_amd import train_graph
+        train_graph.make_capturable(opt)                 # (before the optimizer's first step: device-side step counters)
 
     def step():
         if buckets is not None:
@@ -347,11 +351,21 @@ def _train(args, world, rank, device, dist):
 
     for _ in range(args.warmup):
         step()
+    # whole-step hipGraph (occdepth_amd/train_graph.py): the eager step is ~9600 launches and host-bound.  One rank only:
+    # the gradient buckets launch their collectives from autograd hooks, which has never been captured on > 1 GPU here.
+    graphed, graph_error = None, None
+    if use_graph:
+        gs = train_graph.GraphedTrainStep(model, opt, batch, bf16=args.bf16, warmup=1)
+        if gs.capture():
+            graphed = gs
+            gs()
+        else:
+            graph_error = gs.error
     shard.fence(dist)
     with hip.profile() as prof:
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            loss = step()
+            loss = graphed() if graphed is not None else step()
         shard.fence(dist)
         elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, device)
@@ -369,6 +383,7 @@ def _train(args, world, rank, device, dist):
                    "global_batch": world, "ranks": dist.get_world_size() if dist is not None else 1,
                    "parallelism": f"dp{world}: SyncBatchNorm (packed all-reduce per layer) + "
                                   f"{len(buckets.buckets) if buckets else 0} gradient buckets ({buckets.algo if buckets else 'none'})"},
+        "train_graph": graphed is not None, "train_graph_error": graph_error,
         "loss": float(loss.detach()), "max_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
         "hip_kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in rows},
     }

@@ -114,3 +114,49 @@ def test_train_step_matches_reference_gpu(cfg_name, hip_lib):
 
 # The HIP-vs-ATen comparison of the 3-D stack's backward lives in tests/test_stack3d_backward.py: the stack alone,
 # fixed inputs, ATen float64 reference on the same ReLU masks, elements within 1e-3 rms and norms within 1e-4.
+
+
+def _small_train_setup(cfg_name, device):
+    m, cfg, _ = build_product(cfg_name)
+    m = m.to(device)
+    def to_dev(b):
+        return {k: ([t.to(device) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
+                    (v.to(device) if torch.is_tensor(v) else v)) for k, v in b.items()}
+    batch = gc.occdepth_batch(cfg_name)
+    with torch.no_grad():
+        out = m.eval()(to_dev(batch))
+    shapes = {k: tuple(v.shape) for k, v in out.items() if torch.is_tensor(v)}
+    extras = gc.train_extras(cfg_name, shapes, tuple(cfg.full_scene_size), cfg.n_classes, batch["img"].shape[-2:])
+    return m, to_dev(dict(batch, **extras))
+
+
+@pytest.mark.gpu
+def test_whole_step_hipgraph_matches_eager_gpu(hip_lib):
+    """occdepth_amd/train_graph.py: forward + losses + backward + AdamW of the reduced SemanticKITTI model (training
+    mode) captured into one hipGraph; after rewinding parameters and optimizer state, three replays reproduce three eager
+    steps from the same state (loss values, one parameter)."""
+    import copy
+    from occdepth_amd import train_graph
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m0, batch = _small_train_setup("kitti_small", "cuda")
+    runs = {}
+    for mode in ("eager", "graph"):
+        m = copy.deepcopy(m0).train()
+        m.cur_batch = 0
+        opt = train_graph.make_capturable(torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True))
+        gs = train_graph.GraphedTrainStep(m, opt, batch, warmup=1)
+        if mode == "graph":
+            state = copy.deepcopy(m.state_dict())
+            assert gs.capture(), gs.error
+            m.load_state_dict(state)                      # warm-up + capture pass ran two real steps: rewind
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        losses = [float(gs()) for _ in range(3)]
+        runs[mode] = (losses, next(iter(m.net_3d_decoder.parameters())).detach().float().cpu().clone())
+    (le, pe), (lg, pg) = runs["eager"], runs["graph"]
+    print("eager", le, "graph", lg)
+    assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    assert float((pe - pg).abs().max() / pe.abs().max()) < 5e-3
