@@ -89,12 +89,21 @@ def parity_check(device):
     with torch.no_grad():
         m(batch)                                           # capture pass
         out = m(batch)                                     # replay (what the timed loop runs)
-    errs = {}
+    errs, extra = {}, {}
     for k, v in out.items():
         ref = torch.from_numpy(g[k])
         got = gc.subsample(v.cpu().contiguous())
-        errs[k] = float((got - ref).abs().max() / ref.abs().max())
+        d = (got - ref).double()
+        errs[k] = float(d.abs().max() / ref.abs().max())                  # max |delta| over the tensor's scale
+        if k in ("ssc_logit", "occ_logit"):
+            # finer-grained views of the same comparison: root-mean-square relative error, and the element-wise
+            # relative error of every logit that is not near zero (|ref| >= 1 % of the tensor's scale)
+            big = ref.abs() >= 0.01 * ref.abs().max()
+            extra[k] = {"rms_rel": float(d.norm() / ref.double().norm()),
+                        "max_elementwise_rel_where_ref_ge_1pct_of_scale": float((d.abs()[big] / ref.abs()[big].double()).max()),
+                        "argmax_agreement": float((got.argmax(1) == ref.argmax(1)).double().mean())}
     return {"ssc_logit": errs["ssc_logit"], "occ_logit": errs["occ_logit"], "worst_of_all_outputs": max(errs.values()),
+            "detail": extra,
             "batch_views": bool(m.batch_views), "graph_2d": bool(m.graph_2d),
             "reference": "tests/golden/occdepth_kitti_a100.npz (real reference, CPU fp32)", "bar": 1e-3}
 
