@@ -5,7 +5,10 @@ The reference pulls `rwightman/gen-efficientnet-pytorch` through torch.hub
 so the architecture is restated here with geffnet's module / parameter names (conv_stem, bn1,
 act1, blocks.{stage}.{block}.{conv_pw,bn1,conv_dw,bn2,se.conv_reduce,se.conv_expand,conv_pwl,bn3},
 conv_head, bn2, act2, global_pool, classifier) so hub checkpoints load by key.  TF "SAME"
-padding, swish, SE on the block input width, BN eps 1e-3.  Runs on PyTorch-ROCm / MIOpen.
+padding, swish, SE on the block input width, BN eps 1e-3.  Eval path on the GPU: every MBConv block is 4 launches of the
+in-repo kernels (K11 / K11s pointwise GEMMs with BN / swish / SE gate / skip fused, LDS-staged depthwise + SE pooling, SE
+gate); the expand convolutions of the 1/16 and 1/32 stages and the stem stay on the library (measured faster there).
+Training path: depthwise convolutions and swish on HIP kernels with hand-written backward, the rest on ATen.
 Parity of this file is UNPINNED (no reference copy of geffnet exists here).
 """
 import math

@@ -1,10 +1,13 @@
 """2-D UNet: EfficientNet encoder + AdaBins-style BN decoder (mirror of occdepth/models/unet2d.py).
 
-Convolutions run in PyTorch-ROCm / MIOpen (north_star) except the 3x3 convolutions of the three low-resolution decoder
-levels, which take the Winograd-domain MFMA path (csrc/wino2d.hip + batched GEMMs); BatchNorm + activation, bilinear
-upsample + concat and the depthwise convolutions are fused HIP passes in eval mode.  Faithful quirks: the decoder taps
-encoder features [4, 5, 6, 8, 11] (conv_head output BEFORE bn2), `conv2` is a 1x1 conv with padding=1 (grows the
-1/32 map by 2), and `up1` concatenates the raw image.
+Eval path on the GPU (no autograd): every 3x3 convolution of the decoder runs on the in-repo kernels -- the first one of
+each level as nine low-resolution tap GEMMs + the upsample-shift-accumulate kernel K12 + K10 over the skip channels
+(no upsample+concat tensor), the second one on K10 (fused Winograd MFMA) or, at the 1/8 and 1/16 levels, on the
+Winograd-domain transforms K9 around batched library GEMMs; the 1x1 heads on K11 write pixel-major rows for the lift;
+the encoder's `conv_head` is folded into `conv2`.  Training path: 3x3 convolutions forward / data gradient on K10 through
+`hip.conv2d_3x3_autograd`, the rest on ATen.  Faithful quirks: the decoder taps encoder features [4, 5, 6, 8, 11]
+(conv_head output BEFORE bn2), `conv2` is a 1x1 conv with padding=1 (grows the 1/32 map by 2), and `up1` concatenates
+the raw image.
 """
 import os
 

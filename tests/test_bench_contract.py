@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_final_bench.json, produced by `python bench.py` on an MI355X) carries every
+"""The committed bench line (profiles/r02_final_bench.json, produced by `python bench.py` on an MI355X) carries every
 field the driver contract names, and its derived numbers are self-consistent."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_matches_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_final_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
