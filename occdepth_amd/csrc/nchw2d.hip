@@ -467,9 +467,21 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
                                                             int h, int w, int H, int W, float rh, float rw, long zcs,
                                                             long zbs) {
     __shared__ float L[9 * 4 * kUpNC];
-    const int plane = blockIdx.z;                 // b * Cout + co
+    // Workgroup -> tile mapping.  Vertically adjacent tiles share 2 of their ~4 low-resolution source rows; the
+    // dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2), so in launch order
+    // those rows came back from HBM twice (PMC: 2.2x the z tensor fetched).  XCD-aware bijective remap of the linear id,
+    // then column-major tiles inside a plane: every XCD walks a contiguous run of vertically adjacent tiles.
+    const uint32_t gx = gridDim.x, gy = gridDim.y, per_plane = gx * gy;
+    uint32_t bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    {
+        const uint32_t nwg = per_plane * gridDim.z, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int plane = bid / per_plane;            // b * Cout + co
+    const uint32_t local = bid - plane * per_plane;
+    const int bx = local / gy, by = local - bx * gy;
     const int b = plane / Cout, co = plane - b * Cout;
-    const int X0 = blockIdx.x * 256, oy0 = blockIdx.y * 4;
+    const int X0 = bx * 256, oy0 = by * 4;
     // low-resolution column window of the hi-res columns X0 - 1 .. X0 + 256 (clamped): [xlo, xlo + nc)
     const int xlo = (int)(rw * max(X0 - 1, 0));
     const int xe = (int)(rw * min(X0 + 256, W - 1));
