@@ -11,10 +11,4 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-parity > $O/bench_under_rocprof.json 2> /tmp/prof_bench.err
 f=$(ls /tmp/prof_bench/*/*kernel_trace.csv | head -1)
 python $R/tools/summarize_trace.py $f $O/steady_state_kernel_stats.csv 5 > /dev/null; grep "upconv\|GPU busy" $O/steady_state_kernel_stats.csv | cut -c1-150
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity > /tmp/pmc_f.log 2>&1
-f=$(ls /tmp/pmc_f/*/*counter_collection.csv | head -1)
-python - <<PY
-import csv
-v=[float(r["Counter_Value"]) for r in csv.DictReader(open("$f")) if "upconv_gather" in r["Kernel_Name"] and r["Counter_Name"]=="FETCH_SIZE"]
-print("K12 FETCH per launch: %.1f MB over %d launches" % (sum(v)/len(v)*2048/1e6, len(v)))
-PY
+
