@@ -358,13 +358,28 @@ def ssc_confusion(hist, target, logits=None, labels=None):
     return hist
 
 
+def upconv_gather(z, cout, size, batch_inner=False):
+    """K12 semantics: sum over the 9 taps of shift_t(bilinear_up(z_t, align_corners=True)), zero outside the grid."""
+    if batch_inner:
+        z = z.permute(1, 0, 2, 3)
+    H, W = int(size[0]), int(size[1])
+    out = torch.zeros(z.shape[0], cout, H, W, dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            t = ky * 3 + kx
+            up = F.interpolate(z[:, t * cout:(t + 1) * cout].double(), size=(H, W), mode="bilinear", align_corners=True)
+            out += F.pad(up, (1, 1, 1, 1))[:, :, ky:ky + H, kx:kx + W]
+    return out.float()
+
+
 @contextlib.contextmanager
 def patched():
     saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
-                                          "dwconv2d_same_pool", "se_gate")}
+                                          "dwconv2d_same_pool", "se_gate", "upconv_gather")}
+    hip.upconv_gather = upconv_gather
     hip.dwconv2d_same_pool, hip.se_gate = dwconv2d_same_pool, se_gate
     hip.wino_pack_weights, hip.conv2d_3x3_fused = wino_pack_weights, conv2d_3x3_fused
     hip.pw_pack_weights, hip.conv1x1 = pw_pack_weights, conv1x1

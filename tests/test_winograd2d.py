@@ -270,3 +270,51 @@ def test_swish_and_upsample_cat_autograd_gpu(hip_lib):
     assert float((out.detach().double().cpu() - ref.detach()).abs().max()) < 1e-5
     assert float((ac.grad.double().cpu() - ar.grad).abs().max()) < 1e-5
     assert torch.equal(sc.grad.cpu(), go[:, 6:])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host algebra of the decoder's eval path on the CPU (kernels emulated): tap-GEMM split of the first convolution,
+# BatchNorm folding, skip-channel convolution with the gathered part as residual; conv_head folded into conv2
+@pytest.mark.parametrize("case", [(2, 24, 5, 8, 6, 9, 11, 17), (1, 16, 3, 12, 4, 5, 8, 10)])
+def test_upconv_host_algebra_cpu(case):
+    import copy
+    from occdepth_amd.models.unet2d import UpSampleBN
+    B, cup, cs, cout, h, w, H, W = case
+    torch.manual_seed(cup * 7 + cout)
+    m = UpSampleBN(cup + cs, cout)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    m.eval()
+    x, skip = torch.randn(B, cup, h, w), torch.randn(B, cs, H, W)
+    n = m._net
+    with torch.no_grad():
+        up = F.interpolate(x.double(), size=(H, W), mode="bilinear", align_corners=True)
+        ref = copy.deepcopy(n[:3]).double()(torch.cat([up, skip.double()], 1))       # conv -> BN -> LeakyReLU
+        saved = UpSampleBN.UPCONV_LIB_BELOW
+        try:
+            with emu.patched():
+                for lib in (0, 1 << 62):                      # tap GEMM through the K11 wrapper / through torch.matmul
+                    UpSampleBN.UPCONV_LIB_BELOW = lib
+                    got = m._first_conv_upconv(x, skip, n[0], n[1], n[2])
+                    err = float((got.double() - ref).abs().max() / ref.abs().max())
+                    assert got.shape == ref.shape and err < 2e-5, (lib, err)
+        finally:
+            UpSampleBN.UPCONV_LIB_BELOW = saved
+
+
+def test_merged_head_algebra_cpu():
+    from occdepth_amd.models.unet2d import DecoderBN
+    torch.manual_seed(4)
+    dec = DecoderBN(num_features=64, bottleneck_features=64, out_feature=8, use_decoder=True,
+                    backbone_2d_name="tf_efficientnet_b3_ns", return_up_feats=1)
+    head = torch.nn.Conv2d(24, 64, 1, bias=False)
+    f = torch.randn(2, 24, 5, 7)
+    with torch.no_grad():
+        ref = dec.conv2(head(f))
+        got = dec._conv2_merged(f, head)
+    assert got.shape == ref.shape == (2, 64, 7, 9)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
