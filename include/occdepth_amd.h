@@ -261,6 +261,14 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
 int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch, int32_t Cout, int32_t h, int32_t w,
                             int32_t H, int32_t W, int64_t z_channel_stride, int64_t z_batch_stride, void* stream);
 
+/* The same with the level's remaining pieces fused, for <= 4 skip channels (the 1/1 level: the raw image):
+ *   out = leaky_relu(gather(z) + conv3x3(skip, wskip, pad 1) + shift[co], slope)
+ * skip (B, Cs, H, W), wskip (Cout, Cs, 3, 3) with the BatchNorm scale folded in, shift (Cout): the finished
+ * `LeakyReLU(BN(conv(cat[up(x), skip])))` of `UpSampleBN` (unet2d.py:24-46) in one launch after the tap GEMM.     */
+int occd_upconv_gather_skip_nchw(const float* z, const float* skip, const float* wskip, const float* shift, float* out,
+                                 int32_t batch, int32_t Cout, int32_t Cs, int32_t h, int32_t w, int32_t H, int32_t W,
+                                 int64_t z_channel_stride, int64_t z_batch_stride, float slope, void* stream);
+
 /* Winograd F(2x2, 3x3) transforms for nn.Conv2d(k=3, s=1, p=1) of the 2-D decoder
  * (occdepth/models/unet2d.py:24-46).  T = B * ceil(H/2) * ceil(W/2) tiles, tile (b, ty, tx) -> row (b*th + ty)*tw + tx.
  *   input : x (B, Cin, H, W) -> V (16, T, Cin),  V[4i+j] = (B^T d B)[i][j] of the 4x4 patch at (2ty-1, 2tx-1), zero padded

@@ -463,10 +463,24 @@ __global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* 
 // for the output row oy0 + r + ky - 1.  A thread then needs 2 LDS reads per (tap, output): 72 instead of 144 global ones.
 // Same arithmetic as the direct form up to the order of the two interpolations (vertical first here).
 constexpr int kUpNC = 192;                                   // LDS row length: low-resolution columns a workgroup can touch
+// SKIP: the convolution over the (few: <= kUpSkipC) skip channels, the BatchNorm shift and the LeakyReLU are applied here
+// too, i.e. the kernel emits the finished first convolution of the level (the 1/1 level: 3 raw image channels).  K10 is
+// the wrong tool for K = 3: its per-workgroup prologue / exchange / epilogue is fixed and it ran the 3 -> 80 convolution
+// at 0.76 ms against the 0.2 ms its bytes cost, plus a write + re-read of the gathered tensor (2 x 289 MB).
+struct UpSkipP {
+    const float* skip;      // (B, Cs, H, W)
+    const float* wskip;     // (Cout, Cs, 3, 3), BatchNorm scale folded in
+    const float* shift;     // (Cout)
+    int Cs;
+    float slope;
+};
+constexpr int kUpSkipC = 4, kUpSkipW = 260;                  // skip tile: [Cs][6 rows][258 columns (+2 pad)]
+template <bool SKIP>
 __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
                                                             int h, int w, int H, int W, float rh, float rw, long zcs,
-                                                            long zbs) {
+                                                            long zbs, const UpSkipP sk) {
     __shared__ float L[9 * 4 * kUpNC];
+    __shared__ float S[SKIP ? kUpSkipC * 6 * kUpSkipW : 1];
     // Workgroup -> tile mapping.  Vertically adjacent tiles share 2 of their ~4 low-resolution source rows; the
     // dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2), so in launch order
     // those rows came back from HBM twice (PMC: 2.2x the z tensor fetched).  XCD-aware bijective remap of the linear id,
@@ -515,6 +529,19 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
             }
         }
     }
+    if (SKIP) {
+        // skip tile: rows oy0 - 1 .. oy0 + 4, columns X0 - 1 .. X0 + 256 of every skip channel, zero outside the image
+        const float* sb = sk.skip + (size_t)b * sk.Cs * H * W;
+        const int total = sk.Cs * 6 * 258;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int c = e / (6 * 258), rem = e - c * (6 * 258);
+            const int rr = rem / 258, cc = rem - rr * 258;
+            const int iy = oy0 - 1 + rr, ix = X0 - 1 + cc;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float v = sb[((size_t)c * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+            S[(c * 6 + rr) * kUpSkipW + cc] = ok ? v : 0.f;
+        }
+    }
     __syncthreads();
     const int r = threadIdx.x >> 6;
     const int ox0 = X0 + (threadIdx.x & 63) * 4, oy = oy0 + r;
@@ -540,6 +567,31 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
         for (int i = 0; i < 4; ++i) {
             const int j = i + kx;
             acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
+        }
+    }
+    if (SKIP) {
+        const float* wk = sk.wskip + (size_t)co * sk.Cs * 9;
+        const int lc = ox0 - X0;                              // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
+        for (int c = 0; c < sk.Cs; ++c) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* srow = S + (c * 6 + r + ky) * kUpSkipW + lc;
+                float v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[j] = srow[j];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = wk[(c * 3 + ky) * 3 + kx];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] += v[i + kx] * wv;
+                }
+            }
+        }
+        const float sh = sk.shift[co];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = acc[i] + sh;
+            acc[i] = t > 0.f ? t : t * sk.slope;
         }
     }
     float* op = out + ((size_t)plane * H + oy) * W + ox0;
@@ -718,11 +770,33 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
     static const bool force_direct = getenv("OCCD_UPCONV_DIRECT") != nullptr;        // A/B switch
     if (!force_direct && rw * 258.f + 3.f <= (float)kUpNC)
-        hipLaunchKernelGGL(upconv_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw,
-                           zcs, zbs);
+        hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh,
+                           rw, zcs, zbs, UpSkipP{});
     else
         hipLaunchKernelGGL(upconv_gather_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
                            rh, rw, zcs, zbs);
+    return occd::check_launch();
+}
+
+extern "C" int occd_upconv_gather_skip_nchw(const float* z, const float* skip, const float* wskip, const float* shift,
+                                            float* out, int32_t batch, int32_t Cout, int32_t Cs, int32_t h, int32_t w,
+                                            int32_t H, int32_t W, int64_t z_channel_stride, int64_t z_batch_stride,
+                                            float slope, void* stream) {
+    if (!z || !skip || !wskip || !shift || !out || batch <= 0 || Cout <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 ||
+        (long)batch * Cout > 65535 || Cs < 1 || Cs > kUpSkipC)
+        return OCCD_EINVAL;
+    const long zcs = z_channel_stride > 0 ? z_channel_stride : (long)h * w;
+    const long zbs = z_batch_stride > 0 ? z_batch_stride : 9L * Cout * zcs;
+    if (zcs < (long)h * w) return OCCD_EINVAL;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    if (rw * 258.f + 3.f > (float)kUpNC) return OCCD_EINVAL;          // (upsampling ratios below ~1.4: use the two-kernel form)
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
+    occd::ProfScope prof("upconv_gather_skip_nchw", (hipStream_t)stream, 2.0 * (36 + 9.0 * Cs) * batch * Cout * (double)H * W,
+                         4.0 * batch * (Cout * (9.0 * h * w + (double)H * W) + (double)Cs * H * W));
+    UpSkipP sk{skip, wskip, shift, Cs, slope};
+    hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw,
+                       zcs, zbs, sk);
     return occd::check_launch();
 }
 

@@ -117,6 +117,7 @@ EXPORTS = {
     "occd_dwconv2d_nchw": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
     "occd_upsample_bilinear_cat_nchw": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
     "occd_swish_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "occd_upconv_gather_skip_nchw": (c_int32, [c_void_p] * 5 + [c_int32] * 7 + [c_int64, c_int64, ctypes.c_float, c_void_p]),
     "occd_upconv_gather_nchw": (c_int32, [c_void_p, c_void_p] + [c_int32] * 6 + [c_int64, c_int64, c_void_p]),
     "occd_wino_input_transform_nchw": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                  c_void_p]),
@@ -867,7 +868,7 @@ def upsample_bilinear_cat(x, skip):
     return out
 
 
-def upconv_gather(z, cout, size, batch_inner=False):
+def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift=None, slope=0.01):
     """sum over the 9 taps of shift_t(bilinear_up(z_t)): z (B, 9 * cout, h, w) -> (B, cout, H, W), size = (H, W).
     With z = conv1x1(x, W9) this is conv3x3(pad 1)(bilinear_up(x, align_corners=True)) (see occd_upconv_gather_nchw).
     batch_inner: z is (9 * cout, B, h, w) -- the result of ONE GEMM over the pixels of all images."""
@@ -883,6 +884,13 @@ def upconv_gather(z, cout, size, batch_inner=False):
         raise RuntimeError("upconv_gather: z must have 9 * cout channels")
     H, W = int(size[0]), int(size[1])
     out = torch.empty((B, cout, H, W), device=z.device, dtype=torch.float32)
+    if skip is not None:
+        # fused tail of the level: + conv3x3 over the (<= 4) skip channels + shift, LeakyReLU (occd_upconv_gather_skip_nchw)
+        sk = skip if skip.is_contiguous() else skip.contiguous()
+        _check(load().occd_upconv_gather_skip_nchw(_f32(z, "z"), _f32(sk, "skip"), _f32(wskip, "wskip"), _f32(shift, "shift"),
+                                                   _f32(out, "out"), B, cout, sk.shape[1], h, w, H, W, zcs, zbs, float(slope),
+                                                   _stream()), "occd_upconv_gather_skip_nchw")
+        return out
     _check(load().occd_upconv_gather_nchw(_f32(z, "z"), _f32(out, "out"), B, cout, h, w, H, W, zcs, zbs, _stream()),
            "occd_upconv_gather_nchw")
     return out

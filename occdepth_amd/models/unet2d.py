@@ -102,6 +102,7 @@ class UpSampleBN(nn.Module):
     # library is used (default: always) keeps K11 selectable for A/B.
     UPCONV_LIB_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_LIB_BELOW", str(1 << 62)))
     UPCONV_FOLD_BELOW = int(os.environ.get("OCCDEPTH_UPCONV_FOLD_BELOW", "0"))        # B * h * w (experiment)
+    UPCONV_FUSE_SKIP = os.environ.get("OCCDEPTH_UPCONV_FUSE_SKIP", "1") == "1"
 
     def _upconv_operands(self, conv, bn, cup):
         key = (_stamp(conv, bn), cup)
@@ -114,26 +115,34 @@ class UpSampleBN(nn.Module):
             cout = w.shape[0]
             # rows t * Cout + co (t = ky * 3 + kx) of the tap GEMM, BatchNorm scale folded in
             w9 = (w[:, :cup] * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(9 * cout, cup).contiguous()
+            wskip = (w[:, cup:] * scale.view(-1, 1, 1, 1)).contiguous()
             hit = (key, hip.pw_pack_weights(w9), w9,
-                   hip.wino_pack_weights(w[:, cup:].contiguous(), scale), shift.contiguous())
+                   hip.wino_pack_weights(w[:, cup:].contiguous(), scale), shift.contiguous(), wskip)
             self.__dict__["_upconv_cache"] = hit
         return hit[1:]
 
     def _first_conv_upconv(self, x, skip, conv, bn, act):
-        wpk9, w9, upk_skip, shift = self._upconv_operands(conv, bn, x.shape[1])
+        wpk9, w9, upk_skip, shift, wskip = self._upconv_operands(conv, bn, x.shape[1])
         cout = conv.out_channels
         B, cup, h, w = x.shape
         if B > 1 and B * h * w <= self.UPCONV_FOLD_BELOW:
             # few pixels per image: ONE GEMM over the pixels of all images (the operand copy is small here)
             z = torch.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w)).view(9 * cout, B, h, w)
-            u = hip.upconv_gather(z, cout, skip.shape[2:], batch_inner=True)
+            batch_inner = True
         else:
+            batch_inner = False
             if B * h * w < self.UPCONV_LIB_BELOW:
                 xc = x if x.is_contiguous() else x.contiguous()
                 z = torch.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)
             else:
                 z = hip.conv1x1(x, wpk9, 9 * cout)
-            u = hip.upconv_gather(z, cout, skip.shape[2:])
+        rw = (w - 1) / max(skip.shape[3] - 1, 1)
+        if self.UPCONV_FUSE_SKIP and skip.shape[1] <= 4 and rw * 258.0 + 3.0 <= 191.0:
+            # few skip channels (the 1/1 level: the raw image): their 3x3 convolution, the shift and the LeakyReLU ride in
+            # K12's epilogue -- K10's fixed per-workgroup cost is 4x what a K = 3 convolution's bytes cost
+            return hip.upconv_gather(z, cout, skip.shape[2:], batch_inner=batch_inner, skip=skip, wskip=wskip, shift=shift,
+                                     slope=act.negative_slope)
+        u = hip.upconv_gather(z, cout, skip.shape[2:], batch_inner=batch_inner)
         return hip.conv2d_3x3_fused(skip, upk_skip, cout, shift, "leaky", act.negative_slope, res=u, res_first=True)
 
     def forward(self, x, concat_with):

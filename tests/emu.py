@@ -358,7 +358,7 @@ def ssc_confusion(hist, target, logits=None, labels=None):
     return hist
 
 
-def upconv_gather(z, cout, size, batch_inner=False):
+def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift=None, slope=0.01):
     """K12 semantics: sum over the 9 taps of shift_t(bilinear_up(z_t, align_corners=True)), zero outside the grid."""
     if batch_inner:
         z = z.permute(1, 0, 2, 3)
@@ -369,6 +369,8 @@ def upconv_gather(z, cout, size, batch_inner=False):
             t = ky * 3 + kx
             up = F.interpolate(z[:, t * cout:(t + 1) * cout].double(), size=(H, W), mode="bilinear", align_corners=True)
             out += F.pad(up, (1, 1, 1, 1))[:, :, ky:ky + H, kx:kx + W]
+    if skip is not None:
+        out = F.leaky_relu(out + F.conv2d(skip.double(), wskip.double(), shift.double(), padding=1), slope)
     return out.float()
 
 

@@ -207,7 +207,7 @@ def test_upconv_gather_kernel_gpu(case, hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 40, 9, 16, 7, 9, 13, 18), (1, 24, 3, 8, 6, 20, 12, 40)])
+@pytest.mark.parametrize("case", [(2, 40, 9, 16, 7, 9, 13, 18), (1, 24, 3, 8, 6, 20, 12, 40), (2, 16, 3, 8, 40, 150, 81, 301)])
 def test_upsample_block_upconv_matches_module_gpu(case, hip_lib):
     """A whole decoder level (UpSampleBN, eval): the tap-GEMM form of its first convolution against the module's own
     float64 CPU forward (interpolate -> cat -> conv -> BN -> LeakyReLU, twice), and against the upsample+concat form."""
