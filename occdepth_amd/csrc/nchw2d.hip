@@ -15,6 +15,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
                                                             int h, int w, int H, int W, float rh, float rw, long zcs,
                                                             long zbs, const UpSkipP sk) {
     __shared__ float L[9 * 4 * kUpNC];
-    __shared__ float S[SKIP ? kUpSkipC * 6 * kUpSkipW : 1];
+    __shared__ __attribute__((aligned(16))) float S[SKIP ? kUpSkipC * 6 * kUpSkipW : 4];
     // Workgroup -> tile mapping.  Vertically adjacent tiles share 2 of their ~4 low-resolution source rows; the
     // dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2), so in launch order
     // those rows came back from HBM twice (PMC: 2.2x the z tensor fetched).  XCD-aware bijective remap of the linear id,
@@ -531,15 +532,29 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     }
     if (SKIP) {
         // skip tile: rows oy0 - 1 .. oy0 + 4, columns X0 - 1 .. X0 + 256 of every skip channel, zero outside the image
+        // (thread = tile column, channels x rows unrolled: no index divisions, all loads of a thread independent)
         const float* sb = sk.skip + (size_t)b * sk.Cs * H * W;
-        const int total = sk.Cs * 6 * 258;
-        for (int e = threadIdx.x; e < total; e += 256) {
-            const int c = e / (6 * 258), rem = e - c * (6 * 258);
-            const int rr = rem / 258, cc = rem - rr * 258;
-            const int iy = oy0 - 1 + rr, ix = X0 - 1 + cc;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const float v = sb[((size_t)c * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
-            S[(c * 6 + rr) * kUpSkipW + cc] = ok ? v : 0.f;
+        const int cc0 = threadIdx.x;
+        const int ix0 = X0 - 1 + cc0, ix1 = ix0 + 256;                     // second column only for the first 2 threads
+        const bool okx0 = (unsigned)ix0 < (unsigned)W, okx1 = cc0 < 2 && (unsigned)ix1 < (unsigned)W;
+        const int cx0 = min(max(ix0, 0), W - 1), cx1 = min(max(ix1, 0), W - 1);
+#pragma unroll
+        for (int c = 0; c < kUpSkipC; ++c) {
+            if (c < sk.Cs) {                                                 // (uniform)
+                float v0[6], v1[6];
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    const int iy = min(max(oy0 - 1 + rr, 0), H - 1);
+                    v0[rr] = sb[((size_t)c * H + iy) * W + cx0];
+                    v1[rr] = sb[((size_t)c * H + iy) * W + cx1];
+                }
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    const bool oky = (unsigned)(oy0 - 1 + rr) < (unsigned)H;
+                    S[(c * 6 + rr) * kUpSkipW + cc0] = oky && okx0 ? v0[rr] : 0.f;
+                    if (cc0 < 2) S[(c * 6 + rr) * kUpSkipW + cc0 + 256] = oky && okx1 ? v1[rr] : 0.f;
+                }
+            }
         }
     }
     __syncthreads();
@@ -572,13 +587,16 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     if (SKIP) {
         const float* wk = sk.wskip + (size_t)co * sk.Cs * 9;
         const int lc = ox0 - X0;                              // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
-        for (int c = 0; c < sk.Cs; ++c) {
+#pragma unroll
+        for (int c = 0; c < kUpSkipC; ++c) {
+            if (c >= sk.Cs) break;                                           // (uniform)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const float* srow = S + (c * 6 + r + ky) * kUpSkipW + lc;
-                float v[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) v[j] = srow[j];
+                // (tile rows are 1040 bytes and lc = 4 * lane: one aligned 16-byte + one 8-byte LDS read per row)
+                const f32x4 va = *(const f32x4*)srow;
+                const f32x2 vb = *(const f32x2*)(srow + 4);
+                const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float wv = wk[(c * 3 + ky) * 3 + kx];
