@@ -174,9 +174,11 @@ def test_pointwise_conv_nhwc_output_feeds_the_lift_without_a_transpose(shape, hi
 
 
 @pytest.mark.gpu
-def test_softmax_nchw_gpu(hip_lib):
+@pytest.mark.parametrize("shape", [(2, 104, 47, 153), (1, 7, 5, 9), (3, 128, 3, 70), (1, 130, 6, 11)])
+def test_softmax_nchw_gpu(shape, hip_lib):
+    """depth-bin softmax: the channel-split kernel (C <= 128) and the generic one."""
     from occdepth_amd import hip
-    x = torch.randn(2, 104, 47, 153, generator=torch.Generator().manual_seed(1)) * 5
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1)) * 5
     y = hip.softmax_nchw(x.cuda())
     ref = torch.softmax(x.double(), 1)
     assert float((y.double().cpu() - ref).abs().max()) < 5e-6      # float32 exp + a 104-term sum against float64
