@@ -35,6 +35,12 @@ def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * 3
 
 
+def on_gpu(t):
+    """Gate of the 2-D eval fast paths (fused HIP kernels instead of ATen).  A function, not `t.is_cuda` inline, so that the
+    CPU test-suite can drive the very same host logic through its torch emulation of the kernels (tests/emu.py)."""
+    return t.is_cuda
+
+
 def _stamp(*mods):
     key = []
     for m in mods:

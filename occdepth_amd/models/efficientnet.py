@@ -20,6 +20,7 @@ import torch.nn.functional as F
 import os
 
 from .. import hip
+from .. import fused as _fused
 from ..fused import _stamp, bn_affine_cached, needs_autograd
 
 # K11 / SE-fusion path of the eval forward (OCCDEPTH_PW_FUSED=0 restores the MIOpen / rocBLAS 1x1 convolutions for A/B)
@@ -64,7 +65,7 @@ def pw_operands(owner, conv, bn=None):
 
 def _fast(x, module):
     """eval-mode CUDA tensors take the fused HIP elementwise / depthwise kernels (occdepth_amd/csrc/nchw2d.hip)."""
-    return x.is_cuda and not needs_autograd(module) and x.dtype == torch.float32
+    return _fused.on_gpu(x) and not needs_autograd(module) and x.dtype == torch.float32
 
 # (block type, repeats, kernel, stride, expand, channels) of EfficientNet-B0
 _B0_STAGES = (("ds", 1, 3, 1, 1, 16), ("ir", 2, 3, 2, 6, 24), ("ir", 2, 5, 2, 6, 40), ("ir", 3, 3, 2, 6, 80),

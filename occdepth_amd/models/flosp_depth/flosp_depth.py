@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from ... import hip
 import os
 
+from ... import fused as _fused
 from ...fused import bn_affine_cached, needs_autograd, wino_fused_operands
 
 # DepthNet's 3x3 convolutions on K10 (fused Winograd MFMA kernel, BatchNorm / ReLU / identity skip in its epilogue) instead
@@ -36,7 +37,7 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
 
     def forward(self, x):
-        if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+        if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             if DEPTHNET_K10:                                   # 2 launches per block
                 upk, shift = wino_fused_operands(self, self.conv1, self.bn1)
                 y = hip.conv2d_3x3_fused(x, upk, self.conv1.out_channels, shift, "relu")
@@ -104,14 +105,14 @@ class DepthNet(nn.Module):
         if not self.infer_mode:
             scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
                                                        sync_free=sweep_intrins.is_cuda)
-        if DEPTHNET_K10 and x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+        if DEPTHNET_K10 and _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             upk, shift = wino_fused_operands(self, self.reduce_conv[0], self.reduce_conv[1])
             x = hip.conv2d_3x3_fused(x, upk, self.reduce_conv[0].out_channels, shift, "relu")
         else:
             x = self.reduce_conv(x)
         x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
         x = self.depth_conv(x)
-        if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+        if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             from ..efficientnet import pw_operands, pw_wins
             if pw_wins(x):                                    # 1x1 convolution + bias on the MFMA GEMM (K11)
                 wpk, shift = pw_operands(self, self.depth_pred)
@@ -197,7 +198,7 @@ class FlospDepth(nn.Module):
             intrins[:, :, :3, :3] = k3
             intrins[:, :, 3, 3] = 1
             logits = self.depth_net[0](x=feat, sweep_intrins=intrins, scaled_pixel_size=None)
-        if logits.is_cuda and not needs_autograd(self) and logits.dtype == torch.float32:
+        if _fused.on_gpu(logits) and not needs_autograd(self) and logits.dtype == torch.float32:
             depth = hip.softmax_nchw(logits).reshape(bs, n_cams, self.depth_channels, h, w)
         else:
             depth = logits.softmax(1).reshape(bs, n_cams, self.depth_channels, h, w)

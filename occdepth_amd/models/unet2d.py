@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip
+from .. import fused as _fused
 from ..fused import _stamp, bn_affine_cached, needs_autograd, wino_fused_operands
 from .efficientnet import EfficientNet, pw_operands, pw_wins
 
@@ -146,7 +147,7 @@ class UpSampleBN(nn.Module):
         return hip.conv2d_3x3_fused(skip, upk_skip, cout, shift, "leaky", act.negative_slope, res=u, res_first=True)
 
     def forward(self, x, concat_with):
-        if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32:
+        if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             n = self._net
             if (self.UPCONV and self.FUSED and n[0].kernel_size == (3, 3) and n[0].padding == (1, 1)
                     and n[0].stride == (1, 1) and x.shape[0] * n[0].out_channels <= 65535):
@@ -227,7 +228,7 @@ class DecoderBN(nn.Module):
                 continue
             x = getattr(self, f"up{s}")(x, taps[s])
             head = getattr(self, f"resize_output_1_{s}")
-            if x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32 and pw_wins(x):
+            if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32 and pw_wins(x):
                 # 1x1 convolution + bias on the MFMA GEMM (K11), written pixel-major: the 2D->3D lift gathers pixel rows,
                 # so the (B, C, H, W) result is returned as a channels-last view and no transpose pass exists
                 wpk, shift = pw_operands(self, head)
@@ -275,7 +276,7 @@ class UNet2D(nn.Module):
 
     def forward(self, x, **kwargs):
         head = getattr(self.encoder.original_model, "conv_head", None)
-        if (self.MERGE_HEAD and self.use_decoder and x.is_cuda and not needs_autograd(self) and x.dtype == torch.float32
+        if (self.MERGE_HEAD and self.use_decoder and _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32
                 and isinstance(head, nn.Conv2d) and head.kernel_size == (1, 1) and head.stride == (1, 1)
                 and head.bias is None and head.groups == 1 and self.decoder.conv2.kernel_size == (1, 1)
                 and list(self.encoder.original_model._modules)[:5] == ["conv_stem", "bn1", "act1", "blocks", "conv_head"]

@@ -374,14 +374,59 @@ def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift
     return out.float()
 
 
+def _act2d(y, act, slope):
+    if act == "relu":
+        return F.relu(y)
+    if act == "leaky":
+        return F.leaky_relu(y, slope)
+    if act == "swish":
+        return y * torch.sigmoid(y)
+    return y
+
+
+def affine_act(x, scale, shift, act=None, slope=0.01, res=None, res_first=False, out=None):
+    """occd_affine_act_nchw semantics: act(x * scale[c] + shift[c]) with the residual before or after the activation."""
+    y = x.double()
+    shape = (1, -1) + (1,) * (x.dim() - 2)
+    if scale is not None:
+        y = y * scale.double().view(shape)
+    if shift is not None:
+        y = y + shift.double().view(shape)
+    if res is not None and res_first:
+        y = y + res.double()
+    y = _act2d(y, act, slope)
+    if res is not None and not res_first:
+        y = y + res.double()
+    return y.float()
+
+
+def dwconv2d_same(x, w, scale, shift, stride, act=None):
+    return dwconv2d_same_pool(x, w, scale, shift, stride, act)[0]
+
+
+def upsample_bilinear_cat(x, skip):
+    up = F.interpolate(x.double(), size=skip.shape[2:], mode="bilinear", align_corners=True)
+    return torch.cat([up, skip.double()], 1).float()
+
+
+def softmax_nchw(x):
+    return torch.softmax(x.double(), 1).float()
+
+
 @contextlib.contextmanager
-def patched():
-    saved = {k: getattr(hip, k) for k in ("pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
+def patched(fast2d=False):
+    """fast2d: also route the 2-D eval fast paths (fused.on_gpu gates) through the emulation on CPU tensors."""
+    saved = {k: getattr(hip, k) for k in ("affine_act", "dwconv2d_same", "upsample_bilinear_cat", "softmax_nchw", "pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather")}
     hip.upconv_gather = upconv_gather
+    hip.affine_act, hip.dwconv2d_same = affine_act, dwconv2d_same
+    hip.upsample_bilinear_cat, hip.softmax_nchw = upsample_bilinear_cat, softmax_nchw
+    saved_on_gpu = fused.on_gpu
+    if fast2d:
+        fused.on_gpu = lambda t: True
     hip.dwconv2d_same_pool, hip.se_gate = dwconv2d_same_pool, se_gate
     hip.wino_pack_weights, hip.conv2d_3x3_fused = wino_pack_weights, conv2d_3x3_fused
     hip.pw_pack_weights, hip.conv1x1 = pw_pack_weights, conv1x1
@@ -418,6 +463,7 @@ def patched():
     finally:
         for k, v in saved.items():
             setattr(hip, k, v)
+        fused.on_gpu = saved_on_gpu
         Vox.from_ncdhw = saved_from
         for m, f in old:
             m.as_vox = f
