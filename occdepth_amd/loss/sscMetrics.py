@@ -20,7 +20,14 @@ class SSCMetrics:
         self.reset()
 
     def reset(self):
-        self.hist = None                       # allocated with the first batch (the model is built before .to(device))
+        # The matrix is allocated with the first batch (the model is built before .to(device)) and from then on zeroed
+        # IN PLACE: a captured training-step hipGraph (train_graph.py) keeps accumulating into this very buffer, so
+        # replacing the tensor would leave the replays counting into an orphan and `get_stats()` reading zeros.
+        hist = self.__dict__.get("hist")
+        if hist is not None:
+            hist.zero_()
+        else:
+            self.hist = None
         self.count = 1e-8
 
     def _alloc(self, device):

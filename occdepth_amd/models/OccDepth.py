@@ -57,6 +57,7 @@ class OccDepth(_Base):
         self.infer_mode = infer_mode
         self.batch_views = False  # eval: run all views through net_rgb as one batch (faster, not bit-equal)
         self.graph_2d = False     # eval + batch_views: replay the 2-D network as one captured hipGraph
+        self.graph_all = False    # eval: replay the WHOLE forward (2-D network, lift, 3-D stack) as one captured hipGraph
         self._graphs = {}
         self.fused_lift = True    # training on the GPU: HIP lift + one-launch backward (lift_autograd.py) where it applies
         if infer_mode:
@@ -121,18 +122,27 @@ class OccDepth(_Base):
                 self.depth_loss_fn = DepthClsLoss(downsample_factor=conf["downsample_factor"], d_bound=conf["d_bound"])
 
     # ---------------------------------------------------------------- 2-D side
-    def _net_rgb_stamp(self):
-        """Cheap fingerprint of every tensor the captured 2-D graph bakes pointers / folded copies of: in-place updates
-        (optimizer.step, load_state_dict) bump `_version`; replaced storage changes `data_ptr`."""
-        ts = self.__dict__.get("_net_rgb_tensors")
+    def _stamp_of(self, root, slot):
+        """Exact fingerprint of every tensor a captured graph bakes pointers / folded copies of: in-place updates
+        (optimizer.step, load_state_dict) bump `_version`; replaced storage changes `data_ptr`.  Tuples, not sums (a sum
+        can collide); the tensor list is cached until train() / _apply() / load_state_dict() drop the graphs."""
+        ts = self.__dict__.get(slot)
         if ts is None:
-            ts = list(self.net_rgb.parameters()) + list(self.net_rgb.buffers())
-            self.__dict__["_net_rgb_tensors"] = ts
-        return (len(ts), sum(t._version for t in ts), sum(t.data_ptr() for t in ts))
+            ts = list(root.parameters()) + list(root.buffers())
+            self.__dict__[slot] = ts
+        return (tuple([t._version for t in ts]), tuple([t.data_ptr() for t in ts]))
+
+    def _net_rgb_stamp(self):
+        return self._stamp_of(self.net_rgb, "_net_rgb_tensors")
 
     def _drop_graphs(self):
         self._graphs.clear()
         self.__dict__.pop("_net_rgb_tensors", None)
+        self.__dict__.pop("_all_tensors", None)
+
+    def invalidate_graphs(self):
+        """Forget every captured hipGraph (they are re-captured on the next forward)."""
+        self._drop_graphs()
 
     def train(self, mode=True):
         self._drop_graphs()
@@ -153,8 +163,8 @@ class OccDepth(_Base):
         pointers to the weights AND to tensors derived from them (folded BatchNorm, packed / Winograd-domain weights);
         every entry therefore carries a stamp of the network's tensors and is re-captured when it no longer matches
         (train(), load_state_dict() and device / dtype moves drop the cache outright)."""
-        if not self.graph_2d or not x.is_cuda:
-            return self.net_rgb(x)
+        if not self.graph_2d or not x.is_cuda or torch.cuda.is_current_stream_capturing():
+            return self.net_rgb(x)                          # (inside the whole-forward capture the network is part of it)
         key = (tuple(x.shape), x.device)
         stamp = self._net_rgb_stamp()
         entry = self._graphs.get(key)
@@ -306,7 +316,89 @@ class OccDepth(_Base):
             fov.append(torch.stack([m for _, m in views]))
         return torch.stack(pix), torch.stack(fov)
 
+    # ---------------------------------------------------------------- whole-forward hipGraph
+    @staticmethod
+    def _batch_signature(batch):
+        sig = []
+        for k in sorted(batch):
+            v = batch[k]
+            if torch.is_tensor(v):
+                sig.append((k, tuple(v.shape), v.dtype, v.device))
+            elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+                sig.append((k, tuple((tuple(t.shape), t.dtype, t.device) for t in v)))
+        return tuple(sig)
+
+    @staticmethod
+    def _copy_batch(dst, src):
+        for k, v in src.items():
+            d = dst.get(k)
+            if torch.is_tensor(v) and torch.is_tensor(d):
+                if d.data_ptr() != v.data_ptr():
+                    d.copy_(v, non_blocking=True)
+            elif isinstance(v, (list, tuple)) and isinstance(d, list):
+                for dd, vv in zip(d, v):
+                    if torch.is_tensor(vv) and dd.data_ptr() != vv.data_ptr():
+                        dd.copy_(vv, non_blocking=True)
+
+    def _forward_graphed(self, batch):
+        """`graph_all` (opt-in, eval under no_grad, GPU batch): the WHOLE forward -- 2-D network, FLoSP-Depth, lift, 3-D
+        stack -- captured once per batch signature into ONE hipGraph and replayed per frame: the host only copies the
+        frame's tensors into the graph's static inputs (~20 MB at config 2) and launches the replay, so no launch gap is
+        left between the 2-D network, the lift and the 3-D stack (rocprof r02: 1.4 ms of a 26.8 ms frame).  The returned
+        tensors are the graph's static outputs: valid until the next forward of this model (clone what must survive).
+        Like `graph_2d`, an entry is re-captured when any parameter / buffer changed (exact (_version, data_ptr) stamp),
+        and a failed capture falls back to the eager path with a warning (`graph_all_error`)."""
+        key = ("all", self._batch_signature(batch))
+        stamp = self._stamp_of(self, "_all_tensors")
+        entry = self._graphs.get(key)
+        if entry is not None and entry[3] != stamp:
+            entry = None
+        if entry is None:
+            static = {k: (v.clone() if torch.is_tensor(v) else
+                          [t.clone() if torch.is_tensor(t) else t for t in v] if isinstance(v, (list, tuple)) else v)
+                      for k, v in batch.items()}
+            dev = batch["img"].device
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):                         # warm-up: plans, packed weights, library solvers, K2s counters
+                        self._forward_impl(static, allow_graph_2d=False)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._forward_impl(static, allow_graph_2d=False)
+                entry = (graph, static, static_out, stamp)
+            except (RuntimeError, torch.AcceleratorError) as e:   # capture is an optimisation, never a requirement
+                import warnings
+                warnings.warn(f"occdepth_amd: hipGraph capture of the whole forward failed ({e!r}); running eagerly")
+                self.graph_all = False
+                self.graph_all_error = repr(e)
+                torch.cuda.synchronize(dev)
+                return self._forward_impl(batch)
+            self._graphs[key] = entry
+        graph, static, static_out, _ = entry
+        self._copy_batch(static, batch)
+        graph.replay()
+        return dict(static_out)
+
     def forward(self, batch):
+        if self.graph_all and not needs_autograd(self) and batch["img"].is_cuda \
+                and not torch.cuda.is_current_stream_capturing():
+            return self._forward_graphed(batch)
+        return self._forward_impl(batch)
+
+    def _forward_impl(self, batch, allow_graph_2d=True):
+        if allow_graph_2d or not self.graph_2d:
+            return self._forward_body(batch)
+        self.graph_2d = False                  # (the whole-forward capture contains the 2-D network: no nested replay)
+        try:
+            return self._forward_body(batch)
+        finally:
+            self.graph_2d = True
+
+    def _forward_body(self, batch):
         img = batch["img"].to(device)
         bs, n_views = img.shape[:2]
         x_rgb, n_views = self.process_rgbs(img, batch, n_views)
@@ -377,6 +469,8 @@ class OccDepth(_Base):
 
         if self.sem_scal_loss:
             decay = max(0.1, (1 - self.cur_batch / self.total_batch)) if self.sem_step_decay_loss else 1.0
+            if self.sem_step_decay_loss and getattr(self, "_decay_dev", None) is not None and ssc_pred.is_cuda:
+                decay = self._decay_dev                      # device scalar kept current by train_graph.GraphedTrainStep
             loss_sem_scal = terms["loss_sem_scal"] * decay
             loss = loss + loss_sem_scal
             self._log(step_type + "/loss_sem_scal", loss_sem_scal)

@@ -64,13 +64,19 @@ class GradBuckets:
       only has all-reduce.
     """
 
-    def __init__(self, params, dist, bucket_bytes=128 << 20, algo=None):
+    def __init__(self, params, dist, bucket_bytes=128 << 20, algo=None, force=False, check_used=None):
         import os
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        # `force`: issue the collectives on a single-rank group too (exercises the RCCL path on one GPU)
+        self.active = dist is not None and dist.is_initialized() and (self.world > 1 or force)
         self.algo = algo or os.environ.get("OCCDEPTH_GRAD_ALGO", "all_reduce")
         if self.algo not in ("all_reduce", "rs_ag"):
-            raise ValueError(f"unknown gradient exchange algorithm {self.algo!r}")
+            raise ValueError(f"unknown gradient exchange algorithm {self.algo!r} (expected 'all_reduce' or 'rs_ag')")
+        # the average comes out of the collective itself where the backend can (RCCL: ReduceOp.AVG), so no extra pass
+        # over the ~600 MB of gradients follows it; gloo has no AVG: SUM, then one division per bucket
+        self.avg_in_collective = self.active and dist.get_backend() == "nccl"
+        self.check_used = (os.environ.get("OCCDEPTH_DDP_CHECK", "0") == "1") if check_used is None else bool(check_used)
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []                       # each: dict(flat, items=[(param, offset, numel)], pending, handles)
         cur, cur_bytes = [], 0
@@ -137,16 +143,17 @@ class GradBuckets:
         return ctx()
 
     def _launch(self, b):
-        if self.world <= 1:
+        if not self.active:
             return
         d, flat = self.dist, b["flat"]
+        op = d.ReduceOp.AVG if self.avg_in_collective else d.ReduceOp.SUM
         if self.algo == "rs_ag":
             n = flat.numel() // self.world
             shard = flat[d.get_rank() * n:(d.get_rank() + 1) * n]
-            b["handles"] = [d.reduce_scatter_tensor(shard, flat, op=d.ReduceOp.SUM, async_op=True),
+            b["handles"] = [d.reduce_scatter_tensor(shard, flat, op=op, async_op=True),
                             d.all_gather_into_tensor(flat, shard, async_op=True)]    # same stream: ordered
         else:
-            b["handles"] = [d.all_reduce(flat, op=d.ReduceOp.SUM, async_op=True)]
+            b["handles"] = [d.all_reduce(flat, op=op, async_op=True)]
 
     def _on_grad(self, p):
         b, off, n = self._where[p]
@@ -185,11 +192,28 @@ class GradBuckets:
         for b in self.buckets:
             for h in b["handles"]:
                 h.wait()
-            if self.world > 1:
+            if self.active and self.world > 1 and not self.avg_in_collective:
                 b["flat"].div_(self.world)
+        if self.check_used and self.active:
+            self._check_used_sets()
         for p in unused:
             p.grad = None
         self.reset()
+
+    def _check_used_sets(self):
+        """Debug (OCCDEPTH_DDP_CHECK=1): `finish()` drops the gradient of parameters this rank did not touch from LOCAL
+        knowledge, which is only right when every rank ran the same graph (one frame schema per step, as in the
+        reference's runs).  If a batch-dependent branch (`'occluded' in batch`, a single-view `gt_depth` frame) differs
+        between ranks, a rank would skip AdamW for a parameter the others update: raise instead of diverging silently."""
+        flags = torch.tensor([1 if p in b["touched"] else 0 for b in self.buckets for p, _, _ in b["items"]],
+                             dtype=torch.int32, device=self.buckets[0]["flat"].device)
+        lo, hi = flags.clone(), flags.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            bad = int((lo != hi).sum())
+            raise RuntimeError(f"GradBuckets: {bad} parameter(s) received a gradient on some ranks only (the ranks ran "
+                               "different graphs); their replicas would diverge")
 
     def remove(self):
         for h in self._hooks:
@@ -213,59 +237,102 @@ def allreduce_confusion(hist, dist=None):
     return hist
 
 
+def _group_active(group):
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
+# Single-rank process groups normally skip their collectives (there is nothing to exchange); tests and
+# `bench.py --train` under OCCDEPTH_FORCE_DIST=1 set this to drive the very same RCCL calls on one GPU.
+FORCE_COLLECTIVES = False
+
+
+def _dense(t):
+    """ATen's fused batch-norm kernels take NC* tensors that are dense in the default or in the channels-last order."""
+    if t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)) or \
+            (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)):
+        return t
+    return t.contiguous()
+
+
 class _SyncBNFn(torch.autograd.Function):
-    """Training-mode batch normalisation over the frames of ALL ranks with ONE packed collective per direction:
-    forward all-reduces [sum(x - c), sum((x - c)^2), count] (2C + 1 floats, c = the running mean every rank shares, so
-    the single-pass variance does not cancel), backward all-reduces [sum(gy), sum(gy * xhat)] (2C floats).
-    torch.nn.SyncBatchNorm does the same job with an all_gather of per-rank (mean, invstd, count) plus a CUDA-only
-    combine kernel; this form is backend-agnostic (RCCL on the GPU, gloo in the CPU tests) and is the host side the
-    fused BN-statistics convolution epilogue plugs into."""
+    """Training-mode batch normalisation over the frames of ALL ranks with ONE packed collective per direction.
+
+    forward : every rank takes its own (mean_r, M2_r / n_r) in one Welford pass (`torch.var_mean`), the ranks' moments are
+              merged with Chan's formula -- total mean = sum(n_r mean_r) / n, total M2 = sum(M2_r + n_r mean_r^2) - n mean^2 --
+              from ONE all-reduce of the (2C + 1)-element vector [n_r mean_r, M2_r + n_r mean_r^2, n_r].  Only that small
+              vector is float64 (so the merge cannot cancel, whatever mean / std is: the per-rank pass is centred on the
+              rank's own mean); no full-size float64 or float32 copy of the activation is made or saved.
+    backward: one reduction pass [sum(gy), sum(gy (x - mean))], ONE all-reduce of 2C floats, one element-wise pass.
+    On the GPU the two passes per direction are ATen's fused batch-norm kernels (batch_norm_elemt,
+    batch_norm_backward_reduce / _elemt -- the ones torch.nn.SyncBatchNorm uses); elsewhere (gloo CPU tests) the same
+    arithmetic in plain tensor ops.  The count stays a device tensor: no host synchronisation per layer.
+    torch.nn.SyncBatchNorm itself all_gathers (mean, invstd, count) per layer and needs a CUDA-only combine kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, centre, eps, group):
+    def forward(ctx, x, weight, bias, eps, group):
         import torch.distributed as dist
         C = x.shape[1]
         dims = [0] + list(range(2, x.dim()))
         shape = [1, C] + [1] * (x.dim() - 2)
         acc = torch.float64 if x.dtype == torch.float64 else torch.float32     # bf16 / fp16 activations: fp32 statistics
-        centre = centre.to(acc)
-        xc = x.to(acc) - centre.view(shape)
-        packed = torch.cat([xc.sum(dims), (xc * xc).sum(dims), xc.new_full((1,), float(x.numel() // C))]).double()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        x = _dense(x)
+        var_l, mean_l = torch.var_mean(x if x.dtype == acc else x.to(acc), dims, correction=0)
+        n_l = float(x.numel() // C)
+        m64 = mean_l.double()
+        packed = torch.cat([m64 * n_l, (var_l.double() + m64 * m64) * n_l, m64.new_full((1,), n_l)])
+        if _group_active(group):
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         n = packed[2 * C]
-        m1 = packed[:C] / n
-        var = (packed[C:2 * C] / n - m1 * m1).clamp_min(0.0)
-        mean = (m1 + centre.double()).to(acc)
-        invstd = torch.rsqrt(var.to(acc) + eps)
-        xhat = (x.to(acc) - mean.view(shape)) * invstd.view(shape)
-        y = xhat
-        if weight is not None:
-            y = y * weight.to(acc).view(shape) + bias.to(acc).view(shape)
-        ctx.save_for_backward(xhat, invstd, weight)
-        ctx.group, ctx.n = group, float(n)
-        ctx.mark_non_differentiable(mean, var)
-        return y.to(x.dtype), mean, var.to(acc), n.to(acc)
+        mean64 = packed[:C] / n
+        var64 = (packed[C:2 * C] / n - mean64 * mean64).clamp_min(0.0)
+        mean, var = mean64.to(acc), var64.to(acc)
+        invstd = torch.rsqrt(var + eps)
+        if x.is_cuda and x.dtype != torch.float64:
+            y = torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps)
+        else:
+            scale = invstd if weight is None else invstd * weight.to(acc)
+            shift = -mean * scale if bias is None else bias.to(acc) - mean * scale
+            y = torch.addcmul(shift.view(shape), x.to(acc), scale.view(shape)).to(x.dtype)
+        ctx.save_for_backward(x, mean, invstd, weight, n)
+        ctx.group = group
+        ctx.mark_non_differentiable(mean, var, n)
+        return y, mean, var, n.to(acc)
 
     @staticmethod
     def backward(ctx, gy, _gm, _gv, _gn):
         import torch.distributed as dist
-        xhat, invstd, weight = ctx.saved_tensors
-        C = xhat.shape[1]
-        dims = [0] + list(range(2, xhat.dim()))
-        shape = [1, C] + [1] * (xhat.dim() - 2)
-        g = gy.to(xhat.dtype)
-        sum_dy, sum_dy_xhat = g.sum(dims), (g * xhat).sum(dims)
-        gw = sum_dy_xhat.clone() if weight is not None else None      # parameter gradients stay per-rank sums:
-        gb = sum_dy.clone() if weight is not None else None           # the gradient buckets average them like any other
-        packed = torch.cat([sum_dy, sum_dy_xhat]).double()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
+        x, mean, invstd, weight, n = ctx.saved_tensors
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        shape = [1, C] + [1] * (x.dim() - 2)
+        acc = mean.dtype
+        fused = x.is_cuda and x.dtype != torch.float64
+        if fused:
+            gy = _dense(gy)
+            sum_dy, sum_dy_xmu, gw, gb = torch.batch_norm_backward_reduce(gy, x, mean, invstd, weight, True,
+                                                                           weight is not None, weight is not None)
+        else:
+            g = gy.to(acc)
+            xmu = x.to(acc) - mean.view(shape)
+            sum_dy, sum_dy_xmu = g.sum(dims), (g * xmu).sum(dims)
+            gw = sum_dy_xmu * invstd if weight is not None else None      # parameter gradients stay per-rank sums:
+            gb = sum_dy.clone() if weight is not None else None           # the gradient buckets average them like any other
+        packed = torch.cat([sum_dy, sum_dy_xmu])
+        if _group_active(ctx.group):
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
-        mean_dy = (packed[:C] / ctx.n).to(xhat.dtype).view(shape)
-        mean_dy_xhat = (packed[C:] / ctx.n).to(xhat.dtype).view(shape)
-        scale = invstd if weight is None else invstd * weight.to(xhat.dtype)
-        gx = (g - mean_dy - xhat * mean_dy_xhat) * scale.view(shape)
-        return gx.to(gy.dtype), gw, gb, None, None, None
+        if fused:
+            gx = torch.batch_norm_backward_elemt(gy, x, mean, invstd, weight, packed[:C], packed[C:],
+                                                 n.to(torch.int32).reshape(1))
+        else:
+            nn_ = n.to(acc)
+            mean_dy = (packed[:C] / nn_).view(shape)
+            k = (packed[C:] / nn_ * invstd * invstd).view(shape)            # mean(gy (x - mean)) / var
+            scale = invstd if weight is None else invstd * weight.to(acc)
+            gx = ((g - mean_dy - xmu * k) * scale.view(shape)).to(gy.dtype)
+        if weight is not None:
+            gw, gb = gw.to(weight.dtype), gb.to(weight.dtype)
+        return gx, gw, gb, None, None
 
 
 class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
@@ -286,9 +353,7 @@ class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
         if not self.training and self.track_running_stats:
             return torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                                                   False, 0.0, self.eps)
-        centre = self.running_mean.detach() if self.running_mean is not None else \
-            x.new_zeros(self.num_features, dtype=torch.float32)
-        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, centre, self.eps, self.process_group)
+        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, self.process_group)
         if self.training and self.track_running_stats:
             with torch.no_grad():
                 self.num_batches_tracked += 1
@@ -318,13 +383,18 @@ def convert_sync_batchnorm(module, process_group=None):
     return out
 
 
-def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True):
+def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, force=False, algo=None):
     """What `Trainer(accelerator="ddp", sync_batchnorm=True)` does for the reference (scripts/train.py:176-206),
     without Lightning: BatchNorm -> SyncBatchNorm (statistics over the frames of all ranks; with 1 frame per GPU the
     per-rank statistics would otherwise be those of a single scene) and the gradient buckets.
-    Returns (model, GradBuckets or None)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    Returns (model, GradBuckets or None).  On one rank there is nothing to exchange and the model is returned as is --
+    unless `force` (tests, `OCCDEPTH_FORCE_DIST=1 bench.py --train`): then the converted SyncBatchNorm layers and the
+    buckets run their collectives on the single-rank group, i.e. the real RCCL calls on one GPU."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return model, None
+    if force:
+        global FORCE_COLLECTIVES
+        FORCE_COLLECTIVES = True
     if sync_bn:
         model = convert_sync_batchnorm(model)
-    return model, GradBuckets(model.parameters(), dist, bucket_bytes)
+    return model, GradBuckets(model.parameters(), dist, bucket_bytes, algo=algo, force=force)

@@ -10,8 +10,18 @@ Requirements (checked or enforced here):
     offenders with their Python stack via torch.cuda.set_sync_debug_mode);
   * the batch tensors are STATIC: copy new data into them (`load_batch`) before each replay;
   * the optimizer must be capturable (device-side step counter): `make_capturable` flips the flag before its first step;
-  * the learning rate is baked into the captured update: re-capture (`GraphedTrainStep.recapture`) when a scheduler
-    changes it (MultiStepLR: twice in a run).
+  * the learning rate lives in a DEVICE tensor (`make_capturable` converts `group["lr"]`): torch's schedulers update a
+    tensor learning rate in place, so MultiStepLR's two milestones need no re-capture.
+What a replay does and does not advance (the captured Python code does not run again):
+  * device state -- parameters, optimizer moments and step counters, BatchNorm running statistics, the metric's
+    confusion matrix, the loss terms in `model.logged` -- advances, it is what the kernels write;
+  * host-side counters are mirrored by `__call__`: `model.cur_batch` and the metric's `count` are incremented per replay,
+    and the `sem_step_decay_loss` factor (a function of `cur_batch`) is fed through a device scalar that is refreshed
+    before every replay (`OccDepth._decay_dev`);
+  * `self.log(...)` (Lightning's logger) is NOT called per replay: read `model.logged` instead.
+Warm-up: capture needs the optimizer state allocated and the libraries' solvers chosen, which takes real eager steps.
+They run on a SNAPSHOT: parameters, buffers, optimizer state, metric counts and `cur_batch` are restored afterwards, so
+capturing (or re-capturing) trains nothing -- the reference's eager Lightning loop has no such extra steps.
 Reference: scripts/train.py:176-206 drives the same step through PyTorch-Lightning, eagerly.
 """
 import contextlib
@@ -20,9 +30,50 @@ import torch
 
 
 def make_capturable(opt):
+    """Device-side step counters and a device-side learning rate (before the optimizer's first step)."""
     for g in opt.param_groups:
         g["capturable"] = True
+        if not torch.is_tensor(g["lr"]) and g["params"] and g["params"][0].is_cuda:
+            g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=g["params"][0].device)
     return opt
+
+
+class _Snapshot:
+    """Everything a warm-up step mutates, restored in place (same tensors, same pointers)."""
+
+    def __init__(self, model, opt):
+        self.model, self.opt = model, opt
+        self.tensors = [(t, t.detach().clone()) for t in list(model.parameters()) + list(model.buffers())]
+        self.opt_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                          for p, st in opt.state.items()}
+        self.cur_batch = getattr(model, "cur_batch", None)
+        self.metrics = []
+        for name in ("train_metrics", "val_metrics", "test_metrics"):
+            m = getattr(model, name, None)
+            if m is not None and hasattr(m, "hist"):
+                self.metrics.append((m, None if m.hist is None else m.hist.clone(), m.count))
+
+    def restore(self):
+        with torch.no_grad():
+            for t, saved in self.tensors:
+                t.copy_(saved)
+            for p, st in self.opt.state.items():
+                old = self.opt_state.get(id(p))
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if old is not None and torch.is_tensor(old.get(k)):
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()                      # freshly allocated by the warm-up: back to "never stepped"
+            for m, hist, count in self.metrics:
+                if m.hist is not None:
+                    if hist is not None:
+                        m.hist.copy_(hist)
+                    else:
+                        m.hist.zero_()
+                m.count = count
+        if self.cur_batch is not None:
+            self.model.cur_batch = self.cur_batch
 
 
 @contextlib.contextmanager
@@ -57,8 +108,22 @@ class GraphedTrainStep:
         self.opt.step()
         return loss
 
+    def _sync_decay(self):
+        """`sem_step_decay_loss`: the decay factor is a function of the host counter `cur_batch`; the captured step reads
+        it from a device scalar that is refreshed (an asynchronous fill, no synchronisation) before every replay."""
+        m = self.model
+        if getattr(m, "sem_step_decay_loss", False):
+            dev = next(m.parameters()).device
+            if getattr(m, "_decay_dev", None) is None or m._decay_dev.device != dev:
+                m._decay_dev = torch.ones((), dtype=torch.float32, device=dev)
+            m._decay_dev.fill_(max(0.1, 1.0 - m.cur_batch / m.total_batch))
+
     def capture(self):
         dev = next(self.model.parameters()).device
+        torch.cuda.synchronize(dev)
+        snap = _Snapshot(self.model, self.opt)
+        self.model.cur_batch = getattr(self.model, "cur_batch", 0)
+        self._sync_decay()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -69,15 +134,19 @@ class GraphedTrainStep:
         graph = torch.cuda.CUDAGraph()
         if self.buckets is None:
             self.opt.zero_grad(set_to_none=True)            # gradients are (re)allocated inside the graph's pool
+        ok = True
         try:
             with torch.cuda.graph(graph):
                 self.loss = self._eager()
         except (RuntimeError, torch.AcceleratorError) as e:
             self.error = repr(e)
-            torch.cuda.synchronize(dev)
-            return False
-        self.graph = graph
-        return True
+            ok = False
+        torch.cuda.synchronize(dev)
+        snap.restore()                                      # warm-up and capture trained nothing
+        torch.cuda.synchronize(dev)
+        if ok:
+            self.graph = graph
+        return ok
 
     recapture = capture
 
@@ -95,5 +164,11 @@ class GraphedTrainStep:
     def __call__(self):
         if self.graph is None:
             return self._eager()
+        m = self.model
+        m.cur_batch = getattr(m, "cur_batch", 0) + 1        # what training_step does on the host
+        self._sync_decay()
+        metric = getattr(m, "train_metrics", None)
+        if metric is not None and hasattr(metric, "count"):
+            metric.count += 1
         self.graph.replay()
         return self.loss

@@ -1,0 +1,162 @@
+"""GPU, ONE rank on a real RCCL communicator (backend "nccl" on ROCm): the training-step exchange of SURVEY 8(e) --
+SyncBatchNorm's packed all-reduces and the gradient buckets (all_reduce with ReduceOp.AVG, reduce-scatter + all-gather)
+-- driven through the very calls an 8-GPU run issues, before a multi-GPU node ever sees them (a gpurun box has one GPU;
+world-size-2 semantics are covered over gloo in test_shard_gloo.py).  Reference: scripts/train.py:176-206
+(`accelerator="ddp"`, `sync_batchnorm=True`)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def rccl():
+    import torch.distributed as dist
+    from occdepth_amd import shard
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    saved = shard.FORCE_COLLECTIVES
+    shard.FORCE_COLLECTIVES = True
+    yield dist
+    shard.FORCE_COLLECTIVES = saved
+    dist.destroy_process_group()
+
+
+def test_backend_is_rccl(rccl):
+    assert rccl.get_backend() == "nccl" and rccl.get_world_size() == 1
+    t = torch.arange(8, device=DEV, dtype=torch.float64)
+    rccl.all_reduce(t)                                        # a real collective on the communicator
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("shape,dtype,cl", [((2, 16, 12, 10, 6), torch.float32, True), ((2, 16, 12, 10, 6), torch.float32, False),
+                                            ((3, 24, 17, 33), torch.float32, False), ((2, 32, 9, 20), torch.bfloat16, True)])
+def test_syncbn_on_rccl_matches_batchnorm(rccl, shape, dtype, cl):
+    """forward, input / weight / bias gradients and running statistics of the converted layer (fused ATen passes + the
+    float64 packed all-reduce on the device) against nn.BatchNorm in float64 on the CPU."""
+    from occdepth_amd import shard
+    torch.manual_seed(7)
+    C = shape[1]
+    Norm = torch.nn.BatchNorm3d if len(shape) == 5 else torch.nn.BatchNorm2d
+    x = torch.randn(*shape) * 2.0 + 5.0
+    g = torch.randn(*shape)
+    ref = Norm(C).double().train()
+    bn = shard.convert_sync_batchnorm(Norm(C)).to(DEV).train()
+    assert isinstance(bn, shard.SyncBatchNorm)
+    with torch.no_grad():
+        for b in (bn, ref):
+            b.weight.copy_(torch.linspace(0.5, 1.5, C))
+            b.bias.copy_(torch.linspace(-1, 1, C))
+    xs = x.to(DEV, dtype)
+    if cl:
+        xs = xs.contiguous(memory_format=torch.channels_last_3d if len(shape) == 5 else torch.channels_last)
+    xs = xs.detach().requires_grad_(True)
+    xr = xs.detach().cpu().double().requires_grad_(True)      # (the bf16-rounded values when dtype is bf16)
+    ys = bn(xs)
+    yr = ref(xr)
+    assert ys.dtype == dtype
+    ys.backward(g.to(DEV, dtype))
+    yr.backward(g.to(dtype).double())
+    tol = 3e-5 if dtype == torch.float32 else 2e-2           # bf16: the OUTPUT and gx are rounded to 8 bits
+    assert float((ys.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < tol
+    assert float((xs.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()) < tol
+    ptol = 3e-5 if dtype == torch.float32 else 2e-3          # parameter gradients and statistics accumulate in fp32
+    assert float((bn.weight.grad.cpu().double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < ptol
+    assert float((bn.bias.grad.cpu().double() - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < ptol
+    assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) < ptol * 5
+    assert float((bn.running_var.cpu().double() - ref.running_var).abs().max() / ref.running_var.abs().max()) < ptol
+    assert int(bn.num_batches_tracked) == 1
+
+
+def _toy():
+    torch.manual_seed(4)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                            torch.nn.Linear(64, 3))
+    m.unused = torch.nn.Parameter(torch.ones(5))
+    return m
+
+
+@pytest.mark.parametrize("algo", ["all_reduce", "rs_ag"])
+def test_grad_buckets_on_rccl(rccl, algo):
+    """Bucketed exchange on the RCCL communicator (hooks, async launches in bucket order, AVG inside the collective,
+    padded flat buffers for reduce-scatter + all-gather, no_sync accumulation, unused parameters): gradients equal the
+    plain autograd ones on one rank."""
+    from occdepth_amd import shard
+    m, ref = _toy().to(DEV), _toy().to(DEV)
+    b = shard.GradBuckets(m.parameters(), rccl, bucket_bytes=4096, algo=algo, force=True, check_used=True)
+    assert b.active and b.avg_in_collective and len(b.buckets) > 2
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        x, y = torch.randn(9, 6, generator=g).to(DEV), torch.randn(9, 3, generator=g).to(DEV)
+        if step == 1:
+            m.zero_grad(set_to_none=True)                    # detached gradients are re-adopted by the hooks
+        else:
+            b.zero_grad()
+        ref.zero_grad(set_to_none=True)
+        if step == 2:
+            with b.no_sync():
+                ((m(x) - y) ** 2).mean().backward()
+            ((ref(x) - y) ** 2).mean().backward()
+        ((m(x) - y) ** 2).mean().backward()
+        ((ref(x) - y) ** 2).mean().backward()
+        b.finish()
+        torch.cuda.synchronize()
+        assert m.unused.grad is None
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            if q.grad is None:
+                continue
+            assert float((p.grad - q.grad).abs().max() / q.grad.abs().max().clamp_min(1e-30)) < 1e-6, (step, k)
+    b.remove()
+
+
+def test_prepare_for_ddp_forced_step_matches_plain_step(rccl):
+    """The REAL reduced SemanticKITTI model, one training step (forward, all losses, backward) with
+    prepare_for_ddp(force=True) -- every BatchNorm converted, every gradient through the buckets and RCCL -- against the
+    same step of an identical un-converted model; also under bf16 autocast (statistics stay fp32)."""
+    import golden_cases as gc
+    from test_oracle_vs_golden import build_product
+    from occdepth_amd import shard, synthetic
+    outs = {}
+    for forced in (False, True):
+        torch.manual_seed(0)
+        m, cfg, _ = build_product("kitti_small")
+        m = m.to(DEV).train()
+        batch = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV))
+                 for k, v in gc.occdepth_batch("kitti_small").items()}
+        synthetic.attach_training_targets(m, batch, cfg, seed=3)
+        buckets = None
+        if forced:
+            m, buckets = shard.prepare_for_ddp(m, rccl, force=True)
+            assert buckets is not None and any(isinstance(x, shard.SyncBatchNorm) for x in m.modules())
+            buckets.zero_grad()
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        torch.cuda.synchronize()
+        outs[forced] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+        if buckets is not None:
+            buckets.remove()
+    (l0, g0), (l1, g1) = outs[False], outs[True]
+    assert abs(l0 - l1) / abs(l0) < 1e-4, (l0, l1)
+    assert set(g0) == set(g1)
+    worst = 0.0
+    for k in g0:
+        n0 = float(g0[k].norm())
+        if n0 > 0:
+            worst = max(worst, float((g0[k] - g1[k]).norm()) / n0)
+    print("forced-RCCL step vs plain step: loss", l0, l1, "worst relative gradient-norm difference", worst)
+    # same kernels except the BatchNorm formulation (MIOpen vs the fused ATen passes): round-off level on this small net
+    assert worst < 5e-2, worst

@@ -271,3 +271,32 @@ def test_two_rank_real_model_syncbn_and_buckets_match_batch_of_two():
             assert torch.allclose(torch.from_numpy(v), want_sd[k], rtol=1e-4, atol=1e-6), (r, k)
     for k in PICK:                                       # both ranks end up with the SAME averaged gradient
         assert (got[0][1][k] == got[1][1][k]).all(), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mean,std", [(0.0, 1.0), (50.0, 3.0), (-300.0, 0.5)])
+def test_syncbn_single_process_matches_batchnorm_when_mean_is_far_from_zero(mean, std):
+    """the statistics must not cancel when the batch mean is far from the running mean (first steps:
+    running_mean = 0) or mean / std is large.  float32 activations on the CPU path against nn.BatchNorm3d in float64."""
+    torch.manual_seed(3)
+    x = (torch.randn(2, 5, 6, 7, 4) * std + mean)
+    ref_bn = torch.nn.BatchNorm3d(5).double().train()
+    bn = shard.convert_sync_batchnorm(torch.nn.BatchNorm3d(5)).train()
+    with torch.no_grad():
+        for b in (bn, ref_bn):
+            b.weight.copy_(torch.linspace(0.5, 1.5, 5))
+            b.bias.copy_(torch.linspace(-1, 1, 5))
+    xr = x.double().requires_grad_(True)
+    xs = x.clone().requires_grad_(True)
+    yr, ys = ref_bn(xr), bn(xs)
+    g = torch.randn_like(ys)
+    yr.backward(g.double())
+    ys.backward(g)
+    # float32 input data carries eps * |mean| / std of relative noise per element whatever the algorithm does
+    tol = 2e-6 * max(1.0, abs(mean) / std)
+    err = float((ys.detach().double() - yr.detach()).abs().max())
+    assert err < 3 * tol, err
+    assert float((xs.grad.double() - xr.grad).abs().max() / xr.grad.abs().max()) < 3 * tol
+    assert float((bn.weight.grad.double() - ref_bn.weight.grad).abs().max() / ref_bn.weight.grad.abs().max()) < 3 * tol
+    assert float((bn.running_var.double() - ref_bn.running_var).abs().max() / ref_bn.running_var.abs().max()) < 3 * tol
+    assert float((bn.running_mean.double() - ref_bn.running_mean).abs().max()) < 3 * tol * max(1.0, abs(mean))

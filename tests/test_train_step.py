@@ -133,8 +133,10 @@ def _small_train_setup(cfg_name, device):
 @pytest.mark.gpu
 def test_whole_step_hipgraph_matches_eager_gpu(hip_lib):
     """occdepth_amd/train_graph.py: forward + losses + backward + AdamW of the reduced SemanticKITTI model (training
-    mode) captured into one hipGraph; after rewinding parameters and optimizer state, three replays reproduce three eager
-    steps from the same state (loss values, one parameter)."""
+    mode) captured into one hipGraph.  Capturing trains NOTHING (warm-up steps run on a snapshot: parameters, BatchNorm
+    statistics, optimizer state, metric counts and `cur_batch` are as before); three replays then reproduce three eager
+    steps from the same state (loss values, one parameter); a scheduler's learning-rate change reaches the replays
+    through the device-side lr (no re-capture); resetting the metric between replays keeps counting (in-place reset)."""
     import copy
     from occdepth_amd import train_graph
     torch.backends.cudnn.allow_tf32 = False
@@ -145,16 +147,29 @@ def test_whole_step_hipgraph_matches_eager_gpu(hip_lib):
         m = copy.deepcopy(m0).train()
         m.cur_batch = 0
         opt = train_graph.make_capturable(torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True))
-        gs = train_graph.GraphedTrainStep(m, opt, batch, warmup=1)
+        assert torch.is_tensor(opt.param_groups[0]["lr"]) and opt.param_groups[0]["lr"].is_cuda
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2], gamma=0.4)
+        gs = train_graph.GraphedTrainStep(m, opt, batch, warmup=2)
         if mode == "graph":
-            state = copy.deepcopy(m.state_dict())
+            before = {k: v.detach().clone() for k, v in m.state_dict().items()}
             assert gs.capture(), gs.error
-            m.load_state_dict(state)                      # warm-up + capture pass ran two real steps: rewind
-            for st in opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
-        losses = [float(gs()) for _ in range(3)]
+            after = m.state_dict()
+            assert all(torch.equal(before[k], after[k]) for k in before), "capture must not train"
+            assert m.cur_batch == 0 and m.train_metrics.count == 1e-8
+            assert all(float(v.abs().max()) == 0.0 for st in opt.state.values() for v in st.values() if torch.is_tensor(v))
+            assert m.train_metrics.hist is None or int(m.train_metrics.hist.sum()) == 0
+        losses = []
+        for i in range(4):
+            losses.append(float(gs()))
+            sched.step()                                 # lr 1e-4 -> 4e-5 after the second step
+        lr = float(opt.param_groups[0]["lr"])
+        assert abs(lr - 4e-5) < 1e-9, lr
+        labelled = int((batch["target"] != 255).sum())
+        assert m.cur_batch == 4 and abs(m.train_metrics.count - 4) < 1e-6
+        assert int(m.train_metrics.hist.sum()) == 4 * labelled
+        m.train_metrics.reset()                          # what validation_epoch_end does (must stay the same buffer)
+        losses.append(float(gs()))
+        assert int(m.train_metrics.hist.sum()) == labelled, mode
         runs[mode] = (losses, next(iter(m.net_3d_decoder.parameters())).detach().float().cpu().clone())
     (le, pe), (lg, pg) = runs["eager"], runs["graph"]
     print("eager", le, "graph", lg)
