@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--train", action="store_true", help="training step (configs[2]/[3]) instead of the forward")
     ap.add_argument("--bf16", action="store_true", help="with --train: bf16 autocast (configs[3])")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="2: BASELINE configs[1] (the headline metric); 5: BASELINE configs[4], UNet3D alone on a synthetic "
+                         "512x512x64 grid (auxiliary workload: 3-D-conv MFMA tiling + HBM footprint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -237,7 +240,10 @@ def _setup(args):
 
 def _main(args, real_stdout):
     world, rank, device, dist = _setup(args)
-    res = _train(args, world, rank, device, dist) if args.train else _forward(args, world, rank, device, dist)
+    if args.config == 5:
+        res = _config5(args, world, rank, device, dist)
+    else:
+        res = _train(args, world, rank, device, dist) if args.train else _forward(args, world, rank, device, dist)
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
@@ -367,6 +373,67 @@ def _forward(args, world, rank, device, dist):
     else:
         res["cpu_baseline"] = None
     return res
+
+
+CONFIG5_GFLOP = 9268.2                 # 8718.5 conv + 549.8 CRP bmm
+
+
+def _config5(args, world, rank, device, dist):
+    """BASELINE configs[4]: `UNet3D(kitti)` alone, full_scene_size (512, 512, 64), project_scale 2, feature 64 ->
+    x3d randn(1, 64, 256, 256, 32); CRP with N = 32768 voxels, M = 4096 mega voxels (reference: the `__main__` smoke
+    shape of models/unet3d_kitti.py:129-171 scaled up).  Reported against the fp32-MFMA peak; eval mode, random-init
+    weights, one frame per rank."""
+    import torch.nn as nn
+    from occdepth_amd import hip
+    from occdepth_amd.models.unet3d_kitti import UNet3D
+    from occdepth_amd import shard
+    torch.manual_seed(0)
+    m = UNet3D(20, nn.BatchNorm3d, (512, 512, 64), 64, 2, context_prior=True, cascade_cls=True).to(device).eval()
+    x = hip.Vox.from_ncdhw(torch.randn(1, 64, 256, 256, 32, device=device))
+    torch.cuda.reset_peak_memory_stats()
+
+    def step():
+        with torch.no_grad():
+            return m({"x3d": x})
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    del out
+    shard.fence(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    shard.fence(dist)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device)
+    assert out["ssc_logit"].shape == (1, 20, 512, 512, 64)
+    del out
+    with hip.profile() as prof:
+        step()
+        torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    ms = 1e3 * elapsed / args.steps
+    head = [(k, v) for k, v in prof.rows.items() if HEAD_CONV_TAG in k and k.startswith("conv3d")]
+    hms, hfl, hn = sum(v["ms"] for _, v in head), sum(v["flops"] for _, v in head), sum(v["launches"] for _, v in head)
+    ach = hfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
+    rows = sorted(((k, v) for k, v in prof.rows.items() if k.startswith("conv3d")), key=lambda kv: -kv[1]["ms"])[:12]
+    return {
+        "metric": "frames/sec forward, UNet3D alone, synthetic 512x512x64 voxel grid (BASELINE configs[4])",
+        "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: UNet3D(kitti) alone, full_scene_size 512x512x64, project_scale 2, feature 64, "
+                               "CRP + cascade head, x3d (1, 64, 256, 256, 32)", "frames_per_step": world},
+        "stack3d": {"gflop_per_frame": CONFIG5_GFLOP, "tflops": CONFIG5_GFLOP / ms,
+                    "frac_of_fp32_mfma_peak": CONFIG5_GFLOP / ms / FP32_MFMA_PEAK_TFLOPS},
+        "roofline": {"bound": "mfma", "kernel": "head conv 3x3x3 32->32 @512x512x64 (927.7 GFLOP per launch)",
+                     "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "launches": int(hn), "avg_launch_ms": hms / max(hn, 1),
+                     "head_kernel": sorted({k.split(":")[0] for k, _ in head})},
+        "peak_hbm_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "top_conv_launches_ms": {k: round(v["ms"], 3) for k, v in rows},
+        "cpu_baseline": None,
+    }
 
 
 def _train(args, world, rank, device, dist):

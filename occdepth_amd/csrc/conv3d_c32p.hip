@@ -1,4 +1,5 @@
-// Persistent, weights-stationary 3x3x3 convolutions for <=32 -> <=32 channels on Z = 32 columns: the
+// Persistent, weights-stationary 3x3x3 convolutions for <=32 -> <=32 channels on Z = 32 k columns (32: config 2, 64:
+// BASELINE configs[4]; K2s tiles z in 32-column tiles whose halo is real neighbour data): the
 // segmentation-head convolutions at full resolution (7-8 launches, 87 % of the 3-D stack's FLOPs) and, in training,
 // their data gradients.  Two kernels, same math as conv3d_igemm_kernel (v_mfma_f32_32x32x2_f32, exact fp32):
 //
@@ -34,10 +35,10 @@ struct PersistP {
     const float* res1;
     const float* res2;
     float* out;
-    int batch, X, Y, in_cs, in_coff;
+    int batch, X, Y, Z, in_cs, in_coff;      // Z: a multiple of kTZ (K2s); K2p: Z == kTZ
     int out_cs, out_coff, res1_cs, res1_coff, res2_cs, res2_coff;
     int act_in, act_out, cout_store;
-    int ytiles, tiles_total;
+    int ytiles, ztiles, tiles_total;
 };
 
 constexpr int kTY = 8, kTZ = 32, kWTaps = 27, kWFloat4 = kWTaps * 4 * 64;  // 6912 float4 = 110,592 B
@@ -251,20 +252,22 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
         }
     }
 
-    int sdst[NLOAD], syi[NLOAD], szoff[NLOAD];
+    // staging descriptors: slab row (yi, zi) and 4-channel group c4 of this thread's i-th float4; the z tile (columns
+    // z0 .. z0 + 31 of a Z = 32, 64, ... volume) enters per segment, so a tile's z halo is the neighbouring tile's data
+    int sdst[NLOAD], syi[NLOAD], szi[NLOAD], sc4[NLOAD];
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
         const int f = tid + i * 512;
         const bool live = f < NF4;
         const int row = f / (CH / 4), c4 = f - row * (CH / 4);
         const int yi = row / ZIN, zi = row - yi * ZIN;
-        const int z = zi - D;
         sdst[i] = live ? row * RS4 + c4 : -1;
         syi[i] = yi;
-        szoff[i] = (live && z >= 0 && z < kTZ) ? z * p.in_cs + c4 * 4 : -1;
+        szi[i] = live ? zi - D : -(1 << 20);
+        sc4[i] = c4 * 4;
     }
     const f32x4* const ab = slab4 + (wave * ZIN + li) * RS4 + kk;
-    const size_t plane_stride = (size_t)p.Y * kTZ * p.in_cs;
+    const size_t plane_stride = (size_t)p.Y * p.Z * p.in_cs;
 
     // per-column staging addresses (element offsets of plane x = 0), refreshed per segment
     unsigned coloff[NLOAD];                  // < 2^32 elements: checked by the host
@@ -338,9 +341,10 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
         if (p.bias != nullptr && 4 * tid < p.cout_store) bv = *(const f32x4*)(p.bias + 4 * tid);
         bias4[tid] = bv;
     }
+    int z0 = 0;                                                       // first column of the segment's z tile
     auto res_fetch = [&](int b, int yt, int x) {
         const int y = min(yt * kTY + wave, p.Y - 1);
-        const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * kTZ + li;
+        const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + z0 + li;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c = 8 * g + 4 * kk;
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     auto store2 = [&](int b, int yt, int x) {
         const int y = yt * kTY + wave;
         if (y < p.Y) {
-            const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * kTZ + li;
+            const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + z0 + li;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = 8 * g + 4 * kk;
@@ -388,17 +392,21 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
             }
             break;
         }
-        // segments are ordered (b, range, ytile) with ytile fastest
-        const int yt = seg % p.ytiles;
-        const int rest = seg / p.ytiles;
+        // segments are ordered (b, range, ytile, ztile) with the z tile fastest
+        const int tz = seg % (p.ytiles * p.ztiles);
+        const int zt = tz % p.ztiles, yt = tz / p.ztiles;
+        const int rest = seg / (p.ytiles * p.ztiles);
         const int b = rest / sp.segs_per_col;
         const int q0 = (rest - b * sp.segs_per_col) * sp.seg_len;
         const int q1 = min(q0 + sp.seg_len, p.X);
+        z0 = zt * kTZ;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int y = yt * kTY - D + syi[i];
-            colok[i] = szoff[i] >= 0 && y >= 0 && y < p.Y;
-            coloff[i] = (unsigned)(((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * kTZ * p.in_cs + p.in_coff + max(szoff[i], 0));
+            const int z = z0 + szi[i];
+            colok[i] = z >= 0 && z < p.Z && y >= 0 && y < p.Y;
+            coloff[i] = (unsigned)((((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * p.Z + (colok[i] ? z : 0)) * p.in_cs +
+                                   p.in_coff + sc4[i]);
         }
         int q = q0;
         while (q < q1) {
@@ -508,7 +516,7 @@ int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
     sp.counter = ds->counter + 2 * (g_slot.fetch_add(1) % kSlots);
     // ranges per column: k rounds over the grid; a range of L planes costs L + 2 stagings per run (D > 1: up to two
     // runs).  Few long ranges amortise the two extra planes, but the list must fill whole rounds.
-    const int cols = base.batch * base.ytiles;
+    const int cols = base.batch * base.ytiles * base.ztiles;
     int best_s = 1;
     double best_cost = 1e30;
     for (int k = 1; k <= 16; ++k) {
@@ -558,29 +566,30 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
     const int d = a->dx;
     const bool geom = a->kx == 3 && a->ky == 3 && a->kz == 3 && a->sx == 1 && a->sy == 1 && a->sz == 1 &&
                       a->dy == d && a->dz == d && d >= 1 && d <= 3 && a->px == d && a->py == d && a->pz == d;
-    const bool shape = a->Z == kTZ && a->Xo == a->X && a->Yo == a->Y && a->Zo == a->Z && a->OX == a->X &&
+    static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
+    const bool shape = a->Z % kTZ == 0 && (a->Z == kTZ || !tiled) && a->Xo == a->X && a->Yo == a->Y && a->Zo == a->Z && a->OX == a->X &&
                        a->OY == a->Y && a->OZ == a->Z && a->o_stride_x == 1 && a->o_stride_y == 1 &&
                        a->o_stride_z == 1 && a->o_off_x == 0 && a->o_off_y == 0 && a->o_off_z == 0;
     const int cin8 = (a->cin + 7) & ~7;
     const bool chans = cin8 <= 32 && a->cout <= 32 && a->in_coff + 32 <= a->in_cs && a->act_in != OCCD_ACT_SIGMOID;
     // enough tiles to keep every CU busy for several rounds, otherwise the generic kernel tiles finer
-    const long tiles = (long)a->batch * a->X * ((a->Y + kTY - 1) / kTY);
+    const long tiles = (long)a->batch * a->X * ((a->Y + kTY - 1) / kTY) * (a->Z / kTZ);
     if (!(geom && shape && chans) || cin8 != 32 || tiles < 512 || a->tile_hint != 0) return 0;
     if ((double)a->batch * a->X * a->Y * a->Z * a->in_cs >= 4294967296.0) return 0;   // 32-bit staging offsets
     PersistP p;
     p.in = a->in; p.wpk = a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
-    p.batch = a->batch; p.X = a->X; p.Y = a->Y; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
+    p.batch = a->batch; p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
     p.out_cs = a->out_cs; p.out_coff = a->out_coff;
     p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
     p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
     p.ytiles = (a->Y + kTY - 1) / kTY;
+    p.ztiles = a->Z / kTZ;
     p.tiles_total = (int)tiles;
     const double pos = (double)a->batch * a->X * a->Y * a->Z;
     const double flops = 2.0 * pos * 27 * a->cin * a->cout;
     const double bytes = 4.0 * (pos * a->cin + pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) +
                                 27.0 * a->cin * a->cout);
     ProfScope prof("conv3d_c32p", stream, flops, bytes);
-    static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
     DevState* ds = dev_state();
     if (ds == nullptr) return OCCD_ELAUNCH;
     int rc;

@@ -97,11 +97,17 @@ def test_conv3d_vs_aten(hip, case):
 
 
 PERSIST_CASES = [
-    # shapes that qualify for the persistent weights-stationary head kernel (Z == 32, 25..32 -> <=32 channels)
+    # shapes that qualify for the persistent weights-stationary head kernel (Z == 32 k, 25..32 -> <=32 channels)
     (1, 32, 32, (16, 256, 32), 1),
     (1, 32, 32, (16, 256, 32), 3),
     (2, 30, 22, (9, 250, 32), 2),
     (1, 32, 2, (20, 208, 32), 1),
+    # round 3: Z = 64 / 96 (BASELINE configs[4] is 512x512x64): two / three 32-column z tiles whose halo columns are the
+    # neighbouring tile's data, zero only at the volume's ends
+    (1, 32, 32, (16, 136, 64), 1),
+    (1, 32, 32, (16, 136, 64), 3),
+    (2, 28, 32, (8, 130, 64), 2),
+    (1, 32, 20, (7, 200, 96), 2),
 ]
 
 

@@ -84,7 +84,7 @@ def test_hooks_log_what_the_reference_scripts_monitor(capsys):
     assert tr.logged["val/IoU"] == float(st["iou"])
     assert tr.logged["train/mIoU"] == float(st["iou_ssc_mean"])
     assert np.allclose([tr.logged[f"val_SemIoU/{c}"] for c in m.class_names], st["iou_ssc"], rtol=1e-6)
-    assert m.val_metrics.hist is None and m.train_metrics.hist is None and want_val["iou"] == 0     # reset() happened
+    assert int(m.val_metrics.hist.sum()) == 0 and int(m.train_metrics.hist.sum()) == 0 and want_val["iou"] == 0   # reset() happened (in place)
 
     capsys.readouterr()
     with emu.patched():
@@ -98,7 +98,7 @@ def test_hooks_log_what_the_reference_scripts_monitor(capsys):
     assert lines[4] == "mIoU={:.4f}".format(st["iou_ssc_mean"] * 100)
     assert lines[1] == "Precision={:.4f}, Recall={:.4f}, IoU={:.4f}".format(st["precision"] * 100, st["recall"] * 100,
                                                                              st["iou"] * 100)
-    assert m.test_metrics.hist is None
+    assert int(m.test_metrics.hist.sum()) == 0                # reset() zeroes the matrix in place
     assert "test/loss_frustums" not in tr.logged               # reference: no frustum loss in test
 
 

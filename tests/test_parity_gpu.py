@@ -209,7 +209,7 @@ def test_config2_vs_reference_golden(config2):
     with open("gpurun_out/config2_parity.txt", "w") as f:
         f.write(repr(worst) + "\n")
     assert worst["ssc_logit"] < 1e-3 and worst["occ_logit"] < 1e-3, worst
-    assert max(worst.values()) < 5e-3, worst
+    assert max(worst.values()) < 1e-3, worst          # every intermediate too (measured worst: P_logits 5.0e-4)
 
 
 def config2_errors(out):
@@ -243,7 +243,7 @@ def test_config2_benched_flags_vs_reference_golden():
         worst = config2_errors(out)
         print(f"config-2, benched flags, pass {i}: relative errors vs reference:", {k: f"{e:.2e}" for k, e in worst.items()})
         assert worst["ssc_logit"] < 1e-3 and worst["occ_logit"] < 1e-3, (i, worst)
-        assert max(worst.values()) < 5e-3, (i, worst)
+        assert max(worst.values()) < 1e-3, (i, worst)    # every intermediate too
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/config2_parity_benched_flags.txt", "w") as f:
         f.write(repr(config2_errors(runs[-1])) + "\n")
