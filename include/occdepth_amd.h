@@ -391,6 +391,26 @@ typedef struct occd_conv3d_wgrad_args {
 int64_t occd_conv3d_wgrad_workspace_floats(const occd_conv3d_wgrad_args* a);
 int occd_conv3d_wgrad(const occd_conv3d_wgrad_args* a, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * K2b / K8b: the same convolution forward (data gradient: the forward on dL/dy with flipped weights) and weight
+ * gradient on the bf16 matrix pipe -- v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights -- for the bf16
+ * training step (BASELINE configs[3]; reference call sites as for K2 / K8, plus the 3x3 convolutions of the 2-D decoder,
+ * occdepth/models/unet2d.py:24-46, as X = 1 volumes of channels-last images).
+ * `dtype` selects the storage type of the activation tensors (in, out, res1, res2 / x, gy): 0 = fp32 (converted to
+ * bf16 while staging: "bf16 MFMA, fp32 storage"), 1 = bf16 (pointers are cast; *_cs / *_coff count elements).
+ * bias, dw and the workspace stay fp32.  `wpk` is the image of occd_pack_weights_bf16():
+ *   wpk[tap][k16][nt][lane][j] (bf16),  value = W[cout = nt*32 + (lane & 31)][cin = k16*16 + (lane >> 5)*8 + j][tap].
+ * act_in: NONE or RELU.  K8b stages voxel rows row-major in LDS and reads both MFMA operands with the gfx950
+ * transposed LDS read (ds_read_b64_tr_b16); at most 28 taps.
+ * ------------------------------------------------------------------------ */
+int64_t occd_packed_weight_bf16_elems(int32_t cout, int32_t cin, int32_t taps);
+int occd_pack_weights_bf16(const float* w, const float* scale, void* wpk,
+                           int32_t cout, int32_t cin, int32_t kx, int32_t ky, int32_t kz,
+                           int32_t layout, void* stream);
+int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream);
+int64_t occd_conv3d_wgrad_bf16_workspace_floats(const occd_conv3d_wgrad_args* a, int32_t dtype);
+int occd_conv3d_wgrad_bf16(const occd_conv3d_wgrad_args* a, int32_t dtype, void* stream);
+
 /* SURVEY 8(f) row N1 (first step): the scene-completion losses of one training step as ONE pass over the
  * logits.  Everything occdepth/loss/ssc_loss.py:17-99 (geo_scal_loss, sem_scal_loss, CE_ssc_loss) and the inline
  * frustum-proportion loss of occdepth/models/OccDepth.py:487-521 compute is a function of these sums over voxels

@@ -1,0 +1,466 @@
+// K2b -- implicit-GEMM 3-D convolution on the CDNA4 bf16 matrix pipe (BASELINE configs[3]: the bf16 training step).
+//
+//   out[vox][co] = act_out( sum_{tap,ci} bf16(act_in(in[vox*stride - pad + tap*dil][ci])) * bf16(W[co][ci][tap])
+//                           + bias[co] + res1[vox][co] + res2[vox][co] )          (fp32 accumulate)
+//
+// Same GEMM view, tiling, output scatter and epilogue as K2 (conv3d_igemm.hip); what changes is the instruction --
+// v_mfma_f32_32x32x16_bf16: 16 K values per instruction at 32 cycles, 16x the fp32 MFMA rate -- and with it the
+// bottleneck: operand delivery.  A wave therefore owns up to 4 x 2 tiles of 32 voxels x 32 couts (each B fragment
+// loaded from L2 feeds MT MFMAs, each A fragment read from LDS feeds NT), the staged slab holds bf16 (half the LDS
+// bytes: [YIN][ZIN][32 channels] rows of 64 B + 16 B pad, an odd number of 16-B slots -> conflict-free ds_read_b128),
+// and activations may live in HBM as fp32 (converted once, while staging: "bf16 MFMA, fp32 storage") or as bf16.
+// Fragment layout (pinned on hardware by tools/probe_bf16.hip): lane l holds 8 consecutive K values 8 (l >> 5) + j of
+// row / column l & 31; D as for every 32x32 MFMA: column = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+// The 2-D decoder's 3x3 convolutions run through the same kernel as X = 1 volumes of channels-last (NHWC) images.
+//
+// Reference semantics replaced (training step, N1): occdepth/models/DDR.py:111-139, modules.py:40-46,158-175,278-296,
+// CRP3D.py:54-97, unet2d.py:24-46 -- forward and, on dL/dy with flipped weights, the data gradient.
+#include "common.h"
+
+using occd::FastDiv;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct ConvBP {
+    const void* in;
+    const u32x4* wpk;
+    const float* bias;
+    const void* res1;
+    const void* res2;
+    void* out;
+    int X, Y, Z, cin8, cin16, in_cs, in_coff;
+    int K16tot, NTtot;
+    int out_cs, out_coff, res1_cs, res1_coff, res2_cs, res2_coff;
+    int KX, KY, KZ, SX, SY, SZ, DX, DY, DZ, PX, PY, PZ;
+    int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz, oox, ooy, ooz;
+    int act_in, act_out, cout_store;
+    int TY, TZ, YIN, ZIN, ytiles, ztiles, nwg;
+    FastDiv div_zin, div_tz, div_ztiles, div_ytiles;
+};
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ u32x4 pack_bf16x8(f32x4 a, f32x4 b) {
+    bf16x8 r = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    return __builtin_bit_cast(u32x4, r);
+}
+
+__device__ __forceinline__ f32x4 unpack_lo(u32x2 v) {       // 4 bf16 -> 4 floats
+    f32x4 r;
+    r.x = __builtin_bit_cast(float, v.x << 16);
+    r.y = __builtin_bit_cast(float, v.x & 0xffff0000u);
+    r.z = __builtin_bit_cast(float, v.y << 16);
+    r.w = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    return r;
+}
+
+constexpr int kRSB = 80;   // LDS row stride in bytes: 32 bf16 channels + 16 B pad
+
+template <int MT, int NT, int WM, int WN, bool IN_BF16, bool OUT_BF16>
+__global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p) {
+    constexpr int NTH = WM * WN * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int li = lane & 31;
+    const int h = lane >> 5;
+
+    uint32_t bid = blockIdx.x;   // XCD-aware bijective remap (see K2): an XCD walks a contiguous run of tiles
+    {
+        const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const uint32_t t1 = occd_fastdiv(bid, p.div_ztiles);
+    const int zt = bid - t1 * p.ztiles;
+    const uint32_t t2 = occd_fastdiv(t1, p.div_ytiles);
+    const int yt = t1 - t2 * p.ytiles;
+    const int xo = t2;
+    const int b = blockIdx.y;
+    const int nt0 = (blockIdx.z * WN + wn) * NT;
+
+    int rowbase[MT];   // byte offset of this lane's A row (tap (0,0), k16 0) for each M tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const uint32_t m = (wm * MT + mt) * 32 + li;
+        uint32_t yl = occd_fastdiv(m, p.div_tz);
+        uint32_t zl = m - yl * p.TZ;
+        const bool in_tile = yl < (uint32_t)p.TY;
+        yl = in_tile ? yl : 0u;
+        zl = in_tile ? zl : 0u;
+        rowbase[mt] = (int)((yl * p.SY) * p.ZIN + zl * p.SZ) * kRSB + h * 16;
+    }
+    int wofs[NT];      // u32x4 index of each owned N tile inside one (tap, k16) weight record row
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wofs[nt] = min(nt0 + nt, p.NTtot - 1) * 64;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int y_in0 = yt * p.TY * p.SY - p.PY;
+    const int z_in0 = zt * p.TZ * p.SZ - p.PZ;
+    const size_t w_step = (size_t)p.NTtot * 64;          // u32x4 per (tap, k16)
+    const u32x4* const wlane = p.wpk + lane;
+    const int rows = p.YIN * p.ZIN;
+
+#define OCCD_MFMA_BLOCK()                                                                      \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[nt]),          \
+                                                __builtin_bit_cast(bf16x8, a_cur[mt]), acc[mt][nt], 0, 0, 0)
+
+    for (int kx = 0; kx < p.KX; ++kx) {
+        const int xi = xo * p.SX - p.PX + kx * p.DX;
+        if (xi < 0 || xi >= p.X) continue;   // workgroup-uniform
+        const size_t plane = ((size_t)(b * p.X + xi) * p.Y) * p.Z * p.in_cs + p.in_coff;
+        for (int c0 = 0; c0 < p.cin16; c0 += 32) {
+            const int ck = min(32, p.cin16 - c0);        // 16 or 32 channels in this chunk
+            const int k16n = ck >> 4;
+            const int sh = k16n;                         // chunks of 8 channels per row: 2 (shift 1) or 4 (shift 2)
+            const int S = p.KY * p.KZ * k16n;
+            const u32x4* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.K16tot + (c0 >> 4)) * w_step;
+
+            u32x4 b_cur[NT];   // first B fragments fly while the slab is staged
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b_cur[nt] = wp[wofs[nt]];
+
+            __syncthreads();   // previous slab fully consumed
+            const int F = rows << sh;
+            for (int f0 = 0; f0 < F; f0 += NTH * 4) {
+                u32x4 v[4];
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * NTH + tid;
+                    const int fc = min(f, F - 1);
+                    const uint32_t row = (uint32_t)fc >> sh;
+                    const int c8 = fc & ((1 << sh) - 1);
+                    const uint32_t yi = occd_fastdiv(row, p.div_zin);
+                    const int zi = (int)row - (int)yi * p.ZIN;
+                    const int y = y_in0 + (int)yi, z = z_in0 + zi;
+                    const int c = c0 + c8 * 8;
+                    const bool ok = f < F && c < p.cin8 && (unsigned)y < (unsigned)p.Y && (unsigned)z < (unsigned)p.Z;
+                    const int yc = min(max(y, 0), p.Y - 1), zc = min(max(z, 0), p.Z - 1);
+                    const int cc = min(c, p.cin8 - 8);
+                    const size_t e = plane + ((size_t)yc * p.Z + zc) * p.in_cs + cc;
+                    u32x4 w;
+                    if (IN_BF16) {
+                        w = *(const u32x4*)((const uint16_t*)p.in + e);
+                        if (p.act_in == OCCD_ACT_RELU) {   // bf16 relu on the packed pairs: clear negative halves
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint32_t d = w[q];
+                                if (d & 0x80000000u) d &= 0x0000ffffu;
+                                if (d & 0x00008000u) d &= 0xffff0000u;
+                                w[q] = d;
+                            }
+                        }
+                    } else {
+                        f32x4 lo = *(const f32x4*)((const float*)p.in + e);
+                        f32x4 hi = *(const f32x4*)((const float*)p.in + e + 4);
+                        if (p.act_in == OCCD_ACT_RELU) { lo = relu4(lo); hi = relu4(hi); }
+                        w = pack_bf16x8(lo, hi);
+                    }
+                    v[u] = ok ? w : u32x4{0u, 0u, 0u, 0u};
+                    dst[u] = f < F ? (int)row * kRSB + c8 * 16 : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (dst[u] >= 0) *(u32x4*)(slab + dst[u]) = v[u];
+            }
+            __syncthreads();
+
+            int ky = 0, kz = 0, kl = 0;
+            int lds_off = 0;   // bytes
+            u32x4 a_cur[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *(const u32x4*)(slab + rowbase[mt]);
+
+            for (int s = 0; s < S - 1; ++s) {
+                ++kl;
+                lds_off += 32;
+                wp += w_step;
+                if (kl == k16n) {
+                    kl = 0;
+                    wp += (size_t)(p.K16tot - k16n) * w_step;
+                    if (++kz == p.KZ) { kz = 0; ++ky; }
+                    lds_off = (ky * p.DY * p.ZIN + kz * p.DZ) * kRSB;
+                }
+                u32x4 a_nxt[MT], b_nxt[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const u32x4*)(slab + rowbase[mt] + lds_off);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = wp[wofs[nt]];
+                OCCD_MFMA_BLOCK();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+            }
+            OCCD_MFMA_BLOCK();
+        }
+    }
+#undef OCCD_MFMA_BLOCK
+
+    // ---------------- epilogue (the layout of K2's: lane -> voxel li of the M tile, registers -> couts
+    // (r & 3) + 8 (r >> 2) + 4 h: four groups of 4 consecutive output channels of ONE voxel per lane)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const uint32_t m = (wm * MT + mt) * 32 + li;
+        const uint32_t yl = occd_fastdiv(m, p.div_tz);
+        const uint32_t zl = m - yl * p.TZ;
+        const int yo = yt * p.TY + (int)yl, zo = zt * p.TZ + (int)zl;
+        const bool ok = yl < (uint32_t)p.TY && yo < p.Yo && zo < p.Zo;
+        const size_t vox = ((size_t)(b * p.OX + xo * p.osx + p.oox) * p.OY + (yo * p.osy + p.ooy)) * p.OZ +
+                           (zo * p.osz + p.ooz);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = (nt0 + nt) * 32 + 8 * g + 4 * h;
+                if (ok && c < p.cout_store) {
+                    f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
+                               acc[mt][nt][4 * g + 3]};
+                    if (p.bias != nullptr) v += *(const f32x4*)(p.bias + c);
+                    if (p.act_out == OCCD_ACT_RELU_PRE) v = relu4(v);
+                    if (OUT_BF16) {
+                        if (p.res1 != nullptr)
+                            v += unpack_lo(*(const u32x2*)((const uint16_t*)p.res1 + vox * p.res1_cs + p.res1_coff + c));
+                        if (p.res2 != nullptr)
+                            v += unpack_lo(*(const u32x2*)((const uint16_t*)p.res2 + vox * p.res2_cs + p.res2_coff + c));
+                    } else {
+                        if (p.res1 != nullptr) v += *(const f32x4*)((const float*)p.res1 + vox * p.res1_cs + p.res1_coff + c);
+                        if (p.res2 != nullptr) v += *(const f32x4*)((const float*)p.res2 + vox * p.res2_cs + p.res2_coff + c);
+                    }
+                    if (p.act_out == OCCD_ACT_RELU) v = relu4(v);
+                    if (OUT_BF16) {
+                        bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                        *(u32x2*)((uint16_t*)p.out + vox * p.out_cs + p.out_coff + c) = __builtin_bit_cast(u32x2, o);
+                    } else {
+                        *(f32x4*)((float*)p.out + vox * p.out_cs + p.out_coff + c) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- weight packing (fp32 master weights -> bf16 fragments)
+// wpk[tap][k16][nt][lane][j]: cout = nt * 32 + (lane & 31), cin = k16 * 16 + (lane >> 5) * 8 + j
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         uint16_t* __restrict__ wpk, int cout, int cin, int taps, int K16, int NT,
+                                         int layout, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = i & 7;
+    const int lane = (i >> 3) & 63;
+    long t = i >> 9;
+    const int nt = t % NT; t /= NT;
+    const int k16 = t % K16; t /= K16;
+    const int tap = (int)t;
+    const int co = nt * 32 + (lane & 31);
+    const int ci = k16 * 16 + (lane >> 5) * 8 + j;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+        if (layout == 0) v = w[((size_t)co * cin + ci) * taps + tap];
+        else if (layout == 1) v = w[((size_t)ci * cout + co) * taps + tap];
+        else v = w[(size_t)ci * cout + co];
+        if (scale != nullptr) v *= scale[co];
+    }
+    wpk[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+struct VariantB {
+    int MT, NT, WM, WN;
+    void (*kern[2])(const ConvBP);   // [0] fp32 in / fp32 out, [1] bf16 in / bf16 out
+};
+
+#define OCCD_VARIANT_B(MT, NT, WM, WN) \
+    VariantB { MT, NT, WM, WN, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true> } }
+
+const VariantB kVariantsB[] = {
+    OCCD_VARIANT_B(4, 1, 4, 1),   // 0: M512 x N32
+    OCCD_VARIANT_B(2, 1, 4, 1),   // 1: M256 x N32
+    OCCD_VARIANT_B(1, 1, 4, 1),   // 2: M128 x N32
+    OCCD_VARIANT_B(4, 2, 4, 1),   // 3: M512 x N64
+    OCCD_VARIANT_B(2, 2, 4, 1),   // 4: M256 x N64
+    OCCD_VARIANT_B(4, 2, 2, 2),   // 5: M256 x N128
+    OCCD_VARIANT_B(2, 2, 2, 2),   // 6: M128 x N128
+    OCCD_VARIANT_B(1, 2, 2, 2),   // 7: M64  x N128
+};
+constexpr int kNumVariantsB = sizeof(kVariantsB) / sizeof(kVariantsB[0]);
+constexpr size_t kMaxLdsB = 160 * 1024;
+bool g_attr_set_b[kNumVariantsB][2] = {};
+
+struct TilingB {
+    int TY, TZ, YIN, ZIN, ytiles, ztiles, ngroups;
+    size_t lds;
+    long nwg;
+    double cost;
+};
+
+// Tile of mwg output positions as TY x TZ: the candidate that stages the fewest input rows per launch (halo + ragged
+// edges) among those that fit LDS.  2-D images (Zo = W >> mwg) get a TY > 1 tile instead of a one-row strip.
+bool plan_b(const occd_conv3d_args* a, const VariantB& v, int NTtot, TilingB* best) {
+    const int mwg = v.MT * v.WM * 32;
+    bool found = false;
+    int cands[16];
+    int nc = 0;
+    if (a->Zo <= mwg) cands[nc++] = a->Zo;                       // whole columns (the 3-D stack: Z = 4 ... 32)
+    for (int tz = 8; tz <= mwg; tz *= 2)
+        if (tz < a->Zo) cands[nc++] = tz;
+    for (int i = 0; i < nc; ++i) {
+        TilingB t;
+        t.TZ = cands[i];
+        t.TY = mwg / t.TZ;
+        if (t.TY < 1) continue;
+        if (t.TY > a->Yo) t.TY = a->Yo;
+        t.YIN = (t.TY - 1) * a->sy + (a->ky - 1) * a->dy + 1;
+        t.ZIN = (t.TZ - 1) * a->sz + (a->kz - 1) * a->dz + 1;
+        t.ytiles = (a->Yo + t.TY - 1) / t.TY;
+        t.ztiles = (a->Zo + t.TZ - 1) / t.TZ;
+        t.lds = (size_t)t.YIN * t.ZIN * kRSB;
+        const int nwg_n = v.NT * v.WN;
+        t.ngroups = (NTtot + nwg_n - 1) / nwg_n;
+        t.nwg = (long)a->Xo * t.ytiles * t.ztiles;
+        if (t.lds > kMaxLdsB || (long)t.YIN * t.ZIN >= 65536 || t.nwg >= (1L << 24)) continue;
+        // staged rows per launch + idle M slots of a tile smaller than mwg (they still cost MFMA time)
+        t.cost = (double)t.nwg * ((double)t.YIN * t.ZIN + 2.0 * (mwg - (double)t.TY * t.TZ));
+        if (t.lds > 80 * 1024) t.cost *= 1.15;                   // one workgroup per CU instead of two
+        if (!found || t.cost < best->cost) { *best = t; found = true; }
+    }
+    return found;
+}
+
+}  // namespace
+
+extern "C" int64_t occd_packed_weight_bf16_elems(int32_t cout, int32_t cin, int32_t taps) {
+    if (cout <= 0 || cin <= 0 || taps <= 0) return OCCD_EINVAL;
+    const int64_t K16 = (cin + 15) / 16, NT = (cout + 31) / 32;
+    return (int64_t)taps * K16 * NT * 512;
+}
+
+extern "C" int occd_pack_weights_bf16(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
+                                      int32_t kx, int32_t ky, int32_t kz, int32_t layout, void* stream) {
+    if (!w || !wpk || layout < 0 || layout > 2) return OCCD_EINVAL;
+    const int taps = kx * ky * kz;
+    const int64_t total = occd_packed_weight_bf16_elems(cout, cin, taps);
+    if (total <= 0 || (layout == 2 && taps != 1)) return OCCD_EINVAL;
+    const int K16 = (cin + 15) / 16, NT = (cout + 31) / 32;
+    const int th = 256;
+    const long blocks = (total + th - 1) / th;
+    occd::ProfScope prof("pack_weights_bf16", (hipStream_t)stream, 0.0, (double)total * 6);
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
+                       (uint16_t*)wpk, cout, cin, taps, K16, NT, layout, (long)total);
+    return occd::check_launch();
+}
+
+// `a->in`, `a->out`, `a->res1`, `a->res2` point at fp32 (dtype 0) or bf16 (dtype 1) channels-last rows -- all four
+// the same type --, `a->wpk` at the image of occd_pack_weights_bf16, `a->bias` at fp32.  *_cs / *_coff count ELEMENTS.
+extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream) {
+    if (!a || !a->in || !a->wpk || !a->out || dtype < 0 || dtype > 1) return OCCD_EINVAL;
+    if (a->batch <= 0 || a->X <= 0 || a->Y <= 0 || a->Z <= 0 || a->cin <= 0 || a->cout <= 0) return OCCD_EINVAL;
+    if (a->kx <= 0 || a->ky <= 0 || a->kz <= 0 || a->sx <= 0 || a->sy <= 0 || a->sz <= 0) return OCCD_EINVAL;
+    if (a->Xo <= 0 || a->Yo <= 0 || a->Zo <= 0) return OCCD_EINVAL;
+    const int cin8 = (a->cin + 7) & ~7;
+    const int cin16 = (a->cin + 15) & ~15;
+    const int NTtot = (a->cout + 31) / 32;
+    const int al = dtype == 1 ? 7 : 3;               // 16-byte staging loads: 8 bf16 / 4 (+4) floats
+    const int esz = dtype == 1 ? 2 : 4;
+    if ((a->in_cs & al) || (a->in_coff & al) || a->in_coff + cin8 > a->in_cs) return OCCD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->in) & 15) || (reinterpret_cast<uintptr_t>(a->wpk) & 15)) return OCCD_EINVAL;
+    if (a->cout_store < a->cout || a->cout_store > NTtot * 32 || a->out_coff + a->cout_store > a->out_cs)
+        return OCCD_EINVAL;
+    // 4-channel epilogue groups: 16 B (fp32) / 8 B (bf16) accesses
+    if ((a->cout_store & 3) || (a->out_cs & 3) || (a->out_coff & 3) ||
+        (reinterpret_cast<uintptr_t>(a->out) & (4 * esz - 1)))
+        return OCCD_EINVAL;
+    if (a->res1 && ((a->res1_cs & 3) || (a->res1_coff & 3) || (reinterpret_cast<uintptr_t>(a->res1) & (4 * esz - 1)) ||
+                    a->res1_coff + a->cout_store > a->res1_cs))
+        return OCCD_EINVAL;
+    if (a->res2 && ((a->res2_cs & 3) || (a->res2_coff & 3) || (reinterpret_cast<uintptr_t>(a->res2) & (4 * esz - 1)) ||
+                    a->res2_coff + a->cout_store > a->res2_cs))
+        return OCCD_EINVAL;
+    if (a->bias && (reinterpret_cast<uintptr_t>(a->bias) & 15)) return OCCD_EINVAL;
+    if ((a->Xo - 1) * a->o_stride_x + a->o_off_x >= a->OX || (a->Yo - 1) * a->o_stride_y + a->o_off_y >= a->OY ||
+        (a->Zo - 1) * a->o_stride_z + a->o_off_z >= a->OZ)
+        return OCCD_EINVAL;
+    if (a->act_in != OCCD_ACT_NONE && a->act_in != OCCD_ACT_RELU) return OCCD_EINVAL;
+    if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
+        return OCCD_EINVAL;
+
+    int order[kNumVariantsB];
+    int n = 0;
+    if (a->tile_hint > 0 && a->tile_hint <= kNumVariantsB) {
+        order[n++] = a->tile_hint - 1;
+    } else if (NTtot == 1) {
+        order[n++] = 0; order[n++] = 1; order[n++] = 2;
+    } else if (NTtot == 2) {
+        order[n++] = 3; order[n++] = 4; order[n++] = 6; order[n++] = 7;
+    } else {
+        order[n++] = 5; order[n++] = 6; order[n++] = 7;
+    }
+    int pick = -1;
+    TilingB til{};
+    for (int i = 0; i < n; ++i) {
+        TilingB t{};
+        if (!plan_b(a, kVariantsB[order[i]], NTtot, &t)) continue;
+        pick = order[i];
+        til = t;
+        if (t.nwg * t.ngroups * a->batch >= 512) break;   // else keep refining to the finest fit
+    }
+    if (pick < 0) return OCCD_ENOMEM;
+    const VariantB& v = kVariantsB[pick];
+
+    ConvBP p;
+    p.in = a->in; p.wpk = (const u32x4*)a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
+    p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.cin8 = cin8; p.cin16 = cin16; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
+    p.K16tot = cin16 / 16; p.NTtot = NTtot;
+    p.out_cs = a->out_cs; p.out_coff = a->out_coff;
+    p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
+    p.KX = a->kx; p.KY = a->ky; p.KZ = a->kz; p.SX = a->sx; p.SY = a->sy; p.SZ = a->sz;
+    p.DX = a->dx; p.DY = a->dy; p.DZ = a->dz; p.PX = a->px; p.PY = a->py; p.PZ = a->pz;
+    p.Xo = a->Xo; p.Yo = a->Yo; p.Zo = a->Zo; p.OX = a->OX; p.OY = a->OY; p.OZ = a->OZ;
+    p.osx = a->o_stride_x; p.osy = a->o_stride_y; p.osz = a->o_stride_z;
+    p.oox = a->o_off_x; p.ooy = a->o_off_y; p.ooz = a->o_off_z;
+    p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
+    p.TY = til.TY; p.TZ = til.TZ; p.YIN = til.YIN; p.ZIN = til.ZIN;
+    p.ytiles = til.ytiles; p.ztiles = til.ztiles; p.nwg = (int)til.nwg;
+    p.div_zin = occd::make_fastdiv(til.ZIN); p.div_tz = occd::make_fastdiv(til.TZ);
+    p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
+
+    void (*kern)(const ConvBP) = v.kern[dtype];
+    if (til.lds > 64 * 1024 && !g_attr_set_b[pick][dtype]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kMaxLdsB) != hipSuccess)
+            return OCCD_ELAUNCH;
+        g_attr_set_b[pick][dtype] = true;
+    }
+    const double taps = (double)a->kx * a->ky * a->kz;
+    const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
+    const double flops = 2.0 * pos * taps * a->cin * a->cout;
+    const double bytes = (double)esz * ((double)a->batch * a->X * a->Y * a->Z * a->cin +
+                                        pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr))) +
+                         2.0 * taps * a->cin * a->cout;
+    occd::ProfScope prof(dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16", (hipStream_t)stream, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
+                       dim3(v.WM * v.WN * 64), til.lds, (hipStream_t)stream, p);
+    return occd::check_launch();
+}

