@@ -117,9 +117,9 @@ def cpu_baseline(model, cfg, batch, seed, timed_frames=3):
     """The CPU oracle on the host cores, same weights / inputs as the GPU run (reported, not a target; SURVEY 8(d):
     1 warm-up + >= 3 timed frames, median, thread count stated).  The oracle builds its own batch from the same seed
     (numpy restatement of the dataloader's vox2pix) and it must equal the GPU-projected one bit for bit.
-    torch's CPU pool stops scaling long before a big box's hardware-thread count, so the warm-up frame runs on
-    min(64, os.cpu_count()) threads and a probe frame on os.cpu_count(); the timed frames use the faster of the two and
-    `cores` reports the threads actually used (both probe times are in `sample`)."""
+    torch's CPU pool stops scaling long before a big box's hardware-thread count, so a short conv3d probe picks between
+    min(64, os.cpu_count()) and os.cpu_count() threads; the frames run on the faster of the two and
+    `cores` reports the threads actually used (the probe times are in `sample`)."""
     import copy
     import statistics
     from oracle import inputs
@@ -143,19 +143,31 @@ def cpu_baseline(model, cfg, batch, seed, timed_frames=3):
             orc.occdepth_forward(sd, ocfg, batch_cpu, enc)
         return time.time() - t0
 
-    probes = {}
+    # thread count: torch's CPU pool stops scaling (and can collapse) long before a big box's hardware-thread count, and a full
+    # frame at the wrong count costs minutes; a one-second 3-D convolution probe picks between min(64, hw) and hw instead
+    def conv_probe(threads):
+        torch.set_num_threads(threads)
+        x = torch.randn(1, 32, 64, 64, 32)
+        w = torch.randn(32, 32, 3, 3, 3)
+        torch.nn.functional.conv3d(x, w, padding=1)
+        t0 = time.time()
+        for _ in range(3):
+            torch.nn.functional.conv3d(x, w, padding=1)
+        return (time.time() - t0) / 3
+
     first = min(hw, 64)
-    frame(first)                                        # warm-up (allocator, oneDNN primitive caches)
-    probes[first] = frame(first)
+    probes = {first: conv_probe(first)}
     if hw != first:
-        probes[hw] = frame(hw)
+        probes[hw] = conv_probe(hw)
     threads = min(probes, key=probes.get)
+    log(f"cpu_baseline: conv3d probe {probes} -> {threads} threads")
+    frame(threads)                                      # warm-up (allocator, oneDNN primitive caches)
     times = [frame(threads) for _ in range(timed_frames)]
     med = statistics.median(times)
     return {"value": 1.0 / med, "unit": "frames/s", "cores": threads, "kind": "port",
             "host_hw_threads": hw,
-            "sample": f"{timed_frames} timed full config-2 frames through oracle/occdepth_oracle.py after 1 warm-up + "
-                      f"{len(probes)} thread-count probe frame(s) ({', '.join(f'{k} threads: {v:.2f} s' for k, v in probes.items())}); "
+            "sample": f"{timed_frames} timed full config-2 frames through oracle/occdepth_oracle.py after 1 warm-up frame; thread "
+                      f"count picked by a conv3d probe ({', '.join(f'{k} threads: {1e3 * v:.0f} ms' for k, v in probes.items())}); "
                       f"median {med:.2f} s/frame (min {min(times):.2f}, max {max(times):.2f}) on {threads} torch threads"}
 
 
@@ -181,7 +193,13 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--train", action="store_true", help="training step (configs[2]/[3]) instead of the forward")
-    ap.add_argument("--bf16", action="store_true", help="with --train: bf16 autocast (configs[3])")
+    ap.add_argument("--bf16", action="store_true",
+                    help="with --train (configs[3]): every convolution of the 3-D stack and of the 2-D decoder -- forward, data "
+                         "gradient, weight gradient -- on the bf16 matrix pipe (K2b / K8b: fp32 accumulate, fp32 master weights, "
+                         "fp32 activation storage)")
+    ap.add_argument("--autocast", action="store_true",
+                    help="with --train --bf16: additionally run the step under torch.autocast(bfloat16) (bf16 activation storage "
+                         "where ATen / the libraries produce it)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2: BASELINE configs[1] (the headline metric); 5: BASELINE configs[4], UNet3D alone on a synthetic "
                          "512x512x64 grid (auxiliary workload: 3-D-conv MFMA tiling + HBM footprint)")
@@ -264,8 +282,10 @@ def _forward(args, world, rank, device, dist):
         with torch.no_grad():
             return model(batch)
 
+    log(f"[bench {time.strftime('%H:%M:%S')}] model built, warm-up ({args.warmup} steps; the first captures the hipGraph)")
     for _ in range(args.warmup):
         step()
+    log(f"[bench {time.strftime('%H:%M:%S')}] timed loop")
     # ---- the timed region: K steps, nothing but the forward (no per-launch HIP events, no host work besides the replay)
     shard.fence(dist)
     t0 = time.perf_counter()
@@ -360,11 +380,13 @@ def _forward(args, world, rank, device, dist):
         if getattr(model, attr, None):
             res["config"][attr] = getattr(model, attr)
     if not args.no_parity:
+        log(f"[bench {time.strftime('%H:%M:%S')}] parity check against the real-reference golden")
         try:
             res["parity_rel_err"] = parity_check(device)
         except Exception as e:  # a report, never a reason to lose the measurement
             res["parity_rel_err"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
+        log(f"[bench {time.strftime('%H:%M:%S')}] CPU baseline (oracle, 1 warm-up + 3 timed frames)")
         try:
             res["cpu_baseline"] = cpu_baseline(model, cfg, batch, rank)
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
@@ -439,7 +461,9 @@ def _config5(args, world, rank, device, dist):
 def _train(args, world, rank, device, dist):
     """BASELINE configs[2] (fp32) / configs[3] (--bf16): one frame per rank, the reference's full `training_step`
     (forward, every loss term, backward), the gradient exchange of its DDP run, AdamW."""
-    from occdepth_amd import hip, shard, synthetic
+    from occdepth_amd import autograd3d, hip, shard, synthetic
+    autograd3d.set_bf16_mfma(args.bf16)
+    autocast = bool(args.bf16 and args.autocast)
     model, cfg = build_model(device, train=True)
     with torch.no_grad():
         batch = synthetic.attach_projection(model, synthetic.to_device(synthetic.kitti_frame(seed=rank), device))
@@ -460,7 +484,7 @@ def _train(args, world, rank, device, dist):
             buckets.zero_grad()
         else:
             opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.bf16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             loss = model.training_step(batch, 0)
         loss.backward()
         if buckets is not None:
@@ -473,28 +497,40 @@ def _train(args, world, rank, device, dist):
     # whole-step hipGraph (occdepth_amd/train_graph.py): the eager step is ~9600 launches and host-bound.
     graphed, graph_error = None, None
     if use_graph:
-        gs = train_graph.GraphedTrainStep(model, opt, batch, bf16=args.bf16, buckets=buckets, warmup=1)
+        gs = train_graph.GraphedTrainStep(model, opt, batch, bf16=autocast, buckets=buckets, warmup=1)
         if gs.capture():
             graphed = gs
             gs()
         else:
             graph_error = gs.error
     shard.fence(dist)
-    with hip.profile() as prof:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = graphed() if graphed is not None else step()
-        shard.fence(dist)
-        elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = graphed() if graphed is not None else step()
+    shard.fence(dist)
+    elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, device)
+    loss_value = float(loss.detach())
+    with hip.profile() as prof:                    # kernel table: ONE eager step after the timed loop (HIP events per launch)
+        step()
+        torch.cuda.synchronize()
     if rank != 0:
         return None
     rows = sorted(prof.rows.items(), key=lambda kv: -kv[1]["ms"])[:8]
+    families = {}
+    for k, v in prof.rows.items():
+        fam = k.split(":")[0]
+        families[fam] = families.get(fam, 0.0) + v["ms"]
+    families = {k: round(v, 3) for k, v in sorted(families.items(), key=lambda kv: -kv[1])}
     return {
         "metric": "frames/sec trained (fwd + losses + bwd + gradient exchange + AdamW), SemanticKITTI stereo->256x256x32 voxels",
         "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 autocast (3-D convolutions and loss statistics fp32)" if args.bf16 else "f32",
+        "vs_baseline": None,
+        "dtype": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights) for every convolution of the 3-D "
+                  "stack and the 2-D decoder, forward + dgrad + wgrad; " +
+                  ("torch.autocast(bf16) around the step" if autocast else "fp32 activation storage, EfficientNet encoder fp32"))
+        if args.bf16 else "f32",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{3 if args.bf16 else 2}]: training step, SemanticKITTI stereo 370x1220, "
                                "tf_efficientnet_b7_ns, feature 64, flosp_depth + CRP + cascade head, batch 1/GPU",
@@ -502,8 +538,9 @@ def _train(args, world, rank, device, dist):
                    "parallelism": f"dp{world}: SyncBatchNorm (packed all-reduce per layer) + "
                                   f"{len(buckets.buckets) if buckets else 0} gradient buckets ({buckets.algo if buckets else 'none'})"},
         "train_graph": graphed is not None, "train_graph_error": graph_error,
-        "loss": float(loss.detach()), "max_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
-        "hip_kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in rows},
+        "loss": loss_value, "max_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+        "hip_kernels_ms_per_step": {k: v["ms"] for k, v in rows},
+        "hip_kernel_families_ms_per_step": families,
     }
 
 

@@ -392,6 +392,63 @@ int64_t occd_conv3d_wgrad_workspace_floats(const occd_conv3d_wgrad_args* a);
 int occd_conv3d_wgrad(const occd_conv3d_wgrad_args* a, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * K13: training-mode BatchNorm (+ activation + residual) as HBM-bound passes, forward and backward
+ * (torch.nn.BatchNorm{2,3}d / SyncBatchNorm in training mode: occdepth/models/DDR.py:111-139, modules.py:40-46,158-175,
+ * 278-296, unet2d.py:24-46; scripts/train.py:179 `sync_batchnorm=True`).
+ *   layout 0: channels-last rows (`rows` rows of `*_cs` elements, channels at `*_coff`; dtype 0 fp32 / 1 bf16)
+ *   layout 1: NCHW planes (`batch` x C planes of S fp32 elements; the *_cs / *_coff fields are ignored)
+ * forward : occd_bn_stats (x -> partial) ; occd_bn_stats_combine (partial -> packed[2C+1] float64 =
+ *           [n mean_c, M2_c + n mean_c^2, n], the form that sums over ranks) ; [all-reduce packed] ; occd_bn_finish
+ *           (packed -> mean, invstd, a = gamma invstd, b = beta - mean a, running statistics with the unbiased variance,
+ *           num_batches_tracked += 1) ; occd_bn_apply: out = act(x a + b [+ res if res_first]) [+ res if !res_first],
+ *           act = 0 none / 1 relu / 2 swish / 3 leaky-relu(slope); `cw` (>= ceil4(C), rows layout) channels are written
+ *           per row, those >= C as zeros.
+ * backward: occd_bn_bwd_reduce (g = gy act'(pre), pre from `y`'s sign when y != NULL else x a + b; partial = sum g,
+ *           sum g xhat) ; occd_bn_bwd_combine (partial -> packed[2C] fp32) ; [all-reduce a copy] ; occd_bn_bwd_finish
+ *           (k1, k2, k3, gw = local sum g xhat, gb = local sum g) ; occd_bn_bwd_apply: out = g k1 + x k2 + k3 and,
+ *           when out2 != NULL, out2 = g (the gradient of a residual that was added before the activation).
+ * `partial` holds occd_bn_blocks() * 2 * ceil4(C) floats.
+ * ------------------------------------------------------------------------ */
+typedef struct occd_bn_args {
+    const void* x;
+    const void* gy;
+    const void* y;
+    const void* res;
+    void* out;
+    void* out2;
+    const float* a;
+    const float* b;
+    const float* mean;
+    const float* invstd;
+    const float* k1;
+    const float* k2;
+    const float* k3;
+    float* partial;
+    int64_t rows;
+    int64_t S;
+    int32_t batch;
+    int32_t C, cw;
+    int32_t dtype, layout;
+    int32_t x_cs, x_coff, gy_cs, gy_coff, y_cs, y_coff, res_cs, res_coff, out_cs, out_coff, out2_cs, out2_coff;
+    int32_t act, res_first;
+    float slope;
+    int32_t nblk;
+} occd_bn_args;
+int occd_bn_blocks(const occd_bn_args* a);
+int occd_bn_stats(const occd_bn_args* a, void* stream);
+int occd_bn_stats_combine(const occd_bn_args* a, double* packed, void* stream);
+int occd_bn_finish(const double* packed, int32_t C, float eps, float momentum, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                   float* a, float* b, void* stream);
+int occd_bn_apply(const occd_bn_args* a, void* stream);
+int occd_bn_bwd_reduce(const occd_bn_args* a, void* stream);
+int occd_bn_bwd_combine(const float* partial, int32_t nblk, int32_t C, float* packed, void* stream);
+int occd_bn_bwd_finish(const float* local, const float* total, int32_t C, const double* packed_fwd, const float* mean,
+                       const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw, float* gb,
+                       void* stream);
+int occd_bn_bwd_apply(const occd_bn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * K2b / K8b: the same convolution forward (data gradient: the forward on dL/dy with flipped weights) and weight
  * gradient on the bf16 matrix pipe -- v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights -- for the bf16
  * training step (BASELINE configs[3]; reference call sites as for K2 / K8, plus the 3x3 convolutions of the 2-D decoder,

@@ -13,6 +13,7 @@ Tensors cross the boundary as (B, C, X, Y, Z) views with channels_last_3d stride
 never transpose.
 """
 import itertools
+import os
 
 import torch
 import torch.nn as nn
@@ -20,13 +21,56 @@ import torch.nn as nn
 from . import hip
 from .hip import Vox
 
+# BASELINE configs[3] (the bf16 training step): every convolution of this module -- forward, data gradient and weight
+# gradient -- on the bf16 matrix pipe (K2b / K8b: v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights and
+# fp32 gradients).  Activations keep the dtype they arrive in: float32 tensors stay float32 in HBM and are rounded to
+# bf16 while a kernel stages them ("bf16 MFMA, fp32 storage"), bfloat16 tensors (an autocast region upstream) are
+# consumed and produced as bfloat16.  Off (default): the exact-fp32 MFMA kernels K2 / K2s / K8.
+BF16_MFMA = os.environ.get("OCCDEPTH_BF16_MFMA", "0") == "1"
+
+
+def set_bf16_mfma(flag):
+    """Switch the convolutions of the training path between the exact-fp32 and the bf16 matrix pipe; returns the old value."""
+    global BF16_MFMA
+    old, BF16_MFMA = BF16_MFMA, bool(flag)
+    return old
+
 
 def _to_vox(x):
-    """(B, C, X, Y, Z) float32 CUDA tensor -> Vox; zero-copy for channels_last_3d tensors with C % 8 == 0."""
+    """(B, C, X, Y, Z) CUDA tensor -> Vox; zero-copy for channels_last_3d tensors with C % 8 == 0.  bfloat16 tensors stay
+    bfloat16 in bf16 mode (anything else is float32)."""
+    if x.dtype != torch.float32 and not (BF16_MFMA and x.dtype == torch.bfloat16):
+        x = x.float()
     cl = x.permute(0, 2, 3, 4, 1)
     if x.shape[1] % 8 == 0 and cl.is_contiguous():
         return Vox(cl, x.shape[1])
-    return Vox.from_ncdhw(x)
+    if x.dtype == torch.float32 and x.is_contiguous():
+        return Vox.from_ncdhw(x)                       # NCDHW: one LDS-tiled transpose pass
+    # channels-last with a ragged channel count (or a bf16 NCDHW tensor): one strided copy into zero-padded rows
+    v = Vox(torch.zeros((x.shape[0],) + tuple(x.shape[2:]) + (hip.round_up(x.shape[1], 8),), device=x.device, dtype=x.dtype),
+            x.shape[1])
+    v.buf[..., :x.shape[1]].copy_(cl)
+    return v
+
+
+def _conv(x, w, bias, cout, kernel, out, **kw):
+    """One forward-kernel launch with the weights packed for the active matrix pipe."""
+    if BF16_MFMA:
+        return hip.conv3d_bf16(x, hip.pack_weights_bf16(w), bias, cout, kernel, out, **kw)
+    return hip.conv3d(x, hip.pack_weights(w), bias, cout, kernel, out, **kw)
+
+
+def _wgrad(x, gy, cin, cout, K, stride, dilation, padding):
+    """dW: K8b (bf16 MFMA through transposed LDS reads) for the shapes it is built for -- columns of >= 16 voxels and either
+    many taps (3x3x3, 3x3, the 2x2x2 phases) or more than one cout tile --, the exact-fp32 K8 otherwise."""
+    ntaps = K[0] * K[1] * K[2]
+    if BF16_MFMA and gy.dims[2] >= 16 and (ntaps >= 8 or cout > 32) and ntaps <= 28 and x.buf.dtype == gy.buf.dtype:
+        return hip.conv3d_wgrad_bf16(x, gy, cin, cout, K, stride, dilation, padding)
+    if x.buf.dtype != torch.float32:
+        x = Vox(x.buf.float(), x.C, x.coff)
+    if gy.buf.dtype != torch.float32:
+        gy = Vox(gy.buf.float(), gy.C, gy.coff)
+    return hip.conv3d_wgrad(x, gy, cin, cout, K, stride, dilation, padding)
 
 
 def _axis_phases(K, s, p, d):
@@ -65,7 +109,7 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     cout, cin = w.shape[:2]
     K = tuple(w.shape[2:])
     wt = w.detach().permute(1, 0, 2, 3, 4)                                  # (cin, cout, k): the transposed operator
-    out = Vox.empty(gy.batch, in_dims, cin, gy.buf.device)
+    out = Vox.empty(gy.batch, in_dims, cin, gy.buf.device, dtype=gy.buf.dtype)
     axes = [_axis_phases(K[a], stride[a], padding[a], dilation[a]) for a in range(3)]
     if any(not taps for ax in axes for _, taps, _, _ in ax) or out.cs != cin:
         out.buf.zero_()                                                    # empty phases / channel pad
@@ -76,8 +120,8 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
         n_pos = tuple((in_dims[a] - r + stride[a] - 1) // stride[a] for a, r in enumerate((rx, ry, rz)))
         if min(n_pos) <= 0:
             continue
-        hip.conv3d(gy, hip.pack_weights(sub), None, cin, tuple(sub.shape[2:]), out, dilation=(dx_, dy_, dz_),
-                   padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
+        _conv(gy, sub, None, cin, tuple(sub.shape[2:]), out, dilation=(dx_, dy_, dz_),
+              padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
     return out
 
 
@@ -85,43 +129,49 @@ def _out_dims(dims, K, stride, padding, dilation):
     return tuple((n + 2 * p - d * (k - 1) - 1) // s + 1 for n, k, s, p, d in zip(dims, K, stride, padding, dilation))
 
 
+def _like(gy, ref_dtype):
+    """The incoming gradient in the storage type of the saved activation (the two operands of a launch share it)."""
+    return gy if gy.dtype == ref_dtype else gy.to(ref_dtype)
+
+
 class _Conv3dFn(torch.autograd.Function):
-    # under torch.autocast the 3-D convolutions stay in float32 (exact-fp32 MFMA; the tensors are cast on entry)
+    # No autocast casting here: float32 activations are consumed as they are (exact-fp32 MFMA, or -- BF16_MFMA -- rounded to
+    # bf16 inside the kernels), bfloat16 activations are taken as bfloat16 in bf16 mode and widened otherwise.  The weights
+    # are always the float32 master copies.
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, w, b, stride, padding, dilation):
-        xv = _to_vox(x.detach())
-        cout, cin = w.shape[:2]
-        K = tuple(w.shape[2:])
-        out = Vox.empty(xv.batch, _out_dims(xv.dims, K, stride, padding, dilation), cout, x.device)
-        if out.cs != cout:
-            out.buf.zero_()
-        bias = None
-        if b is not None:
-            bias = torch.zeros(hip.round_up(cout, 32), device=x.device)
-            bias[:cout] = b.detach()
-        hip.conv3d(xv, hip.pack_weights(w.detach()), bias, cout, K, out, stride=stride, dilation=dilation,
-                   padding=padding, cin=cin)
+        with torch.autocast("cuda", enabled=False):
+            xv = _to_vox(x.detach())
+            cout, cin = w.shape[:2]
+            K = tuple(w.shape[2:])
+            out = Vox.empty(xv.batch, _out_dims(xv.dims, K, stride, padding, dilation), cout, x.device, dtype=xv.buf.dtype)
+            if out.cs != cout:
+                out.buf.zero_()
+            bias = None
+            if b is not None:
+                bias = torch.zeros(hip.round_up(cout, 32), device=x.device)
+                bias[:cout] = b.detach().float()
+            _conv(xv, w.detach().float(), bias, cout, K, out, stride=stride, dilation=dilation, padding=padding, cin=cin)
         ctx.save_for_backward(xv.buf, w)
         ctx.geom = (xv.C, xv.coff, stride, padding, dilation, b is not None)
         return out.ncdhw()
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         xbuf, w = ctx.saved_tensors
         C, coff, stride, padding, dilation, has_bias = ctx.geom
-        xv = Vox(xbuf, C, coff)
-        gyv = _to_vox(gy.float())
-        cout, cin = w.shape[:2]
-        K = tuple(w.shape[2:])
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = conv3d_dgrad(gyv, w, xv.dims, stride, padding, dilation).ncdhw()
-        if ctx.needs_input_grad[1]:
-            dw = hip.conv3d_wgrad(xv, gyv, cin, cout, K, stride, dilation, padding)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = gyv.buf.reshape(-1, gyv.cs)[:, gyv.coff:gyv.coff + cout].sum(0)
+        with torch.autocast("cuda", enabled=False):
+            xv = Vox(xbuf, C, coff)
+            gyv = _to_vox(_like(gy, xbuf.dtype))
+            cout, cin = w.shape[:2]
+            K = tuple(w.shape[2:])
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = conv3d_dgrad(gyv, w.float(), xv.dims, stride, padding, dilation).ncdhw()
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad(xv, gyv, cin, cout, K, stride, dilation, padding).to(w.dtype)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = gyv.buf.reshape(-1, gyv.cs)[:, gyv.coff:gyv.coff + cout].sum(0, dtype=torch.float32)
         return dx, dw, db, None, None, None
 
 
@@ -129,43 +179,52 @@ class _ConvTranspose3dFn(torch.autograd.Function):
     """y = conv_transpose3d(x, w (cin, cout, k)) == the data gradient of the convolution whose weight is w."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, w, b, stride, padding, output_padding, dilation):
-        xv = _to_vox(x.detach())
-        cin, cout = w.shape[:2]
-        K = tuple(w.shape[2:])
-        dims = tuple((n - 1) * s - 2 * p + d * (k - 1) + op + 1
-                     for n, k, s, p, d, op in zip(xv.dims, K, stride, padding, dilation, output_padding))
-        out = conv3d_dgrad(xv, w, dims, stride, padding, dilation)
-        y = out.ncdhw()
-        if b is not None:
-            y = y + b.detach().view(1, -1, 1, 1, 1)
+        with torch.autocast("cuda", enabled=False):
+            xv = _to_vox(x.detach())
+            cin, cout = w.shape[:2]
+            K = tuple(w.shape[2:])
+            dims = tuple((n - 1) * s - 2 * p + d * (k - 1) + op + 1
+                         for n, k, s, p, d, op in zip(xv.dims, K, stride, padding, dilation, output_padding))
+            out = conv3d_dgrad(xv, w.detach().float(), dims, stride, padding, dilation)
+            y = out.ncdhw()
+            if b is not None:
+                y = y + b.detach().to(y.dtype).view(1, -1, 1, 1, 1)
         ctx.save_for_backward(xv.buf, w)
         ctx.geom = (xv.C, xv.coff, stride, padding, dilation, b is not None)
         return y
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         xbuf, w = ctx.saved_tensors
         C, coff, stride, padding, dilation, has_bias = ctx.geom
-        xv = Vox(xbuf, C, coff)
-        gyv = _to_vox(gy.float())
-        cin, cout = w.shape[:2]
-        K = tuple(w.shape[2:])
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:                     # the convolution (weight w: "cout" = cin of the transpose)
-            o = Vox.empty(xv.batch, xv.dims, cin, gy.device)
-            if o.cs != cin:
-                o.buf.zero_()
-            hip.conv3d(gyv, hip.pack_weights(w.detach()), None, cin, K, o, stride=stride, dilation=dilation,
-                       padding=padding, out_pos=xv.dims, cin=cout)
-            dx = o.ncdhw()
-        if ctx.needs_input_grad[1]:                     # roles swapped: gy is the conv's input, x its output gradient
-            dw = hip.conv3d_wgrad(gyv, xv, cout, cin, K, stride, dilation, padding)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = gyv.buf.reshape(-1, gyv.cs)[:, gyv.coff:gyv.coff + cout].sum(0)
+        with torch.autocast("cuda", enabled=False):
+            xv = Vox(xbuf, C, coff)
+            gyv = _to_vox(_like(gy, xbuf.dtype))
+            cin, cout = w.shape[:2]
+            K = tuple(w.shape[2:])
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:                     # the convolution (weight w: "cout" = cin of the transpose)
+                o = Vox.empty(xv.batch, xv.dims, cin, gy.device, dtype=gyv.buf.dtype)
+                if o.cs != cin:
+                    o.buf.zero_()
+                _conv(gyv, w.detach().float(), None, cin, K, o, stride=stride, dilation=dilation,
+                      padding=padding, out_pos=xv.dims, cin=cout)
+                dx = o.ncdhw()
+            if ctx.needs_input_grad[1]:                     # roles swapped: gy is the conv's input, x its output gradient
+                dw = _wgrad(gyv, xv, cout, cin, K, stride, dilation, padding).to(w.dtype)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = gyv.buf.reshape(-1, gyv.cs)[:, gyv.coff:gyv.coff + cout].sum(0, dtype=torch.float32)
         return dx, dw, db, None, None, None, None
+
+
+def conv2d_cl(x, w, b=None, padding=0):
+    """nn.Conv2d (stride 1) on the 3-D convolution kernels: the (B, C, H, W) image is the X = 1 volume (B, C, 1, H, W) of
+    channels-last pixel rows, the (Cout, Cin, kh, kw) weight its (1, kh, kw) kernel.  Used by the 2-D decoder in bf16 mode
+    (occdepth/models/unet2d.py:24-46, 65-67, 120-131): forward, data gradient and weight gradient then run on K2b / K8b.
+    Returns a (B, Cout, H', W') tensor with channels-last memory."""
+    p = (0, int(padding), int(padding))
+    return _Conv3dFn.apply(x.unsqueeze(2), w.unsqueeze(2), b, (1, 1, 1), p, (1, 1, 1)).squeeze(2)
 
 
 def _hip_ok(mod, x):

@@ -1,0 +1,253 @@
+"""Training-mode BatchNorm (+ activation + residual) on the K13 kernels (csrc/bn.hip), forward and backward.
+
+    y = bn_act(bn_module, x, act="relu" | "leaky" | "swish" | None, slope=0.01, res=None, res_first=False)
+
+is `act(bn(x) [+ res]) [+ res]` of a `torch.nn.BatchNorm{2,3}d` (or `shard.SyncBatchNorm`) in TRAINING mode -- the pattern of
+every normalisation site of the reference's step (occdepth/models/DDR.py:111-139 `relu(bn(conv(x)))`, `relu(bn5(.) + skip)`;
+modules.py:40-46 `y += bn2(conv2(relu(bn1(conv1(x)))))`; unet2d.py:24-46 conv-BN-LeakyReLU; the EfficientNet blocks'
+BN-swish) -- as two passes over the activation per direction plus per-channel kernels, instead of the backend's
+batch_norm and separate activation / add kernels.  The module keeps its parameters, buffers and state_dict; running
+statistics and `num_batches_tracked` are updated on the device as nn.BatchNorm does.
+
+Statistics that span ranks (`shard.SyncBatchNorm`, the reference's `sync_batchnorm=True`, scripts/train.py:179): the same
+kernels with ONE all-reduce of the packed (2C + 1)-element float64 vector in the forward and one of 2C floats in the
+backward (see csrc/bn.hip); the parameter gradients stay per-rank sums, the gradient buckets average them.
+
+Layouts: channels-last rows ((N, C, *spatial) tensors whose memory is (N, *spatial, cs >= C), fp32 or bf16) and NCHW /
+NCDHW contiguous fp32.  On the CPU (the test-suite's host-logic runs) and for eval mode the call is plain torch.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+ACT = {None: 0, "none": 0, "relu": 1, "swish": 2, "leaky": 3}
+
+
+BnArgs = hip.BnArgs
+
+
+def _rows_geometry(x):
+    """(rows, cs) when x (N, C, *spatial) is laid out channels-last with dense rows of cs >= C elements, else None."""
+    if x.dim() < 3:
+        return None
+    cl = x.permute(0, *range(2, x.dim()), 1)
+    if cl.stride(-1) != 1 and cl.shape[-1] != 1:
+        return None
+    cs = cl.stride(-2)
+    if cs < x.shape[1] or cs % 4 != 0:
+        return None
+    expect = cs
+    for d in range(cl.dim() - 2, -1, -1):
+        if cl.shape[d] != 1 and cl.stride(d) != expect:
+            return None
+        expect *= cl.shape[d]
+    esz = x.element_size()
+    if x.data_ptr() % (4 * esz) != 0:
+        return None
+    return x.numel() // x.shape[1], cs
+
+
+class _Geom:
+    """How a tensor of the call is addressed by the kernels (all tensors of a call share layout, dtype and extent)."""
+
+    def __init__(self, x):
+        self.C = x.shape[1]
+        self.dtype = x.dtype
+        rows = _rows_geometry(x) if not (x.is_contiguous() and x.dtype == torch.float32) or x.dim() == 2 else None
+        if x.is_contiguous() and x.dtype == torch.float32 and x.dim() > 2:
+            self.layout, self.batch, self.S, self.rows = 1, x.shape[0], x[0, 0].numel(), 0
+        elif rows is not None:
+            self.layout, self.batch, self.S, self.rows = 0, 0, 0, rows[0]
+        else:
+            raise RuntimeError("bn_act: unsupported tensor layout")
+
+    @staticmethod
+    def supported(x):
+        if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or x.dim() < 3:
+            return False
+        if x.is_contiguous() and x.dtype == torch.float32:
+            return x.shape[0] * x.shape[1] <= 65535
+        return _rows_geometry(x) is not None
+
+    def like(self, x, t, what):
+        """cs of tensor t, which must have x's shape, dtype and layout kind."""
+        if t.shape != x.shape or t.dtype != x.dtype:
+            raise RuntimeError(f"bn_act: {what} must have the activation's shape and dtype")
+        if self.layout == 1:
+            if not t.is_contiguous():
+                raise RuntimeError(f"bn_act: {what} must be contiguous like the activation")
+            return 0
+        g = _rows_geometry(t)
+        if g is None:
+            raise RuntimeError(f"bn_act: {what} must be channels-last like the activation")
+        return g[1]
+
+    def empty_like(self, x):
+        """Output tensor in x's layout: NCHW contiguous, or channels-last rows padded to ceil8(C) (zero pads)."""
+        if self.layout == 1:
+            return torch.empty_like(x), 0
+        cs = hip.round_up(self.C, 8)
+        buf = torch.empty((x.shape[0],) + tuple(x.shape[2:]) + (cs,), device=x.device, dtype=x.dtype)
+        return buf[..., :self.C].permute(0, x.dim() - 1, *range(1, x.dim() - 1)), cs
+
+    def args(self):
+        a = BnArgs()
+        a.C, a.dtype, a.layout = self.C, 1 if self.dtype == torch.bfloat16 else 0, self.layout
+        a.rows, a.S, a.batch = self.rows, self.S, self.batch
+        return a
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _group_active(group):
+    from . import shard
+    return shard._group_active(group)
+
+
+def _to_rows(t):
+    """t (N, C, *spatial) as a channels-last rows tensor the kernels can address (a copy only when it is not one)."""
+    if _rows_geometry(t) is not None:
+        return t
+    C = t.shape[1]
+    cs = hip.round_up(C, 8)
+    nd = t.dim()
+    buf = torch.zeros((t.shape[0],) + tuple(t.shape[2:]) + (cs,), device=t.device, dtype=t.dtype)
+    buf[..., :C].copy_(t.permute(0, *range(2, nd), 1))
+    return buf[..., :C].permute(0, nd - 1, *range(1, nd - 1))
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, running_mean, running_var, nbt, eps, momentum, act, slope, res_first, group,
+                sync):
+        lib = hip.load()
+        st = hip._stream()
+        geo = _Geom(x)
+        C = geo.C
+        dev = x.device
+        a = geo.args()
+        a.x = x.data_ptr()
+        a.x_cs = geo.like(x, x, "x")
+        a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
+        if a.nblk <= 0:
+            raise RuntimeError("occd_bn_blocks failed")
+        partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
+        a.partial = partial.data_ptr()
+        packed = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
+        hip._check(lib.occd_bn_stats(ctypes.byref(a), st), "occd_bn_stats")
+        hip._check(lib.occd_bn_stats_combine(ctypes.byref(a), packed.data_ptr(), st), "occd_bn_stats_combine")
+        if sync and _group_active(group):
+            import torch.distributed as dist
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        vec = torch.empty(4, C, device=dev, dtype=torch.float32)          # mean, invstd, a, b
+        w = weight.detach().float() if weight is not None else None
+        b = bias.detach().float() if bias is not None else None
+        hip._check(lib.occd_bn_finish(packed.data_ptr(), C, float(eps), float(momentum if momentum is not None else 0.0),
+                                      _ptr(w), _ptr(b), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                      vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st),
+                   "occd_bn_finish")
+        y, ycs = geo.empty_like(x)
+        a.a, a.b = vec[2].data_ptr(), vec[3].data_ptr()
+        a.out, a.out_cs = y.data_ptr(), ycs
+        a.cw = min(hip.round_up(C, 8), ycs) if geo.layout == 0 else 0
+        if res is not None:
+            a.res, a.res_cs = res.data_ptr(), geo.like(x, res, "res")
+        a.act, a.slope, a.res_first = act, float(slope), 1 if res_first else 0
+        hip._check(lib.occd_bn_apply(ctypes.byref(a), st), "occd_bn_apply")
+        # the pre-activation's sign comes from y when a residual entered before the activation (x a + b alone is not it)
+        need_y = act != 0 and res is not None and res_first
+        ctx.save_for_backward(x, vec, packed, weight, y if need_y else None)
+        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, vec, packed, weight, y = ctx.saved_tensors
+        act, slope, res_first, has_res, group, sync = ctx.cfg
+        lib = hip.load()
+        st = hip._stream()
+        geo = _Geom(x)
+        C = geo.C
+        dev = x.device
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gy = gy.contiguous() if geo.layout == 1 else _to_rows(gy)
+        a = geo.args()
+        a.x, a.x_cs = x.data_ptr(), geo.like(x, x, "x")
+        a.gy, a.gy_cs = gy.data_ptr(), geo.like(x, gy, "gy")
+        if y is not None:
+            a.y, a.y_cs = y.data_ptr(), geo.like(x, y, "y")
+        a.mean, a.invstd, a.a, a.b = (vec[i].data_ptr() for i in range(4))
+        a.act, a.slope, a.res_first = act, slope, 1 if res_first else 0
+        a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
+        partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
+        a.partial = partial.data_ptr()
+        hip._check(lib.occd_bn_bwd_reduce(ctypes.byref(a), st), "occd_bn_bwd_reduce")
+        local = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        hip._check(lib.occd_bn_bwd_combine(partial.data_ptr(), a.nblk, C, local.data_ptr(), st), "occd_bn_bwd_combine")
+        total = local
+        if sync and _group_active(group):
+            import torch.distributed as dist
+            total = local.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        k = torch.empty(5, C, device=dev, dtype=torch.float32)            # k1, k2, k3, gw, gb
+        want_w = weight is not None
+        hip._check(lib.occd_bn_bwd_finish(local.data_ptr(), total.data_ptr(), C, packed.data_ptr(), vec[0].data_ptr(),
+                                          vec[1].data_ptr(), vec[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(),
+                                          k[2].data_ptr(), k[3].data_ptr() if want_w else None,
+                                          k[4].data_ptr() if want_w else None, st), "occd_bn_bwd_finish")
+        gx, gcs = geo.empty_like(x)
+        a.k1, a.k2, a.k3 = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
+        a.out, a.out_cs = gx.data_ptr(), gcs
+        a.cw = min(hip.round_up(C, 8), gcs) if geo.layout == 0 else 0
+        gres = None
+        if has_res:
+            if res_first and act != 0:
+                gres, rcs = geo.empty_like(x)
+                a.out2, a.out2_cs = gres.data_ptr(), rcs
+            else:
+                gres = gy                                                   # added after the activation (or no activation)
+        hip._check(lib.occd_bn_bwd_apply(ctypes.byref(a), st), "occd_bn_bwd_apply")
+        gw = k[3].to(weight.dtype) if want_w else None
+        gb = k[4].to(weight.dtype) if want_w else None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None
+
+
+def _torch_reference(bn, x, act, slope, res, res_first):
+    y = bn(x)
+    if res is not None and res_first:
+        y = y + res
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = y * torch.sigmoid(y)
+    elif act == 3:
+        y = F.leaky_relu(y, slope)
+    if res is not None and not res_first:
+        y = y + res
+    return y
+
+
+ENABLED = True      # A/B switch (bench / tests): False sends every site through the backend's batch_norm again
+
+
+def bn_act(bn, x, act=None, slope=0.01, res=None, res_first=False):
+    """act(bn(x) [+ res]) [+ res] for a BatchNorm module; fused HIP passes in training mode on the GPU (see module doc)."""
+    code = ACT[act] if not isinstance(act, int) else act
+    fused = (ENABLED and bn.training and x.is_cuda and _Geom.supported(x) and bn.momentum is not None
+             and bn.track_running_stats and (res is None or (res.shape == x.shape and res.dtype == x.dtype))
+             and not (code == 2 and res is not None and res_first))
+    if fused and res is not None:
+        # the residual must be addressable in x's layout
+        res = res.contiguous() if (x.is_contiguous() and x.dtype == torch.float32) else _to_rows(res)
+    if not fused:
+        return _torch_reference(bn, x, code, slope, res, res_first)
+    from . import shard
+    sync = isinstance(bn, shard.SyncBatchNorm)
+    return _BNActFn.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                          bn.momentum, code, slope, res_first, getattr(bn, "process_group", None), sync)

@@ -1,0 +1,571 @@
+// K13 -- training-mode BatchNorm (+ activation + residual) as HBM-bound passes, forward and backward, for both tensor
+// layouts of the model: channels-last voxel / pixel rows (the 3-D stack, the bf16 decoder) and NCHW planes (the 2-D
+// encoder).  The reference's training step sends every BatchNorm through the backend's batch_norm (MIOpen: statistics
+// pass + normalise pass, then separate ReLU / add kernels; backward: three more passes) and its SyncBatchNorm through an
+// all_gather per layer; here a layer is
+//   forward : statistics pass (shifted sums: sum(x - x0), sum((x - x0)^2), x0 = the tensor's first element of the channel,
+//             so the single pass cannot cancel whatever mean / std is) -> per-channel combine in float64 ->
+//             [ONE packed all-reduce of 2C + 1 doubles when the statistics span ranks] -> finish (mean, invstd, running
+//             statistics, the affine a = gamma * invstd, b = beta - mean * a) -> ONE apply pass
+//             y = act(x * a + b [+ res]) [+ res]   (ReLU / LeakyReLU / swish and the residual add fused);
+//   backward: reduction pass (g = gy * act'(.), sum g, sum g * xhat) -> [ONE all-reduce of 2C floats] -> finish
+//             (gamma / beta gradients, the three per-channel coefficients) -> ONE apply pass gx = g k1 + x k2 + k3.
+// Every partial sum is combined in a fixed order: results are deterministic.
+// Reference semantics replaced: torch.nn.BatchNorm{2,3}d / SyncBatchNorm in training mode as used by
+// occdepth/models/DDR.py:111-139, modules.py:40-46,158-175,278-296, unet2d.py:24-46, scripts/train.py:179 (sync_batchnorm).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kMaxBlocks = 1024;
+
+// ------------------------------------------------------------------------------------------------ element access
+template <bool BF16>
+__device__ __forceinline__ f32x4 ld4(const void* p, size_t e) {
+    if (BF16) {
+        const u32x2 v = *(const u32x2*)((const uint16_t*)p + e);
+        f32x4 r;
+        r.x = __builtin_bit_cast(float, v.x << 16);
+        r.y = __builtin_bit_cast(float, v.x & 0xffff0000u);
+        r.z = __builtin_bit_cast(float, v.y << 16);
+        r.w = __builtin_bit_cast(float, v.y & 0xffff0000u);
+        return r;
+    }
+    return *(const f32x4*)((const float*)p + e);
+}
+
+template <bool BF16>
+__device__ __forceinline__ void st4(void* p, size_t e, f32x4 v) {
+    if (BF16) {
+        const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *(u32x2*)((uint16_t*)p + e) = __builtin_bit_cast(u32x2, o);
+    } else {
+        *(f32x4*)((float*)p + e) = v;
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return occd::swish_fast(v);
+    if (act == 3) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// d act / d pre-activation.  `pre` is the pre-activation, or (sign_only) any value with its sign (the saved output).
+__device__ __forceinline__ float act_bwd(float pre, int act, float slope) {
+    if (act == 1) return pre > 0.f ? 1.f : 0.f;
+    if (act == 3) return pre > 0.f ? 1.f : slope;
+    if (act == 2) {
+        const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(pre * -1.4426950408889634f));
+        return s * (1.f + pre * (1.f - s));
+    }
+    return 1.f;
+}
+
+struct BnP {
+    const void* x;
+    const void* gy;
+    const void* y;
+    const void* res;
+    void* out;
+    void* out2;
+    const float* a;
+    const float* b;
+    const float* mean;
+    const float* invstd;
+    const float* k1;
+    const float* k2;
+    const float* k3;
+    float* partial;
+    long rows;          // layout 0
+    long S;             // layout 1: plane size
+    int batch;          // layout 1
+    int C, C4, cw;
+    int x_cs, x_coff, gy_cs, gy_coff, y_cs, y_coff, res_cs, res_coff, out_cs, out_coff, out2_cs, out2_coff;
+    int act, res_first;
+    float slope;
+    int nblk;
+    long rows_per_blk;
+};
+
+// shared block reduction of (s1[4], s2[4]) over the RPW row-lanes that hold the same channel quad
+__device__ __forceinline__ void reduce_rows_and_store(f32x4 s1, f32x4 s2, float* red, int tid, int QW, int RPW, int q_lane,
+                                                      int r_lane, bool active, float* dst1, float* dst2, int q) {
+    __syncthreads();
+    if (active) {
+        *(f32x4*)(red + (size_t)tid * 8) = s1;
+        *(f32x4*)(red + (size_t)tid * 8 + 4) = s2;
+    }
+    __syncthreads();
+    if (active && r_lane == 0) {
+        for (int r = 1; r < RPW; ++r) {                    // fixed order
+            s1 += *(const f32x4*)(red + (size_t)(r * QW + q_lane) * 8);
+            s2 += *(const f32x4*)(red + (size_t)(r * QW + q_lane) * 8 + 4);
+        }
+        *(f32x4*)(dst1 + 4 * q) = s1;
+        *(f32x4*)(dst2 + 4 * q) = s2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ channels-last rows
+// MODE 0: forward statistics (sum(x - x0), sum((x - x0)^2));  MODE 1: backward sums (sum g, sum g * xhat)
+template <bool BF16, int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_rows_kernel(const BnP p) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 8];
+    const int tid = threadIdx.x;
+    const int QW = min(p.C4, 256), RPW = 256 / QW;
+    const int q_lane = tid % QW, r_lane = tid / QW;
+    const bool active = r_lane < RPW;
+    const long r_begin = (long)blockIdx.x * p.rows_per_blk;
+    const long r_end = min(r_begin + p.rows_per_blk, p.rows);
+    float* dst1 = p.partial + (size_t)blockIdx.x * 2 * p.C4 * 4;
+    float* dst2 = dst1 + p.C4 * 4;
+    for (int q = q_lane; q < p.C4; q += QW) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            if (MODE == 0) {
+                const f32x4 x0 = ld4<BF16>(p.x, (size_t)p.x_coff + 4 * q);
+                for (long r = r_begin + r_lane; r < r_end; r += RPW) {
+                    const f32x4 d = ld4<BF16>(p.x, (size_t)r * p.x_cs + p.x_coff + 4 * q) - x0;
+                    s1 += d;
+                    s2 += d * d;
+                }
+            } else {
+                f32x4 a, b, m, is;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = min(4 * q + j, p.C - 1);
+                    a[j] = p.a[c]; b[j] = p.b[c]; m[j] = p.mean[c]; is[j] = p.invstd[c];
+                }
+                for (long r = r_begin + r_lane; r < r_end; r += RPW) {
+                    const f32x4 xv = ld4<BF16>(p.x, (size_t)r * p.x_cs + p.x_coff + 4 * q);
+                    f32x4 g = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + p.gy_coff + 4 * q);
+                    if (p.act != 0) {
+                        f32x4 pre = p.y != nullptr ? ld4<BF16>(p.y, (size_t)r * p.y_cs + p.y_coff + 4 * q) : xv * a + b;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g[j] *= act_bwd(pre[j], p.act, p.slope);
+                    }
+                    s1 += g;
+                    s2 += g * ((xv - m) * is);
+                }
+            }
+        }
+        reduce_rows_and_store(s1, s2, red, tid, QW, RPW, q_lane, r_lane, active, dst1, dst2, q);
+    }
+}
+
+// MODE 0: y = act(x a + b [+ res]) [+ res];  MODE 1: gx = g k1 + x k2 + k3 with g = gy act'(.), optionally out2 = g
+template <bool BF16, int MODE>
+__global__ void __launch_bounds__(256) bn_apply_rows_kernel(const BnP p) {
+    const int W4 = p.cw >> 2;                                  // quads written per row (channel pads get zeros)
+    const long total = p.rows * W4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / W4;
+        const int q = (int)(i - r * W4);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
+        if (q < p.C4) {
+            const f32x4 xv = ld4<BF16>(p.x, (size_t)r * p.x_cs + p.x_coff + 4 * q);
+            f32x4 a, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = min(4 * q + j, p.C - 1);
+                a[j] = p.a[c]; b[j] = p.b[c];
+            }
+            if (MODE == 0) {
+                f32x4 v = xv * a + b;
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (p.res != nullptr) rr = ld4<BF16>(p.res, (size_t)r * p.res_cs + p.res_coff + 4 * q);
+                if (p.res_first) v += rr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], p.act, p.slope);
+                if (!p.res_first) v += rr;
+                o = v;
+            } else {
+                f32x4 g = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + p.gy_coff + 4 * q);
+                if (p.act != 0) {
+                    f32x4 pre = p.y != nullptr ? ld4<BF16>(p.y, (size_t)r * p.y_cs + p.y_coff + 4 * q) : xv * a + b;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] *= act_bwd(pre[j], p.act, p.slope);
+                }
+                f32x4 k1, k2, k3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = min(4 * q + j, p.C - 1);
+                    k1[j] = p.k1[c]; k2[j] = p.k2[c]; k3[j] = p.k3[c];
+                }
+                o = g * k1 + xv * k2 + k3;
+                o2 = g;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j >= p.C) { o[j] = 0.f; o2[j] = 0.f; }
+        }
+        st4<BF16>(p.out, (size_t)r * p.out_cs + p.out_coff + 4 * q, o);
+        if (MODE == 1 && p.out2 != nullptr) st4<BF16>(p.out2, (size_t)r * p.out2_cs + p.out2_coff + 4 * q, o2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NCHW planes (fp32)
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// grid (nsplit, C): block (s, c) reduces the span s of every image's plane c.  partial[(s)][2][C4 * 4]
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_reduce_planes_kernel(const BnP p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, c = blockIdx.y;
+    const long span = (p.S + gridDim.x - 1) / gridDim.x;
+    const long s0 = (long)blockIdx.x * span, s1e = min(s0 + span, p.S);
+    const float* x = (const float*)p.x;
+    const float* gy = (const float*)p.gy;
+    const float* y = (const float*)p.y;
+    float a1 = 0.f, a2 = 0.f;
+    const float x0 = MODE == 0 ? x[(size_t)c * p.S] : 0.f;
+    const float a = MODE == 1 ? p.a[c] : 0.f, b = MODE == 1 ? p.b[c] : 0.f;
+    const float m = MODE == 1 ? p.mean[c] : 0.f, is = MODE == 1 ? p.invstd[c] : 0.f;
+    for (int bi = 0; bi < p.batch; ++bi) {
+        const size_t off = ((size_t)bi * p.C + c) * p.S;
+        for (long i = s0 + tid; i < s1e; i += 256) {
+            const float xv = x[off + i];
+            if (MODE == 0) {
+                const float d = xv - x0;
+                a1 += d;
+                a2 += d * d;
+            } else {
+                float g = gy[off + i];
+                if (p.act != 0) g *= act_bwd(y != nullptr ? y[off + i] : xv * a + b, p.act, p.slope);
+                a1 += g;
+                a2 += g * ((xv - m) * is);
+            }
+        }
+    }
+    const float t1 = block_sum(a1, red, tid);
+    const float t2 = block_sum(a2, red, tid);
+    if (tid == 0) {
+        float* dst = p.partial + (size_t)blockIdx.x * 2 * p.C4 * 4;
+        dst[c] = t1;
+        dst[p.C4 * 4 + c] = t2;
+    }
+}
+
+// one (b, c) plane per blockIdx.y, grid-stride over the plane
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_apply_planes_kernel(const BnP p) {
+    const int plane = blockIdx.y;
+    const int c = plane % p.C;
+    const size_t off = (size_t)plane * p.S;
+    const float* x = (const float*)p.x;
+    const float a = p.a[c], b = p.b[c];
+    const bool vec = (p.S & 3) == 0;
+    if (MODE == 0) {
+        const float* res = (const float*)p.res;
+        float* out = (float*)p.out;
+        if (vec) {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (p.S >> 2); i += (long)gridDim.x * 256) {
+                f32x4 v = *(const f32x4*)(x + off + 4 * i) * a + b;
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (res != nullptr) rr = *(const f32x4*)(res + off + 4 * i);
+                if (p.res_first) v += rr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], p.act, p.slope);
+                if (!p.res_first) v += rr;
+                *(f32x4*)(out + off + 4 * i) = v;
+            }
+        } else {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.S; i += (long)gridDim.x * 256) {
+                float v = x[off + i] * a + b;
+                const float rr = res != nullptr ? res[off + i] : 0.f;
+                if (p.res_first) v += rr;
+                v = act_fwd(v, p.act, p.slope);
+                if (!p.res_first) v += rr;
+                out[off + i] = v;
+            }
+        }
+    } else {
+        const float* gy = (const float*)p.gy;
+        const float* y = (const float*)p.y;
+        float* out = (float*)p.out;
+        float* out2 = (float*)p.out2;
+        const float k1 = p.k1[c], k2 = p.k2[c], k3 = p.k3[c];
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.S; i += (long)gridDim.x * 256) {
+            const float xv = x[off + i];
+            float g = gy[off + i];
+            if (p.act != 0) g *= act_bwd(y != nullptr ? y[off + i] : xv * a + b, p.act, p.slope);
+            out[off + i] = g * k1 + xv * k2 + k3;
+            if (out2 != nullptr) out2[off + i] = g;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-channel stages
+// partial[nblk][2][Cp] -> packed (float64): forward [n mean_l, M2_l + n mean_l^2, n] (Chan's form, see shard.py) from the
+// shifted sums; x0[c] is re-read from the tensor exactly as the statistics pass read it.
+__global__ void bn_stats_combine_kernel(const float* partial, int nblk, int Cp, int C, const void* x, int dtype, int layout,
+                                        long S, int x_coff, double n_local, double* packed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) packed[2 * C] = n_local;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s1 += (double)partial[(size_t)k * 2 * Cp + c];
+        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
+    }
+    double x0;
+    if (layout == 1) x0 = (double)((const float*)x)[(size_t)c * S];
+    else if (dtype == 1) x0 = (double)__builtin_bit_cast(float, (uint32_t)((const uint16_t*)x)[x_coff + c] << 16);
+    else x0 = (double)((const float*)x)[x_coff + c];
+    const double mean = x0 + s1 / n_local;
+    const double m2 = s2 - s1 * s1 / n_local;
+    packed[c] = n_local * mean;
+    packed[C + c] = m2 + n_local * mean * mean;
+}
+
+__global__ void bn_finish_kernel(const double* packed, int C, float eps, float momentum, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, long* num_batches, float* mean, float* invstd,
+                                 float* a, float* b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches != nullptr) *num_batches += 1;
+    if (c >= C) return;
+    const double n = packed[2 * C];
+    const double mu = packed[c] / n;
+    double var = packed[C + c] / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    const float g = gamma != nullptr ? gamma[c] : 1.f;
+    const float sc = g * is;
+    a[c] = sc;
+    b[c] = (beta != nullptr ? beta[c] : 0.f) - (float)mu * sc;
+    if (running_mean != nullptr) {
+        const double unbiased = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_bwd_combine_kernel(const float* partial, int nblk, int Cp, int C, float* packed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s1 += (double)partial[(size_t)k * 2 * Cp + c];
+        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
+    }
+    packed[c] = (float)s1;
+    packed[C + c] = (float)s2;
+}
+
+// local = this rank's [sum g, sum g xhat] (parameter gradients stay per-rank sums: the gradient buckets average them like
+// any other), total = the same summed over the ranks that share the statistics.
+__global__ void bn_bwd_finish_kernel(const float* local, const float* total, int C, const double* packed_fwd, const float* mean,
+                                     const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw,
+                                     float* gb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float n = (float)packed_fwd[2 * C];
+    const float mg = total[c] / n, mgx = total[C + c] / n;
+    const float sc = a[c], is = invstd[c], mu = mean[c];
+    k1[c] = sc;
+    k2[c] = -is * mgx * sc;
+    k3[c] = (mu * is * mgx - mg) * sc;
+    if (gw != nullptr) gw[c] = local[C + c];
+    if (gb != nullptr) gb[c] = local[c];
+}
+
+int fill(const occd_bn_args* a, BnP& p, bool need_partial) {
+    if (a == nullptr || a->x == nullptr || a->C <= 0 || a->dtype < 0 || a->dtype > 1 || a->layout < 0 || a->layout > 1)
+        return OCCD_EINVAL;
+    if (a->layout == 1 && a->dtype != 0) return OCCD_EINVAL;          // NCHW planes: fp32 only
+    p.x = a->x; p.gy = a->gy; p.y = a->y; p.res = a->res; p.out = a->out; p.out2 = a->out2;
+    p.a = a->a; p.b = a->b; p.mean = a->mean; p.invstd = a->invstd; p.k1 = a->k1; p.k2 = a->k2; p.k3 = a->k3;
+    p.partial = a->partial;
+    p.rows = a->rows; p.S = a->S; p.batch = a->batch;
+    p.C = a->C; p.C4 = (a->C + 3) / 4;
+    p.cw = a->cw;
+    p.x_cs = a->x_cs; p.x_coff = a->x_coff; p.gy_cs = a->gy_cs; p.gy_coff = a->gy_coff; p.y_cs = a->y_cs; p.y_coff = a->y_coff;
+    p.res_cs = a->res_cs; p.res_coff = a->res_coff; p.out_cs = a->out_cs; p.out_coff = a->out_coff;
+    p.out2_cs = a->out2_cs; p.out2_coff = a->out2_coff;
+    p.act = a->act; p.res_first = a->res_first; p.slope = a->slope;
+    if (a->act < 0 || a->act > 3) return OCCD_EINVAL;
+    if (a->layout == 0) {
+        if (a->rows <= 0) return OCCD_EINVAL;
+        const int al = a->dtype == 1 ? 3 : 3;                           // 4-channel accesses: 8 B (bf16) / 16 B (fp32)
+        if ((a->x_cs & al) || (a->x_coff & al) || a->x_coff + p.C4 * 4 > a->x_cs) return OCCD_EINVAL;
+    } else {
+        if (a->batch <= 0 || a->S <= 0) return OCCD_EINVAL;
+    }
+    if (need_partial && (a->partial == nullptr || a->nblk <= 0 || a->nblk > kMaxBlocks)) return OCCD_EINVAL;
+    p.nblk = a->nblk;
+    p.rows_per_blk = a->layout == 0 ? (a->rows + a->nblk - 1) / (a->nblk > 0 ? a->nblk : 1) : 0;
+    return OCCD_OK;
+}
+
+bool rows_tensor_ok(const void* ptr, int cs, int coff, int width) {
+    return ptr == nullptr || ((cs & 3) == 0 && (coff & 3) == 0 && coff + width <= cs);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* number of partial blocks the reduction passes of this geometry use (size of `partial`: nblk * 2 * ceil4(C) floats) */
+int occd_bn_blocks(const occd_bn_args* a) {
+    if (a == nullptr || a->C <= 0) return OCCD_EINVAL;
+    if (a->layout == 0) {
+        const int C4 = (a->C + 3) / 4;
+        const int QW = C4 < 256 ? C4 : 256, RPW = 256 / QW;
+        long n = (a->rows + (long)RPW * 8 - 1) / ((long)RPW * 8);       // >= 8 rows per row-lane
+        if (n < 1) n = 1;
+        if (n > kMaxBlocks) n = kMaxBlocks;
+        return (int)n;
+    }
+    long want = 2048 / a->C;                                          // ~2048 workgroups over the chip
+    long cap = (a->S + 1023) / 1024;                                  // >= 1024 elements of a plane per block
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    return (int)want;
+}
+
+int occd_bn_stats(const occd_bn_args* a, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, true);
+    if (rc != OCCD_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const double bytes = (a->dtype == 1 ? 2.0 : 4.0) * (a->layout == 0 ? (double)a->rows * a->C : (double)a->batch * a->C * a->S);
+    occd::ProfScope prof("bn_stats", st, 0.0, bytes);
+    if (a->layout == 0) {
+        if (a->dtype == 1) hipLaunchKernelGGL((bn_reduce_rows_kernel<true, 0>), dim3(a->nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((bn_reduce_rows_kernel<false, 0>), dim3(a->nblk), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((bn_reduce_planes_kernel<0>), dim3(a->nblk, a->C), dim3(256), 0, st, p);
+    }
+    return occd::check_launch();
+}
+
+int occd_bn_stats_combine(const occd_bn_args* a, double* packed, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, true);
+    if (rc != OCCD_OK || packed == nullptr) return rc != OCCD_OK ? rc : OCCD_EINVAL;
+    const double n = a->layout == 0 ? (double)a->rows : (double)a->batch * (double)a->S;
+    hipLaunchKernelGGL(bn_stats_combine_kernel, dim3((a->C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       (const float*)a->partial, a->nblk, p.C4 * 4, a->C, a->x, a->dtype, a->layout, (long)a->S, a->x_coff, n,
+                       packed);
+    return occd::check_launch();
+}
+
+int occd_bn_finish(const double* packed, int32_t C, float eps, float momentum, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd, float* a,
+                   float* b, void* stream) {
+    if (!packed || C <= 0 || !mean || !invstd || !a || !b || (running_mean == nullptr) != (running_var == nullptr))
+        return OCCD_EINVAL;
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, packed, C, eps, momentum,
+                       gamma, beta, running_mean, running_var, (long*)num_batches_tracked, mean, invstd, a, b);
+    return occd::check_launch();
+}
+
+int occd_bn_apply(const occd_bn_args* a, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, false);
+    if (rc != OCCD_OK) return rc;
+    if (!a->out || !a->a || !a->b) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const double elems = a->layout == 0 ? (double)a->rows * a->C : (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_apply", st, 0.0, (a->dtype == 1 ? 2.0 : 4.0) * elems * (2 + (a->res != nullptr)));
+    if (a->layout == 0) {
+        if (a->cw < p.C4 * 4 || (a->cw & 3) || !rows_tensor_ok(a->out, a->out_cs, a->out_coff, a->cw) ||
+            !rows_tensor_ok(a->res, a->res_cs, a->res_coff, p.C4 * 4))
+            return OCCD_EINVAL;
+        const long total = a->rows * (a->cw >> 2);
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (a->dtype == 1) hipLaunchKernelGGL((bn_apply_rows_kernel<true, 0>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((bn_apply_rows_kernel<false, 0>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    } else {
+        const long planes = (long)a->batch * a->C;
+        if (planes > 65535) return OCCD_EINVAL;
+        long bx = (a->S / 4 + 255) / 256;
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL((bn_apply_planes_kernel<0>), dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, st, p);
+    }
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_reduce(const occd_bn_args* a, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, true);
+    if (rc != OCCD_OK) return rc;
+    if (!a->gy || !a->a || !a->b || !a->mean || !a->invstd) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const double elems = a->layout == 0 ? (double)a->rows * a->C : (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_bwd_reduce", st, 0.0, (a->dtype == 1 ? 2.0 : 4.0) * elems * (2 + (a->y != nullptr)));
+    if (a->layout == 0) {
+        if (!rows_tensor_ok(a->gy, a->gy_cs, a->gy_coff, p.C4 * 4) || !rows_tensor_ok(a->y, a->y_cs, a->y_coff, p.C4 * 4))
+            return OCCD_EINVAL;
+        if (a->dtype == 1) hipLaunchKernelGGL((bn_reduce_rows_kernel<true, 1>), dim3(a->nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((bn_reduce_rows_kernel<false, 1>), dim3(a->nblk), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((bn_reduce_planes_kernel<1>), dim3(a->nblk, a->C), dim3(256), 0, st, p);
+    }
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_combine(const float* partial, int32_t nblk, int32_t C, float* packed, void* stream) {
+    if (!partial || !packed || nblk <= 0 || C <= 0) return OCCD_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk,
+                       ((C + 3) / 4) * 4, C, packed);
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_finish(const float* local, const float* total, int32_t C, const double* packed_fwd, const float* mean,
+                       const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw, float* gb,
+                       void* stream) {
+    if (!local || !total || C <= 0 || !packed_fwd || !mean || !invstd || !a || !k1 || !k2 || !k3) return OCCD_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, local, total, C,
+                       packed_fwd, mean, invstd, a, k1, k2, k3, gw, gb);
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_apply(const occd_bn_args* a, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, false);
+    if (rc != OCCD_OK) return rc;
+    if (!a->out || !a->gy || !a->a || !a->b || !a->k1 || !a->k2 || !a->k3) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const double elems = a->layout == 0 ? (double)a->rows * a->C : (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_bwd_apply", st, 0.0,
+                         (a->dtype == 1 ? 2.0 : 4.0) * elems * (3 + (a->y != nullptr) + (a->out2 != nullptr)));
+    if (a->layout == 0) {
+        if (a->cw < p.C4 * 4 || (a->cw & 3) || !rows_tensor_ok(a->out, a->out_cs, a->out_coff, a->cw) ||
+            !rows_tensor_ok(a->out2, a->out2_cs, a->out2_coff, a->cw) || !rows_tensor_ok(a->gy, a->gy_cs, a->gy_coff, p.C4 * 4) ||
+            !rows_tensor_ok(a->y, a->y_cs, a->y_coff, p.C4 * 4))
+            return OCCD_EINVAL;
+        const long total = a->rows * (a->cw >> 2);
+        long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (a->dtype == 1) hipLaunchKernelGGL((bn_apply_rows_kernel<true, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((bn_apply_rows_kernel<false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    } else {
+        const long planes = (long)a->batch * a->C;
+        if (planes > 65535) return OCCD_EINVAL;
+        long bx = (a->S + 1023) / 1024;
+        if (bx < 1) bx = 1;
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL((bn_apply_planes_kernel<1>), dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, st, p);
+    }
+    return occd::check_launch();
+}
+
+}  // extern "C"

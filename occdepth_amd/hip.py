@@ -93,6 +93,16 @@ class LiftBwdArgs(Structure):
     _fields_ = [("fwd", LiftArgs), ("gout", c_void_p), ("gfeat", (c_void_p * MAX_VIEWS) * MAX_SCALES), ("gdepth", c_void_p)]
 
 
+class BnArgs(Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "gy", "y", "res", "out", "out2", "a", "b", "mean", "invstd", "k1", "k2", "k3",
+                                        "partial")] + \
+        [("rows", c_int64), ("S", c_int64), ("batch", c_int32), ("C", c_int32), ("cw", c_int32), ("dtype", c_int32),
+         ("layout", c_int32)] + \
+        [(n, c_int32) for n in ("x_cs", "x_coff", "gy_cs", "gy_coff", "y_cs", "y_coff", "res_cs", "res_coff", "out_cs",
+                                "out_coff", "out2_cs", "out2_coff", "act", "res_first")] + \
+        [("slope", c_float), ("nblk", c_int32)]
+
+
 class ProfRow(Structure):
     _fields_ = [("tag", c_char * 64), ("launches", c_int64), ("ms", c_double), ("flops", c_double),
                 ("bytes", c_double)]
@@ -148,6 +158,15 @@ EXPORTS = {
     "occd_conv3d_bf16_fwd": (c_int32, [POINTER(Conv3dArgs), c_int32, c_void_p]),
     "occd_conv3d_wgrad_bf16_workspace_floats": (c_int64, [POINTER(WgradArgs), c_int32]),
     "occd_conv3d_wgrad_bf16": (c_int32, [POINTER(WgradArgs), c_int32, c_void_p]),
+    "occd_bn_blocks": (c_int32, [POINTER(BnArgs)]),
+    "occd_bn_stats": (c_int32, [POINTER(BnArgs), c_void_p]),
+    "occd_bn_stats_combine": (c_int32, [POINTER(BnArgs), c_void_p, c_void_p]),
+    "occd_bn_finish": (c_int32, [c_void_p, c_int32, c_float, c_float] + [c_void_p] * 9 + [c_void_p]),
+    "occd_bn_apply": (c_int32, [POINTER(BnArgs), c_void_p]),
+    "occd_bn_bwd_reduce": (c_int32, [POINTER(BnArgs), c_void_p]),
+    "occd_bn_bwd_combine": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "occd_bn_bwd_finish": (c_int32, [c_void_p, c_void_p, c_int32] + [c_void_p] * 9 + [c_void_p]),
+    "occd_bn_bwd_apply": (c_int32, [POINTER(BnArgs), c_void_p]),
     "occd_ssc_stats_len": (c_int64, [c_int32, c_int32]),
     "occd_ssc_loss_stats_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
                                           c_int32, c_int32, c_void_p]),

@@ -11,7 +11,7 @@ import torch
 
 from . import hip
 from .hip import Vox
-from .models.SFA import voxel_layout
+from .models.SFA import pixel_rows, voxel_layout
 
 
 class _LiftFn(torch.autograd.Function):
@@ -21,7 +21,7 @@ class _LiftFn(torch.autograd.Function):
         scale_divs, n_views, scene_size, project_scale, dataset, scale_const = meta
         S = len(scale_divs)
         n_dims, out_dims, strides = voxel_layout(scene_size, project_scale, dataset)
-        rows = [[hip.nchw_to_nhwc(feats_flat[s * n_views + v].detach().float()) for v in range(n_views)] for s in range(S)]
+        rows = [[pixel_rows(feats_flat[s * n_views + v].detach().float()) for v in range(n_views)] for s in range(S)]
         B, C = feats_flat[0].shape[0], feats_flat[0].shape[1]
         out = Vox.empty(B, out_dims, C, feats_flat[0].device)
         if out.cs != C:

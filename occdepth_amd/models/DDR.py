@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
+from ..bn import bn_act
 from ..fused import ACT_RELU, ConvPlan, as_vox, needs_autograd
 
 
@@ -84,22 +85,23 @@ class Bottleneck3D(nn.Module):
         return p[5](o4, res1=skip, act_in=ACT_RELU, act_out=ACT_RELU)
 
     # ------------------------------------------------------------------ ATen (training / autograd)
+    @staticmethod
+    def _side(seq, t):
+        """AvgPool3d -> 1x1x1 conv -> BatchNorm side branch (`downsample*`)"""
+        return bn_act(seq[2], seq[1](seq[0](t)))
+
     def _forward_autograd(self, x):
+        """The reference's graph (DDR.py:111-139); every BatchNorm with its ReLU / residual add as one fused pass (bn.py)."""
         strided = self.stride != 1
-        o1 = F.relu(self.bn1(self.conv1(x)))
-        o2 = self.bn2(self.conv2(o1))
-        o3 = self.bn3(self.conv3(F.relu(o2)))
-        if strided:
-            o2 = self.downsample2(o2)
-        o3 = o3 + o2
-        o4 = self.bn4(self.conv4(F.relu(o3)))
-        if strided:
-            o2 = self.downsample3(o2)
-            o3 = self.downsample4(o3)
-        o4 = o4 + o2 + o3
-        o5 = self.bn5(self.conv5(F.relu(o4)))
-        skip = x if self.downsample is None else self.downsample(x)
-        return F.relu(o5 + skip)
+        o1 = bn_act(self.bn1, self.conv1(x), "relu")
+        o2 = bn_act(self.bn2, self.conv2(o1))
+        o2s = self._side(self.downsample2, o2) if strided else o2
+        o3 = bn_act(self.bn3, self.conv3(F.relu(o2)), res=o2s)                     # bn3(.) + o2
+        o2ss = self._side(self.downsample3, o2s) if strided else o2s
+        o3s = self._side(self.downsample4, o3) if strided else o3
+        o4 = bn_act(self.bn4, self.conv4(F.relu(o3)), res=o2ss + o3s)              # bn4(.) + o2 + o3
+        skip = x if self.downsample is None else self._side(self.downsample, x)
+        return bn_act(self.bn5, self.conv5(F.relu(o4)), "relu", res=skip, res_first=True)   # relu(bn5(.) + skip)
 
     def forward(self, x):
         if needs_autograd(self):

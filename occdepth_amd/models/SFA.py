@@ -28,27 +28,28 @@ def voxel_layout(scene_size, project_scale, dataset):
     raise NotImplementedError(f"SFA has no voxel layout for dataset {dataset!r}")
 
 
+def pixel_rows(f):
+    """(B, H, W, cs) pixel rows of a (B, C, H, W) feature map: zero-copy when every image already is channels-last with rows
+    of >= C floats (what the decoder's 1x1 heads write through K11's NHWC mode or, in bf16-mode training, through K2b; any
+    batch stride, e.g. a view of the two stereo views run as one batch), one transpose pass otherwise."""
+    cl = f.permute(0, 2, 3, 1)
+    cs = cl.stride(2)
+    if (f.dtype == torch.float32 and f.is_cuda and cl.stride(3) == 1 and cs % 4 == 0 and cs >= f.shape[1]
+            and cl.stride(1) == cs * f.shape[3] and cl.data_ptr() % 16 == 0
+            and (f.shape[0] == 1 or cl.stride(0) % 4 == 0)):
+        return cl.as_strided((f.shape[0], f.shape[2], f.shape[3], cs), (cl.stride(0), cl.stride(1), cs, 1))
+    return hip.nchw_to_nhwc(f.float())
+
+
 def lift_scales(feats, scale_divs, projected_pix, fov_mask, scene_size, project_scale, dataset,
                 depth_scale=None, scale_const=100.0):
     """feats[s][v]: (B, C, h_s, w_s) feature maps (any layout) -> Vox (B, X, Y, Z, C).
 
     projected_pix (B, V, N, P, 2) int64 at full image resolution, fov_mask (B, V, N, P) bool."""
     n_dims, out_dims, strides = voxel_layout(scene_size, project_scale, dataset)
-    def rows_of(f):
-        """(B, H, W, cs) pixel rows of a feature map: zero-copy when every image already is channels-last with rows of
-        >= C floats (what the decoder's 1x1 heads write through K11's NHWC mode; any batch stride, e.g. a view of the
-        two stereo views run as one batch), one transpose pass otherwise."""
-        cl = f.permute(0, 2, 3, 1)
-        cs = cl.stride(2)
-        if (f.dtype == torch.float32 and f.is_cuda and cl.stride(3) == 1 and cs % 4 == 0 and cs >= f.shape[1]
-                and cl.stride(1) == cs * f.shape[3] and cl.data_ptr() % 16 == 0
-                and (f.shape[0] == 1 or cl.stride(0) % 4 == 0)):
-            return cl.as_strided((f.shape[0], f.shape[2], f.shape[3], cs), (cl.stride(0), cl.stride(1), cs, 1))
-        return hip.nchw_to_nhwc(f.float())
-
     rows = []
     for per_scale in feats:
-        rows.append([rows_of(f) for f in per_scale])
+        rows.append([pixel_rows(f) for f in per_scale])
     B, C = feats[0][0].shape[0], feats[0][0].shape[1]
     out = Vox.empty(B, out_dims, C, feats[0][0].device)
     return hip.lift(rows, scale_divs, projected_pix.contiguous(), fov_mask.contiguous(), n_dims, strides, out,

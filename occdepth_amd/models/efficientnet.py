@@ -21,6 +21,7 @@ import os
 
 from .. import hip
 from .. import fused as _fused
+from ..bn import bn_act
 from ..fused import _stamp, bn_affine_cached, needs_autograd
 
 # K11 / SE-fusion path of the eval forward (OCCDEPTH_PW_FUSED=0 restores the MIOpen / rocBLAS 1x1 convolutions for A/B)
@@ -165,9 +166,9 @@ class DepthwiseSeparableConv(nn.Module):
             y = hip.dwconv2d_same(x, self.conv_dw.weight, *bn_affine_cached(self.bn1), self.conv_dw.stride[0], "swish")
             y = F.conv2d(self.se(y), self.conv_pw.weight)
             return hip.affine_act(y, *bn_affine_cached(self.bn2), None, res=x if self.skip else None)
-        y = self.se(self.act1(self.bn1(self.conv_dw(x))))
-        y = self.act2(self.bn2(self.conv_pw(y)))
-        return y + x if self.skip else y
+        # training: BatchNorm + swish / BatchNorm + skip as fused passes (bn.py; plain modules on the CPU)
+        y = self.se(bn_act(self.bn1, self.conv_dw(x), "swish"))
+        return bn_act(self.bn2, self.conv_pw(y), res=x if self.skip else None)
 
 
 class InvertedResidual(nn.Module):
@@ -204,10 +205,10 @@ class InvertedResidual(nn.Module):
             y = hip.dwconv2d_same(y, self.conv_dw.weight, *bn_affine_cached(self.bn2), self.conv_dw.stride[0], "swish")
             y = F.conv2d(self.se(y), self.conv_pwl.weight)
             return hip.affine_act(y, *bn_affine_cached(self.bn3), None, res=x if self.skip else None)
-        y = self.act1(self.bn1(self.conv_pw(x)))
-        y = self.se(self.act2(self.bn2(self.conv_dw(y))))
-        y = self.bn3(self.conv_pwl(y))
-        return y + x if self.skip else y
+        # training: BatchNorm + swish / BatchNorm + skip as fused passes (bn.py; plain modules on the CPU)
+        y = bn_act(self.bn1, self.conv_pw(x), "swish")
+        y = self.se(bn_act(self.bn2, self.conv_dw(y), "swish"))
+        return bn_act(self.bn3, self.conv_pwl(y), res=x if self.skip else None)
 
 
 class EfficientNet(nn.Module):

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from .. import hip
 from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
+from ..bn import bn_act
 from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox, needs_autograd
 from .DDR import Bottleneck3D
 
@@ -49,10 +50,17 @@ class _DilatedBranches(nn.Module):
         return y
 
     def _branches_autograd(self, x):
-        y = 0
-        for c1, b1, c2, b2 in zip(self.conv1, self.bn1, self.conv2, self.bn2):
-            y = y + b2(c2(F.relu(b1(c1(x)))))
-        return F.relu(y + x)
+        """relu(sum_d bn2_d(conv2_d(relu(bn1_d(conv1_d(x))))) + x) with every BatchNorm, its ReLU and the running sum as
+        fused passes (bn.py); the last branch takes `y + x` as its pre-activation residual and applies the final ReLU."""
+        y = None
+        last = len(self.conv1) - 1
+        for i, (c1, b1, c2, b2) in enumerate(zip(self.conv1, self.bn1, self.conv2, self.bn2)):
+            t = c2(bn_act(b1, c1(x), "relu"))
+            if i < last:
+                y = bn_act(b2, t, res=y)
+            else:
+                y = bn_act(b2, t, "relu", res=x if y is None else y + x, res_first=True)
+        return y
 
 
 class ASPP(_DilatedBranches):
@@ -203,9 +211,15 @@ class _TransposedBlock(nn.Module):
             return self._plan(x, act_out=ACT_RELU)
         return self._plan(x, res1=skip, act_out=ACT_RELU_PRE)
 
+    def forward_train(self, x, skip=None):
+        """ReLU(BN(ConvTranspose3d(x))) [+ skip]: BatchNorm, ReLU and the decoder's skip addition as one fused pass"""
+        act = "relu" if isinstance(self.main[2], nn.ReLU) else None
+        y = bn_act(self.main[1], self.main[0](x), act, res=skip)
+        return y if act is not None or len(self.main) < 3 else self.main[2](y)
+
     def forward(self, x):
         if needs_autograd(self):
-            return self.main(x)
+            return self.forward_train(x)
         return self.forward_vox(as_vox(x)).ncdhw()
 
 

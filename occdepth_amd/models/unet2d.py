@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import autograd3d as _ag
 from .. import hip
 from .. import fused as _fused
 from ..fused import _stamp, bn_affine_cached, needs_autograd, wino_fused_operands
@@ -146,6 +147,19 @@ class UpSampleBN(nn.Module):
         u = hip.upconv_gather(z, cout, skip.shape[2:], batch_inner=batch_inner)
         return hip.conv2d_3x3_fused(skip, upk_skip, cout, shift, "leaky", act.negative_slope, res=u, res_first=True)
 
+    def _forward_train_cl(self, x, concat_with):
+        """bf16-mode training (autograd3d.BF16_MFMA, BASELINE configs[3]): the level in channels-last memory -- the two 3x3
+        convolutions (forward, data gradient, weight gradient) on the bf16-MFMA implicit-GEMM kernels K2b / K8b as X = 1
+        volumes, BatchNorm + LeakyReLU as fused K13 passes on pixel rows; upsampling and concatenation stay ATen
+        (channels-last in, channels-last out)."""
+        from ..bn import bn_act
+        n = self._net
+        up = F.interpolate(x.contiguous(memory_format=torch.channels_last), size=concat_with.shape[2:], mode="bilinear",
+                           align_corners=True)
+        f = torch.cat([up, concat_with.contiguous(memory_format=torch.channels_last)], dim=1)
+        f = bn_act(n[1], _ag.conv2d_cl(f, n[0].weight, n[0].bias, padding=1), "leaky", n[2].negative_slope)
+        return bn_act(n[4], _ag.conv2d_cl(f, n[3].weight, n[3].bias, padding=1), "leaky", n[5].negative_slope)
+
     def forward(self, x, concat_with):
         if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             n = self._net
@@ -157,6 +171,8 @@ class UpSampleBN(nn.Module):
                 # or applied in one pass behind the MIOpen convolution
                 f = self._conv_bn_act(hip.upsample_bilinear_cat(x, concat_with), n[0], n[1], n[2])
             return self._conv_bn_act(f, n[3], n[4], n[5])
+        if _ag.BF16_MFMA and x.is_cuda and needs_autograd(self):
+            return self._forward_train_cl(x, concat_with)
         if self.TRAIN_K10 and x.is_cuda and x.dtype == torch.float32 and concat_with.dtype == torch.float32:
             f = hip.upsample_bilinear_cat_autograd(x, concat_with)       # one pass instead of upsample + concat copy
         else:
@@ -165,9 +181,10 @@ class UpSampleBN(nn.Module):
         if self.TRAIN_K10 and f.is_cuda and f.dtype in (torch.float32, torch.bfloat16, torch.float16):
             # training on the GPU: the two 3x3 convolutions (forward and data gradient) on K10, BatchNorm / LeakyReLU
             # on ATen; OCCDEPTH_TRAIN_K10=0 restores MIOpen for A/B
+            from ..bn import bn_act
             n = self._net
-            f = n[2](n[1](hip.conv2d_3x3_autograd(f, n[0].weight, n[0].bias)))
-            return n[5](n[4](hip.conv2d_3x3_autograd(f, n[3].weight, n[3].bias)))
+            f = bn_act(n[1], hip.conv2d_3x3_autograd(f, n[0].weight, n[0].bias), "leaky", n[2].negative_slope)
+            return bn_act(n[4], hip.conv2d_3x3_autograd(f, n[3].weight, n[3].bias), "leaky", n[5].negative_slope)
         return self._net(f)
 
 
@@ -213,8 +230,11 @@ class DecoderBN(nn.Module):
 
     def forward(self, features, merged_head=None):
         taps = {16: features[8], 8: features[6], 4: features[5], 2: features[4], 1: features[0]}
+        cl_train = _ag.BF16_MFMA and features[0].is_cuda and needs_autograd(self)
         if merged_head is not None:
             x = self._conv2_merged(features[10], merged_head)
+        elif cl_train:
+            x = _ag.conv2d_cl(features[11], self.conv2.weight, self.conv2.bias, padding=self.conv2.padding[0])
         else:
             x = self.conv2(features[11])
         if not self.use_decoder:
@@ -233,6 +253,8 @@ class DecoderBN(nn.Module):
                 # so the (B, C, H, W) result is returned as a channels-last view and no transpose pass exists
                 wpk, shift = pw_operands(self, head)
                 res[f"1_{s}"] = hip.conv1x1(x, wpk, head.out_channels, shift, nhwc=True)
+            elif cl_train:
+                res[f"1_{s}"] = _ag.conv2d_cl(x, head.weight, head.bias)       # pixel rows: what the lift gathers from
             else:
                 res[f"1_{s}"] = head(x)
         return res

@@ -56,6 +56,8 @@ class _AtenMode:
 
     @staticmethod
     def decode(mod, x, skip):
+        if hasattr(mod, "forward_train"):
+            return mod.forward_train(x, skip)          # BatchNorm + ReLU + skip addition in one fused pass
         return mod(x) + skip
 
     @staticmethod

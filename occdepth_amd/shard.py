@@ -353,6 +353,10 @@ class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
         if not self.training and self.track_running_stats:
             return torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                                                   False, 0.0, self.eps)
+        if x.is_cuda:
+            from . import bn as _bn
+            if _bn.ENABLED and _bn._Geom.supported(x) and self.momentum is not None and self.track_running_stats:
+                return _bn.bn_act(self, x)                      # K13 passes + the packed all-reduces (csrc/bn.hip)
         y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, self.process_group)
         if self.training and self.track_running_stats:
             with torch.no_grad():

@@ -73,6 +73,32 @@ def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1)
     return out
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def pack_weights_bf16(w, scale=None, layout=0):
+    """K2b's weight image: the float32 master weights rounded to bf16 (kept as a float32 tensor of bf16 values)."""
+    pk = pack_weights(w, scale, layout)
+    pk.w = _bf16(pk.w)
+    pk.bf16 = True
+    return pk
+
+
+def conv3d_bf16(x, wpk, bias, cout, kernel, out, **kw):
+    """bf16 operands, exact products, float32 accumulation == the float32 emulation on bf16-rounded inputs."""
+    assert getattr(wpk, "bf16", False), "conv3d_bf16 needs pack_weights_bf16's image"
+    act_in = kw.get("act_in", 0)
+    assert act_in in (0, ACT_RELU)
+    xb = Vox(_bf16(x.buf.float()), x.C, x.coff)
+    return conv3d(xb, wpk, bias, cout, kernel, out, **kw)
+
+
+def conv3d_wgrad_bf16(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0)):
+    return conv3d_wgrad(Vox(_bf16(x.buf.float()), x.C, x.coff), Vox(_bf16(gy.buf.float()), gy.C, gy.coff), cin, cout,
+                        kernel, stride, dilation, padding)
+
+
 def nchw_to_nhwc(x, cs=None):
     C = x.shape[1]
     cs = cs if cs is not None else round_up(C, 4)
@@ -420,7 +446,9 @@ def patched(fast2d=False):
                                           "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
-                                          "dwconv2d_same_pool", "se_gate", "upconv_gather")}
+                                          "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "conv3d_bf16",
+                                          "conv3d_wgrad_bf16")}
+    hip.pack_weights_bf16, hip.conv3d_bf16, hip.conv3d_wgrad_bf16 = pack_weights_bf16, conv3d_bf16, conv3d_wgrad_bf16
     hip.upconv_gather = upconv_gather
     hip.affine_act, hip.dwconv2d_same = affine_act, dwconv2d_same
     hip.upsample_bilinear_cat, hip.softmax_nchw = upsample_bilinear_cat, softmax_nchw

@@ -88,6 +88,50 @@ def test_conv3d_kernels_gpu(name, hip_lib):
     run_conv(name, "cuda", 2e-5)
 
 
+# bf16 mode (autograd3d.BF16_MFMA, BASELINE configs[3]): the same Function classes on K2b / K8b.  Against the float64
+# reference of the UN-rounded operands the error is bf16's: every product carries two 2^-9 roundings, a sum of K of them
+# ~ 2^-8 / sqrt(K) of the result's scale in the mean and a few times that in the maximum: bound 1.5e-2 of the tensor's
+# scale (the kernels themselves are pinned at 2e-5 on bf16-rounded operands in test_bf16_conv.py).
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv3d_bf16_mode_host_logic_cpu(name):
+    old = ag.set_bf16_mfma(True)
+    try:
+        with emu.patched():
+            run_conv(name, "cpu", 1.5e-2)
+    finally:
+        ag.set_bf16_mfma(old)
+
+
+@pytest.mark.parametrize("name", list(CONVT_CASES))
+def test_conv_transpose3d_bf16_mode_host_logic_cpu(name):
+    old = ag.set_bf16_mfma(True)
+    try:
+        with emu.patched():
+            run_convt(name, "cpu", 1.5e-2)
+    finally:
+        ag.set_bf16_mfma(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv3d_bf16_mode_kernels_gpu(name, hip_lib):
+    old = ag.set_bf16_mfma(True)
+    try:
+        run_conv(name, "cuda", 1.5e-2)
+    finally:
+        ag.set_bf16_mfma(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CONVT_CASES))
+def test_conv_transpose3d_bf16_mode_kernels_gpu(name, hip_lib):
+    old = ag.set_bf16_mfma(True)
+    try:
+        run_convt(name, "cuda", 1.5e-2)
+    finally:
+        ag.set_bf16_mfma(old)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(CONVT_CASES))
 def test_conv_transpose3d_kernels_gpu(name, hip_lib):
@@ -147,19 +191,36 @@ def test_wgrad_full_size_head_properties(hip_lib):
 
 
 @pytest.mark.gpu
-def test_autocast_keeps_3d_convolutions_in_fp32(hip_lib):
-    """BASELINE config 4 trains under bf16 autocast: the HIP convolutions and the loss statistics take bf16 / fp32
-    inputs, compute in exact fp32 and return fp32 (custom_fwd cast_inputs), gradients flow in the callers' dtypes."""
+def test_autocast_and_bf16_mode_dtypes(hip_lib):
+    """Under torch.autocast the HIP convolutions do no casting of their own.  Exact mode: a bf16 activation is widened and the
+    result is the exact-fp32 convolution of those values; bf16 mode (BASELINE configs[3]): a bf16 activation stays bf16 in HBM
+    and comes back bf16, a float32 one stays float32 (bf16 MFMA, fp32 storage); weights and their gradients are float32 in
+    every case."""
     from occdepth_amd.loss import ssc_loss
     torch.manual_seed(1)
     conv = ag.Conv3d(16, 20, 3, padding=1).cuda()
     x = torch.randn(1, 16, 8, 8, 8, device="cuda", requires_grad=True)
     target = torch.randint(0, 20, (1, 8, 8, 8), device="cuda").to(torch.uint8)
+    xb = x.detach().to(torch.bfloat16)
+    ref = F.conv3d(xb.float(), conv.weight.detach(), conv.bias.detach(), padding=1)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = conv(x.to(torch.bfloat16))
         assert y.dtype == torch.float32
         loss = ssc_loss.CE_ssc_loss(y.to(torch.bfloat16), target, torch.ones(20, device="cuda"))
     loss.backward()
-    ref = F.conv3d(x.detach().to(torch.bfloat16).float(), conv.weight.detach(), conv.bias.detach(), padding=1)
     close(y, ref.double().cpu(), 2e-5, "autocast y")
     assert x.grad is not None and conv.weight.grad.dtype == torch.float32 and torch.isfinite(conv.weight.grad).all()
+    old = ag.set_bf16_mfma(True)
+    try:
+        refb = F.conv3d(xb.float(), conv.weight.detach().to(torch.bfloat16).float(), conv.bias.detach(), padding=1)
+        conv.zero_grad()
+        yb = conv(xb.clone().requires_grad_(True))
+        assert yb.dtype == torch.bfloat16
+        close(yb.float(), refb.double().cpu(), 6e-3, "bf16 storage y")
+        yf = conv(xb.float().requires_grad_(True))
+        assert yf.dtype == torch.float32
+        close(yf, refb.double().cpu(), 2e-5, "bf16 mfma / fp32 storage y")
+        (yb.float().square().sum() + yf.square().sum()).backward()
+        assert conv.weight.grad.dtype == torch.float32 and torch.isfinite(conv.weight.grad).all()
+    finally:
+        ag.set_bf16_mfma(old)

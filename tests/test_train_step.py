@@ -16,7 +16,7 @@ from test_oracle_vs_golden import build_product, gold
 CFGS = ["kitti_small", "nyu_small"]
 
 
-def run_step(cfg_name, device, force_hip_functions=False):
+def run_step(cfg_name, device, force_hip_functions=False, train_mode=False):
     m, cfg, _ = build_product(cfg_name)
     g = gold("train_step_small")
     over = {f[len(cfg_name) + 10:]: torch.from_numpy(g[f]) for f in g.files if f.startswith(cfg_name + ".override.")}
@@ -36,6 +36,8 @@ def run_step(cfg_name, device, force_hip_functions=False):
     batch = to_dev(batch)
     m.cur_batch = 3
     m.zero_grad()
+    if train_mode:
+        m.train()                                             # BatchNorm on batch statistics (the fused K13 passes on the GPU)
     from occdepth_amd.loss.sscMetrics import SSCMetrics
     metric = SSCMetrics(cfg.n_classes, device=device)
     from occdepth_amd import autograd3d
@@ -128,6 +130,62 @@ def _small_train_setup(cfg_name, device):
     shapes = {k: tuple(v.shape) for k, v in out.items() if torch.is_tensor(v)}
     extras = gc.train_extras(cfg_name, shapes, tuple(cfg.full_scene_size), cfg.n_classes, batch["img"].shape[-2:])
     return m, to_dev(dict(batch, **extras))
+
+
+def _flat_grads(m):
+    return torch.cat([p.grad.detach().double().flatten().cpu() for _, p in sorted(m.named_parameters()) if p.grad is not None])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", CFGS)
+def test_train_step_fused_batchnorm_matches_backend_batchnorm_gpu(cfg_name, hip_lib):
+    """Training mode (batch statistics): the step with every BatchNorm site on the fused K13 passes (bn.bn_act: statistics,
+    apply + activation + residual, backward reduce / apply) against the same step on the backend's batch_norm + separate
+    activation / add kernels -- same loss, same gradient direction and norm, same running statistics."""
+    from occdepth_amd import bn as obn
+    runs = {}
+    for fused in (False, True):
+        obn.ENABLED = fused
+        try:
+            m, loss, _ = run_step(cfg_name, "cuda", train_mode=True)
+        finally:
+            obn.ENABLED = True
+        rv = torch.cat([b.detach().double().flatten().cpu() for k, b in sorted(m.named_buffers()) if k.endswith("running_var")])
+        runs[fused] = (float(loss.detach()), _flat_grads(m), rv)
+    (l0, g0, v0), (l1, g1, v1) = runs[False], runs[True]
+    cos = float(torch.dot(g0, g1) / (g0.norm() * g1.norm()))
+    print(cfg_name, "loss", l0, l1, "gradient cosine", cos, "norm ratio", float(g1.norm() / g0.norm()))
+    assert abs(l0 - l1) / abs(l0) < 2e-4
+    assert float((v0 - v1).abs().max() / v0.abs().max()) < 1e-4
+    assert cos > 0.999 and abs(float(g1.norm() / g0.norm()) - 1.0) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", CFGS)
+def test_train_step_bf16_mode_gpu(cfg_name, hip_lib):
+    """BASELINE configs[3] wiring: the step with autograd3d.BF16_MFMA on -- every convolution of the 3-D stack and of the
+    2-D decoder (channels-last, as X = 1 volumes) forward / dgrad / wgrad on the bf16 matrix pipe -- against the exact-fp32
+    step: loss terms within bf16's error, gradient direction preserved.  (Kernels: pinned at 2e-5 on bf16-rounded operands
+    in test_bf16_conv.py; per-layer gradient error vs float64: profiles/r03_bf16_layer_errors.txt.)"""
+    from occdepth_amd import autograd3d as ag
+    from occdepth_amd import hip
+    runs = {}
+    for bf16 in (False, True):
+        old = ag.set_bf16_mfma(bf16)
+        try:
+            with hip.profile() as prof:
+                m, loss, _ = run_step(cfg_name, "cuda", train_mode=True)
+        finally:
+            ag.set_bf16_mfma(old)
+        runs[bf16] = (float(loss.detach()), _flat_grads(m), {k.split(":")[0] for k in prof.rows},
+                      {k: float(v) for k, v in m.logged.items()})
+    (l0, g0, k0, t0), (l1, g1, k1, t1) = runs[False], runs[True]
+    assert {"conv3d_bf16", "conv3d_wgrad_bf16"} <= k1 and not ({"conv3d_bf16", "conv3d_wgrad_bf16"} & k0), (k0, k1)
+    cos = float(torch.dot(g0, g1) / (g0.norm() * g1.norm()))
+    print(cfg_name, "loss fp32 / bf16-mfma", l0, l1, "gradient cosine", cos, "norm ratio", float(g1.norm() / g0.norm()))
+    for k in t0:
+        assert abs(t0[k] - t1[k]) <= 3e-2 * abs(t0[k]) + 1e-3, (k, t0[k], t1[k])
+    assert cos > 0.98 and abs(float(g1.norm() / g0.norm()) - 1.0) < 0.1
 
 
 @pytest.mark.gpu
