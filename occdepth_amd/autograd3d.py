@@ -85,8 +85,11 @@ def _axis_phases(K, s, p, d):
         offs = sorted(((r + p - k * d) // s, k) for k in ks)          # gy index = j + offset
         cs = [c for c, _ in offs]
         step = cs[1] - cs[0] if len(cs) > 1 else 1
-        if any(b - a != step for a, b in zip(cs, cs[1:])) or cs[0] > 0:
+        if any(b - a != step for a, b in zip(cs, cs[1:])):
             raise NotImplementedError(f"transposed phase of K={K} s={s} p={p} d={d} is not a uniform convolution")
+        # leading pad -cs[0]; negative when the convolution padded more than its kernel reaches (a 1x1 convolution with
+        # padding 1, occdepth/models/unet2d.py:65-67): the data gradient then CROPS gy, which the kernels' coordinate
+        # arithmetic (x_in = x_out * stride - pad + tap * dilation, bounds-checked) expresses as a negative pad
         out.append((r, [k for _, k in offs], step, -cs[0]))
     return out
 

@@ -21,7 +21,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 2048;
 
 // ------------------------------------------------------------------------------------------------ element access
 template <bool BF16>
@@ -112,7 +112,9 @@ __device__ __forceinline__ void reduce_rows_and_store(f32x4 s1, f32x4 s2, float*
 }
 
 // ------------------------------------------------------------------------------------------------ channels-last rows
-// MODE 0: forward statistics (sum(x - x0), sum((x - x0)^2));  MODE 1: backward sums (sum g, sum g * xhat)
+// MODE 0: forward statistics (sum(x - x0), sum((x - x0)^2));  MODE 1: backward sums (sum g, sum g * xhat).
+// A thread owns one channel quad and walks rows RPW apart; the loop is unrolled 4x (2x in the backward) with the loads of
+// all copies issued before the arithmetic: HBM streaming needs several independent 16-byte loads in flight per lane.
 template <bool BF16, int MODE>
 __global__ void __launch_bounds__(256) bn_reduce_rows_kernel(const BnP p) {
     __shared__ __attribute__((aligned(16))) float red[256 * 8];
@@ -127,13 +129,29 @@ __global__ void __launch_bounds__(256) bn_reduce_rows_kernel(const BnP p) {
     for (int q = q_lane; q < p.C4; q += QW) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         if (active) {
+            const size_t xq = (size_t)p.x_coff + 4 * q;
+            long r = r_begin + r_lane;
             if (MODE == 0) {
-                const f32x4 x0 = ld4<BF16>(p.x, (size_t)p.x_coff + 4 * q);
-                for (long r = r_begin + r_lane; r < r_end; r += RPW) {
-                    const f32x4 d = ld4<BF16>(p.x, (size_t)r * p.x_cs + p.x_coff + 4 * q) - x0;
+                const f32x4 x0 = ld4<BF16>(p.x, xq);
+                f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+                for (; r + 3L * RPW < r_end; r += 4L * RPW) {
+                    const f32x4 v0 = ld4<BF16>(p.x, (size_t)r * p.x_cs + xq);
+                    const f32x4 v1 = ld4<BF16>(p.x, (size_t)(r + RPW) * p.x_cs + xq);
+                    const f32x4 v2 = ld4<BF16>(p.x, (size_t)(r + 2L * RPW) * p.x_cs + xq);
+                    const f32x4 v3 = ld4<BF16>(p.x, (size_t)(r + 3L * RPW) * p.x_cs + xq);
+                    const f32x4 d0 = v0 - x0, d1 = v1 - x0, d2 = v2 - x0, d3 = v3 - x0;
+                    s1 += d0 + d1;
+                    t1 += d2 + d3;
+                    s2 += d0 * d0 + d1 * d1;
+                    t2 += d2 * d2 + d3 * d3;
+                }
+                for (; r < r_end; r += RPW) {
+                    const f32x4 d = ld4<BF16>(p.x, (size_t)r * p.x_cs + xq) - x0;
                     s1 += d;
                     s2 += d * d;
                 }
+                s1 += t1;
+                s2 += t2;
             } else {
                 f32x4 a, b, m, is;
 #pragma unroll
@@ -141,16 +159,34 @@ __global__ void __launch_bounds__(256) bn_reduce_rows_kernel(const BnP p) {
                     const int c = min(4 * q + j, p.C - 1);
                     a[j] = p.a[c]; b[j] = p.b[c]; m[j] = p.mean[c]; is[j] = p.invstd[c];
                 }
-                for (long r = r_begin + r_lane; r < r_end; r += RPW) {
-                    const f32x4 xv = ld4<BF16>(p.x, (size_t)r * p.x_cs + p.x_coff + 4 * q);
-                    f32x4 g = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + p.gy_coff + 4 * q);
+                const size_t gq = (size_t)p.gy_coff + 4 * q, yq = (size_t)p.y_coff + 4 * q;
+                auto one = [&](f32x4 xv, f32x4 g, f32x4 pre) {
                     if (p.act != 0) {
-                        f32x4 pre = p.y != nullptr ? ld4<BF16>(p.y, (size_t)r * p.y_cs + p.y_coff + 4 * q) : xv * a + b;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) g[j] *= act_bwd(pre[j], p.act, p.slope);
                     }
                     s1 += g;
                     s2 += g * ((xv - m) * is);
+                };
+                for (; r + RPW < r_end; r += 2L * RPW) {
+                    const f32x4 x0v = ld4<BF16>(p.x, (size_t)r * p.x_cs + xq);
+                    const f32x4 x1v = ld4<BF16>(p.x, (size_t)(r + RPW) * p.x_cs + xq);
+                    const f32x4 g0 = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + gq);
+                    const f32x4 g1 = ld4<BF16>(p.gy, (size_t)(r + RPW) * p.gy_cs + gq);
+                    f32x4 p0 = x0v * a + b, p1 = x1v * a + b;
+                    if (p.act != 0 && p.y != nullptr) {
+                        p0 = ld4<BF16>(p.y, (size_t)r * p.y_cs + yq);
+                        p1 = ld4<BF16>(p.y, (size_t)(r + RPW) * p.y_cs + yq);
+                    }
+                    one(x0v, g0, p0);
+                    one(x1v, g1, p1);
+                }
+                for (; r < r_end; r += RPW) {
+                    const f32x4 xv = ld4<BF16>(p.x, (size_t)r * p.x_cs + xq);
+                    const f32x4 g = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + gq);
+                    f32x4 pre = xv * a + b;
+                    if (p.act != 0 && p.y != nullptr) pre = ld4<BF16>(p.y, (size_t)r * p.y_cs + yq);
+                    one(xv, g, pre);
                 }
             }
         }
@@ -158,54 +194,94 @@ __global__ void __launch_bounds__(256) bn_reduce_rows_kernel(const BnP p) {
     }
 }
 
-// MODE 0: y = act(x a + b [+ res]) [+ res];  MODE 1: gx = g k1 + x k2 + k3 with g = gy act'(.), optionally out2 = g
+// MODE 0: y = act(x a + b [+ res]) [+ res];  MODE 1: gx = g k1 + x k2 + k3 with g = gy act'(.), optionally out2 = g.
+// A thread owns one written quad (pads beyond C get zeros) with its coefficients in registers and walks rows RPW apart,
+// two rows per iteration.
 template <bool BF16, int MODE>
 __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const BnP p) {
-    const int W4 = p.cw >> 2;                                  // quads written per row (channel pads get zeros)
-    const long total = p.rows * W4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long r = i / W4;
-        const int q = (int)(i - r * W4);
-        f32x4 o = {0.f, 0.f, 0.f, 0.f}, o2 = {0.f, 0.f, 0.f, 0.f};
-        if (q < p.C4) {
-            const f32x4 xv = ld4<BF16>(p.x, (size_t)r * p.x_cs + p.x_coff + 4 * q);
-            f32x4 a, b;
+    const int W4 = p.cw >> 2;                                  // quads written per row
+    const int tid = threadIdx.x;
+    const int QW = min(W4, 256), RPW = 256 / QW;
+    const int q_lane = tid % QW, r_lane = tid / QW;
+    if (r_lane >= RPW) return;
+    const long r_begin = (long)blockIdx.x * p.rows_per_blk;
+    const long r_end = min(r_begin + p.rows_per_blk, p.rows);
+    for (int q = q_lane; q < W4; q += QW) {
+        const bool live = q < p.C4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, k1 = a, k2 = a, k3 = a, keep = a;
+        if (live) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = min(4 * q + j, p.C - 1);
                 a[j] = p.a[c]; b[j] = p.b[c];
+                if (MODE == 1) { k1[j] = p.k1[c]; k2[j] = p.k2[c]; k3[j] = p.k3[c]; }
+                keep[j] = 4 * q + j < p.C ? 1.f : 0.f;
             }
+        }
+        const size_t xq = (size_t)p.x_coff + 4 * q, oq = (size_t)p.out_coff + 4 * q;
+        auto row = [&](long r, f32x4 xv, f32x4 second, f32x4 third) {
+            // MODE 0: second = res (or 0);  MODE 1: second = gy, third = the pre-activation source (y or unused)
+            f32x4 o, o2 = {0.f, 0.f, 0.f, 0.f};
             if (MODE == 0) {
                 f32x4 v = xv * a + b;
-                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-                if (p.res != nullptr) rr = ld4<BF16>(p.res, (size_t)r * p.res_cs + p.res_coff + 4 * q);
-                if (p.res_first) v += rr;
+                if (p.res_first) v += second;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], p.act, p.slope);
-                if (!p.res_first) v += rr;
-                o = v;
+                if (!p.res_first) v += second;
+                o = v * keep;
             } else {
-                f32x4 g = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + p.gy_coff + 4 * q);
+                f32x4 g = second;
                 if (p.act != 0) {
-                    f32x4 pre = p.y != nullptr ? ld4<BF16>(p.y, (size_t)r * p.y_cs + p.y_coff + 4 * q) : xv * a + b;
+                    const f32x4 pre = p.y != nullptr ? third : xv * a + b;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] *= act_bwd(pre[j], p.act, p.slope);
                 }
-                f32x4 k1, k2, k3;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = min(4 * q + j, p.C - 1);
-                    k1[j] = p.k1[c]; k2[j] = p.k2[c]; k3[j] = p.k3[c];
-                }
-                o = g * k1 + xv * k2 + k3;
-                o2 = g;
+                o = (g * k1 + xv * k2 + k3) * keep;
+                o2 = g * keep;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * q + j >= p.C) { o[j] = 0.f; o2[j] = 0.f; }
+            st4<BF16>(p.out, (size_t)r * p.out_cs + oq, o);
+            if (MODE == 1 && p.out2 != nullptr) st4<BF16>(p.out2, (size_t)r * p.out2_cs + p.out2_coff + 4 * q, o2);
+        };
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        long r = r_begin + r_lane;
+        if (!live) {
+            for (; r < r_end; r += RPW) {
+                st4<BF16>(p.out, (size_t)r * p.out_cs + oq, zero);
+                if (MODE == 1 && p.out2 != nullptr) st4<BF16>(p.out2, (size_t)r * p.out2_cs + p.out2_coff + 4 * q, zero);
+            }
+            continue;
         }
-        st4<BF16>(p.out, (size_t)r * p.out_cs + p.out_coff + 4 * q, o);
-        if (MODE == 1 && p.out2 != nullptr) st4<BF16>(p.out2, (size_t)r * p.out2_cs + p.out2_coff + 4 * q, o2);
+        for (; r + RPW < r_end; r += 2L * RPW) {
+            const long r1 = r + RPW;
+            const f32x4 x0v = ld4<BF16>(p.x, (size_t)r * p.x_cs + xq), x1v = ld4<BF16>(p.x, (size_t)r1 * p.x_cs + xq);
+            f32x4 s0 = zero, s1v = zero, t0 = zero, t1 = zero;
+            if (MODE == 0) {
+                if (p.res != nullptr) {
+                    s0 = ld4<BF16>(p.res, (size_t)r * p.res_cs + p.res_coff + 4 * q);
+                    s1v = ld4<BF16>(p.res, (size_t)r1 * p.res_cs + p.res_coff + 4 * q);
+                }
+            } else {
+                s0 = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + p.gy_coff + 4 * q);
+                s1v = ld4<BF16>(p.gy, (size_t)r1 * p.gy_cs + p.gy_coff + 4 * q);
+                if (p.act != 0 && p.y != nullptr) {
+                    t0 = ld4<BF16>(p.y, (size_t)r * p.y_cs + p.y_coff + 4 * q);
+                    t1 = ld4<BF16>(p.y, (size_t)r1 * p.y_cs + p.y_coff + 4 * q);
+                }
+            }
+            row(r, x0v, s0, t0);
+            row(r1, x1v, s1v, t1);
+        }
+        for (; r < r_end; r += RPW) {
+            const f32x4 xv = ld4<BF16>(p.x, (size_t)r * p.x_cs + xq);
+            f32x4 s0 = zero, t0 = zero;
+            if (MODE == 0) {
+                if (p.res != nullptr) s0 = ld4<BF16>(p.res, (size_t)r * p.res_cs + p.res_coff + 4 * q);
+            } else {
+                s0 = ld4<BF16>(p.gy, (size_t)r * p.gy_cs + p.gy_coff + 4 * q);
+                if (p.act != 0 && p.y != nullptr) t0 = ld4<BF16>(p.y, (size_t)r * p.y_cs + p.y_coff + 4 * q);
+            }
+            row(r, xv, s0, t0);
+        }
     }
 }
 
@@ -220,11 +296,13 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 }
 
 // grid (nsplit, C): block (s, c) reduces the span s of every image's plane c.  partial[(s)][2][C4 * 4]
+// float4 loads (two in flight per lane) when the plane size is a multiple of 4, scalar otherwise.
 template <int MODE>
 __global__ void __launch_bounds__(256) bn_reduce_planes_kernel(const BnP p) {
     __shared__ float red[4];
     const int tid = threadIdx.x, c = blockIdx.y;
-    const long span = (p.S + gridDim.x - 1) / gridDim.x;
+    long span = (p.S + gridDim.x - 1) / gridDim.x;
+    span = (span + 3) & ~3L;
     const long s0 = (long)blockIdx.x * span, s1e = min(s0 + span, p.S);
     const float* x = (const float*)p.x;
     const float* gy = (const float*)p.gy;
@@ -233,20 +311,46 @@ __global__ void __launch_bounds__(256) bn_reduce_planes_kernel(const BnP p) {
     const float x0 = MODE == 0 ? x[(size_t)c * p.S] : 0.f;
     const float a = MODE == 1 ? p.a[c] : 0.f, b = MODE == 1 ? p.b[c] : 0.f;
     const float m = MODE == 1 ? p.mean[c] : 0.f, is = MODE == 1 ? p.invstd[c] : 0.f;
+    const bool use_y = MODE == 1 && p.act != 0 && y != nullptr;
+    auto one = [&](float xv, float g, float yv) {
+        if (MODE == 0) {
+            const float d = xv - x0;
+            a1 += d;
+            a2 += d * d;
+        } else {
+            if (p.act != 0) g *= act_bwd(use_y ? yv : xv * a + b, p.act, p.slope);
+            a1 += g;
+            a2 += g * ((xv - m) * is);
+        }
+    };
+    const bool vec = (p.S & 3) == 0;
     for (int bi = 0; bi < p.batch; ++bi) {
         const size_t off = ((size_t)bi * p.C + c) * p.S;
-        for (long i = s0 + tid; i < s1e; i += 256) {
-            const float xv = x[off + i];
-            if (MODE == 0) {
-                const float d = xv - x0;
-                a1 += d;
-                a2 += d * d;
-            } else {
-                float g = gy[off + i];
-                if (p.act != 0) g *= act_bwd(y != nullptr ? y[off + i] : xv * a + b, p.act, p.slope);
-                a1 += g;
-                a2 += g * ((xv - m) * is);
+        if (vec) {
+            const long n4 = (s1e - s0) >> 2;                       // s0 and S are multiples of 4
+            const f32x4* x4 = (const f32x4*)(x + off + s0);
+            const f32x4* g4 = MODE == 1 ? (const f32x4*)(gy + off + s0) : nullptr;
+            const f32x4* y4 = use_y ? (const f32x4*)(y + off + s0) : nullptr;
+            long i = tid;
+            for (; i + 256 < n4; i += 512) {
+                const f32x4 xa = x4[i], xb = x4[i + 256];
+                f32x4 ga = xa, gb = xb, ya = xa, yb = xb;
+                if (MODE == 1) { ga = g4[i]; gb = g4[i + 256]; }
+                if (use_y) { ya = y4[i]; yb = y4[i + 256]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { one(xa[j], ga[j], ya[j]); one(xb[j], gb[j], yb[j]); }
             }
+            for (; i < n4; i += 256) {
+                const f32x4 xa = x4[i];
+                f32x4 ga = xa, ya = xa;
+                if (MODE == 1) ga = g4[i];
+                if (use_y) ya = y4[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) one(xa[j], ga[j], ya[j]);
+            }
+        } else {
+            for (long i = s0 + tid; i < s1e; i += 256)
+                one(x[off + i], MODE == 1 ? gy[off + i] : 0.f, use_y ? y[off + i] : 0.f);
         }
     }
     const float t1 = block_sum(a1, red, tid);
@@ -297,12 +401,27 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const BnP p) {
         float* out = (float*)p.out;
         float* out2 = (float*)p.out2;
         const float k1 = p.k1[c], k2 = p.k2[c], k3 = p.k3[c];
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.S; i += (long)gridDim.x * 256) {
-            const float xv = x[off + i];
-            float g = gy[off + i];
-            if (p.act != 0) g *= act_bwd(y != nullptr ? y[off + i] : xv * a + b, p.act, p.slope);
-            out[off + i] = g * k1 + xv * k2 + k3;
-            if (out2 != nullptr) out2[off + i] = g;
+        const bool use_y = p.act != 0 && y != nullptr;
+        if (vec) {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (p.S >> 2); i += (long)gridDim.x * 256) {
+                const f32x4 xv = *(const f32x4*)(x + off + 4 * i);
+                f32x4 g = *(const f32x4*)(gy + off + 4 * i);
+                if (p.act != 0) {
+                    const f32x4 pre = use_y ? *(const f32x4*)(y + off + 4 * i) : xv * a + b;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] *= act_bwd(pre[j], p.act, p.slope);
+                }
+                *(f32x4*)(out + off + 4 * i) = g * k1 + xv * k2 + k3;
+                if (out2 != nullptr) *(f32x4*)(out2 + off + 4 * i) = g;
+            }
+        } else {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.S; i += (long)gridDim.x * 256) {
+                const float xv = x[off + i];
+                float g = gy[off + i];
+                if (p.act != 0) g *= act_bwd(use_y ? y[off + i] : xv * a + b, p.act, p.slope);
+                out[off + i] = g * k1 + xv * k2 + k3;
+                if (out2 != nullptr) out2[off + i] = g;
+            }
         }
     }
 }
@@ -411,6 +530,17 @@ int fill(const occd_bn_args* a, BnP& p, bool need_partial) {
     return OCCD_OK;
 }
 
+// grid of the rows apply kernels: >= 8 rows per row-lane, at most 4096 workgroups; sets the block's row range
+long apply_blocks(const occd_bn_args* a, BnP& p) {
+    const int W4 = a->cw >> 2;
+    const int QW = W4 < 256 ? W4 : 256, RPW = 256 / QW;
+    long blocks = (a->rows + (long)RPW * 8 - 1) / ((long)RPW * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    p.rows_per_blk = (a->rows + blocks - 1) / blocks;
+    return blocks;
+}
+
 bool rows_tensor_ok(const void* ptr, int cs, int coff, int width) {
     return ptr == nullptr || ((cs & 3) == 0 && (coff & 3) == 0 && coff + width <= cs);
 }
@@ -425,7 +555,7 @@ int occd_bn_blocks(const occd_bn_args* a) {
     if (a->layout == 0) {
         const int C4 = (a->C + 3) / 4;
         const int QW = C4 < 256 ? C4 : 256, RPW = 256 / QW;
-        long n = (a->rows + (long)RPW * 8 - 1) / ((long)RPW * 8);       // >= 8 rows per row-lane
+        long n = (a->rows + (long)RPW * 16 - 1) / ((long)RPW * 16);     // >= 16 rows per row-lane
         if (n < 1) n = 1;
         if (n > kMaxBlocks) n = kMaxBlocks;
         return (int)n;
@@ -487,9 +617,7 @@ int occd_bn_apply(const occd_bn_args* a, void* stream) {
         if (a->cw < p.C4 * 4 || (a->cw & 3) || !rows_tensor_ok(a->out, a->out_cs, a->out_coff, a->cw) ||
             !rows_tensor_ok(a->res, a->res_cs, a->res_coff, p.C4 * 4))
             return OCCD_EINVAL;
-        const long total = a->rows * (a->cw >> 2);
-        long blocks = (total + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
+        const long blocks = apply_blocks(a, p);
         if (a->dtype == 1) hipLaunchKernelGGL((bn_apply_rows_kernel<true, 0>), dim3((unsigned)blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((bn_apply_rows_kernel<false, 0>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     } else {
@@ -552,9 +680,7 @@ int occd_bn_bwd_apply(const occd_bn_args* a, void* stream) {
             !rows_tensor_ok(a->out2, a->out2_cs, a->out2_coff, a->cw) || !rows_tensor_ok(a->gy, a->gy_cs, a->gy_coff, p.C4 * 4) ||
             !rows_tensor_ok(a->y, a->y_cs, a->y_coff, p.C4 * 4))
             return OCCD_EINVAL;
-        const long total = a->rows * (a->cw >> 2);
-        long blocks = (total + 255) / 256;
-        if (blocks > 8192) blocks = 8192;
+        const long blocks = apply_blocks(a, p);
         if (a->dtype == 1) hipLaunchKernelGGL((bn_apply_rows_kernel<true, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((bn_apply_rows_kernel<false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     } else {

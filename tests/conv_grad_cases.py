@@ -23,6 +23,11 @@ CONV_CASES = {
     "nyu_5_20": (5, 20, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (10, 6, 10), False),
     "nyu_head": (20, 12, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), (20, 12, 20), True),
     "nyu_aspp": (20, 20, (3, 3, 3), (1, 1, 1), (3, 3, 3), (3, 3, 3), (20, 12, 20), False),
+    # the 2-D decoder as X = 1 volumes (bf16-mode training): 3x3, the 1x1 heads, and `conv2` = 1x1 with padding 1, whose
+    # data gradient crops (negative pad)
+    "dec_3x3": (24, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (1, 9, 20), True),             # unet2d.py:24-46
+    "dec_head_1x1": (16, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (1, 9, 20), True),          # unet2d.py:120-131
+    "dec_conv2_1x1_p1": (32, 24, (1, 1, 1), (1, 1, 1), (0, 1, 1), (1, 1, 1), (1, 5, 7), True),      # unet2d.py:65-67
 }
 # name: (cin, cout, kernel, stride, padding, output_padding, dims, bias)
 CONVT_CASES = {

@@ -69,7 +69,12 @@ def test_bn_act_matches_float64_reference(case):
 
     def dev(t):
         t = t.to(DEV, dtype)
-        return t.contiguous(memory_format=mf) if cl else t.contiguous()
+        if not cl:
+            return t.contiguous()
+        # channels-last: dense rows when C is a multiple of 4, else rows padded to ceil8(C) with zero pads -- the layout
+        # the HIP convolutions hand over for ragged channel counts (an ATen channels_last tensor with C = 34 has rows of
+        # 34 floats: not addressable in 16-byte quads, bn_act falls back to the backend for those)
+        return t.contiguous(memory_format=mf) if C % 4 == 0 else obn._to_rows(t)
 
     xs = dev(x).detach().requires_grad_(True)
     rs = dev(res).detach().requires_grad_(True) if res is not None else None
