@@ -447,6 +447,20 @@ int occd_bn_bwd_finish(const float* local, const float* total, int32_t C, const 
                        const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw, float* gb,
                        void* stream);
 int occd_bn_bwd_apply(const occd_bn_args* a, void* stream);
+/* launch-count reductions for LOCAL statistics: combine + finish in one launch (forward / backward), and the whole forward /
+ * backward of a small NCHW layer (occd_bn_small_ok: layout 1, batch * S <= 32768, C >= 64) in one launch, one workgroup
+ * per channel.                                                                                                       */
+int occd_bn_stats_finish(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float* mean, float* invstd, float* av, float* bv, void* stream);
+int occd_bn_bwd_combine_finish(const float* partial, int32_t nblk, int32_t C, const double* packed_fwd, const float* mean,
+                               const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw, float* gb,
+                               void* stream);
+int occd_bn_small_ok(const occd_bn_args* a);
+int occd_bn_fwd_small(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                      float* av, float* bv, void* stream);
+int occd_bn_bwd_small(const occd_bn_args* a, float* gw, float* gb, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * K2b / K8b: the same convolution forward (data gradient: the forward on dL/dy with flipped weights) and weight

@@ -122,6 +122,9 @@ def _to_rows(t):
 
 
 class _BNActFn(torch.autograd.Function):
+    """Launch plan per direction: [sync] reduce, combine, all-reduce, finish, apply; [local] reduce, combine + finish, apply;
+    [local, small NCHW tensor] ONE launch (occd_bn_fwd_small / occd_bn_bwd_small)."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, res, running_mean, running_var, nbt, eps, momentum, act, slope, res_first, group,
                 sync):
@@ -130,45 +133,51 @@ class _BNActFn(torch.autograd.Function):
         geo = _Geom(x)
         C = geo.C
         dev = x.device
+        exchange = bool(sync and _group_active(group))
         a = geo.args()
         a.x = x.data_ptr()
         a.x_cs = geo.like(x, x, "x")
-        a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
-        if a.nblk <= 0:
-            raise RuntimeError("occd_bn_blocks failed")
-        partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
-        a.partial = partial.data_ptr()
         packed = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
-        hip._check(lib.occd_bn_stats(ctypes.byref(a), st), "occd_bn_stats")
-        hip._check(lib.occd_bn_stats_combine(ctypes.byref(a), packed.data_ptr(), st), "occd_bn_stats_combine")
-        if sync and _group_active(group):
-            import torch.distributed as dist
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         vec = torch.empty(4, C, device=dev, dtype=torch.float32)          # mean, invstd, a, b
         w = weight.detach().float() if weight is not None else None
         b = bias.detach().float() if bias is not None else None
-        hip._check(lib.occd_bn_finish(packed.data_ptr(), C, float(eps), float(momentum if momentum is not None else 0.0),
-                                      _ptr(w), _ptr(b), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
-                                      vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st),
-                   "occd_bn_finish")
+        fin = (float(eps), float(momentum if momentum is not None else 0.0), _ptr(w), _ptr(b), _ptr(running_mean),
+               _ptr(running_var), _ptr(nbt), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr())
         y, ycs = geo.empty_like(x)
-        a.a, a.b = vec[2].data_ptr(), vec[3].data_ptr()
         a.out, a.out_cs = y.data_ptr(), ycs
         a.cw = min(hip.round_up(C, 8), ycs) if geo.layout == 0 else 0
         if res is not None:
             a.res, a.res_cs = res.data_ptr(), geo.like(x, res, "res")
         a.act, a.slope, a.res_first = act, float(slope), 1 if res_first else 0
-        hip._check(lib.occd_bn_apply(ctypes.byref(a), st), "occd_bn_apply")
+        small = (not exchange) and bool(lib.occd_bn_small_ok(ctypes.byref(a)))
+        if small:
+            hip._check(lib.occd_bn_fwd_small(ctypes.byref(a), packed.data_ptr(), *fin, st), "occd_bn_fwd_small")
+        else:
+            a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
+            if a.nblk <= 0:
+                raise RuntimeError("occd_bn_blocks failed")
+            partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
+            a.partial = partial.data_ptr()
+            hip._check(lib.occd_bn_stats(ctypes.byref(a), st), "occd_bn_stats")
+            if exchange:
+                import torch.distributed as dist
+                hip._check(lib.occd_bn_stats_combine(ctypes.byref(a), packed.data_ptr(), st), "occd_bn_stats_combine")
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+                hip._check(lib.occd_bn_finish(packed.data_ptr(), C, *fin, st), "occd_bn_finish")
+            else:
+                hip._check(lib.occd_bn_stats_finish(ctypes.byref(a), packed.data_ptr(), *fin, st), "occd_bn_stats_finish")
+            a.a, a.b = vec[2].data_ptr(), vec[3].data_ptr()
+            hip._check(lib.occd_bn_apply(ctypes.byref(a), st), "occd_bn_apply")
         # the pre-activation's sign comes from y when a residual entered before the activation (x a + b alone is not it)
         need_y = act != 0 and res is not None and res_first
         ctx.save_for_backward(x, vec, packed, weight, y if need_y else None)
-        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, sync)
+        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, exchange, small)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, vec, packed, weight, y = ctx.saved_tensors
-        act, slope, res_first, has_res, group, sync = ctx.cfg
+        act, slope, res_first, has_res, group, exchange, small = ctx.cfg
         lib = hip.load()
         st = hip._stream()
         geo = _Geom(x)
@@ -184,25 +193,10 @@ class _BNActFn(torch.autograd.Function):
             a.y, a.y_cs = y.data_ptr(), geo.like(x, y, "y")
         a.mean, a.invstd, a.a, a.b = (vec[i].data_ptr() for i in range(4))
         a.act, a.slope, a.res_first = act, slope, 1 if res_first else 0
-        a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
-        partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
-        a.partial = partial.data_ptr()
-        hip._check(lib.occd_bn_bwd_reduce(ctypes.byref(a), st), "occd_bn_bwd_reduce")
-        local = torch.empty(2 * C, device=dev, dtype=torch.float32)
-        hip._check(lib.occd_bn_bwd_combine(partial.data_ptr(), a.nblk, C, local.data_ptr(), st), "occd_bn_bwd_combine")
-        total = local
-        if sync and _group_active(group):
-            import torch.distributed as dist
-            total = local.clone()
-            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         k = torch.empty(5, C, device=dev, dtype=torch.float32)            # k1, k2, k3, gw, gb
         want_w = weight is not None
-        hip._check(lib.occd_bn_bwd_finish(local.data_ptr(), total.data_ptr(), C, packed.data_ptr(), vec[0].data_ptr(),
-                                          vec[1].data_ptr(), vec[2].data_ptr(), k[0].data_ptr(), k[1].data_ptr(),
-                                          k[2].data_ptr(), k[3].data_ptr() if want_w else None,
-                                          k[4].data_ptr() if want_w else None, st), "occd_bn_bwd_finish")
+        gw_p, gb_p = (k[3].data_ptr(), k[4].data_ptr()) if want_w else (None, None)
         gx, gcs = geo.empty_like(x)
-        a.k1, a.k2, a.k3 = k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr()
         a.out, a.out_cs = gx.data_ptr(), gcs
         a.cw = min(hip.round_up(C, 8), gcs) if geo.layout == 0 else 0
         gres = None
@@ -212,7 +206,28 @@ class _BNActFn(torch.autograd.Function):
                 a.out2, a.out2_cs = gres.data_ptr(), rcs
             else:
                 gres = gy                                                   # added after the activation (or no activation)
-        hip._check(lib.occd_bn_bwd_apply(ctypes.byref(a), st), "occd_bn_bwd_apply")
+        if small:
+            hip._check(lib.occd_bn_bwd_small(ctypes.byref(a), gw_p, gb_p, st), "occd_bn_bwd_small")
+        else:
+            a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
+            partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
+            a.partial = partial.data_ptr()
+            hip._check(lib.occd_bn_bwd_reduce(ctypes.byref(a), st), "occd_bn_bwd_reduce")
+            kp = [k[i].data_ptr() for i in range(3)]
+            if exchange:
+                import torch.distributed as dist
+                local = torch.empty(2 * C, device=dev, dtype=torch.float32)
+                hip._check(lib.occd_bn_bwd_combine(partial.data_ptr(), a.nblk, C, local.data_ptr(), st), "occd_bn_bwd_combine")
+                total = local.clone()
+                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+                hip._check(lib.occd_bn_bwd_finish(local.data_ptr(), total.data_ptr(), C, packed.data_ptr(), vec[0].data_ptr(),
+                                                  vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st), "occd_bn_bwd_finish")
+            else:
+                hip._check(lib.occd_bn_bwd_combine_finish(partial.data_ptr(), a.nblk, C, packed.data_ptr(), vec[0].data_ptr(),
+                                                          vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st),
+                           "occd_bn_bwd_combine_finish")
+            a.k1, a.k2, a.k3 = kp
+            hip._check(lib.occd_bn_bwd_apply(ctypes.byref(a), st), "occd_bn_bwd_apply")
         gw = k[3].to(weight.dtype) if want_w else None
         gb = k[4].to(weight.dtype) if want_w else None
         return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None

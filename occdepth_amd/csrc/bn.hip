@@ -502,6 +502,196 @@ __global__ void bn_bwd_finish_kernel(const float* local, const float* total, int
     if (gb != nullptr) gb[c] = local[c];
 }
 
+// ---- local statistics (no exchange between ranks): combine + finish in ONE per-channel launch
+__global__ void bn_combine_finish_kernel(const float* partial, int nblk, int Cp, int C, const void* x, int dtype, int layout,
+                                         long S, int x_coff, double n_local, double* packed, float eps, float momentum,
+                                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                         long* num_batches, float* mean, float* invstd, float* a, float* b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) {
+        packed[2 * C] = n_local;
+        if (num_batches != nullptr) *num_batches += 1;
+    }
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s1 += (double)partial[(size_t)k * 2 * Cp + c];
+        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
+    }
+    double x0;
+    if (layout == 1) x0 = (double)((const float*)x)[(size_t)c * S];
+    else if (dtype == 1) x0 = (double)__builtin_bit_cast(float, (uint32_t)((const uint16_t*)x)[x_coff + c] << 16);
+    else x0 = (double)((const float*)x)[x_coff + c];
+    const double mu = x0 + s1 / n_local;
+    double var = (s2 - s1 * s1 / n_local) / n_local;
+    if (var < 0.0) var = 0.0;
+    packed[c] = n_local * mu;
+    packed[C + c] = n_local * (var + mu * mu);
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    const float sc = (gamma != nullptr ? gamma[c] : 1.f) * is;
+    a[c] = sc;
+    b[c] = (beta != nullptr ? beta[c] : 0.f) - (float)mu * sc;
+    if (running_mean != nullptr) {
+        const double unbiased = var * (n_local / (n_local > 1.0 ? n_local - 1.0 : 1.0));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_bwd_combine_finish_kernel(const float* partial, int nblk, int Cp, int C, const double* packed_fwd,
+                                             const float* mean, const float* invstd, const float* a, float* k1, float* k2,
+                                             float* k3, float* gw, float* gb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s1 += (double)partial[(size_t)k * 2 * Cp + c];
+        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
+    }
+    const float n = (float)packed_fwd[2 * C];
+    const float mg = (float)s1 / n, mgx = (float)s2 / n;
+    const float sc = a[c], is = invstd[c], mu = mean[c];
+    k1[c] = sc;
+    k2[c] = -is * mgx * sc;
+    k3[c] = (mu * is * mgx - mg) * sc;
+    if (gw != nullptr) gw[c] = (float)s2;
+    if (gb != nullptr) gb[c] = (float)s1;
+}
+
+// ---- small NCHW tensors (the EfficientNet stages at 1/8 ... 1/32 resolution: a few thousand pixels per plane, up to 3840
+// channels, ~220 BatchNorm calls per step): the whole layer in ONE launch, one workgroup per channel -- reduction pass,
+// per-channel finish in the workgroup, apply pass (the plane comes back from L2).  Local statistics only.
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_small_planes_kernel(const BnP p, float eps, float momentum, const float* gamma,
+                                                              const float* beta, float* running_mean, float* running_var,
+                                                              long* num_batches, double* packed, float* mean_o,
+                                                              float* invstd_o, float* a_o, float* b_o, float* gw, float* gb) {
+    __shared__ float red[4];
+    __shared__ float coef[4];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const float* x = (const float*)p.x;
+    const float* gy = (const float*)p.gy;
+    const float* y = (const float*)p.y;
+    const bool vec = (p.S & 3) == 0;
+    const double n = (double)p.batch * (double)p.S;
+    float a1 = 0.f, a2 = 0.f;
+    const float x0 = MODE == 0 ? x[(size_t)c * p.S] : 0.f;
+    float a = 0.f, b = 0.f, m = 0.f, is = 0.f;
+    if (MODE == 1) { a = p.a[c]; b = p.b[c]; m = p.mean[c]; is = p.invstd[c]; }
+    const bool use_y = MODE == 1 && p.act != 0 && y != nullptr;
+    auto acc1 = [&](float xv, float g, float yv) {
+        if (MODE == 0) {
+            const float d = xv - x0;
+            a1 += d;
+            a2 += d * d;
+        } else {
+            if (p.act != 0) g *= act_bwd(use_y ? yv : xv * a + b, p.act, p.slope);
+            a1 += g;
+            a2 += g * ((xv - m) * is);
+        }
+    };
+    for (int bi = 0; bi < p.batch; ++bi) {
+        const size_t off = ((size_t)bi * p.C + c) * p.S;
+        if (vec) {
+            const f32x4* x4 = (const f32x4*)(x + off);
+            const f32x4* g4 = MODE == 1 ? (const f32x4*)(gy + off) : nullptr;
+            const f32x4* y4 = use_y ? (const f32x4*)(y + off) : nullptr;
+            for (long i = tid; i < (p.S >> 2); i += 256) {
+                const f32x4 xa = x4[i];
+                f32x4 ga = xa, ya = xa;
+                if (MODE == 1) ga = g4[i];
+                if (use_y) ya = y4[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1(xa[j], ga[j], ya[j]);
+            }
+        } else {
+            for (long i = tid; i < p.S; i += 256) acc1(x[off + i], MODE == 1 ? gy[off + i] : 0.f, use_y ? y[off + i] : 0.f);
+        }
+    }
+    const float t1 = block_sum(a1, red, tid);
+    const float t2 = block_sum(a2, red, tid);
+    if (tid == 0) {
+        if (MODE == 0) {
+            const double mu = (double)x0 + (double)t1 / n;
+            double var = ((double)t2 - (double)t1 * (double)t1 / n) / n;
+            if (var < 0.0) var = 0.0;
+            const float isd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = (gamma != nullptr ? gamma[c] : 1.f) * isd;
+            const float sh = (beta != nullptr ? beta[c] : 0.f) - (float)mu * sc;
+            packed[c] = n * mu;
+            packed[p.C + c] = n * (var + mu * mu);
+            if (c == 0) {
+                packed[2 * p.C] = n;
+                if (num_batches != nullptr) *num_batches += 1;
+            }
+            mean_o[c] = (float)mu; invstd_o[c] = isd; a_o[c] = sc; b_o[c] = sh;
+            if (running_mean != nullptr) {
+                const double unbiased = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            coef[0] = sc; coef[1] = sh;
+        } else {
+            const float nf = (float)n;
+            const float mg = t1 / nf, mgx = t2 / nf;
+            coef[0] = a;
+            coef[1] = -is * mgx * a;
+            coef[2] = (m * is * mgx - mg) * a;
+            if (gw != nullptr) gw[c] = t2;
+            if (gb != nullptr) gb[c] = t1;
+        }
+    }
+    __syncthreads();
+    const float c0 = coef[0], c1 = coef[1], c2 = MODE == 1 ? coef[2] : 0.f;
+    const float* res = (const float*)p.res;
+    float* out = (float*)p.out;
+    float* out2 = (float*)p.out2;
+    for (int bi = 0; bi < p.batch; ++bi) {
+        const size_t off = ((size_t)bi * p.C + c) * p.S;
+        const long n4 = vec ? (p.S >> 2) : 0;
+        for (long i = tid; i < n4; i += 256) {
+            const f32x4 xv = *(const f32x4*)(x + off + 4 * i);
+            if (MODE == 0) {
+                f32x4 v = xv * c0 + c1;
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (res != nullptr) rr = *(const f32x4*)(res + off + 4 * i);
+                if (p.res_first) v += rr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_fwd(v[j], p.act, p.slope);
+                if (!p.res_first) v += rr;
+                *(f32x4*)(out + off + 4 * i) = v;
+            } else {
+                f32x4 g = *(const f32x4*)(gy + off + 4 * i);
+                if (p.act != 0) {
+                    const f32x4 pre = use_y ? *(const f32x4*)(y + off + 4 * i) : xv * a + b;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] *= act_bwd(pre[j], p.act, p.slope);
+                }
+                *(f32x4*)(out + off + 4 * i) = g * c0 + xv * c1 + c2;
+                if (out2 != nullptr) *(f32x4*)(out2 + off + 4 * i) = g;
+            }
+        }
+        for (long i = 4 * n4 + tid; i < p.S; i += 256) {
+            const float xv = x[off + i];
+            if (MODE == 0) {
+                float v = xv * c0 + c1;
+                const float rr = res != nullptr ? res[off + i] : 0.f;
+                if (p.res_first) v += rr;
+                v = act_fwd(v, p.act, p.slope);
+                if (!p.res_first) v += rr;
+                out[off + i] = v;
+            } else {
+                float g = gy[off + i];
+                if (p.act != 0) g *= act_bwd(use_y ? y[off + i] : xv * a + b, p.act, p.slope);
+                out[off + i] = g * c0 + xv * c1 + c2;
+                if (out2 != nullptr) out2[off + i] = g;
+            }
+        }
+    }
+}
+
 int fill(const occd_bn_args* a, BnP& p, bool need_partial) {
     if (a == nullptr || a->x == nullptr || a->C <= 0 || a->dtype < 0 || a->dtype > 1 || a->layout < 0 || a->layout > 1)
         return OCCD_EINVAL;
@@ -691,6 +881,70 @@ int occd_bn_bwd_apply(const occd_bn_args* a, void* stream) {
         if (bx > 64) bx = 64;
         hipLaunchKernelGGL((bn_apply_planes_kernel<1>), dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, st, p);
     }
+    return occd::check_launch();
+}
+
+/* Local statistics (one rank, or BatchNorm that is not synchronised): occd_bn_stats_combine + occd_bn_finish as ONE launch
+ * (`packed` is still written: the backward reads n from it), and occd_bn_bwd_combine + occd_bn_bwd_finish as ONE launch. */
+int occd_bn_stats_finish(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float* mean, float* invstd, float* av, float* bv, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, true);
+    if (rc != OCCD_OK) return rc;
+    if (!packed || !mean || !invstd || !av || !bv || (running_mean == nullptr) != (running_var == nullptr)) return OCCD_EINVAL;
+    const double n = a->layout == 0 ? (double)a->rows : (double)a->batch * (double)a->S;
+    hipLaunchKernelGGL(bn_combine_finish_kernel, dim3((a->C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       (const float*)a->partial, a->nblk, p.C4 * 4, a->C, a->x, a->dtype, a->layout, (long)a->S, a->x_coff, n,
+                       packed, eps, momentum, gamma, beta, running_mean, running_var, (long*)num_batches_tracked, mean, invstd,
+                       av, bv);
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_combine_finish(const float* partial, int32_t nblk, int32_t C, const double* packed_fwd, const float* mean,
+                               const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw, float* gb,
+                               void* stream) {
+    if (!partial || nblk <= 0 || C <= 0 || !packed_fwd || !mean || !invstd || !a || !k1 || !k2 || !k3) return OCCD_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_combine_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk,
+                       ((C + 3) / 4) * 4, C, packed_fwd, mean, invstd, a, k1, k2, k3, gw, gb);
+    return occd::check_launch();
+}
+
+/* Small NCHW tensors (layout 1): the whole forward (statistics, finish, apply) / the whole backward (reduction, finish,
+ * apply) of a layer with LOCAL statistics as one launch, one workgroup per channel.  Worth it while batch * S is a few
+ * thousand elements per channel (occd_bn_small_ok).                                                               */
+int occd_bn_small_ok(const occd_bn_args* a) {
+    return a != nullptr && a->layout == 1 && a->dtype == 0 && a->C >= 64 && (double)a->batch * (double)a->S <= 32768.0 ? 1 : 0;
+}
+
+int occd_bn_fwd_small(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                      float* av, float* bv, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, false);
+    if (rc != OCCD_OK) return rc;
+    if (a->layout != 1 || !a->out || !packed || !mean || !invstd || !av || !bv ||
+        (running_mean == nullptr) != (running_var == nullptr))
+        return OCCD_EINVAL;
+    const double elems = (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_fwd_small", (hipStream_t)stream, 0.0, 4.0 * elems * (3 + (a->res != nullptr)));
+    hipLaunchKernelGGL((bn_small_planes_kernel<0>), dim3(a->C), dim3(256), 0, (hipStream_t)stream, p, eps, momentum, gamma, beta,
+                       running_mean, running_var, (long*)num_batches_tracked, packed, mean, invstd, av, bv, (float*)nullptr,
+                       (float*)nullptr);
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_small(const occd_bn_args* a, float* gw, float* gb, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, false);
+    if (rc != OCCD_OK) return rc;
+    if (a->layout != 1 || !a->out || !a->gy || !a->a || !a->b || !a->mean || !a->invstd) return OCCD_EINVAL;
+    const double elems = (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_bwd_small", (hipStream_t)stream, 0.0,
+                         4.0 * elems * (5 + 2 * (a->y != nullptr) + (a->out2 != nullptr)));
+    hipLaunchKernelGGL((bn_small_planes_kernel<1>), dim3(a->C), dim3(256), 0, (hipStream_t)stream, p, 0.f, 0.f,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (long*)nullptr,
+                       (double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, gw, gb);
     return occd::check_launch();
 }
 

@@ -40,7 +40,10 @@ CASES = [
     ((2, 48, 19, 23), False, torch.float32, "swish", None, 0.1, 1.0),            # NCHW encoder: BN + swish
     ((2, 24, 11, 13), False, torch.float32, None, "post", 0.0, 1.0),             # MBConv bn3 + skip
     ((3, 16, 7, 9), False, torch.float32, "relu", "first", 0.0, 1.0),
-    ((1, 640, 6, 20), False, torch.float32, "swish", None, 0.0, 1.0),
+    ((1, 640, 6, 20), False, torch.float32, "swish", None, 0.0, 1.0),            # small NCHW layers: ONE launch per direction
+    ((2, 96, 40, 50), False, torch.float32, "swish", "post", 0.3, 1.2),
+    ((1, 128, 47, 153), False, torch.float32, "relu", "first", 0.0, 1.0),
+    ((2, 288, 31, 37), False, torch.float32, None, None, 20.0, 2.0),
     ((2, 16, 5, 6, 7), False, torch.float32, "relu", None, 0.0, 1.0),            # NCDHW planes
     ((2, 16, 9, 11), False, torch.float32, None, None, 50.0, 3.0),               # mean far from zero
     ((2, 16, 4, 9, 8), True, torch.float32, None, None, -300.0, 0.5),
