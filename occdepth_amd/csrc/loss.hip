@@ -223,6 +223,11 @@ __global__ void __launch_bounds__(256) confusion_kernel(const float* logits, con
         if (h32[i]) atomicAdd(&hist[i], (u64)h32[i]);
 }
 
+__global__ void zero_u64_kernel(u64* p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 int grid_for(long total) {
     long blocks = (total + 255) / 256;
     const long cap = 256 * 4;                          // 4 workgroups per CU: few final flushes, chip still full
@@ -255,7 +260,10 @@ int occd_ssc_loss_stats_fwd(const float* logits, const uint8_t* target, const ui
     q.logits = logits; q.target = target; q.masks = F > 0 ? masks : nullptr; q.weights = weights;
     q.stats = (u64*)stats; q.total = batch * S; q.C = C; q.S = (int)S; q.F = F; q.map_occ = map_occ;
     const size_t n = (size_t)occd_ssc_stats_len(C, F);
-    if (hipMemsetAsync(stats, 0, n * sizeof(int64_t), st) != hipSuccess) return OCCD_ELAUNCH;
+    // zero the accumulators with a KERNEL, not hipMemsetAsync: inside a captured hipGraph (train_graph.py) the memset node of
+    // this odd-sized buffer was observed not to take effect on replays (ROCm 7.0: the statistics kept the previous
+    // contents of the graph pool's block: garbage counts from the second replay on, NaN losses)
+    hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64*)stats, (long)n);
     const double bytes = (double)q.total * (4.0 * C + 1 + F);
     occd::ProfScope prof("ssc_loss_stats", st, (double)q.total * C * 8.0, bytes);
     const dim3 grid(grid_for(q.total));
