@@ -262,12 +262,12 @@ def _main(args, real_stdout):
         res = _config5(args, world, rank, device, dist)
     else:
         res = _train(args, world, rank, device, dist) if args.train else _forward(args, world, rank, device, dist)
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:                                   # the LAST thing on stdout (RCCL prints its banner at its first collective)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
 
 
 def _forward(args, world, rank, device, dist):

@@ -448,7 +448,7 @@ int occd_bn_bwd_finish(const float* local, const float* total, int32_t C, const 
                        void* stream);
 int occd_bn_bwd_apply(const occd_bn_args* a, void* stream);
 /* launch-count reductions for LOCAL statistics: combine + finish in one launch (forward / backward), and the whole forward /
- * backward of a small NCHW layer (occd_bn_small_ok: layout 1, batch * S <= 32768, C >= 64) in one launch, one workgroup
+ * backward of a small NCHW layer (occd_bn_small_ok: layout 1, batch * S <= 8192, C >= 64) in one launch, one workgroup
  * per channel.                                                                                                       */
 int occd_bn_stats_finish(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,

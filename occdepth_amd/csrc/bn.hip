@@ -914,7 +914,7 @@ int occd_bn_bwd_combine_finish(const float* partial, int32_t nblk, int32_t C, co
  * apply) of a layer with LOCAL statistics as one launch, one workgroup per channel.  Worth it while batch * S is a few
  * thousand elements per channel (occd_bn_small_ok).                                                               */
 int occd_bn_small_ok(const occd_bn_args* a) {
-    return a != nullptr && a->layout == 1 && a->dtype == 0 && a->C >= 64 && (double)a->batch * (double)a->S <= 32768.0 ? 1 : 0;
+    return a != nullptr && a->layout == 1 && a->dtype == 0 && a->C >= 64 && (double)a->batch * (double)a->S <= 8192.0 ? 1 : 0;
 }
 
 int occd_bn_fwd_small(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma, const float* beta,

@@ -249,5 +249,8 @@ def test_whole_step_hipgraph_matches_eager_gpu(hip_lib):
         runs[mode] = (losses, next(iter(m.net_3d_decoder.parameters())).detach().float().cpu().clone())
     (le, pe), (lg, pg) = runs["eager"], runs["graph"]
     print("eager", le, "graph", lg)
-    assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    # identical at step 0, then the two runs drift apart at round-off level amplified by training (atomics in the lift
+    # backward, MIOpen algorithm choice inside / outside a capture): 0.6 % after four steps measured
+    assert abs(le[0] - lg[0]) <= 1e-5 * abs(le[0]), (le, lg)
+    assert all(abs(a - b) <= 1.5e-2 * abs(a) for a, b in zip(le, lg)), (le, lg)
     assert float((pe - pg).abs().max() / pe.abs().max()) < 5e-3
