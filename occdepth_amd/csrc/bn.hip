@@ -21,7 +21,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kMaxBlocks = 2048;
+constexpr int kMaxBlocks = 1024;
 
 // ------------------------------------------------------------------------------------------------ element access
 template <bool BF16>
@@ -427,18 +427,41 @@ __global__ void __launch_bounds__(256) bn_apply_planes_kernel(const BnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------ per-channel stages
+// Sum of the nblk partial pairs of channel c: 256 threads = 8 channels x 32 block-lanes, every lane adds its blocks in
+// ascending order, the 32 lanes are combined in a fixed order through LDS (deterministic).  A serial walk over up to 2048
+// partials per channel was 80 us of dependent loads per layer -- more than the passes over the activation themselves.
+__device__ __forceinline__ bool partial_sums(const float* partial, int nblk, int Cp, int C, double* red, double& s1, double& s2,
+                                             int& c_out) {
+    const int tid = threadIdx.x, cl = tid & 7, kl = tid >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C)
+        for (int k = kl; k < nblk; k += 32) {
+            a1 += (double)partial[(size_t)k * 2 * Cp + c];
+            a2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
+        }
+    red[tid * 2] = a1;
+    red[tid * 2 + 1] = a2;
+    __syncthreads();
+    c_out = c;
+    if (kl != 0 || c >= C) return false;
+    s1 = 0.0; s2 = 0.0;
+    for (int k = 0; k < 32; ++k) {
+        s1 += red[(k * 8 + cl) * 2];
+        s2 += red[(k * 8 + cl) * 2 + 1];
+    }
+    return true;
+}
+
 // partial[nblk][2][Cp] -> packed (float64): forward [n mean_l, M2_l + n mean_l^2, n] (Chan's form, see shard.py) from the
 // shifted sums; x0[c] is re-read from the tensor exactly as the statistics pass read it.
 __global__ void bn_stats_combine_kernel(const float* partial, int nblk, int Cp, int C, const void* x, int dtype, int layout,
                                         long S, int x_coff, double n_local, double* packed) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) packed[2 * C] = n_local;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        s1 += (double)partial[(size_t)k * 2 * Cp + c];
-        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
-    }
+    __shared__ double red[512];
+    double s1, s2;
+    int c;
+    if (blockIdx.x == 0 && threadIdx.x == 0) packed[2 * C] = n_local;
+    if (!partial_sums(partial, nblk, Cp, C, red, s1, s2, c)) return;
     double x0;
     if (layout == 1) x0 = (double)((const float*)x)[(size_t)c * S];
     else if (dtype == 1) x0 = (double)__builtin_bit_cast(float, (uint32_t)((const uint16_t*)x)[x_coff + c] << 16);
@@ -474,13 +497,10 @@ __global__ void bn_finish_kernel(const double* packed, int C, float eps, float m
 }
 
 __global__ void bn_bwd_combine_kernel(const float* partial, int nblk, int Cp, int C, float* packed) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        s1 += (double)partial[(size_t)k * 2 * Cp + c];
-        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
-    }
+    __shared__ double red[512];
+    double s1, s2;
+    int c;
+    if (!partial_sums(partial, nblk, Cp, C, red, s1, s2, c)) return;
     packed[c] = (float)s1;
     packed[C + c] = (float)s2;
 }
@@ -507,17 +527,14 @@ __global__ void bn_combine_finish_kernel(const float* partial, int nblk, int Cp,
                                          long S, int x_coff, double n_local, double* packed, float eps, float momentum,
                                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                                          long* num_batches, float* mean, float* invstd, float* a, float* b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) {
+    __shared__ double red[512];
+    double s1, s2;
+    int c;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         packed[2 * C] = n_local;
         if (num_batches != nullptr) *num_batches += 1;
     }
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        s1 += (double)partial[(size_t)k * 2 * Cp + c];
-        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
-    }
+    if (!partial_sums(partial, nblk, Cp, C, red, s1, s2, c)) return;
     double x0;
     if (layout == 1) x0 = (double)((const float*)x)[(size_t)c * S];
     else if (dtype == 1) x0 = (double)__builtin_bit_cast(float, (uint32_t)((const uint16_t*)x)[x_coff + c] << 16);
@@ -543,13 +560,10 @@ __global__ void bn_combine_finish_kernel(const float* partial, int nblk, int Cp,
 __global__ void bn_bwd_combine_finish_kernel(const float* partial, int nblk, int Cp, int C, const double* packed_fwd,
                                              const float* mean, const float* invstd, const float* a, float* k1, float* k2,
                                              float* k3, float* gw, float* gb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        s1 += (double)partial[(size_t)k * 2 * Cp + c];
-        s2 += (double)partial[(size_t)k * 2 * Cp + Cp + c];
-    }
+    __shared__ double red[512];
+    double s1, s2;
+    int c;
+    if (!partial_sums(partial, nblk, Cp, C, red, s1, s2, c)) return;
     const float n = (float)packed_fwd[2 * C];
     const float mg = (float)s1 / n, mgx = (float)s2 / n;
     const float sc = a[c], is = invstd[c], mu = mean[c];
@@ -779,7 +793,7 @@ int occd_bn_stats_combine(const occd_bn_args* a, double* packed, void* stream) {
     const int rc = fill(a, p, true);
     if (rc != OCCD_OK || packed == nullptr) return rc != OCCD_OK ? rc : OCCD_EINVAL;
     const double n = a->layout == 0 ? (double)a->rows : (double)a->batch * (double)a->S;
-    hipLaunchKernelGGL(bn_stats_combine_kernel, dim3((a->C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_stats_combine_kernel, dim3((a->C + 7) / 8), dim3(256), 0, (hipStream_t)stream,
                        (const float*)a->partial, a->nblk, p.C4 * 4, a->C, a->x, a->dtype, a->layout, (long)a->S, a->x_coff, n,
                        packed);
     return occd::check_launch();
@@ -842,7 +856,7 @@ int occd_bn_bwd_reduce(const occd_bn_args* a, void* stream) {
 
 int occd_bn_bwd_combine(const float* partial, int32_t nblk, int32_t C, float* packed, void* stream) {
     if (!partial || !packed || nblk <= 0 || C <= 0) return OCCD_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk,
+    hipLaunchKernelGGL(bn_bwd_combine_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                        ((C + 3) / 4) * 4, C, packed);
     return occd::check_launch();
 }
@@ -894,7 +908,7 @@ int occd_bn_stats_finish(const occd_bn_args* a, double* packed, float eps, float
     if (rc != OCCD_OK) return rc;
     if (!packed || !mean || !invstd || !av || !bv || (running_mean == nullptr) != (running_var == nullptr)) return OCCD_EINVAL;
     const double n = a->layout == 0 ? (double)a->rows : (double)a->batch * (double)a->S;
-    hipLaunchKernelGGL(bn_combine_finish_kernel, dim3((a->C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_combine_finish_kernel, dim3((a->C + 7) / 8), dim3(256), 0, (hipStream_t)stream,
                        (const float*)a->partial, a->nblk, p.C4 * 4, a->C, a->x, a->dtype, a->layout, (long)a->S, a->x_coff, n,
                        packed, eps, momentum, gamma, beta, running_mean, running_var, (long*)num_batches_tracked, mean, invstd,
                        av, bv);
@@ -905,7 +919,7 @@ int occd_bn_bwd_combine_finish(const float* partial, int32_t nblk, int32_t C, co
                                const float* invstd, const float* a, float* k1, float* k2, float* k3, float* gw, float* gb,
                                void* stream) {
     if (!partial || nblk <= 0 || C <= 0 || !packed_fwd || !mean || !invstd || !a || !k1 || !k2 || !k3) return OCCD_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_combine_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, partial, nblk,
+    hipLaunchKernelGGL(bn_bwd_combine_finish_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, nblk,
                        ((C + 3) / 4) * 4, C, packed_fwd, mean, invstd, a, k1, k2, k3, gw, gb);
     return occd::check_launch();
 }

@@ -433,7 +433,8 @@ int plan_b(const occd_conv3d_wgrad_args* a, int dtype, WgradBP& p, bool& cosplit
     lds = (size_t)p.ZT * p.grs + (size_t)a->kx * a->ky * p.pls;
     if (lds > 160 * 1024) return OCCD_ENOMEM;
     const long cogroups = cosplit ? (p.cot + 3) / 4 : p.cot;
-    long chunks = 1024 / (cogroups * p.cit);
+    // two workgroups per CU; every chunk costs a set of partial tiles (ntaps x 4 KB per (co, ci) tile pair) written and read back
+    long chunks = 512 / (cogroups * p.cit);
     if (chunks < 1) chunks = 1;
     if (chunks > units) chunks = units;
     long upc = (units + chunks - 1) / chunks;
