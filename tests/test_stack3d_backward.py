@@ -129,9 +129,18 @@ def relu_masks(record=None, replay=None, flips=None):
         assert next(it, None) is None, "the reference ran fewer ReLUs than the product"
 
 
-def run(name, device):
+def run(name, device, bf16=False):
     """-> (loss, {param name: grad}, dx3d) with the HIP Function classes (emulated on the CPU), and the ATen
-    float64 CPU reference of the same modules on the same ReLU masks."""
+    float64 CPU reference of the same modules on the same ReLU masks.  bf16: autograd3d.BF16_MFMA (K2b / K8b)."""
+    from occdepth_amd import autograd3d
+    old_mode = autograd3d.set_bf16_mfma(bf16)
+    try:
+        return _run(name, device, bf16)
+    finally:
+        autograd3d.set_bf16_mfma(old_mode)
+
+
+def _run(name, device, bf16):
     from occdepth_amd import autograd3d
     m, spec = build_stack(name)
     x = gc.randn(spec["x"], ("stack3d_bwd", name))
@@ -165,13 +174,18 @@ def run(name, device):
         autograd3d._hip_ok = saved
     n_relu = sum(int(k.numel()) for k in masks)
     print(f"{name}: {len(masks)} ReLU calls, {n_relu} inputs, mask flips float32-product vs float64: {flips}")
-    assert sum(n for n, _ in flips) <= 1e-5 * n_relu + 2 and all(r < 1e-5 for _, r in flips), flips
+    if bf16:       # operands rounded to 2^-9: units within that distance of their kink flip; they must stay a small minority
+        assert sum(n for n, _ in flips) <= 2e-2 * n_relu and all(r < 0.15 for _, r in flips), flips[:10]   # measured: 0.8 %, 0.065
+    else:
+        assert sum(n for n, _ in flips) <= 1e-5 * n_relu + 2 and all(r < 1e-5 for _, r in flips), flips
     return (loss, dict(m.named_parameters()), xp.grad), (loss_r, dict(ref.named_parameters()), xr.grad)
 
 
-def compare(name, got, want):
+def compare(name, got, want, elem_tol=ELEM_TOL, norm_tol=NORM_TOL, loss_rel=2e-5, l2=False):
+    """l2: `elem_tol` bounds ||g - r|| / ||r|| per tensor instead of max |g - r| / rms(r) (bf16 mode: the maximum over
+    millions of elements of a heavy-tailed rounding error is not a statement about the tensor)."""
     (loss, params, dx), (loss_r, params_r, dx_r) = got, want
-    assert float(loss.detach()) == pytest.approx(float(loss_r.detach()), rel=2e-5)
+    assert float(loss.detach()) == pytest.approx(float(loss_r.detach()), rel=loss_rel)
     rows = []
     items = [(k, p.grad, params_r[k].grad) for k, p in params.items()] + [("x3d", dx, dx_r)]
     for k, g, r in items:
@@ -181,13 +195,14 @@ def compare(name, got, want):
         assert g is not None, k
         g = g.detach().double().cpu()
         rms = float(r.norm()) / np.sqrt(r.numel())
-        rows.append((float((g - r).abs().max()) / rms, abs(float(g.norm()) / float(r.norm()) - 1.0), k))
+        err = float((g - r).norm()) / float(r.norm()) if l2 else float((g - r).abs().max()) / rms
+        rows.append((err, abs(float(g.norm()) / float(r.norm()) - 1.0), k))
     rows.sort(reverse=True)
-    print(f"{name}: worst |dgrad|/rms(grad) = {rows[0][0]:.2e} ({rows[0][2]}); worst norm error = "
+    print(f"{name}: worst {'||dgrad||/||grad||' if l2 else '|dgrad|/rms(grad)'} = {rows[0][0]:.2e} ({rows[0][2]}); worst norm error = "
           f"{max(r[1] for r in rows):.2e}; {len(rows)} tensors")
     for e, n, k in rows[:5]:
         print(f"   {k}: elem {e:.2e} norm {n:.2e}")
-    bad = [(k, e, n) for e, n, k in rows if e > ELEM_TOL or n > NORM_TOL]
+    bad = [(k, e, n) for e, n, k in rows if e > elem_tol or n > norm_tol]
     assert not bad, bad[:10]
     assert len(rows) > 100
 
@@ -203,3 +218,23 @@ def test_stack3d_backward_hip_vs_aten_float64_gpu(name, hip_lib):
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     compare(name, *run(name, "cuda"))
+
+
+# bf16 mode (BASELINE configs[3]): the same stack, every convolution forward / dgrad / wgrad on the bf16 matrix pipe, against
+# the SAME float64 reference on the product's linear piece.  Stated tolerance: operands carry 2^-9 relative rounding, a
+# K-term dot product averages it down by ~1/sqrt(K), ~25 layers and the flipped ReLU units (0.8 % of them) stack it up again.
+# Stated tolerance, per gradient tensor: ||g - g64|| / ||g64|| < 0.3 and | ||g|| / ||g64|| - 1 | < 0.2, loss within 5e-3.
+# Measured on the emulation (this file's CPU variant) and on the kernels: worst tensor 0.18 (a 16-element BatchNorm
+# weight), the convolution weights 0.05 - 0.15, norms within 0.12 (profiles/r03_bf16_stack3d_backward.txt).
+BF16_ELEM_TOL, BF16_NORM_TOL = 0.3, 0.2
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_stack3d_backward_bf16_mode_cpu(name):
+    compare(name, *run(name, "cpu", bf16=True), elem_tol=BF16_ELEM_TOL, norm_tol=BF16_NORM_TOL, loss_rel=5e-3, l2=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_stack3d_backward_bf16_mode_gpu(name, hip_lib):
+    compare(name, *run(name, "cuda", bf16=True), elem_tol=BF16_ELEM_TOL, norm_tol=BF16_NORM_TOL, loss_rel=5e-3, l2=True)
