@@ -479,6 +479,13 @@ int occd_pack_weights_bf16(const float* w, const float* scale, void* wpk,
                            int32_t cout, int32_t cin, int32_t kx, int32_t ky, int32_t kz,
                            int32_t layout, void* stream);
 int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream);
+/* Opt-in experiment: dtype 2 of occd_conv3d_bf16_fwd = float32 tensors, both operands split into three
+ * bf16 terms (x = hi + mid + lo), six bf16 MFMAs per K step (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid), fp32
+ * accumulate: float32-level accuracy at 6/16 of the fp32-MFMA time.  Its weight image (3 x
+ * occd_packed_weight_bf16_elems() elements: hi | mid | lo) comes from occd_pack_weights_bf16x3.                     */
+int occd_pack_weights_bf16x3(const float* w, const float* scale, void* wpk,
+                             int32_t cout, int32_t cin, int32_t kx, int32_t ky, int32_t kz,
+                             int32_t layout, void* stream);
 int64_t occd_conv3d_wgrad_bf16_workspace_floats(const occd_conv3d_wgrad_args* a, int32_t dtype);
 int occd_conv3d_wgrad_bf16(const occd_conv3d_wgrad_args* a, int32_t dtype, void* stream);
 

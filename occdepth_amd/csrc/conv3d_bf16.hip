@@ -65,10 +65,32 @@ __device__ __forceinline__ f32x4 unpack_lo(u32x2 v) {       // 4 bf16 -> 4 float
 }
 
 constexpr int kRSB = 80;   // LDS row stride in bytes: 32 bf16 channels + 16 B pad
+constexpr int kRSB3 = 208; // SPLIT = 3: three bf16 planes (hi, mid, lo) of the 32 channels + 16 B pad (13 slots: odd)
 
-template <int MT, int NT, int WM, int WN, bool IN_BF16, bool OUT_BF16>
+// x = hi + mid + lo exactly (each bf16, 8 significant bits: 24 together) for every float32 x whose low parts do not
+// underflow; the six products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid then reproduce x*w to ~2^-24 relative.
+__device__ __forceinline__ void split3(f32x4 a, f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+    bf16x8 h = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    float r[8] = {a.x - (float)h[0], a.y - (float)h[1], a.z - (float)h[2], a.w - (float)h[3],
+                  b.x - (float)h[4], b.y - (float)h[5], b.z - (float)h[6], b.w - (float)h[7]};
+    bf16x8 m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m[j] = (__bf16)r[j];
+        l[j] = (__bf16)(r[j] - (float)m[j]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    mid = __builtin_bit_cast(u32x4, m);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+// SPLIT = 1: plain bf16 operands.  SPLIT = 3 (opt-in experiment): float32 activations and weights as
+// three bf16 terms each, six MFMAs per K step instead of one -- float32-level accuracy at 6/16 of the fp32-MFMA time.
+template <int MT, int NT, int WM, int WN, bool IN_BF16, bool OUT_BF16, int SPLIT = 1>
 __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p) {
     constexpr int NTH = WM * WN * 64;
+    constexpr int RSB = SPLIT == 3 ? kRSB3 : kRSB;
+    static_assert(SPLIT == 1 || (SPLIT == 3 && !IN_BF16 && !OUT_BF16), "the 3-way split takes and returns float32");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
 
     const int lane = threadIdx.x & 63;
@@ -101,7 +123,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
         const bool in_tile = yl < (uint32_t)p.TY;
         yl = in_tile ? yl : 0u;
         zl = in_tile ? zl : 0u;
-        rowbase[mt] = (int)((yl * p.SY) * p.ZIN + zl * p.SZ) * kRSB + h * 16;
+        rowbase[mt] = (int)((yl * p.SY) * p.ZIN + zl * p.SZ) * RSB + h * 16;
     }
     int wofs[NT];      // u32x4 index of each owned N tile inside one (tap, k16) weight record row
 #pragma unroll
@@ -118,13 +140,24 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
     const int y_in0 = yt * p.TY * p.SY - p.PY;
     const int z_in0 = zt * p.TZ * p.SZ - p.PZ;
     const size_t w_step = (size_t)p.NTtot * 64;          // u32x4 per (tap, k16)
+    const size_t w_img = (size_t)p.KX * p.KY * p.KZ * p.K16tot * w_step;   // u32x4 per split image of the weights
     const u32x4* const wlane = p.wpk + lane;
     const int rows = p.YIN * p.ZIN;
 
-#define OCCD_MFMA_BLOCK()                                                                      \
+#define OCCD_MFMA1(WS, XS)                                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[nt]),          \
-                                                __builtin_bit_cast(bf16x8, a_cur[mt]), acc[mt][nt], 0, 0, 0)
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b_cur[nt][WS]),                         \
+                                                __builtin_bit_cast(bf16x8, a_cur[mt][XS]), acc[mt][nt], 0, 0, 0)
+    // smallest terms first: (mid, mid), (hi, lo), (lo, hi), (hi, mid), (mid, hi), (hi, hi)
+#define OCCD_MFMA_BLOCK()                                                  \
+    if (SPLIT == 3) {                                                      \
+        OCCD_MFMA1(SPLIT == 3 ? 1 : 0, SPLIT == 3 ? 1 : 0);                \
+        OCCD_MFMA1(0, SPLIT == 3 ? 2 : 0);                                 \
+        OCCD_MFMA1(SPLIT == 3 ? 2 : 0, 0);                                 \
+        OCCD_MFMA1(0, SPLIT == 3 ? 1 : 0);                                 \
+        OCCD_MFMA1(SPLIT == 3 ? 1 : 0, 0);                                 \
+    }                                                                      \
+    OCCD_MFMA1(0, 0)
 
     for (int kx = 0; kx < p.KX; ++kx) {
         const int xi = xo * p.SX - p.PX + kx * p.DX;
@@ -137,14 +170,16 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
             const int S = p.KY * p.KZ * k16n;
             const u32x4* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.K16tot + (c0 >> 4)) * w_step;
 
-            u32x4 b_cur[NT];   // first B fragments fly while the slab is staged
+            u32x4 b_cur[NT][SPLIT];   // first B fragments fly while the slab is staged
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b_cur[nt] = wp[wofs[nt]];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int sp = 0; sp < SPLIT; ++sp) b_cur[nt][sp] = wp[wofs[nt] + sp * w_img];
 
             __syncthreads();   // previous slab fully consumed
             const int F = rows << sh;
             for (int f0 = 0; f0 < F; f0 += NTH * 4) {
-                u32x4 v[4];
+                u32x4 v[4][SPLIT];
                 int dst[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -160,38 +195,45 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
                     const int yc = min(max(y, 0), p.Y - 1), zc = min(max(z, 0), p.Z - 1);
                     const int cc = min(c, p.cin8 - 8);
                     const size_t e = plane + ((size_t)yc * p.Z + zc) * p.in_cs + cc;
-                    u32x4 w;
+                    u32x4 w[SPLIT];
                     if (IN_BF16) {
-                        w = *(const u32x4*)((const uint16_t*)p.in + e);
+                        w[0] = *(const u32x4*)((const uint16_t*)p.in + e);
                         if (p.act_in == OCCD_ACT_RELU) {   // bf16 relu on the packed pairs: clear negative halves
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                uint32_t d = w[q];
+                                uint32_t d = w[0][q];
                                 if (d & 0x80000000u) d &= 0x0000ffffu;
                                 if (d & 0x00008000u) d &= 0xffff0000u;
-                                w[q] = d;
+                                w[0][q] = d;
                             }
                         }
                     } else {
                         f32x4 lo = *(const f32x4*)((const float*)p.in + e);
                         f32x4 hi = *(const f32x4*)((const float*)p.in + e + 4);
                         if (p.act_in == OCCD_ACT_RELU) { lo = relu4(lo); hi = relu4(hi); }
-                        w = pack_bf16x8(lo, hi);
+                        if (SPLIT == 3) split3(lo, hi, w[0], w[SPLIT == 3 ? 1 : 0], w[SPLIT == 3 ? 2 : 0]);
+                        else w[0] = pack_bf16x8(lo, hi);
                     }
-                    v[u] = ok ? w : u32x4{0u, 0u, 0u, 0u};
-                    dst[u] = f < F ? (int)row * kRSB + c8 * 16 : -1;
+#pragma unroll
+                    for (int sp = 0; sp < SPLIT; ++sp) v[u][sp] = ok ? w[sp] : u32x4{0u, 0u, 0u, 0u};
+                    dst[u] = f < F ? (int)row * RSB + c8 * 16 : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (dst[u] >= 0) *(u32x4*)(slab + dst[u]) = v[u];
+                    if (dst[u] >= 0) {
+#pragma unroll
+                        for (int sp = 0; sp < SPLIT; ++sp) *(u32x4*)(slab + dst[u] + sp * 64) = v[u][sp];
+                    }
             }
             __syncthreads();
 
             int ky = 0, kz = 0, kl = 0;
             int lds_off = 0;   // bytes
-            u32x4 a_cur[MT];
+            u32x4 a_cur[MT][SPLIT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a_cur[mt] = *(const u32x4*)(slab + rowbase[mt]);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int sp = 0; sp < SPLIT; ++sp) a_cur[mt][sp] = *(const u32x4*)(slab + rowbase[mt] + sp * 64);
 
             for (int s = 0; s < S - 1; ++s) {
                 ++kl;
@@ -201,22 +243,31 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
                     kl = 0;
                     wp += (size_t)(p.K16tot - k16n) * w_step;
                     if (++kz == p.KZ) { kz = 0; ++ky; }
-                    lds_off = (ky * p.DY * p.ZIN + kz * p.DZ) * kRSB;
+                    lds_off = (ky * p.DY * p.ZIN + kz * p.DZ) * RSB;
                 }
-                u32x4 a_nxt[MT], b_nxt[NT];
+                u32x4 a_nxt[MT][SPLIT], b_nxt[NT][SPLIT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = *(const u32x4*)(slab + rowbase[mt] + lds_off);
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = wp[wofs[nt]];
+                    for (int sp = 0; sp < SPLIT; ++sp) a_nxt[mt][sp] = *(const u32x4*)(slab + rowbase[mt] + lds_off + sp * 64);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int sp = 0; sp < SPLIT; ++sp) b_nxt[nt][sp] = wp[wofs[nt] + sp * w_img];
                 OCCD_MFMA_BLOCK();
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+                    for (int sp = 0; sp < SPLIT; ++sp) a_cur[mt][sp] = a_nxt[mt][sp];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int sp = 0; sp < SPLIT; ++sp) b_cur[nt][sp] = b_nxt[nt][sp];
             }
             OCCD_MFMA_BLOCK();
         }
     }
+#undef OCCD_MFMA1
 #undef OCCD_MFMA_BLOCK
 
     // ---------------- epilogue (the layout of K2's: lane -> voxel li of the M tile, registers -> couts
@@ -264,9 +315,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
 
 // ---------------------------------------------------------------- weight packing (fp32 master weights -> bf16 fragments)
 // wpk[tap][k16][nt][lane][j]: cout = nt * 32 + (lane & 31), cin = k16 * 16 + (lane >> 5) * 8 + j
+// nsplit = 3: three consecutive images hi | mid | lo of the float32 weight (see split3)
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                          uint16_t* __restrict__ wpk, int cout, int cin, int taps, int K16, int NT,
-                                         int layout, long total) {
+                                         int layout, long total, int nsplit) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = i & 7;
@@ -284,30 +336,40 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
         else v = w[(size_t)ci * cout + co];
         if (scale != nullptr) v *= scale[co];
     }
-    wpk[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    const __bf16 hi = (__bf16)v;
+    wpk[i] = __builtin_bit_cast(uint16_t, hi);
+    if (nsplit == 3) {
+        const float r = v - (float)hi;
+        const __bf16 mid = (__bf16)r;
+        wpk[i + total] = __builtin_bit_cast(uint16_t, mid);
+        wpk[i + 2 * total] = __builtin_bit_cast(uint16_t, (__bf16)(r - (float)mid));
+    }
 }
 
 struct VariantB {
     int MT, NT, WM, WN;
-    void (*kern[2])(const ConvBP);   // [0] fp32 in / fp32 out, [1] bf16 in / bf16 out
+    void (*kern[3])(const ConvBP);   // [0] fp32 in / fp32 out, [1] bf16 in / bf16 out, [2] fp32 with the 3-way split (or null)
 };
 
 #define OCCD_VARIANT_B(MT, NT, WM, WN) \
-    VariantB { MT, NT, WM, WN, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true> } }
+    VariantB { MT, NT, WM, WN, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true>, nullptr } }
+#define OCCD_VARIANT_B3(MT, NT, WM, WN) \
+    VariantB { MT, NT, WM, WN, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true>, \
+                                 conv3d_bf16_kernel<MT, NT, WM, WN, false, false, 3> } }
 
 const VariantB kVariantsB[] = {
-    OCCD_VARIANT_B(4, 1, 4, 1),   // 0: M512 x N32
-    OCCD_VARIANT_B(2, 1, 4, 1),   // 1: M256 x N32
-    OCCD_VARIANT_B(1, 1, 4, 1),   // 2: M128 x N32
-    OCCD_VARIANT_B(4, 2, 4, 1),   // 3: M512 x N64
-    OCCD_VARIANT_B(2, 2, 4, 1),   // 4: M256 x N64
-    OCCD_VARIANT_B(4, 2, 2, 2),   // 5: M256 x N128
-    OCCD_VARIANT_B(2, 2, 2, 2),   // 6: M128 x N128
-    OCCD_VARIANT_B(1, 2, 2, 2),   // 7: M64  x N128
+    OCCD_VARIANT_B(4, 1, 4, 1),    // 0: M512 x N32
+    OCCD_VARIANT_B3(2, 1, 4, 1),   // 1: M256 x N32
+    OCCD_VARIANT_B3(1, 1, 4, 1),   // 2: M128 x N32
+    OCCD_VARIANT_B(4, 2, 4, 1),    // 3: M512 x N64
+    OCCD_VARIANT_B3(2, 2, 4, 1),   // 4: M256 x N64
+    OCCD_VARIANT_B(4, 2, 2, 2),    // 5: M256 x N128
+    OCCD_VARIANT_B3(2, 2, 2, 2),   // 6: M128 x N128
+    OCCD_VARIANT_B3(1, 2, 2, 2),   // 7: M64  x N128
 };
 constexpr int kNumVariantsB = sizeof(kVariantsB) / sizeof(kVariantsB[0]);
 constexpr size_t kMaxLdsB = 160 * 1024;
-bool g_attr_set_b[kNumVariantsB][2] = {};
+bool g_attr_set_b[kNumVariantsB][3] = {};
 
 struct TilingB {
     int TY, TZ, YIN, ZIN, ytiles, ztiles, ngroups;
@@ -318,7 +380,7 @@ struct TilingB {
 
 // Tile of mwg output positions as TY x TZ: the candidate that stages the fewest input rows per launch (halo + ragged
 // edges) among those that fit LDS.  2-D images (Zo = W >> mwg) get a TY > 1 tile instead of a one-row strip.
-bool plan_b(const occd_conv3d_args* a, const VariantB& v, int NTtot, TilingB* best) {
+bool plan_b(const occd_conv3d_args* a, const VariantB& v, int NTtot, TilingB* best, int rsb) {
     const int mwg = v.MT * v.WM * 32;
     bool found = false;
     int cands[16];
@@ -336,7 +398,7 @@ bool plan_b(const occd_conv3d_args* a, const VariantB& v, int NTtot, TilingB* be
         t.ZIN = (t.TZ - 1) * a->sz + (a->kz - 1) * a->dz + 1;
         t.ytiles = (a->Yo + t.TY - 1) / t.TY;
         t.ztiles = (a->Zo + t.TZ - 1) / t.TZ;
-        t.lds = (size_t)t.YIN * t.ZIN * kRSB;
+        t.lds = (size_t)t.YIN * t.ZIN * rsb;
         const int nwg_n = v.NT * v.WN;
         t.ngroups = (NTtot + nwg_n - 1) / nwg_n;
         t.nwg = (long)a->Xo * t.ytiles * t.ztiles;
@@ -357,8 +419,22 @@ extern "C" int64_t occd_packed_weight_bf16_elems(int32_t cout, int32_t cin, int3
     return (int64_t)taps * K16 * NT * 512;
 }
 
+static int pack_bf16(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin, int32_t kx, int32_t ky,
+                     int32_t kz, int32_t layout, int nsplit, void* stream);
+
 extern "C" int occd_pack_weights_bf16(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
                                       int32_t kx, int32_t ky, int32_t kz, int32_t layout, void* stream) {
+    return pack_bf16(w, scale, wpk, cout, cin, kx, ky, kz, layout, 1, stream);
+}
+
+// three images (hi | mid | lo), 3 * occd_packed_weight_bf16_elems() elements: the weight operand of the 3-way split
+extern "C" int occd_pack_weights_bf16x3(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
+                                        int32_t kx, int32_t ky, int32_t kz, int32_t layout, void* stream) {
+    return pack_bf16(w, scale, wpk, cout, cin, kx, ky, kz, layout, 3, stream);
+}
+
+static int pack_bf16(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin, int32_t kx, int32_t ky,
+                     int32_t kz, int32_t layout, int nsplit, void* stream) {
     if (!w || !wpk || layout < 0 || layout > 2) return OCCD_EINVAL;
     const int taps = kx * ky * kz;
     const int64_t total = occd_packed_weight_bf16_elems(cout, cin, taps);
@@ -368,14 +444,18 @@ extern "C" int occd_pack_weights_bf16(const float* w, const float* scale, void* 
     const long blocks = (total + th - 1) / th;
     occd::ProfScope prof("pack_weights_bf16", (hipStream_t)stream, 0.0, (double)total * 6);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
-                       (uint16_t*)wpk, cout, cin, taps, K16, NT, layout, (long)total);
+                       (uint16_t*)wpk, cout, cin, taps, K16, NT, layout, (long)total, nsplit);
     return occd::check_launch();
 }
 
 // `a->in`, `a->out`, `a->res1`, `a->res2` point at fp32 (dtype 0) or bf16 (dtype 1) channels-last rows -- all four
 // the same type --, `a->wpk` at the image of occd_pack_weights_bf16, `a->bias` at fp32.  *_cs / *_coff count ELEMENTS.
+// dtype 2 = float32 tensors with the 3-way bf16 split of both operands (wpk from occd_pack_weights_bf16x3): float32-level
+// accuracy on the bf16 matrix pipe, an opt-in experiment beside the exact-fp32 kernels.
 extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream) {
-    if (!a || !a->in || !a->wpk || !a->out || dtype < 0 || dtype > 1) return OCCD_EINVAL;
+    if (!a || !a->in || !a->wpk || !a->out || dtype < 0 || dtype > 2) return OCCD_EINVAL;
+    const int ksel = dtype;                           // kernel table column
+    if (dtype == 2) dtype = 0;                        // storage: float32
     if (a->batch <= 0 || a->X <= 0 || a->Y <= 0 || a->Z <= 0 || a->cin <= 0 || a->cout <= 0) return OCCD_EINVAL;
     if (a->kx <= 0 || a->ky <= 0 || a->kz <= 0 || a->sx <= 0 || a->sy <= 0 || a->sz <= 0) return OCCD_EINVAL;
     if (a->Xo <= 0 || a->Yo <= 0 || a->Zo <= 0) return OCCD_EINVAL;
@@ -417,11 +497,13 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     } else {
         order[n++] = 5; order[n++] = 6; order[n++] = 7;
     }
+    const int rsb = ksel == 2 ? kRSB3 : kRSB;
     int pick = -1;
     TilingB til{};
     for (int i = 0; i < n; ++i) {
         TilingB t{};
-        if (!plan_b(a, kVariantsB[order[i]], NTtot, &t)) continue;
+        if (kVariantsB[order[i]].kern[ksel] == nullptr) continue;
+        if (!plan_b(a, kVariantsB[order[i]], NTtot, &t, rsb)) continue;
         pick = order[i];
         til = t;
         if (t.nwg * t.ngroups * a->batch >= 512) break;   // else keep refining to the finest fit
@@ -446,12 +528,12 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     p.div_zin = occd::make_fastdiv(til.ZIN); p.div_tz = occd::make_fastdiv(til.TZ);
     p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
 
-    void (*kern)(const ConvBP) = v.kern[dtype];
-    if (til.lds > 64 * 1024 && !g_attr_set_b[pick][dtype]) {
+    void (*kern)(const ConvBP) = v.kern[ksel];
+    if (til.lds > 64 * 1024 && !g_attr_set_b[pick][ksel]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kMaxLdsB) != hipSuccess)
             return OCCD_ELAUNCH;
-        g_attr_set_b[pick][dtype] = true;
+        g_attr_set_b[pick][ksel] = true;
     }
     const double taps = (double)a->kx * a->ky * a->kz;
     const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
@@ -459,7 +541,8 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     const double bytes = (double)esz * ((double)a->batch * a->X * a->Y * a->Z * a->cin +
                                         pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr))) +
                          2.0 * taps * a->cin * a->cout;
-    occd::ProfScope prof(dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16", (hipStream_t)stream, flops, bytes);
+    occd::ProfScope prof(ksel == 2 ? "conv3d_bf16x3" : dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16", (hipStream_t)stream, flops,
+                         bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
                        dim3(v.WM * v.WN * 64), til.lds, (hipStream_t)stream, p);
     return occd::check_launch();

@@ -156,6 +156,8 @@ EXPORTS = {
     "occd_pack_weights_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_int32, c_void_p]),
     "occd_conv3d_bf16_fwd": (c_int32, [POINTER(Conv3dArgs), c_int32, c_void_p]),
+    "occd_pack_weights_bf16x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                           c_int32, c_void_p]),
     "occd_conv3d_wgrad_bf16_workspace_floats": (c_int64, [POINTER(WgradArgs), c_int32]),
     "occd_conv3d_wgrad_bf16": (c_int32, [POINTER(WgradArgs), c_int32, c_void_p]),
     "occd_bn_blocks": (c_int32, [POINTER(BnArgs)]),
@@ -371,8 +373,9 @@ def _storage_code(dtype):
     raise RuntimeError(f"the bf16-MFMA kernels take float32 or bfloat16 activations, got {dtype}")
 
 
-def pack_weights_bf16(w, scale=None, layout=0):
-    """fp32 master weights -> the bf16 fragment image of K2b (shapes / layouts as `pack_weights`)."""
+def pack_weights_bf16(w, scale=None, layout=0, split3=False):
+    """fp32 master weights -> the bf16 fragment image of K2b (shapes / layouts as `pack_weights`); split3: the three images
+    hi | mid | lo of the 3-way split experiment (conv3d_bf16(..., split3=True))."""
     if layout == 2:
         cin, cout = w.shape
         k = (1, 1, 1)
@@ -383,24 +386,29 @@ def pack_weights_bf16(w, scale=None, layout=0):
     n = load().occd_packed_weight_bf16_elems(cout, cin, k[0] * k[1] * k[2])
     if n <= 0:
         raise RuntimeError("occd_packed_weight_bf16_elems: bad shape")
-    out = torch.empty(n, device=w.device, dtype=torch.bfloat16)
+    out = torch.empty(3 * n if split3 else n, device=w.device, dtype=torch.bfloat16)
     sc = scale.detach().float().contiguous() if scale is not None else None
-    _check(load().occd_pack_weights_bf16(_f32(w, "w"), _f32(sc, "scale") if sc is not None else None, _ptr(out, "wpk"),
-                                         cout, cin, k[0], k[1], k[2], layout, _stream()), "occd_pack_weights_bf16")
+    fn = load().occd_pack_weights_bf16x3 if split3 else load().occd_pack_weights_bf16
+    _check(fn(_f32(w, "w"), _f32(sc, "scale") if sc is not None else None, _ptr(out, "wpk"),
+              cout, cin, k[0], k[1], k[2], layout, _stream()), "occd_pack_weights_bf16")
     return out
 
 
 def conv3d_bf16(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0),
                 res1=None, res2=None, act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1),
-                o_off=(0, 0, 0), cin=None, tile_hint=0):
+                o_off=(0, 0, 0), cin=None, tile_hint=0, split3=False):
     """K2b: `conv3d` on the bf16 matrix pipe (fp32 accumulate).  x / out / res1 / res2 are all float32 Vox tensors
-    (converted to bf16 while staging) or all bfloat16 ones; wpk = pack_weights_bf16(w)."""
+    (converted to bf16 while staging) or all bfloat16 ones; wpk = pack_weights_bf16(w).
+    split3 (float32 tensors, wpk = pack_weights_bf16(w, split3=True)): the 3-way split experiment, float32-level accuracy."""
     if wpk.dtype != torch.bfloat16:
         raise RuntimeError("conv3d_bf16 needs the bf16 weight image of pack_weights_bf16")
+    if split3 and x.buf.dtype != torch.float32:
+        raise RuntimeError("the 3-way split takes float32 tensors")
     ptr = _act_ptr(x.buf.dtype)
     a = _conv3d_args(x, _ptr(wpk, "wpk"), bias, cout, kernel, out, stride, dilation, padding, res1, res2, act_in, act_out,
                      out_pos, o_stride, o_off, cin, tile_hint, ptr)
-    _check(load().occd_conv3d_bf16_fwd(ctypes.byref(a), _storage_code(x.buf.dtype), _stream()), "occd_conv3d_bf16_fwd")
+    _check(load().occd_conv3d_bf16_fwd(ctypes.byref(a), 2 if split3 else _storage_code(x.buf.dtype), _stream()),
+           "occd_conv3d_bf16_fwd")
     return out
 
 

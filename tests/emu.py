@@ -77,11 +77,14 @@ def _bf16(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def pack_weights_bf16(w, scale=None, layout=0):
-    """K2b's weight image: the float32 master weights rounded to bf16 (kept as a float32 tensor of bf16 values)."""
+def pack_weights_bf16(w, scale=None, layout=0, split3=False):
+    """K2b's weight image: the float32 master weights rounded to bf16 (kept as a float32 tensor of bf16 values); the
+    3-way split keeps float32 (hi + mid + lo carries 24 bits)."""
     pk = pack_weights(w, scale, layout)
-    pk.w = _bf16(pk.w)
+    if not split3:
+        pk.w = _bf16(pk.w)
     pk.bf16 = True
+    pk.split3 = split3
     return pk
 
 
@@ -90,6 +93,10 @@ def conv3d_bf16(x, wpk, bias, cout, kernel, out, **kw):
     assert getattr(wpk, "bf16", False), "conv3d_bf16 needs pack_weights_bf16's image"
     act_in = kw.get("act_in", 0)
     assert act_in in (0, ACT_RELU)
+    if kw.pop("split3", False):
+        assert wpk.split3
+        return conv3d(x, wpk, bias, cout, kernel, out, **kw)
+    assert not wpk.split3
     xb = Vox(_bf16(x.buf.float()), x.C, x.coff)
     return conv3d(xb, wpk, bias, cout, kernel, out, **kw)
 

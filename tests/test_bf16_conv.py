@@ -108,6 +108,35 @@ def test_conv3d_bf16_all_variants(hip, hint):
     assert err < 2e-5, (hint, err)
 
 
+SPLIT3_CASES = ["head_d1", "head_d2", "head_d3", "classes_34_20", "k1_64_16", "k3_s2", "aspp_256", "ragged_5_20", "nyu_z15",
+                "dec_80_80"]
+
+
+@pytest.mark.parametrize("name", SPLIT3_CASES)
+def test_conv3d_bf16x3_reaches_float32_accuracy(hip, name):
+    """The 3-way split experiment (x = hi + mid + lo, six bf16 MFMAs per K step): against float64 on the UN-rounded
+    operands the error must be at float32 level (the dropped terms are <= 2^-24 relative per product; bound 2e-6 of the
+    output maximum, the fp32-MFMA kernel K2 measures ~5e-7 on the same inputs) -- not bf16's 4e-3."""
+    from occdepth_amd.fused import _pad_bias
+    B, cin, cout, dims, k, s, p, d = FWD_CASES[name]
+    x, w, b, r1, odims = fwd_tensors(name)
+    ref = F.relu(F.conv3d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d) + r1.double())
+    wpk = hip.pack_weights_bf16(w.to(DEV), split3=True)
+    out = hip.Vox.empty(B, odims, cout, DEV)
+    hip.conv3d_bf16(vox_of(hip, x, torch.float32), wpk, _pad_bias(b.to(DEV), cout), cout, k, out, stride=s, dilation=d,
+                    padding=p, res1=vox_of(hip, r1, torch.float32), act_out=hip.ACT_RELU, split3=True)
+    err = float((out.ncdhw().cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, (name, err)
+    # the exact-fp32 kernel on the same inputs, for the record next to it
+    out32 = hip.Vox.empty(B, odims, cout, DEV)
+    hip.conv3d(vox_of(hip, x, torch.float32), hip.pack_weights(w.to(DEV)), _pad_bias(b.to(DEV), cout), cout, k, out32,
+               stride=s, dilation=d, padding=p, res1=vox_of(hip, r1, torch.float32), act_out=hip.ACT_RELU)
+    err32 = float((out32.ncdhw().cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"bf16x3 {name}: err {err:.2e} (fp32 MFMA {err32:.2e})")
+    if out.cs > cout:
+        assert float(out.buf[..., cout:].abs().max()) == 0.0
+
+
 def test_conv3d_bf16_output_scatter_phases(hip):
     """ConvTranspose3d(k3, s2, p1, op1) as 8 sub-pixel phase convolutions through the output scatter (the data gradient
     of a strided convolution and the forward of `Upsample` in the bf16 step)."""

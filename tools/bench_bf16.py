@@ -57,6 +57,9 @@ def bench_fwd():
         if cin * cout * k[0] * k[1] * k[2] <= 2784 * 320 * 9:
             wf = hip.pack_weights(w)
             fns["fp32 mfma (K2 / K2s)"] = lambda: hip.conv3d(x32, wf, None, cout, k, o32, dilation=(d,) * 3, padding=pad)
+            w3 = hip.pack_weights_bf16(w, split3=True)
+            fns["bf16x3 split / fp32 store"] = lambda: hip.conv3d_bf16(x32, w3, None, cout, k, o32, dilation=(d,) * 3,
+                                                                        padding=pad, split3=True)
         ms = time_many(fns, rounds=3, iters=4)
         fl = 2.0 * odims[0] * odims[1] * odims[2] * k[0] * k[1] * k[2] * cin * cout
         vox_n = dims[0] * dims[1] * dims[2]
