@@ -40,9 +40,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense v_mfma_f32_32x32x16_bf16 (~2.5 PF, 16x the fp32 MFMA rate)
 HEAD_CONV_TAG = ":32>32 k333 s111"   # 7 launches/frame, 2*256*256*32*27*32*32 = 115.96 GFLOP each
 STACK3D_GFLOP = 1068.3                 # conv 1059.74 + CRP bmm 8.59
 LIFT_MBYTES = 249.0                    # BASELINE.md / SURVEY.md 8(d) algorithmic HBM bytes of the lift
+LIFT_PROJ_MBYTES = 240.4               # the fused lift (occd_lift_proj_fwd): no 8.9 MB of int64 tables / masks; 67.1 written
+#                                        + 167.3 gathered + 6.0 depth volumes
 
 
 def log(*a):
@@ -297,6 +300,9 @@ def _forward(args, world, rank, device, dist):
     assert out["ssc_logit"].shape == (1, 20, 256, 256, 32)
     graph_flags = {"batch_views": bool(model.batch_views), "graph_2d": bool(model.graph_2d),
                    "graph_all": bool(model.graph_all)}
+    from occdepth_amd import fused as _fused
+    if _fused.BF16X3:      # opt-in experiment: the line is NOT the exact-fp32 default and says so
+        graph_flags["bf16x3_split_convs"] = True
 
     # ---- untimed diagnostic passes (the same model, the same frame), eager so that every launch can be bracketed:
     # (1) per-launch HIP events on the launch stream (occd_prof_*) -> roofline.achieved of the head convolution;
@@ -342,6 +348,8 @@ def _forward(args, world, rank, device, dist):
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("conv3d_")) / prof_steps
     lift_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("sfa_lift")) / prof_steps
+    lift_fused = any(k.startswith("sfa_lift_proj") for k in prof.rows)
+    lift_mb = LIFT_PROJ_MBYTES if lift_fused else LIFT_MBYTES
     traffic, traffic_src = None, None
     for name, what in (("head_conv_hbm_bytes_inframe.json", "in-frame launches of this command (incl. the residual rows conv2.* "
                                                             "read): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, separate passes"),
@@ -373,9 +381,20 @@ def _forward(args, world, rank, device, dist):
                     "frac_of_fp32_mfma_peak": STACK3D_GFLOP / conv_ms / FP32_MFMA_PEAK_TFLOPS if conv_ms else 0.0},
         "stages_ms": stages,
         "stages_note": "eager pass with stream events around the three stages; ms_per_step is the graph-replayed frame",
-        "lift": {"ms_per_frame": lift_ms, "gbps": LIFT_MBYTES / lift_ms if lift_ms else 0.0,
-                 "frac_of_8TBps": LIFT_MBYTES / lift_ms / 8000.0 if lift_ms else 0.0},
+        "lift": {"ms_per_frame": lift_ms, "gbps": lift_mb / lift_ms if lift_ms else 0.0,
+                 "frac_of_8TBps": lift_mb / lift_ms / 8000.0 if lift_ms else 0.0, "algorithmic_mbytes": lift_mb,
+                 "kernel": "lift_proj_kernel (projection + frustum sample + gather in one launch)" if lift_fused
+                           else "lift_p1_kernel (tables from the batch) + flosp_sample_kernel"},
     }
+    if _fused.BF16X3:
+        # the experiment's roofline is priced against the instruction it issues: six bf16 MFMAs per algorithmic MAC
+        res["roofline"].update({
+            "kernel": "conv3d_bf16_kernel<SPLIT=3>: 3x3x3 32->32 @256x256x32 (6 x v_mfma_f32_32x32x16_bf16 per K step)",
+            "peak": BF16_MFMA_PEAK_TFLOPS, "achieved": 6.0 * ach, "frac": 6.0 * ach / BF16_MFMA_PEAK_TFLOPS,
+            "algorithmic_tflops": ach, "traffic": None,
+            "traffic_source": None,
+            "note": "opt-in OCCDEPTH_BF16X3=1 experiment, not the exact-fp32 default; achieved = issued MFMA flops "
+                    "(6 x algorithmic) / time"})
     for attr in ("graph_2d_error", "graph_all_error"):
         if getattr(model, attr, None):
             res["config"][attr] = getattr(model, attr)

@@ -171,6 +171,24 @@ typedef struct occd_lift_args {
 
 int occd_lift_fwd(const occd_lift_args* a, void* stream);
 
+/* The eval lift without its tables (SURVEY 8(f) N2 fused into K1b): the kernel projects every voxel
+ * centroid itself (the arithmetic of occd_project_voxels: occdepth/data/utils/helpers.py:94-169, integer-exact), samples the
+ * FLoSP depth frustum for the voxel (the arithmetic of occd_flosp_sample_fwd: flosp_depth.py:561-602) and applies
+ * `* depth * scale_const` (OccDepth.py:339) -- no (B, V, N, 1, 2) int64 `projected_pix`, no `fov_mask`, no (B, N)
+ * depth vector in HBM.  Single-point pattern (pattern_id 0), power-of-two scales and grid dims, <= 2 views.
+ * lift.pix / lift.fov / lift.depth_scale are ignored; lift.dimA/B/C = the voxel grid (X, Y, Z) of the projection.
+ * frustum.depth == NULL: no depth scaling (trans_2d_to_3d = "flosp"); frustum.out is ignored.                        */
+typedef struct occd_lift_proj_args {
+    occd_lift_args lift;
+    const double* cam;      /* DEVICE (B, V, 20) float64: cam_E[16] row major (lidar -> camera), fx, fy, cx, cy -- the
+                               intrinsics rounded to float32 first, like the dataloader                               */
+    double voxel_size;      /* metres per voxel of the lifted grid (0.2 * project_scale)                              */
+    float origin[3];        /* float32(vox_origin)                                                                    */
+    int32_t img_w, img_h;
+    occd_flosp_args frustum;
+} occd_lift_proj_args;
+int occd_lift_proj_fwd(const occd_lift_proj_args* a, void* stream);
+
 /* Backward of occd_lift_fwd for single-point patterns (P = 1): what autograd computes through
  * SFA.forward x 4 scales and the `* depth * 100` of occdepth/models/OccDepth.py:266-298,339 in training_step.
  * gout (B, out_rows, out_cs) = d loss / d out, same rows as the forward output.  gfeat[s][v]: gradient maps with the

@@ -13,6 +13,7 @@
 // occdepth/models/flosp_depth/flosp_depth.py:561-602, f2v/frustum_grid_generator.py:70-152,
 // f2v/utils/{transform_utils.py:5-26,depth_utils.py:24-26,grid_utils.py:4-19}, f2v/sampler.py:59-64.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -33,6 +34,39 @@ __device__ __forceinline__ float group_sum(float v) {
     if (LPV >= 32) v += __shfl_xor(v, 16, 64);
     if (LPV >= 64) v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+// SURVEY.md 8(f) row N2, one voxel: occdepth/data/utils/helpers.py:94-169 with fusion.py:203-217 (vox2world: float32
+// origin, float64 arithmetic, float32 store), :518-522 (rigid transform in float64) and :336-337 (round(x * fx / z + cx),
+// float32 intrinsics, numpy round-half-even).  Every product / sum is an explicitly rounded IEEE double operation (no FMA
+// contraction) so the pixels are the ones numpy computes.  Returns the FOV flag.
+__device__ __forceinline__ bool project_one(const double* __restrict__ E, double fx, double fy, double cx, double cy,
+                                            double vox_size, const float* origin, int ix, int iy, int iz, int img_w,
+                                            int img_h, long& px, long& py, double& camz) {
+    const int idx[3] = {ix, iy, iz};
+    double pt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double a = __dadd_rn((double)origin[j], __dmul_rn(vox_size, (double)(float)idx[j]));
+        pt[j] = (double)(float)__dadd_rn(a, __dmul_rn(vox_size, 0.5));
+    }
+    double cam[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double acc = __dmul_rn(E[r * 4 + 0], pt[0]);
+        acc = __dadd_rn(acc, __dmul_rn(E[r * 4 + 1], pt[1]));
+        acc = __dadd_rn(acc, __dmul_rn(E[r * 4 + 2], pt[2]));
+        cam[r] = __dadd_rn(acc, E[r * 4 + 3]);
+    }
+    double xr = rint(__dadd_rn(__ddiv_rn(__dmul_rn(cam[0], fx), cam[2]), cx));
+    double yr = rint(__dadd_rn(__ddiv_rn(__dmul_rn(cam[1], fy), cam[2]), cy));
+    // non-finite projections (z == 0) are clamped like oracle/inputs.py; they are out of the FOV anyway
+    xr = isnan(xr) ? -1e9 : fmin(fmax(xr, -1e9), 1e9);
+    yr = isnan(yr) ? -1e9 : fmin(fmax(yr, -1e9), 1e9);
+    px = (long)xr;
+    py = (long)yr;
+    camz = cam[2];
+    return px >= 0 && px < img_w && py >= 0 && py < img_h && cam[2] > 0.0;
 }
 
 struct LiftP {
@@ -356,12 +390,10 @@ __device__ __forceinline__ float from_homog_scale(float w) {
     return fabsf(w) > 1e-8f ? 1.f / (w + 1e-8f) : 1.f;
 }
 
-__global__ void __launch_bounds__(256) flosp_sample_kernel(const FlospP pp) {
+// One voxel of the frustum sample (shared by the standalone kernel and the fused lift).
+__device__ __forceinline__ float frustum_sample_one(const FlospP& pp, int b, long n) {
     const occd_flosp_args& a = pp.a;
     const long nvox = (long)a.A * a.Bdim * a.C;
-    const long n = (long)blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (n >= nvox) return;
     const long bc = (long)a.Bdim * a.C;
     const int ia = (int)(n / bc);
     const long rem = n - (long)ia * bc;
@@ -435,7 +467,134 @@ __global__ void __launch_bounds__(256) flosp_sample_kernel(const FlospP pp) {
     }
     float r = feat_sum;
     if (a.n_cams > 1 && a.mean_mode && mask_sum > 0.f) r = feat_sum / mask_sum;
-    a.out[(size_t)b * nvox + n] = r;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) flosp_sample_kernel(const FlospP pp) {
+    const occd_flosp_args& a = pp.a;
+    const long nvox = (long)a.A * a.Bdim * a.C;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= nvox) return;
+    a.out[(size_t)b * nvox + n] = frustum_sample_one(pp, b, n);
+}
+
+// ------------------------------------------------------------ fused lift: projection + frustum sample + SFA gather
+// VERDICT r2 item 7 / SURVEY 8(f) N2: the eval lift without its tables.  A workgroup owns T = 4 * (256 / LPV)
+// consecutive voxels.  Phase A: T * V threads project one (voxel, view) each in explicitly rounded float64 (project_one:
+// the integers the dataloader's numba vox2pix produces) and T more threads sample the depth frustum of one voxel each
+// (frustum_sample_one); pixels and depth scales are staged in LDS -- no (B, V, N, 1, 2) int64 table, no fov mask, no
+// (B, N) depth_scale vector in HBM.  Phase B: the lane groups walk their 4 voxels two at a time, 2 * V * S independent
+// 16-byte gathers in flight per lane, fuse (sfa_fuse) and write channels-last voxel rows.
+struct LiftProjP {
+    LiftP l;                 // l.a.pix / fov / depth_scale are unused (null)
+    const double* cam;       // (B, V, 20) device doubles: E[16] row major, fx, fy, cx, cy (float32-rounded, widened)
+    double vox_size;
+    float origin[3];
+    int img_w, img_h;
+    FlospP fr;
+    int has_frustum;
+};
+
+template <int LPV, int V, int U>   // U = voxels in flight per lane group (1, 2 or 4)
+__global__ void __launch_bounds__(256) lift_proj_kernel(const LiftProjP pp) {
+    constexpr int G = 256 / LPV, T = 4 * G;
+    const occd_lift_args& a = pp.l.a;
+    __shared__ int s_pix[T * V];        // py << 16 | px, or -1 outside the field of view
+    __shared__ float s_ds[T];
+    const int tid = threadIdx.x;
+    uint32_t bid = blockIdx.x;
+    if (a.xcd_mode == 1) {
+        const uint32_t nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    } else if (a.xcd_mode == 2) {
+        const uint32_t wps = (uint32_t)(((long)a.dimB * a.dimC) / T);       // workgroups per a-slab (multiple of 8)
+        const uint32_t per = wps >> 3, xcd = bid & 7, idx = bid >> 3;
+        bid = (idx / per) * wps + xcd * per + idx % per;
+    }
+    const long n0 = (long)bid * T;
+    const int b = blockIdx.y;
+
+    // ---- phase A
+    for (int i = tid; i < T * V + (pp.has_frustum ? T : 0); i += 256) {
+        if (i < T * V) {
+            const int t = i / V, v = i - t * V;
+            const long n = n0 + t;
+            int code = -1;
+            if (n < a.N) {
+                const uint32_t n32 = (uint32_t)n;
+                const int ix = (int)(n32 >> pp.l.bc_shift);
+                const uint32_t rem = n32 & ((1u << pp.l.bc_shift) - 1u);
+                const int iy = (int)(rem >> pp.l.c_shift), iz = (int)(rem & ((1u << pp.l.c_shift) - 1u));
+                const double* cam = pp.cam + ((size_t)b * V + v) * 20;
+                long px, py;
+                double camz;
+                if (project_one(cam, cam[16], cam[17], cam[18], cam[19], pp.vox_size, pp.origin, ix, iy, iz, pp.img_w,
+                                pp.img_h, px, py, camz))
+                    code = (int)((py << 16) | px);
+            }
+            s_pix[i] = code;
+        } else {
+            const int t = i - T * V;
+            const long n = n0 + t;
+            s_ds[t] = n < a.N ? frustum_sample_one(pp.fr, b, n) : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B
+    const int sub = tid % LPV, grp = tid / LPV;
+    const int c = sub * 4;
+    const bool ch_ok = c < a.C;
+    const int cc = ch_ok ? c : 0;
+#pragma unroll
+    for (int q = 0; q < 4 / U; ++q) {
+        f32x4 g[U][OCCD_MAX_SCALES][V];
+        float m[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = (U * q + u) * G + grp;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int code = s_pix[t * V + v];
+                const bool in = code >= 0;
+                const int px = in ? code & 0xFFFF : 0, py = in ? code >> 16 : 0;
+                m[u][v] = in ? 1.f : 0.f;
+                const uint32_t keep = in && ch_ok ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                for (int s = 0; s < OCCD_MAX_SCALES; ++s) {
+                    const int ss = s < a.n_scales ? s : 0;                   // (absent scales re-read scale 0: discarded)
+                    const int w = a.feat_w[ss], cs = a.feat_cs[ss];
+                    const int idx = (py >> pp.l.sshift[ss]) * w + (px >> pp.l.sshift[ss]);
+                    const f32x4 tv = *(const f32x4*)(a.feat[ss][v] + (size_t)b * a.feat_bstride[ss][v] + (size_t)idx * cs + cc);
+                    const uint32_t k = s < a.n_scales ? keep : 0u;
+                    g[u][s][v] = f32x4{__uint_as_float(__float_as_uint(tv.x) & k), __uint_as_float(__float_as_uint(tv.y) & k),
+                                       __uint_as_float(__float_as_uint(tv.z) & k), __uint_as_float(__float_as_uint(tv.w) & k)};
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = (U * q + u) * G + grp;
+            const long n = n0 + t;
+            f32x4 total = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < OCCD_MAX_SCALES; ++s)
+                if (s < a.n_scales) {
+                    const f32x4 o = sfa_fuse<LPV, V>(g[u][s], m[u]);
+                    if (s == 0) total = o; else total += o;
+                }
+            if (pp.has_frustum) total = total * s_ds[t] * a.scale_const;
+            if (n < a.N && c < a.out_cs) {
+                const uint32_t n32 = (uint32_t)n;
+                const uint32_t ia = n32 >> pp.l.bc_shift, rem = n32 & ((1u << pp.l.bc_shift) - 1u);
+                const uint32_t ib = rem >> pp.l.c_shift, ic = rem & ((1u << pp.l.c_shift) - 1u);
+                const long row = (long)ia * a.row_a + (long)ib * a.row_b + (long)ic * a.row_c;
+                float* o = a.out + ((size_t)b * a.out_rows + row) * a.out_cs + c;
+                *(f32x4*)o = ch_ok ? total : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------ layout helpers
@@ -619,6 +778,81 @@ extern "C" int occd_flosp_sample_fwd(const occd_flosp_args* a, void* stream) {
     return occd::check_launch();
 }
 
+extern "C" int occd_lift_proj_fwd(const occd_lift_proj_args* q, void* stream) {
+    if (!q || !q->cam || !q->lift.out) return OCCD_EINVAL;
+    const occd_lift_args* a = &q->lift;
+    if (a->n_scales < 1 || a->n_scales > OCCD_MAX_SCALES || a->n_views < 1 || a->n_views > OCCD_MAX_VIEWS)
+        return OCCD_EINVAL;
+    if (a->C <= 0 || (a->C & 3) || a->C > 256 || (a->out_cs & 3) || a->out_cs < a->C || a->out_cs > 256)
+        return OCCD_EINVAL;
+    if (a->N <= 0 || a->batch <= 0 || q->voxel_size <= 0 || q->img_w <= 0 || q->img_h <= 0 || q->img_w > 65535 ||
+        q->img_h > 32767)
+        return OCCD_EINVAL;
+    if ((long)a->dimA * a->dimB * a->dimC != (long)a->N) return OCCD_EINVAL;
+    for (int s = 0; s < a->n_scales; ++s) {
+        if (a->scale_div[s] <= 0 || (a->feat_cs[s] & 3) || a->feat_cs[s] < a->C) return OCCD_EINVAL;
+        for (int v = 0; v < a->n_views; ++v)
+            if (!a->feat[s][v] || (reinterpret_cast<uintptr_t>(a->feat[s][v]) & 15)) return OCCD_EINVAL;
+    }
+    LiftProjP p;
+    p.l.a = *a;
+    p.l.a.pix = nullptr; p.l.a.fov = nullptr; p.l.a.depth_scale = nullptr; p.l.a.P = 1;
+    auto lg2 = [](long v) { int s = 0; while ((1L << s) < v) ++s; return (1L << s) == v ? s : -1; };
+    for (int s = 0; s < OCCD_MAX_SCALES; ++s) {
+        p.l.sshift[s] = s < a->n_scales ? lg2(a->scale_div[s]) : 0;
+        if (p.l.sshift[s] < 0) return OCCD_EINVAL;          // power-of-two scales and grids only (every KITTI config)
+    }
+    p.l.bc_shift = lg2((long)a->dimB * a->dimC);
+    p.l.c_shift = lg2(a->dimC);
+    if (p.l.bc_shift < 0 || p.l.c_shift < 0) return OCCD_EINVAL;
+    for (int s = 0; s < a->n_scales; ++s)
+        for (int v = 0; v < a->n_views; ++v)
+            if (p.l.a.feat_bstride[s][v] == 0) p.l.a.feat_bstride[s][v] = (int64_t)a->feat_h[s] * a->feat_w[s] * a->feat_cs[s];
+    p.cam = q->cam;
+    p.vox_size = q->voxel_size;
+    for (int j = 0; j < 3; ++j) p.origin[j] = q->origin[j];
+    p.img_w = q->img_w; p.img_h = q->img_h;
+    p.has_frustum = q->frustum.depth != nullptr;
+    if (p.has_frustum) {
+        const occd_flosp_args* f = &q->frustum;
+        if (!f->grids && (!f->trans || !f->proj || !f->ida)) return OCCD_EINVAL;
+        if (f->batch != a->batch || f->n_cams <= 0 || f->D <= 1 || f->h <= 0 || f->w <= 0) return OCCD_EINVAL;
+        if (f->A != a->dimA || f->Bdim != a->dimB || f->C != a->dimC) return OCCD_EINVAL;
+        p.fr.a = *f;
+        p.fr.bin_size = (float)(2.0 * ((double)f->depth_max - (double)f->depth_min) / ((double)f->D * (1.0 + f->D)));
+    } else {
+        p.fr = FlospP{};
+    }
+    const int need = a->out_cs / 4;
+    const int lpv = need <= 8 ? 8 : need <= 16 ? 16 : need <= 32 ? 32 : 64;
+    const int T = 4 * (256 / lpv);
+    if (p.l.a.xcd_mode < 0 || p.l.a.xcd_mode > 2) return OCCD_EINVAL;
+    if (p.l.a.xcd_mode == 2 && (((long)a->dimB * a->dimC) % ((long)T * 8) != 0 || a->N % T != 0)) p.l.a.xcd_mode = 0;
+    const dim3 grid((unsigned)((a->N + T - 1) / T), (unsigned)a->batch);
+    // algorithmic bytes: output rows + one gathered pixel row per view / scale (+ the depth volumes once)
+    const double bytes = (double)a->batch * a->N * (4.0 * a->C * (1 + (double)a->n_views * a->n_scales)) +
+                         (p.has_frustum ? 4.0 * a->batch * q->frustum.n_cams * q->frustum.D * q->frustum.h * q->frustum.w : 0.0);
+    occd::ProfScope prof("sfa_lift_proj", (hipStream_t)stream, 0.0, bytes);
+    hipStream_t st = (hipStream_t)stream;
+    // voxels in flight per lane group: 2 measured best at config 2 (profiles/r03_lift_proj.txt); OCCD_LIFT_INFLIGHT is
+    // a tuning knob, read once
+    static const int inflight = [] {
+        const char* e = getenv("OCCD_LIFT_INFLIGHT");
+        const int v = e ? atoi(e) : 2;
+        return v == 1 || v == 4 ? v : 2;
+    }();
+#define OCCD_LP(L, VV)                                                                                            \
+    if (lpv == L && a->n_views == VV) {                                                                           \
+        if (inflight == 1) hipLaunchKernelGGL((lift_proj_kernel<L, VV, 1>), grid, dim3(256), 0, st, p);           \
+        else if (inflight == 4) hipLaunchKernelGGL((lift_proj_kernel<L, VV, 4>), grid, dim3(256), 0, st, p);      \
+        else hipLaunchKernelGGL((lift_proj_kernel<L, VV, 2>), grid, dim3(256), 0, st, p);                         \
+    }
+    OCCD_LP(8, 1) OCCD_LP(8, 2) OCCD_LP(16, 1) OCCD_LP(16, 2) OCCD_LP(32, 1) OCCD_LP(32, 2) OCCD_LP(64, 1) OCCD_LP(64, 2)
+#undef OCCD_LP
+    if (a->n_views > 2) return OCCD_EINVAL;
+    return occd::check_launch();
+}
+
 extern "C" int occd_nchw_to_nhwc(const float* in, float* out, int32_t batch, int32_t C, int64_t S, int32_t cs,
                                  void* stream) {
     if (!in || !out || batch <= 0 || C <= 0 || S <= 0 || cs < C) return OCCD_EINVAL;
@@ -675,31 +909,14 @@ __global__ void __launch_bounds__(256) project_voxels_kernel(const ProjP p) {
     const int iz = (int)(n % p.Z);
     const long t = n / p.Z;
     const int iy = (int)(t % p.Y), ix = (int)(t / p.Y);
-    const int idx[3] = {ix, iy, iz};
-    double pt[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double a = __dadd_rn((double)p.origin[j], __dmul_rn(p.vox_size, (double)(float)idx[j]));
-        pt[j] = (double)(float)__dadd_rn(a, __dmul_rn(p.vox_size, 0.5));
-    }
-    double cam[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double acc = __dmul_rn(p.E[r * 4 + 0], pt[0]);
-        acc = __dadd_rn(acc, __dmul_rn(p.E[r * 4 + 1], pt[1]));
-        acc = __dadd_rn(acc, __dmul_rn(p.E[r * 4 + 2], pt[2]));
-        cam[r] = __dadd_rn(acc, p.E[r * 4 + 3]);
-    }
-    double xr = rint(__dadd_rn(__ddiv_rn(__dmul_rn(cam[0], p.fx), cam[2]), p.cx));
-    double yr = rint(__dadd_rn(__ddiv_rn(__dmul_rn(cam[1], p.fy), cam[2]), p.cy));
-    // non-finite projections (z == 0) are clamped like oracle/inputs.py; they are out of the FOV anyway
-    xr = isnan(xr) ? -1e9 : fmin(fmax(xr, -1e9), 1e9);
-    yr = isnan(yr) ? -1e9 : fmin(fmax(yr, -1e9), 1e9);
-    const long px = (long)xr, py = (long)yr;
+    long px, py;
+    double camz;
+    const bool in = project_one(p.E, p.fx, p.fy, p.cx, p.cy, p.vox_size, p.origin, ix, iy, iz, p.img_w, p.img_h, px, py,
+                                camz);
     p.pix[n * 2] = px;
     p.pix[n * 2 + 1] = py;
-    p.fov[n] = (px >= 0 && px < p.img_w && py >= 0 && py < p.img_h && cam[2] > 0.0) ? 1 : 0;
-    if (p.pix_z) p.pix_z[n] = (float)cam[2];
+    p.fov[n] = in ? 1 : 0;
+    if (p.pix_z) p.pix_z[n] = (float)camz;
 }
 
 }  // namespace

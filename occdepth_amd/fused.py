@@ -6,6 +6,8 @@ statistics into (weight scale, bias) and packs on first use; the packed image is
 whenever a source tensor is replaced or modified in place (load_state_dict, optimizer step),
 detected through (data_ptr, _version).
 """
+import os
+
 import torch
 
 from . import hip
@@ -94,6 +96,46 @@ def _pad_bias(bias, cout):
     return out
 
 
+# VERDICT r2 item 8 experiment, OFF by default: run the eval path's K2 convolutions on the bf16 matrix pipe with the 3-way
+# operand split (csrc/conv3d_bf16.hip, float32-level accuracy).  The exact-fp32 MFMA kernels stay the default.
+BF16X3 = os.environ.get("OCCDEPTH_BF16X3", "0") == "1"
+
+
+def set_bf16x3(on):
+    global BF16X3
+    BF16X3 = bool(on)
+
+
+class _DualW:
+    """Both weight images of a plan while the experiment is on: the 3-way split one for the launches K2b takes (rows padded
+    to 8 channels, dilation 1 unless OCCDEPTH_BF16X3_DILATED=1 -- the dilated head convolutions measured slower than the
+    fp32 kernel, profiles/r03_bf16x3_ab.txt), the exact-fp32 one for the rest."""
+
+    def __init__(self, f32, x3):
+        self.f32, self.x3 = f32, x3
+
+
+BF16X3_DILATED = os.environ.get("OCCDEPTH_BF16X3_DILATED", "0") == "1"
+
+
+def _pack_w(w, scale=None, layout=0):
+    if BF16X3:
+        return _DualW(hip.pack_weights(w, scale, layout), hip.pack_weights_bf16(w, scale, layout, split3=True))
+    return hip.pack_weights(w, scale, layout)
+
+
+def _conv3d(x, wpk, bias, cout, kernel, out, **kw):
+    if isinstance(wpk, _DualW):
+        aligned = x.cs % 8 == 0 and x.coff % 8 == 0          # K2b stages 8 channels per 16-byte LDS chunk
+        dil = tuple(kw.get("dilation", (1, 1, 1)))
+        big = kernel[0] * kernel[1] * kernel[2] >= 8
+        if aligned and big and (dil == (1, 1, 1) or BF16X3_DILATED) and kw.get("cin") is None and \
+                kw.get("act_in", ACT_NONE) in (ACT_NONE, ACT_RELU):
+            return hip.conv3d_bf16(x, wpk.x3, bias, cout, kernel, out, split3=True, **kw)
+        wpk = wpk.f32
+    return hip.conv3d(x, wpk, bias, cout, kernel, out, **kw)
+
+
 class ConvPlan:
     """conv (+ optional conv bias) + optional BatchNorm3d as one K2 launch."""
 
@@ -108,7 +150,7 @@ class ConvPlan:
         return self.conv.out_channels
 
     def _prepare(self):
-        key = _stamp(self.conv, self.bn)
+        key = (_stamp(self.conv, self.bn), BF16X3)
         if key == self._key:
             return
         w = self.conv.weight.detach().float()
@@ -122,7 +164,7 @@ class ConvPlan:
             # mean over the pooling window then 1x1x1 conv == conv with k = stride = window, w / |window|
             kx, ky, kz = self.pool
             w = (w / float(kx * ky * kz)).expand(-1, -1, kx, ky, kz).contiguous()
-        self._wpk = hip.pack_weights(w, scale)
+        self._wpk = _pack_w(w, scale)
         self._bias = _pad_bias(shift, cout)
         self._key = key
 
@@ -141,7 +183,7 @@ class ConvPlan:
         k, s, d, p = self.geometry()
         if out is None:
             out = Vox.empty(x.batch, self.out_dims(x.dims), self.cout, x.buf.device)
-        return hip.conv3d(x, self._wpk, self._bias, self.cout, k, out, stride=s, dilation=d, padding=p,
+        return _conv3d(x, self._wpk, self._bias, self.cout, k, out, stride=s, dilation=d, padding=p,
                           res1=res1, res2=res2, act_in=act_in, act_out=act_out)
 
 
@@ -159,13 +201,13 @@ class DerivedConvPlan:
         self.cout = self.kernel = None
 
     def _prepare(self):
-        key = _stamp(*self.modules)
+        key = (_stamp(*self.modules), BF16X3)
         if key == self._key:
             return
         w, b = self.derive()
         w = w.detach().float().contiguous()
         self.cout, self.kernel = w.shape[0], tuple(w.shape[2:])
-        self._wpk = hip.pack_weights(w)
+        self._wpk = _pack_w(w)
         self._bias = _pad_bias(b.detach().float(), self.cout) if b is not None else None
         self._key = key
 
@@ -175,7 +217,7 @@ class DerivedConvPlan:
             dims = tuple((n + 2 * p - d * (k - 1) - 1) // s + 1
                          for n, k, s, d, p in zip(x.dims, self.kernel, self.stride, self.dilation, self.padding))
             out = Vox.empty(x.batch, dims, self.cout, x.buf.device, cs=out_cs)
-        return hip.conv3d(x, self._wpk, self._bias, self.cout, self.kernel, out, stride=self.stride,
+        return _conv3d(x, self._wpk, self._bias, self.cout, self.kernel, out, stride=self.stride,
                           dilation=self.dilation, padding=self.padding, res1=res1, res2=res2, act_in=act_in,
                           act_out=act_out)
 
@@ -205,7 +247,7 @@ class ConvTransposePlan:
         return self.convt.out_channels
 
     def _prepare(self):
-        key = _stamp(self.convt, self.bn)
+        key = (_stamp(self.convt, self.bn), BF16X3)
         if key == self._key:
             return
         wt = self.convt.weight.detach().float()  # (Cin, Cout, 3, 3, 3)
@@ -217,7 +259,7 @@ class ConvTransposePlan:
         w = wt.permute(1, 0, 2, 3, 4)  # (Cout, Cin, k, k, k), k indexes the scatter offset o = s*i - 1 + k
         phases = []
         if self.up == 1:
-            phases.append(((0, 0, 0), (3, 3, 3), (1, 1, 1), hip.pack_weights(w.flip(2, 3, 4).contiguous(), scale)))
+            phases.append(((0, 0, 0), (3, 3, 3), (1, 1, 1), _pack_w(w.flip(2, 3, 4).contiguous(), scale)))
         else:
             # even outputs (o = 2j) see only k=1 at i=j; odd outputs (o = 2j+1) see k=2 at i=j and k=0 at i=j+1
             taps = ([1], [2, 0])
@@ -225,7 +267,7 @@ class ConvTransposePlan:
                 for py in (0, 1):
                     for pz in (0, 1):
                         sub = w[:, :, taps[px]][:, :, :, taps[py]][:, :, :, :, taps[pz]].contiguous()
-                        phases.append(((px, py, pz), tuple(sub.shape[2:]), (0, 0, 0), hip.pack_weights(sub, scale)))
+                        phases.append(((px, py, pz), tuple(sub.shape[2:]), (0, 0, 0), _pack_w(sub, scale)))
         self._phases = phases
         self._bias = _pad_bias(shift, self.cout)
         self._key = key
@@ -238,7 +280,7 @@ class ConvTransposePlan:
         if out is None:
             out = Vox.empty(x.batch, self.out_dims(x.dims), self.cout, x.buf.device)
         for off, kern, pad, wpk in self._phases:
-            hip.conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
+            _conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
                        out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
         return out
 
@@ -248,8 +290,8 @@ def gemm_rows(a, b_rows, out, act_in=ACT_NONE):
 
     b_rows is a dense (K, N) row-major device matrix (packed on the fly with occd_pack_weights layout 2)."""
     K, N = b_rows.shape
-    wpk = hip.pack_weights(b_rows, layout=2)
-    return hip.conv3d(a, wpk, None, N, (1, 1, 1), out, act_in=act_in, cin=K)
+    wpk = _pack_w(b_rows, layout=2)
+    return _conv3d(a, wpk, None, N, (1, 1, 1), out, act_in=act_in, cin=K)
 
 
 def as_vox(x):

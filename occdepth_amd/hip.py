@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 6   # 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 7   # 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -78,6 +78,11 @@ class LiftArgs(Structure):
     ]
 
 
+class LiftProjArgs(Structure):
+    _fields_ = [("lift", LiftArgs), ("cam", c_void_p), ("voxel_size", ctypes.c_double), ("origin", c_float * 3),
+                ("img_w", c_int32), ("img_h", c_int32), ("frustum", FlospArgs)]
+
+
 class WinoArgs(Structure):
     _fields_ = [("x", c_void_p), ("upk", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("y", c_void_p)] + \
         [(n, c_int32) for n in ("batch", "cin", "cout", "H", "W", "act", "res_first", "tile_hint")] + [("slope", c_float)]
@@ -116,6 +121,7 @@ EXPORTS = {
     "occd_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
+    "occd_lift_proj_fwd": (c_int32, [POINTER(LiftProjArgs), c_void_p]),
     "occd_lift_fwd": (c_int32, [POINTER(LiftArgs), c_void_p]),
     "occd_lift_bwd": (c_int32, [POINTER(LiftBwdArgs), c_void_p]),
     "occd_nchw_to_nhwc": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p]),
@@ -478,25 +484,42 @@ def conv3d_wgrad_bf16(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1
 
 
 # ----------------------------------------------------------------------------- K1
+class Frustum:
+    """The operands of the FLoSP-Depth frustum sample (occd_flosp_args without its output), so that the sample can run
+    either on its own (`flosp_sample`) or inside the fused lift (`lift_proj`)."""
+
+    def __init__(self, depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, mean_mode=True, grids=None):
+        self.depth, self.trans, self.proj, self.ida, self.grids = depth, trans, proj, ida, grids
+        self.voxel_num = tuple(int(v) for v in voxel_num)
+        self.final_dim, self.d_min, self.d_max, self.mean_mode = final_dim, d_min, d_max, mean_mode
+
+    def fill(self, a):
+        B, V, D, h, w = self.depth.shape
+        a.depth = _f32(self.depth, "depth")
+        if self.grids is None:
+            a.trans, a.proj, a.ida = _f32(self.trans, "trans"), _f32(self.proj, "proj"), _f32(self.ida, "ida")
+        else:
+            a.grids = _f32(self.grids, "grids")
+        a.batch, a.n_cams, a.D, a.h, a.w = B, V, D, h, w
+        a.A, a.Bdim, a.C = self.voxel_num
+        a.img_h, a.img_w = float(self.final_dim[0]), float(self.final_dim[1])
+        a.depth_min, a.depth_max = float(self.d_min), float(self.d_max)
+        a.mean_mode = 1 if self.mean_mode else 0
+
+    def sample(self):
+        B = self.depth.shape[0]
+        A, Bd, C = self.voxel_num
+        out = torch.empty((B, A * Bd * C), device=self.depth.device, dtype=torch.float32)
+        a = FlospArgs()
+        self.fill(a)
+        a.out = _f32(out, "out")
+        _check(load().occd_flosp_sample_fwd(ctypes.byref(a), _stream()), "occd_flosp_sample_fwd")
+        return out
+
+
 def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, mean_mode=True, grids=None):
     """depth (B, V, D, h, w) -> (B, A*B*C) sampled voxel volume (see occd_flosp_sample_fwd)."""
-    B, V, D, h, w = depth.shape
-    A, Bd, C = (int(v) for v in voxel_num)
-    out = torch.empty((B, A * Bd * C), device=depth.device, dtype=torch.float32)
-    a = FlospArgs()
-    a.depth = _f32(depth, "depth")
-    if grids is None:
-        a.trans, a.proj, a.ida = _f32(trans, "trans"), _f32(proj, "proj"), _f32(ida, "ida")
-    else:
-        a.grids = _f32(grids, "grids")
-    a.out = _f32(out, "out")
-    a.batch, a.n_cams, a.D, a.h, a.w = B, V, D, h, w
-    a.A, a.Bdim, a.C = A, Bd, C
-    a.img_h, a.img_w = float(final_dim[0]), float(final_dim[1])
-    a.depth_min, a.depth_max = float(d_min), float(d_max)
-    a.mean_mode = 1 if mean_mode else 0
-    _check(load().occd_flosp_sample_fwd(ctypes.byref(a), _stream()), "occd_flosp_sample_fwd")
-    return out
+    return Frustum(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, mean_mode, grids).sample()
 
 
 # workgroup -> XCD placement of the lift (profiles/r02_lift_xcd_modes.txt): 2 = y-blocks per XCD, the HBM fetch of the
@@ -521,14 +544,17 @@ def _lift_args(a, feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_s
         a.scale_div[s] = int(scale_divs[s])
     a.n_scales, a.n_views, a.batch = S, V, B
     a.C = out.C
-    if pix.dtype != torch.int64:
-        raise RuntimeError("projected_pix must be int64")
-    a.pix = _ptr(pix, "projected_pix")
-    fov8 = fov.view(torch.uint8) if fov.dtype == torch.bool else fov
-    if fov8.dtype != torch.uint8:
-        raise RuntimeError("fov_mask must be bool/uint8")
-    a.fov = _ptr(fov8, "fov_mask")
-    a.N, a.P = pix.shape[2], pix.shape[3]
+    if pix is None:                    # occd_lift_proj_fwd: the kernel projects
+        a.N, a.P = int(n_dims[0]) * int(n_dims[1]) * int(n_dims[2]), 1
+    else:
+        if pix.dtype != torch.int64:
+            raise RuntimeError("projected_pix must be int64")
+        a.pix = _ptr(pix, "projected_pix")
+        fov8 = fov.view(torch.uint8) if fov.dtype == torch.bool else fov
+        if fov8.dtype != torch.uint8:
+            raise RuntimeError("fov_mask must be bool/uint8")
+        a.fov = _ptr(fov8, "fov_mask")
+        a.N, a.P = pix.shape[2], pix.shape[3]
     if depth_scale is not None:
         a.depth_scale = _f32(depth_scale, "depth_scale")
     a.scale_const = float(scale_const)
@@ -550,6 +576,27 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     a = LiftArgs()
     _lift_args(a, feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale, scale_const, xcd_mode)
     _check(load().occd_lift_fwd(ctypes.byref(a), _stream()), "occd_lift_fwd")
+    return out
+
+
+def lift_proj(feats, scale_divs, cam, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None, scale_const=100.0,
+              xcd_mode=None):
+    """The eval lift without its tables (occd_lift_proj_fwd): cam (B, V, 20) float64 device tensor (cam_E row major, fx,
+    fy, cx, cy), the voxel grid n_dims = (X, Y, Z) of `voxel_size` metres from `origin`; frustum: a `Frustum` or None."""
+    if cam.dtype != torch.float64 or not cam.is_cuda or not cam.is_contiguous() or cam.shape[-1] != 20:
+        raise RuntimeError("cam must be a contiguous (B, V, 20) float64 GPU tensor")
+    q = LiftProjArgs()
+    _lift_args(q.lift, feats, scale_divs, None, None, n_dims, row_strides, out, None, scale_const, xcd_mode)
+    if tuple(cam.shape[:2]) != (q.lift.batch, q.lift.n_views):
+        raise RuntimeError("cam must be (batch, views, 20)")
+    q.cam = cam.data_ptr()
+    q.voxel_size = float(voxel_size)
+    for j in range(3):
+        q.origin[j] = float(origin[j])
+    q.img_w, q.img_h = int(img_wh[0]), int(img_wh[1])
+    if frustum is not None:
+        frustum.fill(q.frustum)
+    _check(load().occd_lift_proj_fwd(ctypes.byref(q), _stream()), "occd_lift_proj_fwd")
     return out
 
 

@@ -11,12 +11,14 @@ autograd, with the 3-D convolutions on the HIP forward / dgrad / wgrad kernels (
 Lightning `*_step` hooks assemble the reference's losses from one statistics pass (loss/ssc_loss.py) and keep the
 SSC metrics on the GPU.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..fused import needs_autograd
-from .SFA import SFA, lift_scales
+from .SFA import SFA, lift_scales, lift_scales_proj
 from .flosp_depth import flosp_depth_conf_map
 from .flosp_depth.flosp_depth import FlospDepth
 from .unet2d import UNet2D
@@ -235,7 +237,7 @@ class OccDepth(_Base):
         return F.grid_sample(x_single_rgb, grid, mode="bilinear", padding_mode="border", align_corners=False)
 
     # ---------------------------------------------------------------- 2D -> 3D
-    def _depth_volume(self, batch, x_rgb, vox_origin):
+    def _depth_volume(self, batch, x_rgb, vox_origin, defer_sample=False):
         layer = "1_{}".format(self.flosp_depth_conf["downsample_factor"])
         n_views = 1 if self.dataset == "NYU" else len(x_rgb)
         img_feat = torch.stack([x_rgb[j][layer] for j in range(n_views)], 1).to(device)
@@ -244,9 +246,41 @@ class OccDepth(_Base):
         else:
             kw = {"img_feat": img_feat, "cam_k": batch["cam_k"], "T_velo_2_cam": batch["T_velo_2_cam"],
                   "ida_mats": batch["ida_mats"], "vox_origin": vox_origin}
+        if defer_sample:
+            kw["defer_sample"] = True
         if self.with_depth_gt:
             return self.flosp_depth(**kw)
         return self.flosp_depth(**kw), None
+
+    # the eval lift projects the voxels and samples the depth frustum inside the kernel
+    # (csrc/lift.hip lift_proj_kernel) whenever the batch carries the calibration the tables were made from -- the
+    # dataloader's float64 extrinsics (`T_velo_2_cam_f64`) -- or no tables at all.  A batch with tables and only the
+    # float32 extrinsics keeps the table path: float32 extrinsics move a few voxels by one pixel.
+    lift_in_kernel = os.environ.get("OCCDEPTH_LIFT_PROJ", "1") == "1"
+
+    def _lift_calibration(self, batch, img, key):
+        """(B, V, 20) float64 device tensor [cam_E (16), fx, fy, cx, cy] for hip.lift_proj, or None when the in-kernel
+        projection does not apply (NYU geometry, multi-point patterns, tables without float64 extrinsics)."""
+        if not self.lift_in_kernel or self.dataset != "kitti" or "cam_k" not in batch:
+            return None
+        if "T_velo_2_cam_f64" in batch:
+            ext = batch["T_velo_2_cam_f64"]
+        elif key not in batch and "T_velo_2_cam" in batch:
+            ext = batch["T_velo_2_cam"]
+        else:
+            return None
+        if key in batch and batch[key][0].shape[-2] != 1:
+            return None                                          # multi-point pattern: table path
+        dims = [int(d) // int(self.project_scale) for d in self.full_scene_size]
+        if any(v & (v - 1) for v in dims + [int(r) for r in self.project_res]):
+            return None                                          # the fused kernel indexes with shifts
+        dev = img.device
+        E = torch.stack([e.to(dev) for e in ext]).to(torch.float64).reshape(img.shape[0], -1, 16)
+        k = torch.stack([c.to(dev) for c in batch["cam_k"]]).to(torch.float32).to(torch.float64)
+        k = k.reshape(img.shape[0], -1, 9)
+        if E.shape[1] != img.shape[1] or E.shape[1] > 2:
+            return None
+        return torch.cat([E, k[..., [0, 4, 2, 5]]], -1).contiguous()
 
     def _forward_2d_to_3d(self, batch, x_rgb, img, bs, vox_origin):
         """eval: returns (Vox, depth_pred); training: ((B, C, X, Y, Z) tensor, depth_pred)."""
@@ -254,6 +288,18 @@ class OccDepth(_Base):
         mkey = "fov_mask_{}".format(self.project_scale)
         scales = [int(s) for s in self.project_res]
         depth_vol = depth_pred = None
+        if not needs_autograd(self):
+            cam = self._lift_calibration(batch, img, key)
+            if cam is not None:
+                frustum = None
+                if self.trans_2d_to_3d == "flosp_depth":
+                    frustum, depth_pred = self._depth_volume(batch, x_rgb, vox_origin, defer_sample=True)
+                feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
+                H, W = img.shape[-2:]
+                vox = lift_scales_proj(feats, scales, cam, self._kitti_origin(), 0.2 * self.project_scale, (W, H),
+                                       self.projects[str(scales[0])].scene_size, self.project_scale, self.dataset,
+                                       frustum=frustum, scale_const=100.0)
+                return vox, depth_pred
         if self.trans_2d_to_3d == "flosp_depth":
             depth_vol, depth_pred = self._depth_volume(batch, x_rgb, vox_origin)
         if not needs_autograd(self):
@@ -294,6 +340,11 @@ class OccDepth(_Base):
             x3ds = x3ds * depth_vol * 100
         return x3ds, depth_pred
 
+    def _kitti_origin(self):
+        """SemanticKITTI voxel origin (kitti_dataset.py: vox_origin = (0, -25.6, -2) for the 51.2 m wide scene): the grid is
+        centred on the sensor in y, whatever the scene width of a reduced test config."""
+        return (0.0, -0.1 * float(self.full_scene_size[1]), -2.0)
+
     def project_voxels_on_gpu(self, batch, img):
         """when the batch carries no `projected_pix_{s}` / `fov_mask_{s}` (the dataloader's
         numba `vox2pix`, kitti_dataset.py:253-273), compute them on the GPU from the calibration
@@ -310,7 +361,7 @@ class OccDepth(_Base):
             # float32 copy.  `T_velo_2_cam_f64`, when present, reproduces the dataloader's tables bit for bit.
             ext = batch.get("T_velo_2_cam_f64", batch["T_velo_2_cam"])
             views = [hip.project_voxels(ext[i][v].detach().cpu().double().numpy(),
-                                        batch["cam_k"][i][v].detach().cpu().double().numpy(), (0.0, -25.6, -2.0),
+                                        batch["cam_k"][i][v].detach().cpu().double().numpy(), self._kitti_origin(),
                                         0.2 * ps, dims, W, H, device=img.device) for v in range(img.shape[1])]
             pix.append(torch.stack([p for p, _ in views]))
             fov.append(torch.stack([m for _, m in views]))

@@ -181,7 +181,9 @@ class FlospDepth(nn.Module):
         self._grid_dims = tuple(int(v) for v in num)
 
     def forward(self, img_feat, cam_k=None, T_velo_2_cam=None, ida_mats=None, vox_origin=None, grids=None,
-                scaled_pixel_size=None):
+                scaled_pixel_size=None, defer_sample=False):
+        """defer_sample (eval on the GPU): return a `hip.Frustum` (the operands of the frustum sample) in place of the
+        sampled volume -- the fused lift (hip.lift_proj) samples it per voxel itself."""
         if vox_origin is not None and not self.infer_mode:
             self._rebound_nyu(vox_origin)
         bs, n_cams, c, h, w = img_feat.shape
@@ -209,8 +211,8 @@ class FlospDepth(nn.Module):
             dvol = depth.float().contiguous()
             if self.infer_mode:
                 g = torch.stack(list(grids)).float().contiguous()          # (n_cams, B, X, Y, Z, 3)
-                flat = hip.flosp_sample(dvol, None, None, None, self._grid_dims, self.final_dim, self.d_bound[0],
-                                        self.d_bound[1], self.agg_voxel_mode == "mean", grids=g)
+                fr = hip.Frustum(dvol, None, None, None, self._grid_dims, self.final_dim, self.d_bound[0],
+                                 self.d_bound[1], self.agg_voxel_mode == "mean", grids=g)
             else:
                 gkey = (tuple(self._pc_range), self._grid_dims, t_v2c.device)
                 if getattr(self, "_g2l_key", None) != gkey:     # cached on the device: no per-frame H2D copy
@@ -219,9 +221,11 @@ class FlospDepth(nn.Module):
                 g2l = self._g2l_dev
                 trans = (t_v2c @ g2l).contiguous()
                 proj = intrins[:, :, :3, :].contiguous()
-                flat = hip.flosp_sample(dvol, trans, proj, ida.contiguous(), self._grid_dims, self.final_dim,
-                                        self.d_bound[0], self.d_bound[1], self.agg_voxel_mode == "mean")
-            vox = flat.view(bs, 1, *self._grid_dims)
+                fr = hip.Frustum(dvol, trans, proj, ida.contiguous(), self._grid_dims, self.final_dim,
+                                 self.d_bound[0], self.d_bound[1], self.agg_voxel_mode == "mean")
+            if defer_sample:
+                return (fr, depth) if self.return_depth else fr
+            vox = fr.sample().view(bs, 1, *self._grid_dims)
         if self.return_depth:
             return vox, depth
         return vox

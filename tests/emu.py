@@ -183,6 +183,32 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     return out
 
 
+def lift_proj(feats, scale_divs, cam, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None, scale_const=100.0,
+              xcd_mode=None):
+    """occd_lift_proj_fwd = the numpy vox2pix restatement per (sample, view) + the frustum sample + `lift`."""
+    import numpy as np
+    from oracle.inputs import vox2pix
+    B, V = cam.shape[:2]
+    scene = tuple(float(d) * voxel_size for d in n_dims)
+    pix, fov = [], []
+    for b in range(B):
+        pv, fv = [], []
+        for v in range(V):
+            c = cam[b, v].double().numpy()
+            k = np.array([[c[16], 0, c[18]], [0, c[17], c[19]], [0, 0, 1]])
+            p, m, _ = vox2pix(c[:16].reshape(4, 4), k, origin, voxel_size, img_wh[0], img_wh[1], scene, 0)
+            pv.append(torch.from_numpy(p))
+            fv.append(torch.from_numpy(m))
+        pix.append(torch.stack(pv))
+        fov.append(torch.stack(fv))
+    ds = None
+    if frustum is not None:
+        ds = flosp_sample(frustum.depth, frustum.trans, frustum.proj, frustum.ida, frustum.voxel_num, frustum.final_dim,
+                          frustum.d_min, frustum.d_max, frustum.mean_mode, frustum.grids)
+    return lift(feats, scale_divs, torch.stack(pix), torch.stack(fov), n_dims, row_strides, out, depth_scale=ds,
+                scale_const=scale_const)
+
+
 def cascade_tail(part, occ_off, wn, nbr):
     soft = F.softmax(part.buf[..., occ_off:occ_off + 2], dim=-1).permute(0, 4, 1, 2, 3)
     y = F.conv3d(soft, wn.detach().float(), None, padding=1).permute(0, 2, 3, 4, 1) + part.buf[..., :nbr]
@@ -450,7 +476,7 @@ def softmax_nchw(x):
 def patched(fast2d=False):
     """fast2d: also route the 2-D eval fast paths (fused.on_gpu gates) through the emulation on CPU tensors."""
     saved = {k: getattr(hip, k) for k in ("affine_act", "dwconv2d_same", "upsample_bilinear_cat", "softmax_nchw", "pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
-                                          "flosp_sample", "lift", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
+                                          "flosp_sample", "lift", "lift_proj", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "conv3d_bf16",
@@ -472,6 +498,10 @@ def patched(fast2d=False):
     saved_as_vox = fused.as_vox
     hip.pack_weights, hip.conv3d, hip.nchw_to_nhwc = pack_weights, conv3d, nchw_to_nhwc
     hip.softmax_channels, hip.flosp_sample, hip.lift = softmax_channels, flosp_sample, lift
+    hip.lift_proj = lift_proj
+    saved_sample = hip.Frustum.sample
+    hip.Frustum.sample = lambda fr: flosp_sample(fr.depth, fr.trans, fr.proj, fr.ida, fr.voxel_num, fr.final_dim, fr.d_min,
+                                                 fr.d_max, fr.mean_mode, fr.grids)
     hip.cascade_tail = cascade_tail
     Vox.from_ncdhw = staticmethod(vox_from_ncdhw)
 
@@ -499,6 +529,7 @@ def patched(fast2d=False):
         for k, v in saved.items():
             setattr(hip, k, v)
         fused.on_gpu = saved_on_gpu
+        hip.Frustum.sample = saved_sample
         Vox.from_ncdhw = saved_from
         for m, f in old:
             m.as_vox = f

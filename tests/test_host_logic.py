@@ -60,6 +60,42 @@ def test_occdepth_eval_path(cfg_name):
         close(gc.maybe_subsample(v.contiguous()), g[f"{cfg_name}.{k}"], tol=3e-4, what=f"{cfg_name}.{k}")
 
 
+def test_occdepth_eval_path_in_kernel_lift():
+    """VERDICT r2 item 7 host logic: with the dataloader's float64 extrinsics in the batch the eval forward hands the
+    calibration to the fused lift (hip.lift_proj; here its emulation = numpy vox2pix + frustum sample + SFA) instead of the
+    tables -- same golden, same bar; without them (or with the switch off) it reads the tables."""
+    from occdepth_amd import hip
+    from oracle import inputs
+    m, cfg, sd = build_product("kitti_small")
+    g = gold("occdepth_small")
+    batch = gc.occdepth_batch("kitti_small")
+    tr2 = inputs.KITTI_TR.copy()
+    tr2[0, 3] = -0.54
+    b64 = dict(batch, T_velo_2_cam_f64=[torch.from_numpy(np.stack([inputs.KITTI_TR, tr2])) for _ in batch["cam_k"]])
+    calls = []
+    with emu.patched(), torch.no_grad():
+        real = hip.lift_proj
+        hip.lift_proj = lambda *a, **k: (calls.append("proj"), real(*a, **k))[1]
+        real_t = hip.lift
+        hip.lift = lambda *a, **k: (calls.append("table"), real_t(*a, **k))[1]
+        out = m(b64)
+        assert calls == ["proj"]
+        for k, v in out.items():
+            close(gc.maybe_subsample(v.contiguous()), g[f"kitti_small.{k}"], tol=3e-4, what=f"kitti_small.{k}")
+        del calls[:]
+        m(batch)                                                   # tables, float32 extrinsics only: table path
+        assert calls == ["table"]
+        m.lift_in_kernel = False
+        m(b64)
+        assert calls == ["table", "table"]
+        # no tables at all: projects from the float32 extrinsics
+        m.lift_in_kernel = True
+        del calls[:]
+        m({k: v for k, v in b64.items() if not (k.startswith("projected_pix") or k.startswith("fov_mask")
+                                               or k == "T_velo_2_cam_f64")})
+        assert calls[0] == "proj"
+
+
 @pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small"])
 def test_occdepth_eval_path_fast2d(cfg_name):
     """The same end-to-end run, with the 2-D eval FAST paths taken too (fused.on_gpu forced on, every HIP entry point

@@ -1,0 +1,111 @@
+"""The eval lift without its tables (occd_lift_proj_fwd): in-kernel voxel projection + in-kernel
+frustum sample + SFA gather must reproduce the three-kernel path (occd_project_voxels -> int64 tables,
+occd_flosp_sample_fwd -> depth vector, occd_lift_fwd) BIT FOR BIT -- the projection is integer-exact by construction
+(explicitly rounded float64, tests/test_parity_gpu.py::test_project_voxels_bit_exact pins it to the dataloader's numpy
+semantics) and the float32 arithmetic downstream is the same device code.  The table path itself is pinned to the real
+reference by the SFA / flosp goldens of tests/test_parity_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+KITTI_K = np.array([[707.0912, 0, 601.8873], [0, 707.0912, 183.1104], [0, 0, 1]], dtype=np.float64)
+KITTI_TR = np.array([[0, -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]], dtype=np.float64)
+
+
+def calibration(batch, views, jitter):
+    g = np.random.default_rng(5)
+    E, K = [], []
+    for b in range(batch):
+        eb, kb = [], []
+        for v in range(views):
+            e = KITTI_TR.copy()
+            e[0, 3] = -0.54 * v
+            e[:3, 3] += jitter * g.normal(size=3) * 0.05
+            k = KITTI_K.copy()
+            k[0, 0] *= 1 + jitter * 0.01 * b
+            eb.append(e)
+            kb.append(k)
+        E.append(np.stack(eb))
+        K.append(np.stack(kb))
+    return np.stack(E), np.stack(K)
+
+
+def build_case(hip, batch, views, C, scales, dims, img_hw, with_frustum, jitter=1.0, seed=0):
+    from occdepth_amd.models.flosp_depth.flosp_depth import _grid_to_lidar
+    torch.manual_seed(seed)
+    H, W = img_hw
+    E, K = calibration(batch, views, jitter)
+    feats = []
+    for s in scales:
+        h, w = -(-H // s), -(-W // s)
+        stacked = torch.randn(batch, views, h, w, C, device=DEV)
+        feats.append([stacked[:, v] for v in range(views)])          # batch stride != h * w * C: exercised on purpose
+    voxel = 51.2 / dims[0]
+    pix, fov = [], []
+    for b in range(batch):
+        tabs = [hip.project_voxels(E[b, v], K[b, v], (0.0, -25.6, -2.0), voxel, dims, W, H) for v in range(views)]
+        pix.append(torch.stack([p for p, _ in tabs]))
+        fov.append(torch.stack([m for _, m in tabs]))
+    pix, fov = torch.stack(pix), torch.stack(fov)
+    cam = torch.cat([torch.from_numpy(E).reshape(batch, views, 16),
+                     torch.from_numpy(K.astype(np.float32).astype(np.float64)).reshape(batch, views, 9)[..., [0, 4, 2, 5]]],
+                    -1).to(DEV).contiguous()
+    frustum = None
+    if with_frustum:
+        D, h, w = 104, -(-H // 8), -(-W // 8)
+        depth = torch.softmax(torch.randn(batch, views, D, h, w, device=DEV), 2).contiguous()
+        g2l = _grid_to_lidar([0, -25.6, -2, 51.2, 25.6, 4.4], dims).to(DEV)
+        t = torch.from_numpy(E.astype(np.float32)).to(DEV)
+        intr = torch.zeros(batch, views, 4, 4, device=DEV)
+        intr[:, :, :3, :3] = torch.from_numpy(K.astype(np.float32)).to(DEV)
+        intr[:, :, 3, 3] = 1
+        ida = torch.eye(4, device=DEV).repeat(batch, views, 1, 1).contiguous()
+        frustum = hip.Frustum(depth, (t @ g2l).contiguous(), intr[:, :, :3, :].contiguous(), ida, dims, (H, W), 2.0, 54.0,
+                              True)
+    return feats, pix, fov, cam, frustum, voxel
+
+
+CASES = {
+    # name: (batch, views, C, scales, grid, image, frustum)
+    "config2": (1, 2, 64, (1, 2, 4, 8), (128, 128, 16), (370, 1220), True),
+    "config2_no_depth": (1, 2, 64, (1, 2, 4, 8), (128, 128, 16), (370, 1220), False),
+    "batch2_c32": (2, 2, 32, (1, 2), (64, 64, 8), (185, 610), True),
+    "mono_c128": (1, 1, 128, (2, 4), (64, 64, 8), (370, 1220), True),
+    "c24_pad": (2, 2, 24, (1, 4, 8), (32, 32, 4), (96, 320), False),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_lift_proj_bit_identical_to_table_path(name):
+    from occdepth_amd import hip
+    from occdepth_amd.hip import Vox
+    batch, views, C, scales, dims, img_hw, with_frustum = CASES[name]
+    feats, pix, fov, cam, frustum, voxel = build_case(hip, batch, views, C, scales, dims, img_hw, with_frustum)
+    strides = (dims[1] * dims[2], dims[2], 1)
+    ref = Vox.empty(batch, dims, C, DEV)
+    ds = frustum.sample() if frustum is not None else None
+    hip.lift(feats, scales, pix, fov, dims, strides, ref, depth_scale=ds, scale_const=100.0)
+    assert 0.2 < fov.float().mean().item() < 0.98
+    for mode in (0, 1, 2):
+        out = Vox.empty(batch, dims, C, DEV)
+        out.buf.fill_(float("nan"))
+        hip.lift_proj(feats, scales, cam, (0.0, -25.6, -2.0), voxel, (img_hw[1], img_hw[0]), dims, strides, out,
+                      frustum=frustum, scale_const=100.0, xcd_mode=mode)
+        assert torch.equal(out.buf, ref.buf), (name, mode, float((out.buf - ref.buf).abs().max()))
+
+
+def test_lift_proj_rejects_what_it_cannot_do():
+    from occdepth_amd import hip
+    from occdepth_amd.hip import Vox
+    feats, pix, fov, cam, frustum, voxel = build_case(hip, 1, 2, 32, (1, 2), (64, 64, 8), (185, 610), False)
+    out = Vox.empty(1, (64, 64, 8), 32, DEV)
+    with pytest.raises(RuntimeError):                       # non-power-of-two scale
+        hip.lift_proj(feats, (1, 3), cam, (0.0, -25.6, -2.0), voxel, (610, 185), (64, 64, 8), (512, 8, 1), out)
+    with pytest.raises(RuntimeError):                       # float32 calibration
+        hip.lift_proj(feats, (1, 2), cam.float(), (0.0, -25.6, -2.0), voxel, (610, 185), (64, 64, 8), (512, 8, 1), out)
+    with pytest.raises(RuntimeError):                       # non-power-of-two grid
+        hip.lift_proj(feats, (1, 2), cam, (0.0, -25.6, -2.0), voxel, (610, 185), (60, 64, 8), (512, 8, 1),
+                      Vox.empty(1, (60, 64, 8), 32, DEV))

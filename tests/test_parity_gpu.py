@@ -408,6 +408,32 @@ def test_forward_without_projection_inputs(config2):
     assert moved.float().mean().item() < 1e-3, moved.float().mean().item()
 
 
+def test_in_kernel_lift_matches_table_path(config2):
+    """with the dataloader's float64 extrinsics in the batch the eval forward takes the fused lift
+    (projection + frustum sample inside the kernel, no tables read); switching it off (table path) must give the same
+    logits bit for bit, and the fused path must not launch the standalone frustum sample / table lift."""
+    from occdepth_amd import hip, synthetic
+    m, cfg, batch, out = config2
+    b64 = dict(batch, T_velo_2_cam_f64=[t.to(DEV) for t in synthetic.kitti_frame(seed=gc.SEED)["T_velo_2_cam_f64"]])
+    saved = (m.lift_in_kernel, getattr(m, "graph_all", False))
+    try:
+        m.graph_all = False
+        m.lift_in_kernel = True
+        with torch.no_grad(), hip.profile() as prof:
+            o_k = m(b64)
+            torch.cuda.synchronize()
+        tags = {k.split(":")[0] for k in prof.rows}
+        assert "sfa_lift_proj" in tags and "sfa_lift" not in tags and "flosp_sample" not in tags, sorted(tags)
+        m.lift_in_kernel = False
+        with torch.no_grad():
+            o_t = m(b64)
+        assert torch.equal(o_k["ssc_logit"], o_t["ssc_logit"])
+        scale = out["ssc_logit"].abs().max()
+        assert ((o_k["ssc_logit"] - out["ssc_logit"]).abs().max() / scale).item() < 1e-3
+    finally:
+        m.lift_in_kernel, m.graph_all = saved
+
+
 def test_argmax_labels(config2):
     """N4: GPU arg-max over the channels-last logits == numpy argmax of the softmax (generate_output.py:94-95)."""
     import numpy as np
