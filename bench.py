@@ -379,6 +379,9 @@ def _forward(args, world, rank, device, dist):
                                  "model right after the timed loop (the timed loop itself carries no events)"},
         "stack3d": {"ms_per_frame": conv_ms, "tflops": STACK3D_GFLOP / conv_ms if conv_ms else 0.0,
                     "frac_of_fp32_mfma_peak": STACK3D_GFLOP / conv_ms / FP32_MFMA_PEAK_TFLOPS if conv_ms else 0.0},
+        "stack3d_launches_ms_per_frame": {k: [int(v["launches"] // prof_steps), round(v["ms"] / prof_steps, 3)] for k, v in
+                                          sorted(((k, v) for k, v in prof.rows.items() if k.startswith("conv3d")),
+                                                 key=lambda kv: -kv[1]["ms"])[:24]},
         "stages_ms": stages,
         "stages_note": "eager pass with stream events around the three stages; ms_per_step is the graph-replayed frame",
         "lift": {"ms_per_frame": lift_ms, "gbps": lift_mb / lift_ms if lift_ms else 0.0,

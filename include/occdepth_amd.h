@@ -180,8 +180,9 @@ int occd_lift_fwd(const occd_lift_args* a, void* stream);
  * frustum.depth == NULL: no depth scaling (trans_2d_to_3d = "flosp"); frustum.out is ignored.                        */
 typedef struct occd_lift_proj_args {
     occd_lift_args lift;
-    const double* cam;      /* DEVICE (B, V, 20) float64: cam_E[16] row major (lidar -> camera), fx, fy, cx, cy -- the
-                               intrinsics rounded to float32 first, like the dataloader                               */
+    const double* cam_E;    /* DEVICE (B, V, 4, 4) float64 extrinsics (lidar -> camera), the batch's T_velo_2_cam       */
+    const double* cam_k;    /* DEVICE (B, V, 3, 3) float64 intrinsics, the batch's cam_k; fx, fy, cx, cy are rounded to
+                               float32 inside the kernel, like the dataloader does (fusion.py:336-337)                */
     double voxel_size;      /* metres per voxel of the lifted grid (0.2 * project_scale)                              */
     float origin[3];        /* float32(vox_origin)                                                                    */
     int32_t img_w, img_h;

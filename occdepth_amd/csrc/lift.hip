@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(256) flosp_sample_kernel(const FlospP pp) {
 // 16-byte gathers in flight per lane, fuse (sfa_fuse) and write channels-last voxel rows.
 struct LiftProjP {
     LiftP l;                 // l.a.pix / fov / depth_scale are unused (null)
-    const double* cam;       // (B, V, 20) device doubles: E[16] row major, fx, fy, cx, cy (float32-rounded, widened)
+    const double* cam_E;     // (B, V, 16) device doubles, row major (lidar -> camera)
+    const double* cam_k;     // (B, V, 9) device doubles, row major; fx, fy, cx, cy are rounded to float32 here
     double vox_size;
     float origin[3];
     int img_w, img_h;
@@ -526,11 +527,12 @@ __global__ void __launch_bounds__(256) lift_proj_kernel(const LiftProjP pp) {
                 const int ix = (int)(n32 >> pp.l.bc_shift);
                 const uint32_t rem = n32 & ((1u << pp.l.bc_shift) - 1u);
                 const int iy = (int)(rem >> pp.l.c_shift), iz = (int)(rem & ((1u << pp.l.c_shift) - 1u));
-                const double* cam = pp.cam + ((size_t)b * V + v) * 20;
+                const double* E = pp.cam_E + ((size_t)b * V + v) * 16;
+                const double* K = pp.cam_k + ((size_t)b * V + v) * 9;
                 long px, py;
                 double camz;
-                if (project_one(cam, cam[16], cam[17], cam[18], cam[19], pp.vox_size, pp.origin, ix, iy, iz, pp.img_w,
-                                pp.img_h, px, py, camz))
+                if (project_one(E, (double)(float)K[0], (double)(float)K[4], (double)(float)K[2], (double)(float)K[5],
+                                pp.vox_size, pp.origin, ix, iy, iz, pp.img_w, pp.img_h, px, py, camz))
                     code = (int)((py << 16) | px);
             }
             s_pix[i] = code;
@@ -779,7 +781,7 @@ extern "C" int occd_flosp_sample_fwd(const occd_flosp_args* a, void* stream) {
 }
 
 extern "C" int occd_lift_proj_fwd(const occd_lift_proj_args* q, void* stream) {
-    if (!q || !q->cam || !q->lift.out) return OCCD_EINVAL;
+    if (!q || !q->cam_E || !q->cam_k || !q->lift.out) return OCCD_EINVAL;
     const occd_lift_args* a = &q->lift;
     if (a->n_scales < 1 || a->n_scales > OCCD_MAX_SCALES || a->n_views < 1 || a->n_views > OCCD_MAX_VIEWS)
         return OCCD_EINVAL;
@@ -808,7 +810,8 @@ extern "C" int occd_lift_proj_fwd(const occd_lift_proj_args* q, void* stream) {
     for (int s = 0; s < a->n_scales; ++s)
         for (int v = 0; v < a->n_views; ++v)
             if (p.l.a.feat_bstride[s][v] == 0) p.l.a.feat_bstride[s][v] = (int64_t)a->feat_h[s] * a->feat_w[s] * a->feat_cs[s];
-    p.cam = q->cam;
+    p.cam_E = q->cam_E;
+    p.cam_k = q->cam_k;
     p.vox_size = q->voxel_size;
     for (int j = 0; j < 3; ++j) p.origin[j] = q->origin[j];
     p.img_w = q->img_w; p.img_h = q->img_h;
@@ -834,12 +837,12 @@ extern "C" int occd_lift_proj_fwd(const occd_lift_proj_args* q, void* stream) {
                          (p.has_frustum ? 4.0 * a->batch * q->frustum.n_cams * q->frustum.D * q->frustum.h * q->frustum.w : 0.0);
     occd::ProfScope prof("sfa_lift_proj", (hipStream_t)stream, 0.0, bytes);
     hipStream_t st = (hipStream_t)stream;
-    // voxels in flight per lane group: 2 measured best at config 2 (profiles/r03_lift_proj.txt); OCCD_LIFT_INFLIGHT is
-    // a tuning knob, read once
+    // voxels in flight per lane group: 1 measured best at config 2 (60.8 us; 2: 71.6 us, 4: 83.9 us -- more registers,
+    // half the waves, profiles/r03_lift_proj.txt); OCCD_LIFT_INFLIGHT is a tuning knob, read once
     static const int inflight = [] {
         const char* e = getenv("OCCD_LIFT_INFLIGHT");
-        const int v = e ? atoi(e) : 2;
-        return v == 1 || v == 4 ? v : 2;
+        const int v = e ? atoi(e) : 1;
+        return v == 2 || v == 4 ? v : 1;
     }();
 #define OCCD_LP(L, VV)                                                                                            \
     if (lpv == L && a->n_views == VV) {                                                                           \

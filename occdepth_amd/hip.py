@@ -79,7 +79,8 @@ class LiftArgs(Structure):
 
 
 class LiftProjArgs(Structure):
-    _fields_ = [("lift", LiftArgs), ("cam", c_void_p), ("voxel_size", ctypes.c_double), ("origin", c_float * 3),
+    _fields_ = [("lift", LiftArgs), ("cam_E", c_void_p), ("cam_k", c_void_p), ("voxel_size", ctypes.c_double),
+                ("origin", c_float * 3),
                 ("img_w", c_int32), ("img_h", c_int32), ("frustum", FlospArgs)]
 
 
@@ -579,17 +580,18 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     return out
 
 
-def lift_proj(feats, scale_divs, cam, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None, scale_const=100.0,
-              xcd_mode=None):
-    """The eval lift without its tables (occd_lift_proj_fwd): cam (B, V, 20) float64 device tensor (cam_E row major, fx,
-    fy, cx, cy), the voxel grid n_dims = (X, Y, Z) of `voxel_size` metres from `origin`; frustum: a `Frustum` or None."""
-    if cam.dtype != torch.float64 or not cam.is_cuda or not cam.is_contiguous() or cam.shape[-1] != 20:
-        raise RuntimeError("cam must be a contiguous (B, V, 20) float64 GPU tensor")
+def lift_proj(feats, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None,
+              scale_const=100.0, xcd_mode=None):
+    """The eval lift without its tables (occd_lift_proj_fwd): cam_E (B, V, 4, 4) / cam_k (B, V, 3, 3) float64 device
+    tensors (the batch's extrinsics and intrinsics), the voxel grid n_dims = (X, Y, Z) of `voxel_size` metres from
+    `origin`; frustum: a `Frustum` or None."""
     q = LiftProjArgs()
     _lift_args(q.lift, feats, scale_divs, None, None, n_dims, row_strides, out, None, scale_const, xcd_mode)
-    if tuple(cam.shape[:2]) != (q.lift.batch, q.lift.n_views):
-        raise RuntimeError("cam must be (batch, views, 20)")
-    q.cam = cam.data_ptr()
+    for t, shape, what in ((cam_E, (4, 4), "cam_E"), (cam_k, (3, 3), "cam_k")):
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or \
+                tuple(t.shape) != (q.lift.batch, q.lift.n_views) + shape:
+            raise RuntimeError(f"{what} must be a contiguous (batch, views, {shape[0]}, {shape[1]}) float64 GPU tensor")
+    q.cam_E, q.cam_k = cam_E.data_ptr(), cam_k.data_ptr()
     q.voxel_size = float(voxel_size)
     for j in range(3):
         q.origin[j] = float(origin[j])

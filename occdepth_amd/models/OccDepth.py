@@ -259,7 +259,7 @@ class OccDepth(_Base):
     lift_in_kernel = os.environ.get("OCCDEPTH_LIFT_PROJ", "1") == "1"
 
     def _lift_calibration(self, batch, img, key):
-        """(B, V, 20) float64 device tensor [cam_E (16), fx, fy, cx, cy] for hip.lift_proj, or None when the in-kernel
+        """(cam_E (B, V, 4, 4), cam_k (B, V, 3, 3)) float64 device tensors for hip.lift_proj, or None when the in-kernel
         projection does not apply (NYU geometry, multi-point patterns, tables without float64 extrinsics)."""
         if not self.lift_in_kernel or self.dataset != "kitti" or "cam_k" not in batch:
             return None
@@ -272,15 +272,14 @@ class OccDepth(_Base):
         if key in batch and batch[key][0].shape[-2] != 1:
             return None                                          # multi-point pattern: table path
         dims = [int(d) // int(self.project_scale) for d in self.full_scene_size]
-        if any(v & (v - 1) for v in dims + [int(r) for r in self.project_res]):
+        if any(v & (v - 1) for v in dims[1:] + [int(r) for r in self.project_res]):
             return None                                          # the fused kernel indexes with shifts
         dev = img.device
-        E = torch.stack([e.to(dev) for e in ext]).to(torch.float64).reshape(img.shape[0], -1, 16)
-        k = torch.stack([c.to(dev) for c in batch["cam_k"]]).to(torch.float32).to(torch.float64)
-        k = k.reshape(img.shape[0], -1, 9)
-        if E.shape[1] != img.shape[1] or E.shape[1] > 2:
+        E = torch.stack([e.to(dev) for e in ext]).to(torch.float64)          # (B, V, 4, 4): 1-2 small launches
+        k = torch.stack([c.to(dev) for c in batch["cam_k"]]).to(torch.float64)
+        if E.shape[:2] != img.shape[:2] or E.shape[1] > 2 or k.shape[:2] != E.shape[:2]:
             return None
-        return torch.cat([E, k[..., [0, 4, 2, 5]]], -1).contiguous()
+        return E.contiguous(), k.contiguous()
 
     def _forward_2d_to_3d(self, batch, x_rgb, img, bs, vox_origin):
         """eval: returns (Vox, depth_pred); training: ((B, C, X, Y, Z) tensor, depth_pred)."""
@@ -296,7 +295,7 @@ class OccDepth(_Base):
                     frustum, depth_pred = self._depth_volume(batch, x_rgb, vox_origin, defer_sample=True)
                 feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
                 H, W = img.shape[-2:]
-                vox = lift_scales_proj(feats, scales, cam, self._kitti_origin(), 0.2 * self.project_scale, (W, H),
+                vox = lift_scales_proj(feats, scales, cam[0], cam[1], self._kitti_origin(), 0.2 * self.project_scale, (W, H),
                                        self.projects[str(scales[0])].scene_size, self.project_scale, self.dataset,
                                        frustum=frustum, scale_const=100.0)
                 return vox, depth_pred

@@ -56,16 +56,16 @@ def lift_scales(feats, scale_divs, projected_pix, fov_mask, scene_size, project_
                     depth_scale=depth_scale, scale_const=scale_const)
 
 
-def lift_scales_proj(feats, scale_divs, cam, origin, voxel_size, img_wh, scene_size, project_scale, dataset, frustum=None,
-                     scale_const=100.0):
-    """`lift_scales` without the tables: the kernel projects the voxels from `cam` (B, V, 20) float64 (hip.lift_proj) and,
-    with a `hip.Frustum`, samples the depth frustum and applies `* depth * scale_const` itself."""
+def lift_scales_proj(feats, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, scene_size, project_scale, dataset,
+                     frustum=None, scale_const=100.0):
+    """`lift_scales` without the tables: the kernel projects the voxels from the calibration (hip.lift_proj) and, with a
+    `hip.Frustum`, samples the depth frustum and applies `* depth * scale_const` itself."""
     n_dims, out_dims, strides = voxel_layout(scene_size, project_scale, dataset)
     rows = [[pixel_rows(f) for f in per_scale] for per_scale in feats]
     B, C = feats[0][0].shape[0], feats[0][0].shape[1]
     out = Vox.empty(B, out_dims, C, feats[0][0].device)
-    return hip.lift_proj(rows, scale_divs, cam, origin, voxel_size, img_wh, n_dims, strides, out, frustum=frustum,
-                         scale_const=scale_const)
+    return hip.lift_proj(rows, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, n_dims, strides, out,
+                         frustum=frustum, scale_const=scale_const)
 
 
 class SFA(nn.Module):

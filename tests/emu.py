@@ -183,20 +183,19 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     return out
 
 
-def lift_proj(feats, scale_divs, cam, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None, scale_const=100.0,
-              xcd_mode=None):
+def lift_proj(feats, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None,
+              scale_const=100.0, xcd_mode=None):
     """occd_lift_proj_fwd = the numpy vox2pix restatement per (sample, view) + the frustum sample + `lift`."""
     import numpy as np
     from oracle.inputs import vox2pix
-    B, V = cam.shape[:2]
+    B, V = cam_E.shape[:2]
     scene = tuple(float(d) * voxel_size for d in n_dims)
     pix, fov = [], []
     for b in range(B):
         pv, fv = [], []
         for v in range(V):
-            c = cam[b, v].double().numpy()
-            k = np.array([[c[16], 0, c[18]], [0, c[17], c[19]], [0, 0, 1]])
-            p, m, _ = vox2pix(c[:16].reshape(4, 4), k, origin, voxel_size, img_wh[0], img_wh[1], scene, 0)
+            p, m, _ = vox2pix(cam_E[b, v].double().numpy(), cam_k[b, v].double().numpy(), origin, voxel_size, img_wh[0],
+                              img_wh[1], scene, 0)
             pv.append(torch.from_numpy(p))
             fv.append(torch.from_numpy(m))
         pix.append(torch.stack(pv))

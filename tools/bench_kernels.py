@@ -79,6 +79,27 @@ def bench_lift():
                    rounds=5, iters=20)["lift"]
     print(f"sfa_lift config2: {ms * 1e3:.1f} us -> {249.0 / ms / 1e3:.2f} TB/s of algorithmic bytes "
           f"({249.0 / ms / 1e3 / 8 * 100:.1f}% of 8 TB/s)")
+    # the fused lift (projection + frustum sample in the kernel) against the table path + its frustum-sample launch
+    import numpy as np
+    from occdepth_amd.models.flosp_depth.flosp_depth import _grid_to_lidar
+    cam_E = b["T_velo_2_cam_f64"][0].unsqueeze(0).cuda().contiguous()
+    cam_k = b["cam_k"][0].unsqueeze(0).cuda().contiguous()
+    dvol = torch.softmax(torch.randn(1, 2, 104, 47, 153, device="cuda"), 2).contiguous()
+    g2l = _grid_to_lidar([0, -25.6, -2, 51.2, 25.6, 4.4], (128, 128, 16)).cuda()
+    intr = torch.zeros(1, 2, 4, 4, device="cuda")
+    intr[:, :, :3, :3] = b["cam_k"][0].float().cuda()
+    intr[:, :, 3, 3] = 1
+    fr = hip.Frustum(dvol, (b["T_velo_2_cam"][0].cuda().unsqueeze(0) @ g2l).contiguous(), intr[:, :, :3, :].contiguous(),
+                     torch.eye(4, device="cuda").repeat(1, 2, 1, 1).contiguous(), (128, 128, 16), (370, 1220), 2.0, 54.0, True)
+    fns = {"tables: flosp_sample + lift": lambda: hip.lift(rows, [1, 2, 4, 8], pix, fov, n_dims, strides, out,
+                                                           depth_scale=fr.sample())}
+    for mode in (0, 1, 2):
+        fns[f"fused lift_proj xcd_mode={mode}"] = lambda mode=mode: hip.lift_proj(
+            rows, [1, 2, 4, 8], cam_E, cam_k, (0.0, -25.6, -2.0), 0.4, (1220, 370), n_dims, strides, out, frustum=fr, xcd_mode=mode)
+    for name, t in time_many(fns, rounds=5, iters=20).items():
+        mb = 249.0 if name.startswith("tables") else 240.4
+        print(f"{name:34s} (OCCD_LIFT_INFLIGHT={os.environ.get('OCCD_LIFT_INFLIGHT', '1')}): {t * 1e3:6.1f} us -> "
+              f"{mb / t / 1e3:.2f} TB/s of {mb} MB algorithmic ({mb / t / 1e3 / 8 * 100:.1f}% of 8 TB/s)")
     x = torch.randn(2, 64, 370, 1220, device="cuda")
     ms = time_many({"t": lambda: hip.nchw_to_nhwc(x)}, rounds=3, iters=10)["t"]
     print(f"nchw_to_nhwc 2x64x370x1220: {ms * 1e3:.1f} us ({2 * x.numel() * 4 / ms / 1e9:.2f} TB/s)")
