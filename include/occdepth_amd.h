@@ -171,6 +171,26 @@ typedef struct occd_lift_args {
 
 int occd_lift_fwd(const occd_lift_args* a, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * K14: one stride-1 DDR Bottleneck3D (occdepth/models/DDR.py:111-139 with BatchNorm folded) in two launches:
+ *   o1 = relu(W1 x + b1); o2 = conv_z(o1) + b2; o3 = conv_y(relu(o2)) + b3 + o2; o4 = conv_x(relu(o3)) + b4 + o2 + o3;
+ *   y = relu(W5 relu(o4) + b5 + x).       x, y: channels-last (B, X, Y, Z, cs) rows; C = channels of x and y, P = planes.
+ * w: occd_bottleneck3d_weight_floats(C, P) floats = W1^T [C][P] | b1 [P] | W2 [3][P][P] (tap, in, out) | b2 | W3 | b3 |
+ *    W4 | b4 | W5^T [P][C] | b5 [C]   (tap k <-> offset (k - 1) * dilation).   o2: workspace of B*X*Y*Z*P floats.
+ * P in {16, 32, 64}, C a multiple of 32, Z <= 64.  d0 / d1 / d2: dilation of the Z / Y / X convolution.
+ * ------------------------------------------------------------------------ */
+typedef struct occd_bneck_args {
+    const float* x;
+    float* y;
+    float* o2;
+    const float* w;
+    int32_t batch, X, Y, Z, C, P;
+    int32_t x_cs, x_coff, y_cs, y_coff;
+    int32_t d0, d1, d2;
+} occd_bneck_args;
+int64_t occd_bottleneck3d_weight_floats(int32_t C, int32_t P);
+int occd_bottleneck3d_fwd(const occd_bneck_args* a, void* stream);
+
 /* The eval lift without its tables (SURVEY 8(f) N2 fused into K1b): the kernel projects every voxel
  * centroid itself (the arithmetic of occd_project_voxels: occdepth/data/utils/helpers.py:94-169, integer-exact), samples the
  * FLoSP depth frustum for the voxel (the arithmetic of occd_flosp_sample_fwd: flosp_depth.py:561-602) and applies

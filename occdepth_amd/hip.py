@@ -84,6 +84,11 @@ class LiftProjArgs(Structure):
                 ("img_w", c_int32), ("img_h", c_int32), ("frustum", FlospArgs)]
 
 
+class BneckArgs(Structure):
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("o2", c_void_p), ("w", c_void_p)] + \
+        [(n, c_int32) for n in ("batch", "X", "Y", "Z", "C", "P", "x_cs", "x_coff", "y_cs", "y_coff", "d0", "d1", "d2")]
+
+
 class WinoArgs(Structure):
     _fields_ = [("x", c_void_p), ("upk", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("y", c_void_p)] + \
         [(n, c_int32) for n in ("batch", "cin", "cout", "H", "W", "act", "res_first", "tile_hint")] + [("slope", c_float)]
@@ -122,6 +127,8 @@ EXPORTS = {
     "occd_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
+    "occd_bottleneck3d_weight_floats": (c_int64, [c_int32, c_int32]),
+    "occd_bottleneck3d_fwd": (c_int32, [POINTER(BneckArgs), c_void_p]),
     "occd_lift_proj_fwd": (c_int32, [POINTER(LiftProjArgs), c_void_p]),
     "occd_lift_fwd": (c_int32, [POINTER(LiftArgs), c_void_p]),
     "occd_lift_bwd": (c_int32, [POINTER(LiftBwdArgs), c_void_p]),
@@ -577,6 +584,30 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     a = LiftArgs()
     _lift_args(a, feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale, scale_const, xcd_mode)
     _check(load().occd_lift_fwd(ctypes.byref(a), _stream()), "occd_lift_fwd")
+    return out
+
+
+def bottleneck3d_supported(C, P, dims):
+    """Geometries K14 (occd_bottleneck3d_fwd) is built for; everything else keeps the five-launch K2 form."""
+    return P in (16, 32, 64) and C % 32 == 0 and dims[2] <= 64
+
+
+def bottleneck3d(x, w, P, dilation, out=None):
+    """K14: y = one stride-1 DDR Bottleneck3D of the float32 Vox x (BatchNorm folded into `w`, packed as
+    occd_bottleneck3d_fwd documents); dilation = (d_z, d_y, d_x) of conv2 / conv3 / conv4."""
+    C = x.C
+    if w.dtype != torch.float32 or w.numel() != load().occd_bottleneck3d_weight_floats(C, P):
+        raise RuntimeError("bottleneck3d: packed weight buffer has the wrong size")
+    if out is None:
+        out = Vox.empty(x.batch, x.dims, C, x.buf.device)
+    X, Y, Z = x.dims
+    o2 = torch.empty(x.batch * X * Y * Z * P, device=x.buf.device, dtype=torch.float32)
+    a = BneckArgs()
+    a.x, a.y, a.o2, a.w = _f32(x.buf, "x"), _f32(out.buf, "y"), _f32(o2, "o2"), _f32(w, "w")
+    a.batch, a.X, a.Y, a.Z, a.C, a.P = x.batch, X, Y, Z, C, P
+    a.x_cs, a.x_coff, a.y_cs, a.y_coff = x.cs, x.coff, out.cs, out.coff
+    a.d0, a.d1, a.d2 = (int(d) for d in dilation)
+    _check(load().occd_bottleneck3d_fwd(ctypes.byref(a), _stream()), "occd_bottleneck3d_fwd")
     return out
 
 

@@ -11,12 +11,17 @@ forward is five K2 launches with BatchNorm folded and every ReLU / residual add 
 where p2/p3/p4 are the AvgPool+1x1x1+BN side branches (identity when stride == 1), run as
 k = stride = window convolutions.
 """
+import os
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip
+
 from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
 from ..bn import bn_act
-from ..fused import ACT_RELU, ConvPlan, as_vox, needs_autograd
+from ..fused import ACT_RELU, ConvPlan, _bn_affine, _stamp, as_vox, needs_autograd
 
 
 def _axis(value, axis, other):
@@ -69,7 +74,37 @@ class Bottleneck3D(nn.Module):
             p["skip"] = ConvPlan(self.downsample[1], self.downsample[2], pool=pool.kernel_size)
         return p
 
+    # K14 (csrc/bneck3d.hip): the stride-1 block as two launches.  OFF by default -- measured round 3:
+    # 157.6 us against 187.1 us for the five K2 launches at the 128x128x16 level in isolation, but 0.8 ms SLOWER per frame
+    # in the replayed graph (the 32- and 64-plane levels run one wave per workgroup on the vector ALU).  Kept as a tested
+    # opt-in (OCCDEPTH_FUSED_BOTTLENECK=1) until its reductions move to the matrix pipe.
+    FUSED = os.environ.get("OCCDEPTH_FUSED_BOTTLENECK", "0") == "1"
+
+    def _packed_block(self):
+        """W1^T | b1 | W2 | b2 | W3 | b3 | W4 | b4 | W5^T | b5 with the BatchNorm scales folded into the weights (the layout
+        occd_bottleneck3d_fwd documents), rebuilt when a source tensor changes."""
+        mods = [getattr(self, f"{k}{i}") for i in range(1, 6) for k in ("conv", "bn")]
+        key = _stamp(*mods)
+        if getattr(self, "_k14_key", None) == key:
+            return self._k14_w
+        parts = []
+        for i in range(1, 6):
+            conv, bn = getattr(self, f"conv{i}"), getattr(self, f"bn{i}")
+            w = conv.weight.detach().float()
+            cout = w.shape[0]
+            scale, shift = _bn_affine(bn, cout, w.device)
+            w = w.reshape(cout, w.shape[1], -1) * scale.view(-1, 1, 1)       # (out, in, taps)
+            parts += [w.permute(2, 1, 0).reshape(-1), shift.float().reshape(-1)]   # (tap, in, out)
+        self._k14_w = torch.cat(parts).contiguous()
+        self._k14_key = key
+        return self._k14_w
+
     def forward_vox(self, x):
+        if (self.FUSED and self.stride == 1 and self.downsample is None and x.buf.dtype == torch.float32
+                and hip.bottleneck3d_supported(x.C, self.conv1.out_channels, x.dims)
+                and self.conv5.out_channels == x.C):
+            d = self.dilation
+            return hip.bottleneck3d(x, self._packed_block(), self.conv1.out_channels, (d[0], d[1], d[2]))
         if self._plans is None:
             self._plans = self._build_plans()
         p = self._plans

