@@ -177,7 +177,8 @@ int occd_lift_fwd(const occd_lift_args* a, void* stream);
  *   y = relu(W5 relu(o4) + b5 + x).       x, y: channels-last (B, X, Y, Z, cs) rows; C = channels of x and y, P = planes.
  * w: occd_bottleneck3d_weight_floats(C, P) floats = W1^T [C][P] | b1 [P] | W2 [3][P][P] (tap, in, out) | b2 | W3 | b3 |
  *    W4 | b4 | W5^T [P][C] | b5 [C]   (tap k <-> offset (k - 1) * dilation).   o2: workspace of B*X*Y*Z*P floats.
- * P in {16, 32, 64}, C a multiple of 32, Z <= 64.  d0 / d1 / d2: dilation of the Z / Y / X convolution.
+ * P in {16, 32}, C a multiple of 16, Z in {4, 8, 16} (a 16-voxel MFMA column block holds whole Z columns).
+ * d0 / d1 / d2: dilation of the Z / Y / X convolution.
  * ------------------------------------------------------------------------ */
 typedef struct occd_bneck_args {
     const float* x;

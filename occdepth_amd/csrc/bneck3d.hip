@@ -10,14 +10,15 @@
 // The five-launch form (fused.ConvPlan x 5 on K2) moves x, three P-channel intermediates and y through HBM with ~110
 // small launches per frame that each run at about a third of the HBM rate; the block is HBM work (C = 4 P, 8.7 kFLOP per
 // voxel at P = 16).  Here:
-//   bneck_a: columns of Z voxels, one thread per voxel: o1 = relu(W1 x) from an LDS-staged tile of x rows (coalesced
-//            loads, 32 channels at a time), conv_z through LDS, o2 written once (P floats per voxel).
-//   bneck_b: a TX x TY x Z tile, one thread per voxel: o3 on the tile plus its +-d2 planes along X straight from o2 rows
-//            (three 4P-byte rows per voxel, L2 hits), o3 and o2 + o3 in LDS, conv_x, then y in chunks of 32 output
-//            channels through an LDS transposition so that the residual read and the store are coalesced row segments.
-// Arithmetic: float32 FMA on the vector ALU with the weights as SCALAR operands (they are uniform: s_load + v_fmac).  The
-// fp32 MFMA rate equals the fp32 vector rate on gfx950 (157 TFLOP/s, MI355X_MICROARCH.md), so for these 16..64-channel
-// reductions the matrix pipe would buy nothing but operand shuffles.
+//   bneck_a: NT consecutive voxels (whole Z columns) per workgroup, 16 voxels per MFMA column block: conv1 straight from
+//            the global x rows (one 16-byte load per lane and 16 channels, 64 contiguous bytes per voxel), o1 to LDS,
+//            conv_z out of LDS, o2 written once (P floats per voxel).
+//   bneck_b: a TX x TY x Z tile: o3 on the tile plus its +-d2 planes along X straight from the o2 rows (L2 hits for the
+//            halo), o3 and o2 + o3 in LDS, conv_x out of LDS, conv5 from the accumulator registers, residual x and y as
+//            16-byte accesses per lane.  No staging tile, no transposition pass.
+// Round 3 first tried one THREAD per voxel on the vector ALU with scalar weight operands: 157.6 us per block at
+// 128x128x16 against 187.1 us for the five launches in isolation and SLOWER in the replayed frame (one wave per workgroup at
+// P = 32 / 64); the matrix pipe form below replaced it.
 // HBM bytes per voxel: read x (4C) + write o2 (4P) | read o2 (4P, +halo from L2) + read x (4C) + write y (4C)
 //   = 4 (3C + 2P) = 896 B at C = 64 (235 MB per block at 128x128x16) against 4 (3C + 8P) + launch tails before.
 #include "common.h"
@@ -26,9 +27,6 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-
-constexpr int kCH = 32;        // channel chunk of the x / y staging tiles
-constexpr int kPadX = kCH + 4; // floats per staged row (16-byte aligned, conflict-free for 16 lanes of b128)
 
 struct BneckP {
     const float* x;
@@ -50,200 +48,228 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
 }
 
-// acc[n] += sum_k in[k] * w[k][n], in = K floats at `row` (LDS or global, 16-byte aligned), w uniform ([K][wstride])
-template <int N, bool RELU_IN>
-__device__ __forceinline__ void fma_rows(float (&acc)[N], const float* __restrict__ w, int wstride,
-                                         const float* __restrict__ row, int K, bool valid) {
-    for (int k4 = 0; k4 < K; k4 += 4) {
-        f32x4 v = *(const f32x4*)(row + k4);
-        if (RELU_IN) v = relu4(v);
-        if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Every reduction runs as  D^T (couts x voxels) = W (couts x cin) . X^T (cin x voxels)  on v_mfma_f32_16x16x4_f32:
+//   A operand = weights: lane l supplies W[cout 16 m + (l & 15)][k], k = l >> 4;
+//   B operand = data:    lane l supplies X[voxel l & 15][k];
+//   D: lane l holds couts 16 m + 4 (l >> 4) + {0..3} of voxel l & 15  -> ONE float4 of consecutive channels per lane.
+// The K order of a 16-channel "super-step" t is permuted so that a lane's four k values are the four CONSECUTIVE channels
+// 16 t + 4 (l >> 4) + e, e = 0..3: data arrives as one 16-byte load per lane (global rows or LDS rows, 64 contiguous bytes
+// per voxel across its 4 lanes), and a D fragment IS the B operand of the next 1x1 reduction (conv5 reads relu(o4) from
+// registers).  Weight fragments live in LDS in that order: [t][m][lane][e].
+template <int M>
+__device__ __forceinline__ void mma_step(f32x4 (&acc)[M], const float* wfrag, int lane, f32x4 data) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* __restrict__ wr = w + (size_t)(k4 + j) * wstride;
+    for (int m = 0; m < M; ++m) {
+        const f32x4 w = *(const f32x4*)(wfrag + (m * 64 + lane) * 4);
 #pragma unroll
-            for (int n = 0; n < N; ++n) acc[n] = fmaf(v[j], wr[n], acc[n]);
-        }
+        for (int e = 0; e < 4; ++e) acc[m] = mfma16(w[e], data[e], acc[m]);
     }
 }
 
-// ---------------------------------------------------------------- A: x -> o1 -> o2
+// global [cin][cout] (row stride `stride`) -> LDS fragments [t][m][lane][e] of a KIN x MOUT reduction
+__device__ __forceinline__ void load_frags(float* dst, const float* __restrict__ src, int KIN, int MOUT, int stride, int tid,
+                                           int nthreads) {
+    const int mt = MOUT >> 4;
+    for (int idx = tid; idx < KIN * MOUT; idx += nthreads) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
+        const int m = rest % mt, t = rest / mt;
+        dst[idx] = src[(size_t)(16 * t + 4 * (lane >> 4) + e) * stride + 16 * m + (lane & 15)];
+    }
+}
+
+// ---------------------------------------------------------------- A: x -> o1 -> o2      (16 % Z == 0: a tile = whole columns)
 template <int P, int NT>
 __global__ void __launch_bounds__(NT) bneck_a_kernel(const BneckP p) {
-    constexpr int PS = P + 4;                         // floats per o1 row in LDS
+    constexpr int M = P / 16, NW = NT / 64, TPW = 4;     // cout tiles, waves, 16-voxel tiles per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;                                  // [NT][kPadX]
-    float* o1s = lds + NT * kPadX;                    // [NT][PS]
-    const int tid = threadIdx.x;
-    const int ncol = NT / p.Z;                        // columns per workgroup
-    const int nvox = ncol * p.Z;                      // voxels per workgroup (contiguous rows: z fastest, then y, x, b)
-    const long v0 = (long)blockIdx.x * nvox;
-    const long vtot = p.ncols * p.Z;
-    const int z = tid % p.Z;
-    const bool live = tid < nvox && v0 + tid < vtot;
-
-    float acc[P];
-#pragma unroll
-    for (int n = 0; n < P; ++n) acc[n] = p.b1[n];
-    for (int c0 = 0; c0 < p.C; c0 += kCH) {           // (C is a multiple of 32: checked by the host)
-        __syncthreads();
-        for (int i = tid; i < nvox * (kCH / 4); i += NT) {
-            const int r = i >> 3, q = i & 7;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + r < vtot)
-                v = *(const f32x4*)(p.x + (size_t)(v0 + r) * p.x_cs + p.x_coff + c0 + q * 4);
-            *(f32x4*)(xs + r * kPadX + q * 4) = v;
-        }
-        __syncthreads();
-        fma_rows<P, false>(acc, p.w1 + (size_t)c0 * P, P, xs + (tid < nvox ? tid : 0) * kPadX, kCH, true);
-    }
-#pragma unroll
-    for (int n = 0; n < P; n += 4)
-        *(f32x4*)(o1s + tid * PS + n) = relu4(f32x4{acc[n], acc[n + 1], acc[n + 2], acc[n + 3]});
+    const int CT = p.C >> 4;                              // super-steps of conv1
+    float* w1f = lds;                                     // [CT][M][64][4]
+    float* w2f = w1f + p.C * P;                           // [3][M(t)][M][64][4]
+    float* o1s = w2f + 3 * P * P;                         // [NT][P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    load_frags(w1f, p.w1, p.C, P, P, tid, NT);
+    for (int k = 0; k < 3; ++k) load_frags(w2f + k * P * P, p.w2 + (size_t)k * P * P, P, P, P, tid, NT);
     __syncthreads();
-
-    float o2[P];
+    const long v0 = (long)blockIdx.x * NT;
+    const long vtot = p.ncols * p.Z;
+    f32x4 b1v[M], b2v[M];
 #pragma unroll
-    for (int n = 0; n < P; ++n) o2[n] = p.b2[n];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int zz = z + (k - 1) * p.d0;
-        const bool ok = zz >= 0 && zz < p.Z && tid < nvox;
-        fma_rows<P, false>(o2, p.w2 + (size_t)k * P * P, P, o1s + (ok ? tid + (k - 1) * p.d0 : tid) * PS, P, ok);
+    for (int m = 0; m < M; ++m) {
+        b1v[m] = *(const f32x4*)(p.b1 + 16 * m + 4 * g);
+        b2v[m] = *(const f32x4*)(p.b2 + 16 * m + 4 * g);
     }
-    if (live) {
-        float* dst = p.o2 + (size_t)(v0 + tid) * P;
+    for (int it = 0; it < TPW; ++it) {
+        const int row = (wave * TPW + it) * 16 + j;       // voxel of this lane inside the workgroup tile
+        const long v = v0 + row;
+        const bool live = v < vtot;
+        const float* xr = p.x + (size_t)(live ? v : 0) * p.x_cs + p.x_coff + 4 * g;
+        f32x4 acc[M];
 #pragma unroll
-        for (int n = 0; n < P; n += 4) *(f32x4*)(dst + n) = f32x4{o2[n], o2[n + 1], o2[n + 2], o2[n + 3]};
+        for (int m = 0; m < M; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < CT; t0 += 4) {              // 4 super-steps of loads in flight
+            f32x4 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = t0 + u < CT ? *(const f32x4*)(xr + 16 * (t0 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < CT) mma_step<M>(acc, w1f + (size_t)(t0 + u) * M * 256, lane, d[u]);
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) *(f32x4*)(o1s + row * P + 16 * m + 4 * g) = relu4(acc[m] + b1v[m]);
+        __syncthreads();                                  // (uniform trip count; the tile's columns are complete)
+        const int z = row % p.Z;
+        f32x4 o2[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) o2[m] = b2v[m];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int zz = z + (k - 1) * p.d0;
+            const bool ok = zz >= 0 && zz < p.Z;
+            const float* src = o1s + (ok ? row + (k - 1) * p.d0 : row) * P + 4 * g;
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                f32x4 d = *(const f32x4*)(src + 16 * t);
+                if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma_step<M>(o2, w2f + (size_t)(k * M + t) * M * 256, lane, d);
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) *(f32x4*)(p.o2 + (size_t)v * P + 16 * m + 4 * g) = o2[m];
+        }
     }
 }
 
-// ---------------------------------------------------------------- B: o2 -> o3 -> o4 -> y
+// ---------------------------------------------------------------- B: o2 -> o3 -> o4 -> y    (TY * Z a multiple of 16)
 template <int P, int NT>
 __global__ void __launch_bounds__(NT) bneck_b_kernel(const BneckP p) {
-    constexpr int PS = P + 4;
+    constexpr int M = P / 16, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
     const int TYZ = p.TY * p.Z;
-    const int nvox = p.TX * TYZ;                       // voxels (threads at work) of the tile
-    const int XR = p.TX + 2 * p.d2;                    // o3 planes held
-    float* o3s = lds;                                  // [XR * TYZ][PS]   raw o3 (zero outside the volume)
-    float* ys = lds;                                   // [nvox][kPadX]    aliases o3s after the conv_x pass
-    float* cs = lds + std::max((size_t)XR * TYZ * PS, (size_t)nvox * kPadX);   // [nvox][PS]  o2 + o3, later relu(o4)
+    const int nvox = p.TX * TYZ;                           // == NT
+    const int XR = p.TX + 2 * p.d2;
+    const int CT = p.C >> 4;
+    float* w3f = lds;                                      // [3][M][M][64][4]
+    float* w4f = w3f + 3 * P * P;
+    float* w5f = w4f + 3 * P * P;                          // [M(t)][CT][64][4]
+    float* o3s = w5f + P * p.C;                            // [XR * TYZ][P]   raw o3 (zero outside the volume)
+    float* cs = o3s + (size_t)XR * TYZ * P;                // [nvox][P]       o2 + o3
+    for (int k = 0; k < 3; ++k) {
+        load_frags(w3f + k * P * P, p.w3 + (size_t)k * P * P, P, P, P, tid, NT);
+        load_frags(w4f + k * P * P, p.w4 + (size_t)k * P * P, P, P, P, tid, NT);
+    }
+    load_frags(w5f, p.w5, P, p.C, p.C, tid, NT);
+    __syncthreads();
     const int b = blockIdx.y;
     const int xt = blockIdx.x / p.ytiles, yt = blockIdx.x - xt * p.ytiles;
     const int x0 = xt * p.TX, y0 = yt * p.TY;
     const float* o2b = p.o2 + (size_t)b * p.X * p.Y * p.Z * P;
+    f32x4 b3v[M], b4v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        b3v[m] = *(const f32x4*)(p.b3 + 16 * m + 4 * g);
+        b4v[m] = *(const f32x4*)(p.b4 + 16 * m + 4 * g);
+    }
 
-    // ---- o3 on the tile and its X halo
-    for (int r = tid; r < XR * TYZ; r += NT) {
+    // ---- o3 on the tile and its X halo, 16 region voxels per MFMA column block
+    for (int rt = wave; rt < XR * TYZ / 16; rt += NW) {
+        const int r = rt * 16 + j;
         const int xr = r / TYZ, rem = r - xr * TYZ;
         const int ty = rem / p.Z, z = rem - ty * p.Z;
         const int xx = x0 - p.d2 + xr, yy = y0 + ty;
-        float o3[P];
-        float o2c[P];
         const bool in = xx >= 0 && xx < p.X && yy < p.Y;
-        const size_t col = ((size_t)(in ? xx : 0) * p.Y + (in ? yy : 0)) * p.Z + z;
-        {
-            const float* src = o2b + col * P;
-#pragma unroll
-            for (int n = 0; n < P; n += 4) {
-                const f32x4 v = *(const f32x4*)(src + n);
-                o2c[n] = v.x; o2c[n + 1] = v.y; o2c[n + 2] = v.z; o2c[n + 3] = v.w;
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < P; ++n) o3[n] = p.b3[n] + o2c[n];
+        f32x4 d[3][M];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int yk = yy + (k - 1) * p.d1;
             const bool ok = in && yk >= 0 && yk < p.Y;
-            const float* src = o2b + (((size_t)(in ? xx : 0) * p.Y + (ok ? yk : 0)) * p.Z + z) * P;
-            fma_rows<P, true>(o3, p.w3 + (size_t)k * P * P, P, src, P, ok);
+            const float* src = o2b + (((size_t)(in ? xx : 0) * p.Y + (ok ? yk : 0)) * p.Z + z) * P + 4 * g;
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                d[k][t] = *(const f32x4*)(src + 16 * t);
+                if (!ok) d[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
+        f32x4 o3[M];
 #pragma unroll
-        for (int n = 0; n < P; n += 4)
-            *(f32x4*)(o3s + (size_t)r * PS + n) = in ? f32x4{o3[n], o3[n + 1], o3[n + 2], o3[n + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (xr >= p.d2 && xr < p.d2 + p.TX) {
-            const int tc = r - p.d2 * TYZ;
+        for (int m = 0; m < M; ++m) o3[m] = b3v[m] + d[1][m];        // + o2 (the centre rows ARE the D-layout residual)
 #pragma unroll
-            for (int n = 0; n < P; n += 4)
-                *(f32x4*)(cs + (size_t)tc * PS + n) = f32x4{o2c[n] + o3[n], o2c[n + 1] + o3[n + 1], o2c[n + 2] + o3[n + 2],
-                                                           o2c[n + 3] + o3[n + 3]};
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int t = 0; t < M; ++t) mma_step<M>(o3, w3f + (size_t)(k * M + t) * M * 256, lane, relu4(d[k][t]));
+        const bool centre = xr >= p.d2 && xr < p.d2 + p.TX;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            *(f32x4*)(o3s + (size_t)r * P + 16 * m + 4 * g) = in ? o3[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (centre) *(f32x4*)(cs + (size_t)(r - p.d2 * TYZ) * P + 16 * m + 4 * g) = d[1][m] + o3[m];
         }
     }
     __syncthreads();
 
-    // ---- o4 = conv_x(relu(o3)) + b4 + o2 + o3, kept as relu(o4) in `cs`
-    const int tv = tid < nvox ? tid : 0;
-    {
-        float o4[P];
+    // ---- o4 = conv_x(relu(o3)) + b4 + o2 + o3; y = relu(W5 relu(o4) + b5 + x) straight from the D fragments
+    for (int ct = wave; ct < nvox / 16; ct += NW) {
+        const int tv = ct * 16 + j;
+        const int tx = tv / TYZ, rem = tv - tx * TYZ;
+        const int ty = rem / p.Z, z = rem - ty * p.Z;
+        const int xx = x0 + tx, yy = y0 + ty;
+        const bool live = xx < p.X && yy < p.Y;
+        const size_t vrow = (((size_t)b * p.X + (live ? xx : 0)) * p.Y + (live ? yy : 0)) * p.Z + z;
+        const float* xres = p.x + vrow * p.x_cs + p.x_coff + 4 * g;
+        f32x4 o4[M];
 #pragma unroll
-        for (int n = 0; n < P; n += 4) {
-            const f32x4 v = *(const f32x4*)(cs + (size_t)tv * PS + n);
-            o4[n] = v.x + p.b4[n]; o4[n + 1] = v.y + p.b4[n + 1]; o4[n + 2] = v.z + p.b4[n + 2]; o4[n + 3] = v.w + p.b4[n + 3];
-        }
+        for (int m = 0; m < M; ++m) o4[m] = b4v[m] + *(const f32x4*)(cs + (size_t)tv * P + 16 * m + 4 * g);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            fma_rows<P, true>(o4, p.w4 + (size_t)k * P * P, P, o3s + (size_t)(tv + k * p.d2 * TYZ) * PS, P, true);
-        __syncthreads();                                // every conv_x read of o3s is done: the staging tile may alias it
-        if (tid < nvox) {
 #pragma unroll
-            for (int n = 0; n < P; n += 4)
-                *(f32x4*)(cs + (size_t)tv * PS + n) = relu4(f32x4{o4[n], o4[n + 1], o4[n + 2], o4[n + 3]});
-        }
-    }
-    // (each thread reads back only its own `cs` row below: no barrier needed for it)
-
-    // ---- y = relu(W5 relu(o4) + b5 + x), 32 output channels at a time
-    for (int c0 = 0; c0 < p.C; c0 += kCH) {               // (C is a multiple of 32: checked by the host)
-        __syncthreads();
-        for (int i = tid; i < nvox * (kCH / 4); i += NT) {      // residual rows of x, coalesced
-            const int r = i >> 3, q = i & 7;
-            const int tx = r / TYZ, rem = r - tx * TYZ;
-            const int ty = rem / p.Z, z = rem - ty * p.Z;
-            const int xx = x0 + tx, yy = y0 + ty;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xx < p.X && yy < p.Y)
-                v = *(const f32x4*)(p.x + ((((size_t)b * p.X + xx) * p.Y + yy) * p.Z + z) * p.x_cs + p.x_coff + c0 + q * 4);
-            *(f32x4*)(ys + r * kPadX + q * 4) = v;
-        }
-        __syncthreads();
-        float acc[kCH];
+            for (int t = 0; t < M; ++t)
+                mma_step<M>(o4, w4f + (size_t)(k * M + t) * M * 256, lane,
+                            relu4(*(const f32x4*)(o3s + (size_t)(tv + k * p.d2 * TYZ) * P + 16 * t + 4 * g)));
 #pragma unroll
-        for (int n = 0; n < kCH; n += 4) {
-            const f32x4 v = *(const f32x4*)(ys + tv * kPadX + n);
-            acc[n] = v.x; acc[n + 1] = v.y; acc[n + 2] = v.z; acc[n + 3] = v.w;
-        }
+        for (int m = 0; m < M; ++m) o4[m] = relu4(o4[m]);
+        float* yrow = p.y + vrow * p.y_cs + p.y_coff + 4 * g;
+        for (int mo = 0; mo < CT; mo += 4) {               // 4 output tiles (64 channels) per round, residual loads first
+            f32x4 res[4], bias[4], acc[4];
 #pragma unroll
-        for (int n = 0; n < kCH; ++n) acc[n] += p.b5[c0 + n];
-        fma_rows<kCH, false>(acc, p.w5 + c0, p.C, cs + (size_t)tv * PS, P, true);
-        if (tid < nvox) {
+            for (int u = 0; u < 4; ++u) {
+                const bool on = mo + u < CT;
+                res[u] = on ? *(const f32x4*)(xres + 16 * (mo + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bias[u] = on ? *(const f32x4*)(p.b5 + 16 * (mo + u) + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-            for (int n = 0; n < kCH; n += 4)
-                *(f32x4*)(ys + tv * kPadX + n) = relu4(f32x4{acc[n], acc[n + 1], acc[n + 2], acc[n + 3]});
-        }
-        __syncthreads();
-        for (int i = tid; i < nvox * (kCH / 4); i += NT) {      // coalesced store
-            const int r = i >> 3, q = i & 7;
-            const int tx = r / TYZ, rem = r - tx * TYZ;
-            const int ty = rem / p.Z, z = rem - ty * p.Z;
-            const int xx = x0 + tx, yy = y0 + ty;
-            if (xx < p.X && yy < p.Y)
-                *(f32x4*)(p.y + ((((size_t)b * p.X + xx) * p.Y + yy) * p.Z + z) * p.y_cs + p.y_coff + c0 + q * 4) =
-                    *(const f32x4*)(ys + r * kPadX + q * 4);
+            for (int u = 0; u < 4; ++u) {
+                if (mo + u >= CT) continue;
+#pragma unroll
+                for (int t = 0; t < M; ++t) {
+                    const f32x4 w = *(const f32x4*)(w5f + ((size_t)(t * CT + mo + u) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u] = mfma16(w[e], o4[t][e], acc[u]);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (mo + u < CT) *(f32x4*)(yrow + 16 * (mo + u)) = relu4(acc[u] + bias[u] + res[u]);
+            }
         }
     }
 }
 
 template <int P, int NT>
 int launch(const BneckP& p, hipStream_t st) {
-    constexpr int PS = P + 4;
-    const int ncol = NT / p.Z;
-    const size_t lds_a = (size_t)NT * (kPadX + PS) * sizeof(float);
-    const long blocks_a = (p.ncols + ncol - 1) / ncol;
-    const int TYZ = p.TY * p.Z, nvox = p.TX * TYZ;
-    const size_t lds_b = sizeof(float) * (std::max((size_t)(p.TX + 2 * p.d2) * TYZ * PS, (size_t)nvox * kPadX) + (size_t)nvox * PS);
+    const size_t lds_a = sizeof(float) * ((size_t)p.C * P + 3 * P * P + (size_t)NT * P);
+    const long vtot = p.ncols * p.Z;
+    const long blocks_a = (vtot + NT - 1) / NT;
+    const int TYZ = p.TY * p.Z;
+    const size_t lds_b = sizeof(float) * ((size_t)6 * P * P + (size_t)P * p.C + (size_t)(p.TX + 2 * p.d2) * TYZ * P + (size_t)NT * P);
+    if (lds_a > 160 * 1024 || lds_b > 160 * 1024) return OCCD_ENOMEM;
     if (lds_a > 64 * 1024 || lds_b > 64 * 1024) {
         static bool done = false;                      // per instantiation
         if (!done) {
@@ -253,7 +279,6 @@ int launch(const BneckP& p, hipStream_t st) {
             done = true;
         }
     }
-    if (lds_a > 160 * 1024 || lds_b > 160 * 1024) return OCCD_ENOMEM;
     hipLaunchKernelGGL((bneck_a_kernel<P, NT>), dim3((unsigned)blocks_a), dim3(NT), lds_a, st, p);
     hipLaunchKernelGGL((bneck_b_kernel<P, NT>), dim3((unsigned)(p.xtiles * p.ytiles), (unsigned)p.batch), dim3(NT), lds_b, st, p);
     return occd::check_launch();
@@ -268,9 +293,9 @@ extern "C" int64_t occd_bottleneck3d_weight_floats(int32_t C, int32_t P) {
 
 extern "C" int occd_bottleneck3d_fwd(const occd_bneck_args* a, void* stream) {
     if (!a || !a->x || !a->y || !a->o2 || !a->w) return OCCD_EINVAL;
-    if (a->batch <= 0 || a->X <= 0 || a->Y <= 0 || a->Z <= 0 || a->Z > 64) return OCCD_EINVAL;
-    if (a->P != 16 && a->P != 32 && a->P != 64) return OCCD_EINVAL;
-    if (a->C <= 0 || (a->C & 31) || a->d0 <= 0 || a->d1 <= 0 || a->d2 <= 0) return OCCD_EINVAL;
+    if (a->batch <= 0 || a->X <= 0 || a->Y <= 0 || a->Z <= 0 || a->Z > 16) return OCCD_EINVAL;
+    if (a->P != 16 && a->P != 32) return OCCD_EINVAL;
+    if (a->C <= 0 || (a->C & 15) || a->d0 <= 0 || a->d1 <= 0 || a->d2 <= 0) return OCCD_EINVAL;
     if ((a->x_cs & 3) || (a->x_coff & 3) || (a->y_cs & 3) || (a->y_coff & 3) || a->x_coff + a->C > a->x_cs ||
         a->y_coff + a->C > a->y_cs)
         return OCCD_EINVAL;
@@ -290,23 +315,20 @@ extern "C" int occd_bottleneck3d_fwd(const occd_bneck_args* a, void* stream) {
     p.x_cs = a->x_cs; p.x_coff = a->x_coff; p.y_cs = a->y_cs; p.y_coff = a->y_coff;
     p.d0 = a->d0; p.d1 = a->d1; p.d2 = a->d2;
     p.ncols = (long)a->batch * a->X * a->Y;
-    // workgroup size: one thread per voxel; fewer threads where the grid is small (more workgroups) or P is wide (LDS)
+    // one lane quartet per voxel: a workgroup of NT threads owns NT voxels (4 tiles of 16 per wave)
     const long nvox_total = p.ncols * a->Z;
-    int NT = P == 16 ? 256 : P == 32 ? 128 : 64;
-    while (NT > 64 && nvox_total / NT < 512) NT >>= 1;
-    if (a->Z > NT) return OCCD_EINVAL;
-    const int cols = NT / a->Z;                        // columns of the B tile: TX x TY with TY <= 2
-    p.TY = cols >= 8 && a->Y >= 2 ? 2 : 1;
-    p.TX = std::max(1, cols / p.TY);
-    if (p.TX > a->X) p.TX = a->X;
+    const int NT = P == 16 ? 256 : 128;
+    if (16 % a->Z != 0) return OCCD_EINVAL;            // a 16-voxel tile must hold whole columns (Z = 4, 8, 16)
+    p.TY = a->Z == 16 ? 2 : 16 / a->Z;                  // TY * Z a multiple of 16
+    if (a->Z == 8) p.TY = 2;
+    p.TX = NT / (p.TY * a->Z);
     p.xtiles = (a->X + p.TX - 1) / p.TX;
     p.ytiles = (a->Y + p.TY - 1) / p.TY;
     const double vox = (double)nvox_total;
     occd::ProfScope prof("bottleneck3d", (hipStream_t)stream, vox * 2.0 * (2.0 * C * P + 9.0 * P * P),
                          vox * 4.0 * (3.0 * C + 2.0 * P));
     hipStream_t st = (hipStream_t)stream;
-#define OCCD_BN(PP, TT) if (P == PP && NT == TT) return launch<PP, TT>(p, st);
-    OCCD_BN(16, 256) OCCD_BN(16, 128) OCCD_BN(16, 64) OCCD_BN(32, 128) OCCD_BN(32, 64) OCCD_BN(64, 64)
-#undef OCCD_BN
+    if (P == 16) return launch<16, 256>(p, st);
+    if (P == 32) return launch<32, 128>(p, st);
     return OCCD_EINVAL;
 }

@@ -589,7 +589,7 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
 
 def bottleneck3d_supported(C, P, dims):
     """Geometries K14 (occd_bottleneck3d_fwd) is built for; everything else keeps the five-launch K2 form."""
-    return P in (16, 32, 64) and C % 32 == 0 and dims[2] <= 64
+    return P in (16, 32) and C % 16 == 0 and dims[2] in (4, 8, 16)
 
 
 def bottleneck3d(x, w, P, dilation, out=None):

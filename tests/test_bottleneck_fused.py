@@ -1,7 +1,7 @@
 """K14 (csrc/bneck3d.hip, occd_bottleneck3d_fwd): one stride-1 DDR Bottleneck3D as two launches, against the module's own
 differentiable ATen graph (the reference's formulation, occdepth/models/DDR.py:111-139) evaluated in float64 on the CPU.
 CPU: the packing host logic (BatchNorm folding, tap / channel order of the packed buffer) through the emulation.
-GPU: the kernels at the three shapes of the config-2 stack (C = 64 / 128 / 256 at Z = 16 / 8 / 4), ragged X / Y extents,
+GPU: the kernels at the three shapes of the config-2 stack (C = 64 / 128 at Z = 16 / 8 / 4; P = 64 and odd Z fall back to the five launches), ragged X / Y extents,
 batch 2, dilations 1-3, and the five-launch K2 form of the same block on the same inputs."""
 import copy
 
@@ -18,8 +18,10 @@ CASES = {
     "l1_d2_ragged": (64, 16, (5, 3, 16), 2, 1),
     "l2_d2": (128, 32, (10, 9, 8), 2, 1),
     "l2_d3": (128, 32, (7, 8, 8), 3, 2),
-    "crp_d1": (256, 64, (6, 5, 4), 1, 1),
-    "z5_odd": (64, 16, (6, 6, 5), 2, 1),
+    "l2_z4": (128, 32, (6, 5, 4), 1, 1),
+    "l1_z8_d2": (64, 16, (5, 9, 8), 2, 2),
+    "crp_p64_fallback": (256, 64, (6, 5, 4), 1, 1),        # P = 64 and odd Z: the five-launch form (K14 declines)
+    "z5_fallback": (64, 16, (6, 6, 5), 2, 1),
 }
 
 
@@ -41,7 +43,7 @@ def reference(m, x):
         return copy.deepcopy(m).double()._forward_autograd(x.double())
 
 
-@pytest.mark.parametrize("name", ["l1_d3", "l2_d2", "z5_odd"])
+@pytest.mark.parametrize("name", ["l1_d3", "l2_d2", "l1_z8_d2"])
 def test_bottleneck_packing_host_logic_cpu(name, monkeypatch):
     C, P, dims, d, B = CASES[name]
     m = make_block(C, P, d, seed=len(name))

@@ -46,7 +46,7 @@ def act_masks(record=None, replay=None, flips=None):
         if record is not None:
             record.append((x.detach() > 0).cpu())
             return real[1](x, slope) if slope else real[0](x)
-        mask = next(it)
+        mask = next(it).to(x.device)
         assert mask.shape == x.shape, (tuple(mask.shape), tuple(x.shape))
         diff = (x.detach() > 0) != mask
         if diff.any():
