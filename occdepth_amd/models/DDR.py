@@ -74,11 +74,10 @@ class Bottleneck3D(nn.Module):
             p["skip"] = ConvPlan(self.downsample[1], self.downsample[2], pool=pool.kernel_size)
         return p
 
-    # K14 (csrc/bneck3d.hip): the stride-1 block as two launches.  OFF by default -- measured round 3:
-    # 157.6 us against 187.1 us for the five K2 launches at the 128x128x16 level in isolation, but 0.8 ms SLOWER per frame
-    # in the replayed graph (the 32- and 64-plane levels run one wave per workgroup on the vector ALU).  Kept as a tested
-    # opt-in (OCCDEPTH_FUSED_BOTTLENECK=1) until its reductions move to the matrix pipe.
-    FUSED = os.environ.get("OCCDEPTH_FUSED_BOTTLENECK", "0") == "1"
+    # K14 (csrc/bneck3d.hip): the stride-1 block as two launches on the fp32 matrix pipe (P = 16 / 32 planes, Z = 4 / 8 / 16):
+    # 67.5 us against 192 us for the five K2 launches at 128x128x16, -0.3 ms per config-2 frame (profiles/r03_k14_ab.txt).
+    # OCCDEPTH_FUSED_BOTTLENECK=0 keeps the five launches for A/B.
+    FUSED = os.environ.get("OCCDEPTH_FUSED_BOTTLENECK", "1") == "1"
 
     def _packed_block(self):
         """W1^T | b1 | W2 | b2 | W3 | b3 | W4 | b4 | W5^T | b5 with the BatchNorm scales folded into the weights (the layout
