@@ -279,19 +279,61 @@ class ConvTransposePlan:
         self._prepare()
         if out is None:
             out = Vox.empty(x.batch, self.out_dims(x.dims), self.cout, x.buf.device)
-        for off, kern, pad, wpk in self._phases:
-            _conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
-                       out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
+        def phase(off, kern, pad, wpk):
+            return lambda: _conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
+                                   out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
+
+        thunks = [phase(*ph) for ph in self._phases]
+        if x.buf.is_cuda and len(thunks) > 1:
+            run_parallel(thunks)                     # the phases write disjoint voxels of `out`
+        else:
+            for th in thunks:
+                th()
         return out
+
+
+def pack_rows(b_rows):
+    """(K, N) row-major device matrix -> the packed B operand of `gemm_rows` (occd_pack_weights layout 2)."""
+    return _pack_w(b_rows, layout=2), tuple(b_rows.shape)
 
 
 def gemm_rows(a, b_rows, out, act_in=ACT_NONE):
     """out[row, :] = act_in(a[row, :K]) @ b_rows[:K, :N] for channels-last Vox a/out (CRP bmm).
 
-    b_rows is a dense (K, N) row-major device matrix (packed on the fly with occd_pack_weights layout 2)."""
-    K, N = b_rows.shape
-    wpk = _pack_w(b_rows, layout=2)
+    b_rows is a dense (K, N) row-major device matrix (packed on the fly) or the result of `pack_rows`."""
+    wpk, (K, N) = b_rows if isinstance(b_rows, tuple) else pack_rows(b_rows)
     return _conv3d(a, wpk, None, N, (1, 1, 1), out, act_in=act_in, cin=K)
+
+
+# Independent small launches (the 8 sub-pixel phases of a transposed convolution, the ASPP's dilation branches, the CRP's
+# relation branches) CAN be issued round-robin on a few side streams forked from -- and joined back into -- the current
+# stream (inside a hipGraph capture the fork / join become graph edges); the thunks must not allocate.  Measured round 3
+# and NOT adopted: the config-2 frame went from 25.15 ms (one stream) to 25.25 / 26.04 / 25.73 ms with 2 / 3 / 4 streams --
+# a branching graph costs more in cross-queue barriers than the overlapped tails give back.  Default 1 = sequential.
+PARALLEL_STREAMS = int(os.environ.get("OCCDEPTH_PARALLEL_STREAMS", "1"))
+_side_streams = {}
+
+
+def run_parallel(thunks, width=None):
+    width = PARALLEL_STREAMS if width is None else width
+    if width < 2 or len(thunks) < 2 or not torch.cuda.is_available():
+        for th in thunks:
+            th()
+        return
+    cur = torch.cuda.current_stream()
+    key = (cur.device, width)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=cur.device) for _ in range(width)]
+    pool = _side_streams[key][:min(width, len(thunks))]
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    for s in pool:
+        s.wait_event(fork)
+    for i, th in enumerate(thunks):
+        with torch.cuda.stream(pool[i % len(pool)]):
+            th()
+    for s in pool:
+        cur.wait_stream(s)
 
 
 def as_vox(x):

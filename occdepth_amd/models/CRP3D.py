@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import hip
 from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
-from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows, needs_autograd
+from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows, needs_autograd, pack_rows, run_parallel
 from .modules import ASPP, Process
 
 
@@ -62,18 +62,38 @@ class CPMegaVoxels(nn.Module):
         cat = torch.empty((B,) + dims + (C + R * C2,), device=dev, dtype=torch.float32)
         cat[..., :C] = x.buf[..., x.coff:x.coff + C]           # torch.cat's first operand
         x_agg = self.aspp.forward_vox(x)
-        mega = pl["mega"](x_agg)                                # (B, X/2, Y/2, Z/2, 2C): rows = mega voxels
         m_cs = hip.round_up(M, 8)
         logits = torch.empty((R * B,) + dims + (m_cs,), device=dev, dtype=torch.float32)
-        for r in range(R):
-            lg = Vox(logits[r * B:(r + 1) * B], M)
-            pl["logits"][r](x_agg, out=lg)
-            for b in range(B):
-                rows_b = mega.buf[b].reshape(M, mega.cs)[:, :C2]
-                if not rows_b.is_contiguous():
-                    rows_b = rows_b.contiguous()
-                gemm_rows(Vox(lg.buf[b:b + 1], M), rows_b, Vox(cat[b:b + 1], C2, C + r * C2),
-                          act_in=ACT_SIGMOID)
+        mega_plan = pl["mega"]
+        mega_plan._prepare()
+        for plan in pl["logits"]:
+            plan._prepare()                                     # (weight packing allocates: not inside the side streams)
+        mega = Vox.empty(B, mega_plan.out_dims(x_agg.dims), mega_plan.cout, dev)   # (B, X/2, Y/2, Z/2, 2C): rows = mega voxels
+        lgs = [Vox(logits[r * B:(r + 1) * B], M) for r in range(R)]
+        # mega_context (64 workgroups) and the R relation-logit convolutions all read x_agg and nothing else
+        first = [lambda: mega_plan(x_agg, out=mega)] + [(lambda r=r: pl["logits"][r](x_agg, out=lgs[r])) for r in range(R)]
+        if x.buf.is_cuda:
+            run_parallel(first)
+        else:
+            for th in first:
+                th()
+        packed = []                                             # the mega rows are the B operand of all R products
+        for b in range(B):
+            rows_b = mega.buf[b].reshape(M, mega.cs)[:, :C2]
+            packed.append(pack_rows(rows_b if rows_b.is_contiguous() else rows_b.contiguous()))
+
+        def product(r):
+            def run():
+                for b in range(B):
+                    gemm_rows(Vox(lgs[r].buf[b:b + 1], M), packed[b], Vox(cat[b:b + 1], C2, C + r * C2), act_in=ACT_SIGMOID)
+            return run
+
+        second = [product(r) for r in range(R)]                 # sigmoid(logits_r) @ mega: independent, disjoint outputs
+        if x.buf.is_cuda:
+            run_parallel(second)
+        else:
+            for th in second:
+                th()
         y = pl["resize"](Vox(cat, C + R * C2))
         y = self.resize[1].forward_vox(y)
         p_logits = logits.view(R, B, N, m_cs)[..., :M].permute(1, 0, 3, 2)

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
 from ..bn import bn_act
-from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox, needs_autograd
+from ..fused import ACT_RELU, ACT_RELU_PRE, ConvPlan, ConvTransposePlan, DerivedConvPlan, Vox, as_vox, needs_autograd, run_parallel
 from .DDR import Bottleneck3D
 
 
@@ -38,9 +38,25 @@ class _DilatedBranches(nn.Module):
         return [(ConvPlan(c1, b1), ConvPlan(c2, b2))
                 for c1, b1, c2, b2 in zip(self.conv1, self.bn1, self.conv2, self.bn2)]
 
+    # small volumes (the CRP's 32x32x4 ASPP: 256 workgroups per launch, 62 % MFMA-bound): the branches' first
+    # convolutions are independent and run side by side on forked streams (fused.run_parallel)
+    PARALLEL_BELOW = 65536
+
     def _branches_vox(self, plans, x, out=None):
         y = None
         last = len(plans) - 1
+        if x.buf.is_cuda and len(plans) > 1 and x.batch * x.dims[0] * x.dims[1] * x.dims[2] <= self.PARALLEL_BELOW:
+            for first, second in plans:
+                first._prepare()
+                second._prepare()
+            ts = [Vox.empty(x.batch, first.out_dims(x.dims), first.cout, x.buf.device) for first, _ in plans]
+            run_parallel([(lambda f=first, t=t: f(x, out=t, act_out=ACT_RELU)) for (first, _), t in zip(plans, ts)])
+            for i, ((_, second), t) in enumerate(zip(plans, ts)):
+                if i < last:
+                    y = second(t, res1=y)
+                else:
+                    y = second(t, out=out, res1=y, res2=x, act_out=ACT_RELU)
+            return y
         for i, (first, second) in enumerate(plans):
             t = first(x, act_out=ACT_RELU)
             if i < last:
