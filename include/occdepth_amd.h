@@ -291,6 +291,13 @@ int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const
 int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* out, int32_t batch,
                                     int32_t C, int32_t Cskip, int32_t h, int32_t w, int32_t H,
                                     int32_t W, void* stream);
+/* Channels-last twins for the bf16-mode training step (decoder levels as (B, H, W, C) pixel rows): the same resize + concat
+ * with x (B, h, w, C), skip (B, H, W, Cskip), out (B, H, W, C + Cskip) dense rows, and the backward of the resized part as a
+ * gather: gx (B, h, w, C) from gout (B, H, W, gout_cs) rows (its first C channels), the exact transpose of the forward.    */
+int occd_upsample_bilinear_cat_nhwc(const float* x, const float* skip, float* out, int32_t batch, int32_t C, int32_t Cskip,
+                                    int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
+int occd_upsample_bilinear_nhwc_bwd(const float* gout, float* gx, int32_t batch, int32_t C, int32_t gout_cs, int32_t h,
+                                    int32_t w, int32_t H, int32_t W, void* stream);
 
 /* conv3x3(pad 1)(bilinear_up(x))  ==  sum_t shift_t(bilinear_up(W_t . x)): given z (B, 9 * Cout, h, w) = the nine per-tap
  * channel mixings of the LOW-resolution map (one pointwise GEMM, tap t = ky * 3 + kx in channel block t), writes
@@ -519,6 +526,14 @@ int occd_pack_weights_bf16(const float* w, const float* scale, void* wpk,
                            int32_t cout, int32_t cin, int32_t kx, int32_t ky, int32_t kz,
                            int32_t layout, void* stream);
 int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream);
+/* Pack a VIEW of a dense float32 weight tensor: element (co, ci, tap) of the packed operator is
+ * w[co * s_co + ci * s_ci + tap_ofs[tap]] (tap_ofs: HOST array of ntaps <= 27 element offsets).  One launch instead of the
+ * permute / index_select / contiguous chain autograd's data gradient needs for the transposed, flipped, tap-subset kernels
+ * of its sub-pixel phases (torch.nn.grad.conv3d_input semantics; occdepth/models/OccDepth.py:535-537 backward).          */
+int occd_pack_weights_gather(const float* w, const float* scale, float* wpk, int32_t cout, int32_t cin, int32_t ntaps,
+                             int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, void* stream);
+int occd_pack_weights_bf16_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
+                                  int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, void* stream);
 /* Opt-in experiment: dtype 2 of occd_conv3d_bf16_fwd = float32 tensors, both operands split into three
  * bf16 terms (x = hi + mid + lo), six bf16 MFMAs per K step (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid), fp32
  * accumulate: float32-level accuracy at 6/16 of the fp32-MFMA time.  Its weight image (3 x

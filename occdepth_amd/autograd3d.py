@@ -60,6 +60,15 @@ def _conv(x, w, bias, cout, kernel, out, **kw):
     return hip.conv3d(x, hip.pack_weights(w), bias, cout, kernel, out, **kw)
 
 
+def _conv_view(x, w, n_out, n_in, s_out, s_in, tap_ofs, kernel, out, **kw):
+    """Forward-kernel launch whose operator is a VIEW of the dense weight `w` (hip.pack_weights_gather): no permute /
+    index_select / contiguous temporaries."""
+    if BF16_MFMA:
+        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16=True), None, n_out,
+                               kernel, out, **kw)
+    return hip.conv3d(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel), None, n_out, kernel, out, **kw)
+
+
 def _wgrad(x, gy, cin, cout, K, stride, dilation, padding):
     """dW: K8b (bf16 MFMA through transposed LDS reads) for the shapes it is built for -- columns of >= 16 voxels and either
     many taps (3x3x3, 3x3, the 2x2x2 phases) or more than one cout tile --, the exact-fp32 K8 otherwise."""
@@ -111,7 +120,9 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz)."""
     cout, cin = w.shape[:2]
     K = tuple(w.shape[2:])
-    wt = w.detach().permute(1, 0, 2, 3, 4)                                  # (cin, cout, k): the transposed operator
+    wd = w.detach()
+    wd = wd if wd.dtype == torch.float32 and wd.is_contiguous() else wd.float().contiguous()
+    ntap = K[0] * K[1] * K[2]
     out = Vox.empty(gy.batch, in_dims, cin, gy.buf.device, dtype=gy.buf.dtype)
     axes = [_axis_phases(K[a], stride[a], padding[a], dilation[a]) for a in range(3)]
     if any(not taps for ax in axes for _, taps, _, _ in ax) or out.cs != cin:
@@ -119,12 +130,14 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     for (rx, tx, dx_, px), (ry, ty, dy_, py), (rz, tz, dz_, pz) in itertools.product(*axes):
         if not (tx and ty and tz):
             continue
-        sub = wt.index_select(2, _taps(tx, wt.device)).index_select(3, _taps(ty, wt.device)).index_select(4, _taps(tz, wt.device))
         n_pos = tuple((in_dims[a] - r + stride[a] - 1) // stride[a] for a, r in enumerate((rx, ry, rz)))
         if min(n_pos) <= 0:
             continue
-        _conv(gy, sub, None, cin, tuple(sub.shape[2:]), out, dilation=(dx_, dy_, dz_),
-              padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
+        # the transposed operator of this phase, W'[ci][co][a, b, c] = w[co][ci][tx[a], ty[b], tz[c]], packed straight
+        # from w (one launch; the permute + 3 index_select + contiguous chain was 5 launches per phase)
+        ofs = [(a * K[1] + b_) * K[2] + c for a in tx for b_ in ty for c in tz]
+        _conv_view(gy, wd, cin, cout, ntap, cin * ntap, ofs, (len(tx), len(ty), len(tz)), out, dilation=(dx_, dy_, dz_),
+                   padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
     return out
 
 

@@ -18,6 +18,13 @@ struct ProfScope {
 // 1 = launched, 0 = geometry does not qualify (use the generic kernel), <0 = error.
 int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream);
 
+// occd_pack_weights*_gather: where element (co, ci, tap) of a packed operator lives in a dense source tensor
+constexpr int kMaxTaps = 27;
+struct TapMap {
+    int64_t s_co, s_ci;
+    int32_t ofs[kMaxTaps];
+};
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? OCCD_OK : OCCD_ELAUNCH;

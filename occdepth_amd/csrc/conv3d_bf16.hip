@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
 // nsplit = 3: three consecutive images hi | mid | lo of the float32 weight (see split3)
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                          uint16_t* __restrict__ wpk, int cout, int cin, int taps, int K16, int NT,
-                                         int layout, long total, int nsplit) {
+                                         int layout, long total, int nsplit, const occd::TapMap tm) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = i & 7;
@@ -333,7 +333,8 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
     if (co < cout && ci < cin) {
         if (layout == 0) v = w[((size_t)co * cin + ci) * taps + tap];
         else if (layout == 1) v = w[((size_t)ci * cout + co) * taps + tap];
-        else v = w[(size_t)ci * cout + co];
+        else if (layout == 2) v = w[(size_t)ci * cout + co];
+        else v = w[(size_t)co * tm.s_co + (size_t)ci * tm.s_ci + tm.ofs[tap]];     // (see pack_weights_kernel, layout 3)
         if (scale != nullptr) v *= scale[co];
     }
     const __bf16 hi = (__bf16)v;
@@ -444,7 +445,25 @@ static int pack_bf16(const float* w, const float* scale, void* wpk, int32_t cout
     const long blocks = (total + th - 1) / th;
     occd::ProfScope prof("pack_weights_bf16", (hipStream_t)stream, 0.0, (double)total * 6);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
-                       (uint16_t*)wpk, cout, cin, taps, K16, NT, layout, (long)total, nsplit);
+                       (uint16_t*)wpk, cout, cin, taps, K16, NT, layout, (long)total, nsplit, occd::TapMap{});
+    return occd::check_launch();
+}
+
+extern "C" int occd_pack_weights_bf16_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
+                                             int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs,
+                                             void* stream) {
+    if (!w || !wpk || !tap_ofs || ntaps <= 0 || ntaps > occd::kMaxTaps) return OCCD_EINVAL;
+    const int64_t total = occd_packed_weight_bf16_elems(cout, cin, ntaps);
+    if (total <= 0) return OCCD_EINVAL;
+    occd::TapMap tm{};
+    tm.s_co = s_co; tm.s_ci = s_ci;
+    for (int i = 0; i < ntaps; ++i) tm.ofs[i] = tap_ofs[i];
+    const int K16 = (cin + 15) / 16, NT = (cout + 31) / 32;
+    const int th = 256;
+    const long blocks = (total + th - 1) / th;
+    occd::ProfScope prof("pack_weights_bf16", (hipStream_t)stream, 0.0, (double)total * 6);
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
+                       (uint16_t*)wpk, cout, cin, ntaps, K16, NT, 3, (long)total, 1, tm);
     return occd::check_launch();
 }
 

@@ -276,9 +276,11 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
 }
 
 // ---------------------------------------------------------------- weight packing
+// layout 3 (occd_pack_weights_gather): element (co, ci, tap) of the packed operator is w[co * s_co + ci * s_ci + ofs[tap]] --
+// any transposed / flipped / tap-subset view of a dense weight tensor without materialising it (the data-gradient phases)
 __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                     float* __restrict__ wpk, int cout, int cin, int taps, int KT, int NT,
-                                    int layout, long total) {
+                                    int layout, long total, const occd::TapMap tm) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int q = i & 3;
@@ -293,7 +295,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     if (co < cout && ci < cin) {
         if (layout == 0) v = w[((size_t)co * cin + ci) * taps + tap];
         else if (layout == 1) v = w[((size_t)ci * cout + co) * taps + tap];
-        else v = w[(size_t)ci * cout + co];
+        else if (layout == 2) v = w[(size_t)ci * cout + co];
+        else v = w[(size_t)co * tm.s_co + (size_t)ci * tm.s_ci + tm.ofs[tap]];
         if (scale != nullptr) v *= scale[co];
     }
     wpk[i] = v;
@@ -372,7 +375,24 @@ extern "C" int occd_pack_weights(const float* w, const float* scale, float* wpk,
     const long blocks = (total + th - 1) / th;
     occd::ProfScope prof("pack_weights", (hipStream_t)stream, 0.0, (double)total * 8);
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
-                       wpk, cout, cin, taps, KT, NT, layout, (long)total);
+                       wpk, cout, cin, taps, KT, NT, layout, (long)total, occd::TapMap{});
+    return occd::check_launch();
+}
+
+extern "C" int occd_pack_weights_gather(const float* w, const float* scale, float* wpk, int32_t cout, int32_t cin,
+                                        int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, void* stream) {
+    if (!w || !wpk || !tap_ofs || ntaps <= 0 || ntaps > occd::kMaxTaps) return OCCD_EINVAL;
+    const int64_t total = occd_packed_weight_floats(cout, cin, ntaps);
+    if (total <= 0) return OCCD_EINVAL;
+    occd::TapMap tm{};
+    tm.s_co = s_co; tm.s_ci = s_ci;
+    for (int i = 0; i < ntaps; ++i) tm.ofs[i] = tap_ofs[i];
+    const int KT = (cin + 7) / 8, NT = (cout + 31) / 32;
+    const int th = 256;
+    const long blocks = (total + th - 1) / th;
+    occd::ProfScope prof("pack_weights", (hipStream_t)stream, 0.0, (double)total * 8);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
+                       wpk, cout, cin, ntaps, KT, NT, 3, (long)total, tm);
     return occd::check_launch();
 }
 

@@ -799,6 +799,79 @@ extern "C" int occd_dwconv2d_pool_nchw(const float* x, const float* w, const flo
     return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, pool_part, stream);
 }
 
+// ---- channels-last twins (bf16-mode training: the decoder levels live as (B, H, W, C) pixel rows) ------------------
+// forward: out[b, Y, X, :C] = bilinear(x)(Y, X) (align_corners=True, the arithmetic of upsample_cat_kernel),
+//          out[b, Y, X, C:] = skip[b, Y, X, :].   One thread per output element, channels fastest (coalesced rows; the
+//          channel counts are not multiples of 4: 163 = 160 + 3 at the full-resolution level).
+__global__ void __launch_bounds__(256) upsample_cat_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                                float* __restrict__ out, int C, int Cs, int h, int w, int H,
+                                                                int W, float rh, float rw, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ct = C + Cs;
+    const int c = (int)(i % ct);
+    long t = i / ct;
+    const int ox = (int)(t % W); t /= W;
+    const int oy = (int)(t % H);
+    const int b = (int)(t / H);
+    float v;
+    if (c >= C) {
+        v = skip[(((size_t)b * H + oy) * W + ox) * Cs + (c - C)];
+    } else {
+        const float sy = rh * oy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < h - 1);
+        const float ly = sy - y0, hy = 1.f - ly;
+        const float sx = rw * ox;
+        const int x0 = (int)sx;
+        const int x1 = x0 + (x0 < w - 1);
+        const float lx = sx - x0, hx = 1.f - lx;
+        const float* p0 = x + (((size_t)b * h + y0) * w) * C + c;
+        const float* p1 = x + (((size_t)b * h + y1) * w) * C + c;
+        v = hy * (hx * p0[(size_t)x0 * C] + lx * p0[(size_t)x1 * C]) + ly * (hx * p1[(size_t)x0 * C] + lx * p1[(size_t)x1 * C]);
+    }
+    out[i] = v;
+}
+
+// backward of the upsampled part as a GATHER (ATen's nhwc backward scatters with atomics: 0.39 ms per level at config 2):
+// gx[b, y, x, c] = sum over the output pixels whose 2 x 2 footprint contains (y, x) of their weight * gout[b, Y, X, c],
+// every candidate re-deriving (y0, y1, ly) with the forward's own arithmetic, so the pair is an exact transpose.
+__global__ void __launch_bounds__(256) upsample_nhwc_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gx, int C,
+                                                                int gcs, int h, int w, int H, int W, float rh, float rw,
+                                                                float inv_rh, float inv_rw, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int b = (int)(t / h);
+    // candidate output rows / columns: src = dst * r in (y - 1, y + 1)
+    const int Ya = max(0, (int)floorf((y - 1) * inv_rh) - 1), Yb = min(H - 1, (int)ceilf((y + 1) * inv_rh) + 1);
+    const int Xa = max(0, (int)floorf((x - 1) * inv_rw) - 1), Xb = min(W - 1, (int)ceilf((x + 1) * inv_rw) + 1);
+    float acc = 0.f;
+    for (int Y = Ya; Y <= Yb; ++Y) {
+        const float sy = rh * Y;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < h - 1);
+        const float ly = sy - y0;
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        const float* row = gout + (((size_t)b * H + Y) * W) * gcs + c;
+        float part = 0.f;
+        for (int X = Xa; X <= Xb; ++X) {
+            const float sx = rw * X;
+            const int x0 = (int)sx;
+            const int x1 = x0 + (x0 < w - 1);
+            const float lx = sx - x0;
+            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            if (wx != 0.f) part += wx * row[(size_t)X * gcs];
+        }
+        acc += wy * part;
+    }
+    gx[i] = acc;
+}
+
 extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* out, int32_t batch, int32_t C,
                                                int32_t Cskip, int32_t h, int32_t w, int32_t H, int32_t W,
                                                void* stream) {
@@ -813,6 +886,34 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
                          4.0 * batch * ((double)C * h * w + 2.0 * Cskip * H * W + (double)C * H * W));
     hipLaunchKernelGGL(upsample_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, skip, out, C, Cskip, h, w, H, W,
                        rh, rw);
+    return occd::check_launch();
+}
+
+extern "C" int occd_upsample_bilinear_cat_nhwc(const float* x, const float* skip, float* out, int32_t batch, int32_t C,
+                                               int32_t Cskip, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
+    if (!x || !out || batch <= 0 || C <= 0 || Cskip < 0 || (Cskip > 0 && !skip) || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return OCCD_EINVAL;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = (long)batch * H * W * (C + Cskip);
+    occd::ProfScope prof("upsample_cat_nhwc", (hipStream_t)stream, 0.0,
+                         4.0 * batch * ((double)C * h * w + 2.0 * Cskip * H * W + (double)C * H * W));
+    hipLaunchKernelGGL(upsample_cat_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       skip, out, C, Cskip, h, w, H, W, rh, rw, total);
+    return occd::check_launch();
+}
+
+extern "C" int occd_upsample_bilinear_nhwc_bwd(const float* gout, float* gx, int32_t batch, int32_t C, int32_t gout_cs,
+                                               int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
+    if (!gout || !gx || batch <= 0 || C <= 0 || gout_cs < C || h <= 0 || w <= 0 || H <= 0 || W <= 0) return OCCD_EINVAL;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    // (rh == 0: every output pixel reads source 0 -- all of them are candidates)
+    const float inv_rh = rh > 0.f ? 1.f / rh : (float)H, inv_rw = rw > 0.f ? 1.f / rw : (float)W;
+    const long total = (long)batch * h * w * C;
+    occd::ProfScope prof("upsample_nhwc_bwd", (hipStream_t)stream, 0.0, 4.0 * batch * C * ((double)h * w + (double)H * W));
+    hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gout,
+                       gx, C, gout_cs, h, w, H, W, rh, rw, inv_rh, inv_rw, total);
     return occd::check_launch();
 }
 

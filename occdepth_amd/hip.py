@@ -170,6 +170,12 @@ EXPORTS = {
     "occd_pack_weights_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_int32, c_void_p]),
     "occd_conv3d_bf16_fwd": (c_int32, [POINTER(Conv3dArgs), c_int32, c_void_p]),
+    "occd_upsample_bilinear_cat_nhwc": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_upsample_bilinear_nhwc_bwd": (c_int32, [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_pack_weights_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                           c_void_p, c_void_p]),
+    "occd_pack_weights_bf16_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                                c_void_p, c_void_p]),
     "occd_pack_weights_bf16x3": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                            c_int32, c_void_p]),
     "occd_conv3d_wgrad_bf16_workspace_floats": (c_int64, [POINTER(WgradArgs), c_int32]),
@@ -320,6 +326,27 @@ def pack_weights(w, scale=None, layout=0):
     _check(load().occd_pack_weights(_f32(w, "w"), _f32(sc, "scale") if sc is not None else None,
                                     _f32(out, "wpk"), cout, cin, k[0], k[1], k[2], layout, _stream()),
            "occd_pack_weights")
+    return out
+
+
+def pack_weights_gather(w, cout, cin, s_co, s_ci, tap_ofs, kernel=None, bf16=False):
+    """Packed image of the operator W'[co][ci][tap] = w.flat[co * s_co + ci * s_ci + tap_ofs[tap]] (a transposed / flipped /
+    tap-subset view of the dense float32 tensor `w`) for `conv3d` (bf16=False) or `conv3d_bf16`; one launch, no temporaries.
+    `kernel` (the (kx, ky, kz) the taps enumerate) is only read by the CPU emulation."""
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        raise RuntimeError("pack_weights_gather needs a contiguous float32 source tensor")
+    n = len(tap_ofs)
+    ofs = (c_int32 * n)(*[int(o) for o in tap_ofs])
+    if max(ofs) + (cout - 1) * s_co + (cin - 1) * s_ci >= w.numel():
+        raise RuntimeError("pack_weights_gather: view exceeds the source tensor")
+    if bf16:
+        out = torch.empty(load().occd_packed_weight_bf16_elems(cout, cin, n), device=w.device, dtype=torch.bfloat16)
+        _check(load().occd_pack_weights_bf16_gather(_f32(w, "w"), None, _ptr(out, "wpk"), cout, cin, n, s_co, s_ci,
+                                                    ctypes.cast(ofs, c_void_p), _stream()), "occd_pack_weights_bf16_gather")
+    else:
+        out = torch.empty(packed_weight_floats(cout, cin, n), device=w.device, dtype=torch.float32)
+        _check(load().occd_pack_weights_gather(_f32(w, "w"), None, _f32(out, "wpk"), cout, cin, n, s_co, s_ci,
+                                               ctypes.cast(ofs, c_void_p), _stream()), "occd_pack_weights_gather")
     return out
 
 
@@ -974,6 +1001,44 @@ class _UpCatFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gs = g[:, C:]
         return gx, gs
+
+
+class _UpCatClFn(torch.autograd.Function):
+    """Channels-last twin of _UpCatFn for the bf16-mode decoder: x, skip and the result are logical (B, C, H, W) tensors in
+    channels_last memory; forward = one launch (occd_upsample_bilinear_cat_nhwc), backward of the resized part = one gather
+    launch (occd_upsample_bilinear_nhwc_bwd; ATen's nhwc backward scatters with atomics), the skip gradient is a view."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        B, C, h, w = x.shape
+        Cs, H, W = skip.shape[1], skip.shape[2], skip.shape[3]
+        xr = x.detach().float().permute(0, 2, 3, 1).contiguous()
+        sr = skip.detach().float().permute(0, 2, 3, 1).contiguous()
+        out = torch.empty((B, H, W, C + Cs), device=x.device, dtype=torch.float32)
+        _check(load().occd_upsample_bilinear_cat_nhwc(_f32(xr, "x"), _f32(sr, "skip"), _f32(out, "out"), B, C, Cs, h, w, H, W,
+                                                      _stream()), "occd_upsample_bilinear_cat_nhwc")
+        ctx.geom = (B, C, Cs, h, w, H, W)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, Cs, h, w, H, W = ctx.geom
+        gr = g.float().permute(0, 2, 3, 1)
+        if not gr.is_contiguous():
+            gr = gr.contiguous()
+        gx = gs = None
+        if ctx.needs_input_grad[0]:
+            gxr = torch.empty((B, h, w, C), device=g.device, dtype=torch.float32)
+            _check(load().occd_upsample_bilinear_nhwc_bwd(_f32(gr, "gout"), _f32(gxr, "gx"), B, C, C + Cs, h, w, H, W,
+                                                          _stream()), "occd_upsample_bilinear_nhwc_bwd")
+            gx = gxr.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gs = gr[..., C:].permute(0, 3, 1, 2)
+        return gx, gs
+
+
+def upsample_bilinear_cat_cl_autograd(x, skip):
+    return _UpCatClFn.apply(x, skip)
 
 
 def upsample_bilinear_cat_autograd(x, skip):

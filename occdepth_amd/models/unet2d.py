@@ -150,13 +150,16 @@ class UpSampleBN(nn.Module):
     def _forward_train_cl(self, x, concat_with):
         """bf16-mode training (autograd3d.BF16_MFMA, BASELINE configs[3]): the level in channels-last memory -- the two 3x3
         convolutions (forward, data gradient, weight gradient) on the bf16-MFMA implicit-GEMM kernels K2b / K8b as X = 1
-        volumes, BatchNorm + LeakyReLU as fused K13 passes on pixel rows; upsampling and concatenation stay ATen
-        (channels-last in, channels-last out)."""
+        volumes, BatchNorm + LeakyReLU as fused K13 passes on pixel rows, upsampling + concatenation as one channels-last launch
+        with a gather backward (hip._UpCatClFn)."""
         from ..bn import bn_act
         n = self._net
-        up = F.interpolate(x.contiguous(memory_format=torch.channels_last), size=concat_with.shape[2:], mode="bilinear",
-                           align_corners=True)
-        f = torch.cat([up, concat_with.contiguous(memory_format=torch.channels_last)], dim=1)
+        if x.dtype == torch.float32 and concat_with.dtype == torch.float32:
+            f = hip.upsample_bilinear_cat_cl_autograd(x, concat_with)      # one launch forward, one gather launch backward
+        else:
+            up = F.interpolate(x.contiguous(memory_format=torch.channels_last), size=concat_with.shape[2:], mode="bilinear",
+                               align_corners=True)
+            f = torch.cat([up, concat_with.contiguous(memory_format=torch.channels_last)], dim=1)
         f = bn_act(n[1], _ag.conv2d_cl(f, n[0].weight, n[0].bias, padding=1), "leaky", n[2].negative_slope)
         return bn_act(n[4], _ag.conv2d_cl(f, n[3].weight, n[3].bias, padding=1), "leaky", n[5].negative_slope)
 

@@ -101,6 +101,16 @@ def conv3d_bf16(x, wpk, bias, cout, kernel, out, **kw):
     return conv3d(xb, wpk, bias, cout, kernel, out, **kw)
 
 
+def pack_weights_gather(w, cout, cin, s_co, s_ci, tap_ofs, kernel=None, bf16=False):
+    """The logical operator of occd_pack_weights*_gather, materialised with an index gather."""
+    flat = w.detach().float().reshape(-1)
+    co = torch.arange(cout).view(-1, 1, 1) * s_co
+    ci = torch.arange(cin).view(1, -1, 1) * s_ci
+    idx = co + ci + torch.tensor([int(o) for o in tap_ofs]).view(1, 1, -1)
+    sub = flat[idx].reshape(cout, cin, *kernel)
+    return pack_weights_bf16(sub) if bf16 else pack_weights(sub)
+
+
 def conv3d_wgrad_bf16(x, gy, cin, cout, kernel, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0)):
     return conv3d_wgrad(Vox(_bf16(x.buf.float()), x.C, x.coff), Vox(_bf16(gy.buf.float()), gy.C, gy.coff), cin, cout,
                         kernel, stride, dilation, padding)
@@ -518,9 +528,10 @@ def patched(fast2d=False):
                                           "flosp_sample", "lift", "lift_proj", "bottleneck3d", "cascade_tail", "ssc_loss_stats", "ssc_loss_grad",
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
-                                          "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "conv3d_bf16",
+                                          "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "pack_weights_gather", "conv3d_bf16",
                                           "conv3d_wgrad_bf16")}
     hip.pack_weights_bf16, hip.conv3d_bf16, hip.conv3d_wgrad_bf16 = pack_weights_bf16, conv3d_bf16, conv3d_wgrad_bf16
+    hip.pack_weights_gather = pack_weights_gather
     hip.upconv_gather = upconv_gather
     hip.affine_act, hip.dwconv2d_same = affine_act, dwconv2d_same
     hip.upsample_bilinear_cat, hip.softmax_nchw = upsample_bilinear_cat, softmax_nchw
