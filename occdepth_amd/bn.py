@@ -127,23 +127,47 @@ class _BNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, running_mean, running_var, nbt, eps, momentum, act, slope, res_first, group,
-                sync):
+                sync, ngroups):
+        geo = _Geom(x)
+        C = geo.C
+        dev = x.device
+        G = int(ngroups)
+        if x.shape[0] % G:
+            raise RuntimeError("bn_act: the batch does not divide into the view groups")
+        n = x.shape[0] // G
+        exchange = bool(sync and _group_active(group))
+        packed = torch.empty(G, 2 * C + 1, device=dev, dtype=torch.float64)
+        vec = torch.empty(G, 4, C, device=dev, dtype=torch.float32)       # per group: mean, invstd, a, b
+        w = weight.detach().float() if weight is not None else None
+        b = bias.detach().float() if bias is not None else None
+        y, _ = geo.empty_like(x)
+        small = True
+        for g in range(G):                                                # one statistics group per stacked view, in call order
+            sl = slice(g * n, (g + 1) * n)
+            small = _BNActFn._forward_group(x[sl] if G > 1 else x, y[sl] if G > 1 else y,
+                                            (res[sl] if G > 1 else res) if res is not None else None, w, b, running_mean,
+                                            running_var, nbt, eps, momentum, act, slope, res_first, group, exchange, vec[g],
+                                            packed[g]) and small
+        # the pre-activation's sign comes from y when a residual entered before the activation (x a + b alone is not it)
+        need_y = act != 0 and res is not None and res_first
+        ctx.save_for_backward(x, vec, packed, weight, y if need_y else None)
+        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, exchange, G)
+        return y
+
+    @staticmethod
+    def _forward_group(x, y, res, w, b, running_mean, running_var, nbt, eps, momentum, act, slope, res_first, group, exchange,
+                       vec, packed):
         lib = hip.load()
         st = hip._stream()
         geo = _Geom(x)
         C = geo.C
         dev = x.device
-        exchange = bool(sync and _group_active(group))
         a = geo.args()
         a.x = x.data_ptr()
         a.x_cs = geo.like(x, x, "x")
-        packed = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
-        vec = torch.empty(4, C, device=dev, dtype=torch.float32)          # mean, invstd, a, b
-        w = weight.detach().float() if weight is not None else None
-        b = bias.detach().float() if bias is not None else None
         fin = (float(eps), float(momentum if momentum is not None else 0.0), _ptr(w), _ptr(b), _ptr(running_mean),
                _ptr(running_var), _ptr(nbt), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr())
-        y, ycs = geo.empty_like(x)
+        ycs = geo.like(x, y, "y") if geo.layout == 0 else 0
         a.out, a.out_cs = y.data_ptr(), ycs
         a.cw = min(hip.round_up(C, 8), ycs) if geo.layout == 0 else 0
         if res is not None:
@@ -168,24 +192,44 @@ class _BNActFn(torch.autograd.Function):
                 hip._check(lib.occd_bn_stats_finish(ctypes.byref(a), packed.data_ptr(), *fin, st), "occd_bn_stats_finish")
             a.a, a.b = vec[2].data_ptr(), vec[3].data_ptr()
             hip._check(lib.occd_bn_apply(ctypes.byref(a), st), "occd_bn_apply")
-        # the pre-activation's sign comes from y when a residual entered before the activation (x a + b alone is not it)
-        need_y = act != 0 and res is not None and res_first
-        ctx.save_for_backward(x, vec, packed, weight, y if need_y else None)
-        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, exchange, small)
-        return y
+        return small
 
     @staticmethod
     def backward(ctx, gy):
         x, vec, packed, weight, y = ctx.saved_tensors
-        act, slope, res_first, has_res, group, exchange, small = ctx.cfg
-        lib = hip.load()
-        st = hip._stream()
+        act, slope, res_first, has_res, group, exchange, G = ctx.cfg
         geo = _Geom(x)
         C = geo.C
         dev = x.device
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         gy = gy.contiguous() if geo.layout == 1 else _to_rows(gy)
+        k = torch.empty(G, 5, C, device=dev, dtype=torch.float32)         # per group: k1, k2, k3, gw, gb
+        want_w = weight is not None
+        gx, _ = geo.empty_like(x)
+        gres = None
+        if has_res:
+            if res_first and act != 0:
+                gres, _ = geo.empty_like(x)
+            else:
+                gres = gy                                                   # added after the activation (or no activation)
+        n = x.shape[0] // G
+        for g in range(G):
+            sl = slice(g * n, (g + 1) * n)
+            cut = (lambda t: t[sl] if t is not None and G > 1 else t)
+            _BNActFn._backward_group(cut(x), cut(gy), cut(y), cut(gx), cut(gres) if (has_res and res_first and act != 0) else None,
+                                     vec[g], packed[g], k[g], want_w, act, slope, res_first, group, exchange)
+        gw = k[:, 3].sum(0).to(weight.dtype) if want_w else None           # parameter gradients: sum over the groups
+        gb = k[:, 4].sum(0).to(weight.dtype) if want_w else None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_group(x, gy, y, gx, gres, vec, packed, k, want_w, act, slope, res_first, group, exchange):
+        lib = hip.load()
+        st = hip._stream()
+        geo = _Geom(x)
+        C = geo.C
+        dev = x.device
         a = geo.args()
         a.x, a.x_cs = x.data_ptr(), geo.like(x, x, "x")
         a.gy, a.gy_cs = gy.data_ptr(), geo.like(x, gy, "gy")
@@ -193,44 +237,35 @@ class _BNActFn(torch.autograd.Function):
             a.y, a.y_cs = y.data_ptr(), geo.like(x, y, "y")
         a.mean, a.invstd, a.a, a.b = (vec[i].data_ptr() for i in range(4))
         a.act, a.slope, a.res_first = act, slope, 1 if res_first else 0
-        k = torch.empty(5, C, device=dev, dtype=torch.float32)            # k1, k2, k3, gw, gb
-        want_w = weight is not None
         gw_p, gb_p = (k[3].data_ptr(), k[4].data_ptr()) if want_w else (None, None)
-        gx, gcs = geo.empty_like(x)
+        gcs = geo.like(x, gx, "gx") if geo.layout == 0 else 0
         a.out, a.out_cs = gx.data_ptr(), gcs
         a.cw = min(hip.round_up(C, 8), gcs) if geo.layout == 0 else 0
-        gres = None
-        if has_res:
-            if res_first and act != 0:
-                gres, rcs = geo.empty_like(x)
-                a.out2, a.out2_cs = gres.data_ptr(), rcs
-            else:
-                gres = gy                                                   # added after the activation (or no activation)
+        if gres is not None:
+            a.out2, a.out2_cs = gres.data_ptr(), (geo.like(x, gres, "gres") if geo.layout == 0 else 0)
+        small = (not exchange) and bool(lib.occd_bn_small_ok(ctypes.byref(a)))
         if small:
             hip._check(lib.occd_bn_bwd_small(ctypes.byref(a), gw_p, gb_p, st), "occd_bn_bwd_small")
+            return
+        a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
+        partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
+        a.partial = partial.data_ptr()
+        hip._check(lib.occd_bn_bwd_reduce(ctypes.byref(a), st), "occd_bn_bwd_reduce")
+        kp = [k[i].data_ptr() for i in range(3)]
+        if exchange:
+            import torch.distributed as dist
+            local = torch.empty(2 * C, device=dev, dtype=torch.float32)
+            hip._check(lib.occd_bn_bwd_combine(partial.data_ptr(), a.nblk, C, local.data_ptr(), st), "occd_bn_bwd_combine")
+            total = local.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            hip._check(lib.occd_bn_bwd_finish(local.data_ptr(), total.data_ptr(), C, packed.data_ptr(), vec[0].data_ptr(),
+                                              vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st), "occd_bn_bwd_finish")
         else:
-            a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
-            partial = torch.empty(a.nblk * 2 * hip.round_up(C, 4), device=dev, dtype=torch.float32)
-            a.partial = partial.data_ptr()
-            hip._check(lib.occd_bn_bwd_reduce(ctypes.byref(a), st), "occd_bn_bwd_reduce")
-            kp = [k[i].data_ptr() for i in range(3)]
-            if exchange:
-                import torch.distributed as dist
-                local = torch.empty(2 * C, device=dev, dtype=torch.float32)
-                hip._check(lib.occd_bn_bwd_combine(partial.data_ptr(), a.nblk, C, local.data_ptr(), st), "occd_bn_bwd_combine")
-                total = local.clone()
-                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-                hip._check(lib.occd_bn_bwd_finish(local.data_ptr(), total.data_ptr(), C, packed.data_ptr(), vec[0].data_ptr(),
-                                                  vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st), "occd_bn_bwd_finish")
-            else:
-                hip._check(lib.occd_bn_bwd_combine_finish(partial.data_ptr(), a.nblk, C, packed.data_ptr(), vec[0].data_ptr(),
-                                                          vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st),
-                           "occd_bn_bwd_combine_finish")
-            a.k1, a.k2, a.k3 = kp
-            hip._check(lib.occd_bn_bwd_apply(ctypes.byref(a), st), "occd_bn_bwd_apply")
-        gw = k[3].to(weight.dtype) if want_w else None
-        gb = k[4].to(weight.dtype) if want_w else None
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None
+            hip._check(lib.occd_bn_bwd_combine_finish(partial.data_ptr(), a.nblk, C, packed.data_ptr(), vec[0].data_ptr(),
+                                                      vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st),
+                       "occd_bn_bwd_combine_finish")
+        a.k1, a.k2, a.k3 = kp
+        hip._check(lib.occd_bn_bwd_apply(ctypes.byref(a), st), "occd_bn_bwd_apply")
 
 
 def _torch_reference(bn, x, act, slope, res, res_first):
@@ -250,6 +285,34 @@ def _torch_reference(bn, x, act, slope, res, res_first):
 
 ENABLED = True      # A/B switch (bench / tests): False sends every site through the backend's batch_norm again
 
+# Statistics groups along the batch dimension (view-batched training, models/OccDepth.py process_rgbs): the reference runs
+# the 2-D network once per stereo view, so every BatchNorm sees ONE view's samples per call and updates its running
+# statistics once per view, in view order.  With the views stacked view-major into one batch, `view_groups(V)` makes every
+# bn_act site normalise each of the V contiguous batch chunks with its own statistics and apply the V running-statistics
+# updates in the same order -- the same numbers, half the launches of everything that is not a BatchNorm.
+GROUPS = 1
+
+
+class view_groups:
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global GROUPS
+        self.saved, GROUPS = GROUPS, self.n
+
+    def __exit__(self, *exc):
+        global GROUPS
+        GROUPS = self.saved
+        return False
+
+
+def module_call(bn, x):
+    """`bn(x)` for a BatchNorm module called directly by model code: group-aware like bn_act."""
+    if GROUPS > 1 and bn.training:
+        return bn_act(bn, x)
+    return bn(x)
+
 
 def bn_act(bn, x, act=None, slope=0.01, res=None, res_first=False):
     """act(bn(x) [+ res]) [+ res] for a BatchNorm module; fused HIP passes in training mode on the GPU (see module doc)."""
@@ -260,9 +323,15 @@ def bn_act(bn, x, act=None, slope=0.01, res=None, res_first=False):
     if fused and res is not None:
         # the residual must be addressable in x's layout
         res = res.contiguous() if (x.is_contiguous() and x.dtype == torch.float32) else _to_rows(res)
+    G = GROUPS if bn.training else 1
     if not fused:
+        if G > 1:                                    # per-view statistics on the backend: chunk, normalise, concatenate
+            n = x.shape[0] // G
+            return torch.cat([_torch_reference(bn, x[g * n:(g + 1) * n], code, slope,
+                                               res[g * n:(g + 1) * n] if res is not None else None, res_first)
+                              for g in range(G)], 0)
         return _torch_reference(bn, x, code, slope, res, res_first)
     from . import shard
     sync = isinstance(bn, shard.SyncBatchNorm)
     return _BNActFn.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                          bn.momentum, code, slope, res_first, getattr(bn, "process_group", None), sync)
+                          bn.momentum, code, slope, res_first, getattr(bn, "process_group", None), sync, G)

@@ -61,6 +61,7 @@ class OccDepth(_Base):
         self.graph_2d = False     # eval + batch_views: replay the 2-D network as one captured hipGraph
         self.graph_all = False    # eval: replay the WHOLE forward (2-D network, lift, 3-D stack) as one captured hipGraph
         self._graphs = {}
+        self.batch_views_train = os.environ.get("OCCDEPTH_TRAIN_BATCH_VIEWS", "1") == "1"
         self.fused_lift = True    # training on the GPU: HIP lift + one-launch backward (lift_autograd.py) where it applies
         if infer_mode:
             self.context_prior = False
@@ -206,6 +207,15 @@ class OccDepth(_Base):
             both = self._net_rgb_graphed(img.reshape(bs * n_views, *img.shape[2:]))
             x_rgb = [{k: v.reshape(bs, n_views, *v.shape[1:])[:, i] for k, v in both.items()}
                      for i in range(n_views)]
+        elif self.training and self.batch_views_train and n_views > 1 and not self.share_2d_backbone_gradient:
+            # training: both views through the 2-D network as ONE view-major batch with per-view BatchNorm statistics
+            # (bn.view_groups) -- the numbers of the reference's per-view loop, half the launches and no gradient
+            # accumulation kernels for the shared parameters
+            from .. import bn as bn_mod
+            stacked = img.transpose(0, 1).reshape(n_views * bs, *img.shape[2:])
+            with bn_mod.view_groups(n_views):
+                both = self.net_rgb(stacked)
+            x_rgb = [{k: v[i * bs:(i + 1) * bs] for k, v in both.items()} for i in range(n_views)]
         else:
             x_rgb = [self.net_rgb(img[:, 0])]
             for i in range(1, n_views):

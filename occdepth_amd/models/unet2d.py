@@ -188,7 +188,10 @@ class UpSampleBN(nn.Module):
             n = self._net
             f = bn_act(n[1], hip.conv2d_3x3_autograd(f, n[0].weight, n[0].bias), "leaky", n[2].negative_slope)
             return bn_act(n[4], hip.conv2d_3x3_autograd(f, n[3].weight, n[3].bias), "leaky", n[5].negative_slope)
-        return self._net(f)
+        from ..bn import bn_act
+        n = self._net
+        f = bn_act(n[1], n[0](f), "leaky", n[2].negative_slope)          # (= self._net(f); group-aware BatchNorm)
+        return bn_act(n[4], n[3](f), "leaky", n[5].negative_slope)
 
 
 class DecoderBN(nn.Module):
@@ -281,6 +284,9 @@ class Encoder(nn.Module):
                     features.append(stage(features[-1]))
             elif skip_head and name in self.HEAD:
                 features.append(None)
+            elif isinstance(mod, nn.modules.batchnorm._BatchNorm):
+                from ..bn import module_call
+                features.append(module_call(mod, features[-1]))       # (per-view statistics in view-batched training)
             else:
                 features.append(mod(features[-1]))
         return features
