@@ -2,7 +2,7 @@
 """Headline benchmark: frames/s of OccDepth.forward, SemanticKITTI stereo 1220x370 -> 256x256x32 voxels
 (BASELINE.json configs[1]: EfficientNet-B7, feature 64, FLoSP-Depth + CRP + cascade head, batch 1 per GPU).
 
-    python bench.py --gpus N --steps K --warmup W [--train [--bf16]]
+    python bench.py --gpus N --steps K --warmup W [--train [--bf16]] [--config 5]
 
 N > 1: one rank per GPU over RCCL.  Under `torch.distributed.run` (WORLD_SIZE set) the ranks are the launcher's;
 a bare `python bench.py --gpus N` re-executes itself through `torch.distributed.run` on 127.0.0.1, so the printed
@@ -10,16 +10,21 @@ a bare `python bench.py --gpus N` re-executes itself through `torch.distributed.
 the forward path has no data-path collective, so scaling is "weak" (one frame per rank per step).
 
 Default (forward): a step = one forward of one synthetic stereo frame per rank, inputs already resident in HBM,
-random-init weights of the named architecture, eval mode, fp32 (the 3-D stack runs on exact-fp32 MFMA).
+random-init weights of the named architecture, eval mode, fp32 (the 3-D stack runs on exact-fp32 MFMA); the whole forward
+is replayed from ONE hipGraph and the timed loop carries no events -- the roofline / stage numbers come from a separate
+eager pass of the same model right after it.
+`--config 5` (BASELINE configs[4]): UNet3D alone on a synthetic 512x512x64 grid (9268.2 GFLOP per frame).
 `--train` (BASELINE configs[2]/[3]): a step = forward + losses + backward + gradient exchange (shard.prepare_for_ddp:
-SyncBatchNorm + bucketed RCCL all-reduce, as the reference's DDP run) + AdamW on one frame per rank; `--bf16` runs it
-under bf16 autocast (configs[3]).
+SyncBatchNorm + bucketed RCCL all-reduce, as the reference's DDP run) + AdamW on one frame per rank, replayed as one
+hipGraph on one rank; `--bf16` = the bf16-MFMA mode (configs[3]: hand-written bf16 MFMA convolutions, fp32 master weights
+and fp32 storage; `--autocast` adds torch autocast on top); OCCDEPTH_FORCE_DIST=1 drives SyncBatchNorm + buckets through a
+single-rank RCCL group on one GPU.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline       : dominant kernel (3x3x3 32->32 head convolution, 115.96 GFLOP per launch) timed live with HIP
                    events on the launch stream, against the fp32-MFMA peak (157.3 TF/s);
   cpu_baseline   : the CPU oracle (oracle/occdepth_oracle.py, a port of the reference's PyTorch path) timed on
-                   this box's host cores on ONE frame of the same workload (N=1 only);
+                   this box's host cores: 1 warm-up + 3 timed frames of the same workload, median (N=1 only);
   parity_rel_err : the SAME configuration flags as the timed model (batch_views, graph_2d, in-repo 2-D kernels), run once
                    untimed on the golden frame with the golden weights and compared with the real reference's
                    outputs (tests/golden/occdepth_kitti_a100.npz); max |delta| / max |ref| per output.

@@ -634,6 +634,8 @@ def bottleneck3d(x, w, P, dilation, out=None):
     a.batch, a.X, a.Y, a.Z, a.C, a.P = x.batch, X, Y, Z, C, P
     a.x_cs, a.x_coff, a.y_cs, a.y_coff = x.cs, x.coff, out.cs, out.coff
     a.d0, a.d1, a.d2 = (int(d) for d in dilation)
+    if _PROFILING:
+        set_tag("%d/%d d%d%d%d @%dx%dx%d" % ((C, P) + tuple(int(d) for d in dilation) + (X, Y, Z)))
     _check(load().occd_bottleneck3d_fwd(ctypes.byref(a), _stream()), "occd_bottleneck3d_fwd")
     return out
 
