@@ -351,7 +351,7 @@ def _forward(args, world, rank, device, dist):
     ms = sum(v["ms"] for _, v in head)
     flops = sum(v["flops"] for _, v in head)
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith(("conv3d_", "bottleneck3d"))) / prof_steps
+    conv_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith(("conv3d_", "bottleneck3d", "rows_gemm"))) / prof_steps
     lift_ms = sum(v["ms"] for k, v in prof.rows.items() if k.startswith("sfa_lift")) / prof_steps
     lift_fused = any(k.startswith("sfa_lift_proj") for k in prof.rows)
     lift_mb = LIFT_PROJ_MBYTES if lift_fused else LIFT_MBYTES
@@ -385,7 +385,7 @@ def _forward(args, world, rank, device, dist):
         "stack3d": {"ms_per_frame": conv_ms, "tflops": STACK3D_GFLOP / conv_ms if conv_ms else 0.0,
                     "frac_of_fp32_mfma_peak": STACK3D_GFLOP / conv_ms / FP32_MFMA_PEAK_TFLOPS if conv_ms else 0.0},
         "stack3d_launches_ms_per_frame": {k: [int(v["launches"] // prof_steps), round(v["ms"] / prof_steps, 3)] for k, v in
-                                          sorted(((k, v) for k, v in prof.rows.items() if k.startswith(("conv3d", "bottleneck3d"))),
+                                          sorted(((k, v) for k, v in prof.rows.items() if k.startswith(("conv3d", "bottleneck3d", "rows_gemm"))),
                                                  key=lambda kv: -kv[1]["ms"])[:24]},
         "stages_ms": stages,
         "stages_note": "eager pass with stream events around the three stages; ms_per_step is the graph-replayed frame",
@@ -465,7 +465,7 @@ def _config5(args, world, rank, device, dist):
     head = [(k, v) for k, v in prof.rows.items() if HEAD_CONV_TAG in k and k.startswith("conv3d")]
     hms, hfl, hn = sum(v["ms"] for _, v in head), sum(v["flops"] for _, v in head), sum(v["launches"] for _, v in head)
     ach = hfl / (hms * 1e-3) / 1e12 if hms > 0 else 0.0
-    rows = sorted(((k, v) for k, v in prof.rows.items() if k.startswith(("conv3d", "bottleneck3d"))), key=lambda kv: -kv[1]["ms"])[:12]
+    rows = sorted(((k, v) for k, v in prof.rows.items() if k.startswith(("conv3d", "bottleneck3d", "rows_gemm"))), key=lambda kv: -kv[1]["ms"])[:12]
     return {
         "metric": "frames/sec forward, UNet3D alone, synthetic 512x512x64 voxel grid (BASELINE configs[4])",
         "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -192,6 +192,30 @@ typedef struct occd_bneck_args {
 int64_t occd_bottleneck3d_weight_floats(int32_t C, int32_t P);
 int occd_bottleneck3d_fwd(const occd_bneck_args* a, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * K15: pointwise (1x1x1) convolution / row GEMM on channels-last voxel rows:
+ *   out[r][n] = act_out( sum_k act_in(a[r][k]) * w[k][n] + bias[n] (+ res[r][n]) ),   r < rows, k < K, n < N.
+ * a / out / res: float32 rows with strides *_cs and channel offsets *_coff (a Vox or a channel slice of one); w: the
+ * image occd_rows_gemm_pack makes of a dense [K][N] matrix (the (cin, cout) transpose of a 1x1x1 convolution weight with
+ * the BatchNorm scale folded, or the mega-voxel rows of the CRP product, occdepth/models/CRP3D.py:80): MFMA fragment
+ * records of occd_rows_gemm_packed_floats(K, N) floats.  K a multiple of 16, N a multiple of 4; w_stride is unused.
+ * act_in: NONE / RELU / SIGMOID; act_out: NONE / RELU (after the residual) / RELU_PRE (before it).
+ * ------------------------------------------------------------------------ */
+typedef struct occd_rows_gemm_args {
+    const float* a;
+    const float* w;
+    const float* bias;      /* N floats, padded to a multiple of 4, or NULL */
+    const float* res;       /* or NULL */
+    float* out;
+    int64_t rows;
+    int32_t K, N;
+    int32_t a_cs, a_coff, out_cs, out_coff, res_cs, res_coff, w_stride;
+    int32_t act_in, act_out;
+} occd_rows_gemm_args;
+int occd_rows_gemm_fwd(const occd_rows_gemm_args* a, void* stream);
+int64_t occd_rows_gemm_packed_floats(int32_t K, int32_t N);
+int occd_rows_gemm_pack(const float* w, float* wpk, int32_t K, int32_t N, int32_t w_stride, void* stream);
+
 /* The eval lift without its tables (SURVEY 8(f) N2 fused into K1b): the kernel projects every voxel
  * centroid itself (the arithmetic of occd_project_voxels: occdepth/data/utils/helpers.py:94-169, integer-exact), samples the
  * FLoSP depth frustum for the voxel (the arithmetic of occd_flosp_sample_fwd: flosp_depth.py:561-602) and applies

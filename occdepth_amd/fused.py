@@ -166,6 +166,11 @@ class ConvPlan:
             w = (w / float(kx * ky * kz)).expand(-1, -1, kx, ky, kz).contiguous()
         self._wpk = _pack_w(w, scale)
         self._bias = _pad_bias(shift, cout)
+        self._wrows = None
+        if self.pool is None and tuple(w.shape[2:]) == (1, 1, 1) and _triple(self.conv.stride) == (1, 1, 1):
+            w2 = w.reshape(cout, -1)
+            if ROWS_GEMM and w2.is_cuda and w2.shape[1] % 16 == 0 and cout % 8 == 0:
+                self._wrows = hip.RowsGemmWeights((w2 * scale.view(-1, 1) if scale is not None else w2).t().contiguous())
         self._key = key
 
     def geometry(self):
@@ -183,6 +188,9 @@ class ConvPlan:
         k, s, d, p = self.geometry()
         if out is None:
             out = Vox.empty(x.batch, self.out_dims(x.dims), self.cout, x.buf.device)
+        if (ROWS_GEMM and self._wrows is not None and res2 is None and x.buf.is_cuda and _rows_gemm_wins(x, self._wrows.K)
+                and hip.rows_gemm_supported(self._wrows.K, self.cout, x, out, res1)):
+            return hip.rows_gemm(x, self._wrows, out, bias=self._bias, res=res1, act_in=act_in, act_out=act_out)
         return _conv3d(x, self._wpk, self._bias, self.cout, k, out, stride=s, dilation=d, padding=p,
                           res1=res1, res2=res2, act_in=act_in, act_out=act_out)
 
@@ -292,8 +300,24 @@ class ConvTransposePlan:
         return out
 
 
+# K15 (csrc/rows_gemm.hip): 1x1x1 convolutions and the CRP product as a row GEMM whose data operand never touches LDS.
+# OFF by default -- measured round 3 (sessions 21-23, profiles/r03_rows_gemm_ab.txt): 512>512 on 4096 rows 55-57 us against
+# K2's 63, 256>512 30 against 27, 2304>256 205-216 against 78; the config-2 frame 25.28-25.44 ms against 25.09-25.21.  With
+# 256 workgroups on 256 CUs nothing hides the L2 latency of the per-stage weight fetch (3.5 us per 32-k stage for 0.85 us of
+# MFMA work); K2's in-workgroup split-K (16 waves) does.  OCCDEPTH_ROWS_GEMM=1 enables it for small volumes / long K.
+ROWS_GEMM = os.environ.get("OCCDEPTH_ROWS_GEMM", "0") == "1"
+
+
+def _rows_gemm_wins(x, K):
+    rows = x.batch * x.dims[0] * x.dims[1] * x.dims[2]
+    return rows <= 65536 or K >= 256
+
+
 def pack_rows(b_rows):
-    """(K, N) row-major device matrix -> the packed B operand of `gemm_rows` (occd_pack_weights layout 2)."""
+    """(K, N) row-major device matrix -> the B operand of `gemm_rows`: the matrix itself for K15, else K2's packed image
+    (occd_pack_weights layout 2)."""
+    if ROWS_GEMM and b_rows.is_cuda and b_rows.dtype == torch.float32 and b_rows.shape[0] % 16 == 0 and b_rows.shape[1] % 8 == 0:
+        return hip.RowsGemmWeights(b_rows), tuple(b_rows.shape)
     return _pack_w(b_rows, layout=2), tuple(b_rows.shape)
 
 
@@ -302,6 +326,10 @@ def gemm_rows(a, b_rows, out, act_in=ACT_NONE):
 
     b_rows is a dense (K, N) row-major device matrix (packed on the fly) or the result of `pack_rows`."""
     wpk, (K, N) = b_rows if isinstance(b_rows, tuple) else pack_rows(b_rows)
+    if isinstance(wpk, hip.RowsGemmWeights):
+        if not hip.rows_gemm_supported(K, N, a, out):
+            raise RuntimeError("gemm_rows: operands do not fit the row-GEMM kernel")
+        return hip.rows_gemm(a, wpk, out, act_in=act_in)
     return _conv3d(a, wpk, None, N, (1, 1, 1), out, act_in=act_in, cin=K)
 
 

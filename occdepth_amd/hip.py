@@ -89,6 +89,12 @@ class BneckArgs(Structure):
         [(n, c_int32) for n in ("batch", "X", "Y", "Z", "C", "P", "x_cs", "x_coff", "y_cs", "y_coff", "d0", "d1", "d2")]
 
 
+class RowsGemmArgs(Structure):
+    _fields_ = [("a", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("out", c_void_p), ("rows", c_int64)] + \
+        [(n, c_int32) for n in ("K", "N", "a_cs", "a_coff", "out_cs", "out_coff", "res_cs", "res_coff", "w_stride", "act_in",
+                                "act_out")]
+
+
 class WinoArgs(Structure):
     _fields_ = [("x", c_void_p), ("upk", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("y", c_void_p)] + \
         [(n, c_int32) for n in ("batch", "cin", "cout", "H", "W", "act", "res_first", "tile_hint")] + [("slope", c_float)]
@@ -127,6 +133,9 @@ EXPORTS = {
     "occd_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
+    "occd_rows_gemm_fwd": (c_int32, [POINTER(RowsGemmArgs), c_void_p]),
+    "occd_rows_gemm_packed_floats": (c_int64, [c_int32, c_int32]),
+    "occd_rows_gemm_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "occd_bottleneck3d_weight_floats": (c_int64, [c_int32, c_int32]),
     "occd_bottleneck3d_fwd": (c_int32, [POINTER(BneckArgs), c_void_p]),
     "occd_lift_proj_fwd": (c_int32, [POINTER(LiftProjArgs), c_void_p]),
@@ -612,6 +621,48 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
     _lift_args(a, feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale, scale_const, xcd_mode)
     _check(load().occd_lift_fwd(ctypes.byref(a), _stream()), "occd_lift_fwd")
     return out
+
+
+class RowsGemmWeights:
+    """The fragment-ordered image of a dense (K, N) float32 matrix for `rows_gemm` (occd_rows_gemm_pack)."""
+
+    def __init__(self, w_rows):
+        if w_rows.dtype != torch.float32 or w_rows.stride(1) != 1 or not w_rows.is_cuda:
+            raise RuntimeError("rows_gemm: the weight matrix must be a float32 GPU tensor with unit column stride")
+        self.K, self.N = int(w_rows.shape[0]), int(w_rows.shape[1])
+        self.buf = torch.empty(load().occd_rows_gemm_packed_floats(self.K, self.N), device=w_rows.device, dtype=torch.float32)
+        _check(load().occd_rows_gemm_pack(w_rows.data_ptr(), self.buf.data_ptr(), self.K, self.N, int(w_rows.stride(0)),
+                                          _stream()), "occd_rows_gemm_pack")
+
+
+def rows_gemm(a, w, out, bias=None, res=None, act_in=ACT_NONE, act_out=ACT_NONE):
+    """K15: out[row, :N] = act_out(act_in(a[row, :K]) @ W[:K, :N] + bias (+ res[row, :N])) on float32 Vox rows;
+    w: a dense (K, N) float32 device matrix (packed on the fly) or a `RowsGemmWeights`."""
+    if not isinstance(w, RowsGemmWeights):
+        w = RowsGemmWeights(w)
+    K, N = w.K, w.N
+    q = RowsGemmArgs()
+    q.a, q.w, q.out = _f32(a.buf, "a"), w.buf.data_ptr(), _f32(out.buf, "out")
+    q.bias = _f32(bias, "bias") if bias is not None else None
+    q.res = _f32(res.buf, "res") if res is not None else None
+    q.rows = a.batch * a.dims[0] * a.dims[1] * a.dims[2]
+    q.K, q.N = K, N
+    q.a_cs, q.a_coff, q.out_cs, q.out_coff = a.cs, a.coff, out.cs, out.coff
+    if res is not None:
+        q.res_cs, q.res_coff = res.cs, res.coff
+    q.w_stride = N
+    q.act_in, q.act_out = act_in, act_out
+    if _PROFILING:
+        set_tag("%d>%d @%d rows" % (K, N, q.rows))
+    _check(load().occd_rows_gemm_fwd(ctypes.byref(q), _stream()), "occd_rows_gemm_fwd")
+    return out
+
+
+def rows_gemm_supported(K, N, a, out, res=None):
+    """(N % 8: the kernel writes exactly N channels, and the consumers of a Vox read its rows in 8-channel groups)"""
+    ok = K % 16 == 0 and N % 8 == 0 and a.cs % 4 == 0 and a.coff % 4 == 0 and out.cs % 4 == 0 and out.coff % 4 == 0
+    ok = ok and a.buf.dtype == torch.float32 and a.coff + K <= a.cs and out.coff + N <= out.cs
+    return ok and (res is None or (res.cs % 4 == 0 and res.coff % 4 == 0))
 
 
 def bottleneck3d_supported(C, P, dims):
