@@ -175,8 +175,10 @@ int occd_lift_fwd(const occd_lift_args* a, void* stream);
  * K14: one stride-1 DDR Bottleneck3D (occdepth/models/DDR.py:111-139 with BatchNorm folded) in two launches:
  *   o1 = relu(W1 x + b1); o2 = conv_z(o1) + b2; o3 = conv_y(relu(o2)) + b3 + o2; o4 = conv_x(relu(o3)) + b4 + o2 + o3;
  *   y = relu(W5 relu(o4) + b5 + x).       x, y: channels-last (B, X, Y, Z, cs) rows; C = channels of x and y, P = planes.
- * w: occd_bottleneck3d_weight_floats(C, P) floats = W1^T [C][P] | b1 [P] | W2 [3][P][P] (tap, in, out) | b2 | W3 | b3 |
- *    W4 | b4 | W5^T [P][C] | b5 [C]   (tap k <-> offset (k - 1) * dilation).   o2: workspace of B*X*Y*Z*P floats.
+ * w: occd_bottleneck3d_weight_floats(C, P) floats = F(W1^T [C][P]) | b1 [P] | F(W2[0]) F(W2[1]) F(W2[2]) (per tap, [P in][P
+ *    out]) | b2 | F(W3[.]) | b3 | F(W4[.]) | b4 | F(W5^T [P][C]) | b5 [C]   (tap k <-> offset (k - 1) * dilation), where
+ *    F(W [KIN][MOUT]) is the matrix in MFMA fragment order: F[((t * MOUT/16 + m) * 64 + lane) * 4 + e] =
+ *    W[16 t + 4 (lane >> 4) + e][16 m + (lane & 15)].   o2: workspace of B*X*Y*Z*P floats.
  * P in {16, 32}, C a multiple of 16, Z in {4, 8, 16} (a 16-voxel MFMA column block holds whole Z columns).
  * d0 / d1 / d2: dilation of the Z / Y / X convolution.
  * ------------------------------------------------------------------------ */

@@ -32,11 +32,11 @@ struct BneckP {
     const float* x;
     float* y;
     float* o2;
-    const float* w1; const float* b1;     // [C][P], [P]
-    const float* w2; const float* b2;     // [3][P][P] (tap, in, out), [P]
+    const float* w1; const float* b1;     // fragments of W1^T [C][P], [P]
+    const float* w2; const float* b2;     // 3 x fragments of [P][P] (tap; in, out), [P]
     const float* w3; const float* b3;
     const float* w4; const float* b4;
-    const float* w5; const float* b5;     // [P][C], [C]
+    const float* w5; const float* b5;     // fragments of W5^T [P][C], [C]
     int batch, X, Y, Z, C;
     int x_cs, x_coff, y_cs, y_coff;
     int d0, d1, d2;
@@ -70,15 +70,12 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[M], const float* wfrag, in
     }
 }
 
-// global [cin][cout] (row stride `stride`) -> LDS fragments [t][m][lane][e] of a KIN x MOUT reduction
-__device__ __forceinline__ void load_frags(float* dst, const float* __restrict__ src, int KIN, int MOUT, int stride, int tid,
-                                           int nthreads) {
-    const int mt = MOUT >> 4;
-    for (int idx = tid; idx < KIN * MOUT; idx += nthreads) {
-        const int e = idx & 3, lane = (idx >> 2) & 63, rest = idx >> 8;
-        const int m = rest % mt, t = rest / mt;
-        dst[idx] = src[(size_t)(16 * t + 4 * (lane >> 4) + e) * stride + 16 * m + (lane & 15)];
-    }
+// The packed weight buffer holds every matrix ALREADY in fragment order ([t][m][lane][e], element = W[cin 16 t + 4 (lane >> 4)
+// + e][cout 16 m + (lane & 15)]; models/DDR.py builds it with one permute per matrix when the weights change), so filling
+// LDS is a linear, coalesced 16-byte copy.  (The first version gathered the fragments from [cin][cout] matrices with 4-byte
+// loads: 80 dependent loads per thread at 32 planes, 72 us for a 64x64x8 block whose HBM time is 12 us.)
+__device__ __forceinline__ void copy_frags(float* dst, const float* __restrict__ src, int n, int tid, int nthreads) {
+    for (int i = tid * 4; i < n; i += nthreads * 4) *(f32x4*)(dst + i) = *(const f32x4*)(src + i);
 }
 
 // ---------------------------------------------------------------- A: x -> o1 -> o2      (16 % Z == 0: a tile = whole columns)
@@ -92,8 +89,8 @@ __global__ void __launch_bounds__(NT) bneck_a_kernel(const BneckP p) {
     float* o1s = w2f + 3 * P * P;                         // [NT][P]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
-    load_frags(w1f, p.w1, p.C, P, P, tid, NT);
-    for (int k = 0; k < 3; ++k) load_frags(w2f + k * P * P, p.w2 + (size_t)k * P * P, P, P, P, tid, NT);
+    copy_frags(w1f, p.w1, p.C * P, tid, NT);
+    copy_frags(w2f, p.w2, 3 * P * P, tid, NT);
     __syncthreads();
     const long v0 = (long)blockIdx.x * NT;
     const long vtot = p.ncols * p.Z;
@@ -161,11 +158,9 @@ __global__ void __launch_bounds__(NT) bneck_b_kernel(const BneckP p) {
     float* w5f = w4f + 3 * P * P;                          // [M(t)][CT][64][4]
     float* o3s = w5f + P * p.C;                            // [XR * TYZ][P]   raw o3 (zero outside the volume)
     float* cs = o3s + (size_t)XR * TYZ * P;                // [nvox][P]       o2 + o3
-    for (int k = 0; k < 3; ++k) {
-        load_frags(w3f + k * P * P, p.w3 + (size_t)k * P * P, P, P, P, tid, NT);
-        load_frags(w4f + k * P * P, p.w4 + (size_t)k * P * P, P, P, P, tid, NT);
-    }
-    load_frags(w5f, p.w5, P, p.C, p.C, tid, NT);
+    copy_frags(w3f, p.w3, 3 * P * P, tid, NT);
+    copy_frags(w4f, p.w4, 3 * P * P, tid, NT);
+    copy_frags(w5f, p.w5, P * p.C, tid, NT);
     __syncthreads();
     const int b = blockIdx.y;
     const int xt = blockIdx.x / p.ytiles, yt = blockIdx.x - xt * p.ytiles;

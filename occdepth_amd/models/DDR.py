@@ -80,8 +80,9 @@ class Bottleneck3D(nn.Module):
     FUSED = os.environ.get("OCCDEPTH_FUSED_BOTTLENECK", "1") == "1"
 
     def _packed_block(self):
-        """W1^T | b1 | W2 | b2 | W3 | b3 | W4 | b4 | W5^T | b5 with the BatchNorm scales folded into the weights (the layout
-        occd_bottleneck3d_fwd documents), rebuilt when a source tensor changes."""
+        """F(W1^T) | b1 | F(W2[k]) | b2 | F(W3[k]) | b3 | F(W4[k]) | b4 | F(W5^T) | b5 with the BatchNorm scales folded into the
+        weights and every [cin][cout] matrix in MFMA fragment order (the layout occd_bottleneck3d_fwd documents), rebuilt
+        when a source tensor changes."""
         mods = [getattr(self, f"{k}{i}") for i in range(1, 6) for k in ("conv", "bn")]
         key = _stamp(*mods)
         if getattr(self, "_k14_key", None) == key:
@@ -93,7 +94,10 @@ class Bottleneck3D(nn.Module):
             cout = w.shape[0]
             scale, shift = _bn_affine(bn, cout, w.device)
             w = w.reshape(cout, w.shape[1], -1) * scale.view(-1, 1, 1)       # (out, in, taps)
-            parts += [w.permute(2, 1, 0).reshape(-1), shift.float().reshape(-1)]   # (tap, in, out)
+            cin = w.shape[1]
+            m = w.permute(2, 1, 0)                                            # (tap, in, out)
+            frag = m.reshape(-1, cin // 16, 4, 4, cout // 16, 16).permute(0, 1, 4, 2, 5, 3)   # (tap, t, m, g, i, e)
+            parts += [frag.reshape(-1), shift.float().reshape(-1)]
         self._k14_w = torch.cat(parts).contiguous()
         self._k14_key = key
         return self._k14_w

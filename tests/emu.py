@@ -230,15 +230,20 @@ def bottleneck3d(x, w, P, dilation, out=None):
         off[0] += n
         return t
 
-    w1 = take(C * P).view(C, P).t().reshape(P, C, 1, 1, 1)
+    def unfrag(flat, ntap, cin, cout):
+        """fragment order (tap, t, m, g, i, e) -> (tap, cin, cout)"""
+        f = flat.view(ntap, cin // 16, cout // 16, 4, 16, 4)
+        return f.permute(0, 1, 3, 5, 2, 4).reshape(ntap, cin, cout)
+
+    w1 = unfrag(take(C * P), 1, C, P)[0].t().reshape(P, C, 1, 1, 1)
     b1 = take(P)
     taps = []
     for axis in (2, 1, 0):                                       # conv2: Z, conv3: Y, conv4: X
-        wk = take(3 * P * P).view(3, P, P).permute(2, 1, 0)     # (out, in, tap)
+        wk = unfrag(take(3 * P * P), 3, P, P).permute(2, 1, 0)  # (out, in, tap)
         shape = [1, 1, 1]
         shape[axis] = 3
         taps.append((wk.reshape(P, P, *shape), take(P), axis))
-    w5 = take(P * C).view(P, C).t().reshape(C, P, 1, 1, 1)
+    w5 = unfrag(take(P * C), 1, P, C)[0].t().reshape(C, P, 1, 1, 1)
     b5 = take(C)
     assert off[0] == w.numel()
 
