@@ -25,6 +25,10 @@ from .unet2d import UNet2D
 from .unet3d_kitti import UNet3D as UNet3DKitti
 from .unet3d_nyu import UNet3D as UNet3DNYU
 
+# hipStreamCaptureModeThreadLocal: only the capturing thread's calls are checked, so a process group's watchdog thread
+# (event queries) cannot invalidate -- or abort -- a capture running beside it (N > 1 ranks, OCCDEPTH_FORCE_DIST=1)
+CAPTURE_MODE = "thread_local"
+
 try:  # the reference's base class; absent in this image -> plain nn.Module with the hooks it uses
     import pytorch_lightning as pl
     _Base = pl.LightningModule
@@ -183,7 +187,7 @@ class OccDepth(_Base):
                         self.net_rgb(static_in)
                 torch.cuda.current_stream(x.device).wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                     static_out = self.net_rgb(static_in)
                 entry = (graph, static_in, static_out, stamp)
             except (RuntimeError, torch.AcceleratorError) as e:   # capture is an optimisation, never a requirement
@@ -427,7 +431,7 @@ class OccDepth(_Base):
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                     static_out = self._forward_impl(static, allow_graph_2d=False)
                 entry = (graph, static, static_out, stamp)
             except (RuntimeError, torch.AcceleratorError) as e:   # capture is an optimisation, never a requirement

@@ -28,6 +28,10 @@ import contextlib
 
 import torch
 
+# hipStreamCaptureModeThreadLocal: only the capturing thread's calls are checked, so a process group's watchdog thread
+# (event queries) cannot invalidate -- or abort -- a capture running beside it (N > 1 ranks, OCCDEPTH_FORCE_DIST=1)
+CAPTURE_MODE = "thread_local"
+
 
 def make_capturable(opt):
     """Device-side step counters and a device-side learning rate (before the optimizer's first step)."""
@@ -136,7 +140,7 @@ class GraphedTrainStep:
             self.opt.zero_grad(set_to_none=True)            # gradients are (re)allocated inside the graph's pool
         ok = True
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 self.loss = self._eager()
         except (RuntimeError, torch.AcceleratorError) as e:
             self.error = repr(e)
