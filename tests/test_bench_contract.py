@@ -1,5 +1,5 @@
-"""The committed bench line (profiles/r02_final_bench.json, produced by `python bench.py` on an MI355X) carries every
-field the driver contract names, and its derived numbers are self-consistent."""
+"""The committed bench lines (profiles/r02_final_bench.json, profiles/r03_bench.json, produced by `python bench.py` on an
+MI355X) carry every field the driver contract names, and their derived numbers are self-consistent."""
 import json
 import os
 
@@ -8,8 +8,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_matches_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_final_bench.json")))
+@pytest.mark.parametrize("name", ["r02_final_bench.json", "r03_bench.json"])
+def test_committed_bench_line_matches_contract(name):
+    d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
