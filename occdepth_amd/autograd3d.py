@@ -103,19 +103,6 @@ def _axis_phases(K, s, p, d):
     return out
 
 
-_TAPS = {}
-
-
-def _taps(ks, device):
-    """Tap index list -> cached device LongTensor (indexing with a Python list uploads it on every call: a host sync per
-    phase per layer, and illegal inside hipGraph capture of the training step)."""
-    key = (tuple(ks), str(device))
-    t = _TAPS.get(key)
-    if t is None:
-        t = _TAPS[key] = torch.tensor(list(ks), dtype=torch.long, device=device)
-    return t
-
-
 def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz)."""
     cout, cin = w.shape[:2]

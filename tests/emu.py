@@ -196,7 +196,6 @@ def lift(feats, scale_divs, pix, fov, n_dims, row_strides, out, depth_scale=None
 def lift_proj(feats, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, n_dims, row_strides, out, frustum=None,
               scale_const=100.0, xcd_mode=None):
     """occd_lift_proj_fwd = the numpy vox2pix restatement per (sample, view) + the frustum sample + `lift`."""
-    import numpy as np
     from oracle.inputs import vox2pix
     B, V = cam_E.shape[:2]
     scene = tuple(float(d) * voxel_size for d in n_dims)

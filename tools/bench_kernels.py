@@ -80,7 +80,6 @@ def bench_lift():
     print(f"sfa_lift config2: {ms * 1e3:.1f} us -> {249.0 / ms / 1e3:.2f} TB/s of algorithmic bytes "
           f"({249.0 / ms / 1e3 / 8 * 100:.1f}% of 8 TB/s)")
     # the fused lift (projection + frustum sample in the kernel) against the table path + its frustum-sample launch
-    import numpy as np
     from occdepth_amd.models.flosp_depth.flosp_depth import _grid_to_lidar
     cam_E = b["T_velo_2_cam_f64"][0].unsqueeze(0).cuda().contiguous()
     cam_k = b["cam_k"][0].unsqueeze(0).cuda().contiguous()
