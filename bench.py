@@ -2,7 +2,7 @@
 """Headline benchmark: frames/s of OccDepth.forward, SemanticKITTI stereo 1220x370 -> 256x256x32 voxels
 (BASELINE.json configs[1]: EfficientNet-B7, feature 64, FLoSP-Depth + CRP + cascade head, batch 1 per GPU).
 
-    python bench.py --gpus N --steps K --warmup W [--train [--bf16]] [--config 5]
+    python bench.py --gpus N --steps K --warmup W [--train [--bf16]] [--config 5] [--no-extras]
 
 N > 1: one rank per GPU over RCCL.  Under `torch.distributed.run` (WORLD_SIZE set) the ranks are the launcher's;
 a bare `python bench.py --gpus N` re-executes itself through `torch.distributed.run` on 127.0.0.1, so the printed
@@ -25,9 +25,11 @@ Rank 0 prints ONE JSON line with the contract fields plus
                    events on the launch stream, against the fp32-MFMA peak (157.3 TF/s);
   cpu_baseline   : the CPU oracle (oracle/occdepth_oracle.py, a port of the reference's PyTorch path) timed on
                    this box's host cores: 1 warm-up + 3 timed frames of the same workload, median (N=1 only);
-  parity_rel_err : the SAME configuration flags as the timed model (batch_views, graph_2d, in-repo 2-D kernels), run once
-                   untimed on the golden frame with the golden weights and compared with the real reference's
-                   outputs (tests/golden/occdepth_kitti_a100.npz); max |delta| / max |ref| per output.
+  parity_rel_err : the SAME configuration as the timed model (whole-forward hipGraph, batched views, table-free lift, the
+                   default convolution mode), run once untimed on the golden frame with the golden weights and compared
+                   with the real reference's outputs (tests/golden/occdepth_kitti_a100.npz); max |delta| / max |ref| per
+                   output, and `lift_kernels` = the lift launches an eager twin of that model makes;
+  extras         : (N = 1, default run) config 5 and the fp32 / bf16 training step, each a short child run of this script.
 The oracle / golden machinery is used by the `cpu_baseline` and `parity_rel_err` legs only, as the checker.
 """
 import argparse
@@ -79,7 +81,23 @@ def build_model(device, train=False):
     if train:
         return m.to(device).train(), cfg
     m.batch_views, m.graph_2d, m.graph_all = model_flags()
+    m.clone_graph_outputs = clone_outputs()
     return m.to(device).eval(), cfg
+
+
+def clone_outputs():
+    """Fresh output tensors per forward (the reference's contract, `OccDepth.enable_fast_eval(clone_outputs=True)`, the
+    default) or the graph's static buffers (OCCDEPTH_CLONE_OUTPUTS=0)."""
+    return os.environ.get("OCCDEPTH_CLONE_OUTPUTS", "1") == "1"
+
+
+def bench_batch(batch):
+    """What the timed forward receives: the frame's images and calibration (float64 extrinsics included) and NO voxel->pixel
+    tables -- the eval lift projects inside its kernel (`OccDepth.lift_in_kernel` "auto").  OCCDEPTH_LIFT_PROJ=0 keeps the
+    tables (the table-path lift, for A/B)."""
+    if os.environ.get("OCCDEPTH_LIFT_PROJ", "auto") == "0":
+        return batch
+    return {k: v for k, v in batch.items() if not (k.startswith("projected_pix") or k.startswith("fov_mask"))}
 
 
 def parity_check(device):
@@ -94,13 +112,23 @@ def parity_check(device):
         m, cfg, _ = build_product("kitti_a100")
     m = m.to(device).eval()
     m.batch_views, m.graph_2d, m.graph_all = model_flags()
-    batch = {k: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device))
-             for k, v in gc.occdepth_batch("kitti_a100").items()}
+    m.clone_graph_outputs = clone_outputs()
+    from occdepth_amd import synthetic
+    raw = dict(gc.occdepth_batch("kitti_a100"), T_velo_2_cam_f64=synthetic.kitti_frame(seed=gc.SEED)["T_velo_2_cam_f64"])
+    batch = bench_batch({k: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device)) for k, v in raw.items()})
     g = np.load(os.path.join(ROOT, "tests", "golden", "occdepth_kitti_a100.npz"))
+    from occdepth_amd import hip
     with torch.no_grad():
         m(batch)                                           # capture pass
         out = m(batch)                                     # replay (what the timed loop runs)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        flags = (m.graph_2d, m.graph_all)
+        m.graph_2d = m.graph_all = False                   # eager twin: which lift kernel does this configuration launch?
+        with hip.profile() as prof:
+            m(batch)
+            torch.cuda.synchronize()
+        m.graph_2d, m.graph_all = flags
+    lift_tags = sorted({k.split(":")[0] for k in prof.rows if k.startswith(("sfa_lift", "flosp_sample"))})
     errs, extra = {}, {}
     for k, v in out.items():
         ref = torch.from_numpy(g[k])
@@ -117,6 +145,7 @@ def parity_check(device):
     return {"ssc_logit": errs["ssc_logit"], "occ_logit": errs["occ_logit"], "worst_of_all_outputs": max(errs.values()),
             "detail": extra,
             "batch_views": bool(m.batch_views), "graph_2d": bool(m.graph_2d), "graph_all": bool(m.graph_all),
+            "fresh_outputs": bool(m.clone_graph_outputs), "lift_kernels": lift_tags,
             "metric": "max |delta| / max |ref| per output tensor (tensor-scale relative error; finer views under `detail`)",
             "reference": "tests/golden/occdepth_kitti_a100.npz (real reference, CPU fp32)", "bar": 1e-3}
 
@@ -179,6 +208,44 @@ def cpu_baseline(model, cfg, batch, seed, timed_frames=3):
                       f"median {med:.2f} s/frame (min {min(times):.2f}, max {max(times):.2f}) on {threads} torch threads"}
 
 
+def run_extras():
+    """The auxiliary workloads next to the headline (numbers only the builder had seen), each as a
+    short child run of this very script -- same code path as `python bench.py --config 5` / `--train [--bf16]`, its own
+    process (no state shared with the headline measurement, which is finished by the time this runs).  Untimed for the
+    headline; every leg reports its own ms/step.  OCCDEPTH_BENCH_EXTRAS=0 or --no-extras skips them."""
+    legs = {"config5": ["--config", "5", "--steps", "5", "--warmup", "2"],
+            "train_fp32": ["--train", "--steps", "3", "--warmup", "1"],
+            "train_bf16": ["--train", "--bf16", "--steps", "3", "--warmup", "1"]}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "OCCDEPTH_FORCE_DIST")}
+    out = {}
+    for name, extra in legs.items():
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-parity",
+                                "--no-extras"] + extra, env=env, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+                continue
+            t = json.loads(line[-1])
+            leg = {"ms_per_step": t["ms_per_step"], "value": t["value"], "unit": t["unit"], "steps": t["steps"],
+                   "warmup": t["warmup"], "dtype": t["dtype"], "workload": t["config"]["workload"],
+                   "wall_s_incl_startup": round(time.time() - t0, 1)}
+            if name == "config5":
+                leg.update({"tflops": t["stack3d"]["tflops"], "frac_of_fp32_mfma_peak": t["stack3d"]["frac_of_fp32_mfma_peak"],
+                            "gflop_per_frame": t["stack3d"]["gflop_per_frame"], "peak_hbm_GiB": t["peak_hbm_GiB"],
+                            "head_conv": {k: t["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms")}})
+            else:
+                leg.update({"loss": t["loss"], "train_graph": t["train_graph"], "train_graph_error": t["train_graph_error"],
+                            "max_mem_GiB": t["max_mem_GiB"], "parallelism": t["config"]["parallelism"],
+                            "top_kernel_families_ms": dict(list(t["hip_kernel_families_ms_per_step"].items())[:6])})
+            out[name] = leg
+        except Exception as e:  # a report, never a reason to lose the measurement
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def respawn(args):
     """`python bench.py --gpus N` without a launcher: run N ranks through torch.distributed.run and relay their output
     (rank 0 prints the JSON line)."""
@@ -213,6 +280,8 @@ def main():
                          "512x512x64 grid (auxiliary workload: 3-D-conv MFMA tiling + HBM footprint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the auxiliary legs of the default run (config 5, fp32 / bf16 training step: `extras` in the JSON line)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 5 if args.train else 20
@@ -284,7 +353,8 @@ def _forward(args, world, rank, device, dist):
     # one stereo frame per rank; the voxel->pixel tables come from the product's GPU projection (dataloader work,
     # done once, outside the timed region -- exactly what the reference's dataloader hands to the model)
     with torch.no_grad():
-        batch = synthetic.attach_projection(model, synthetic.to_device(synthetic.kitti_frame(seed=rank), device))
+        full_batch = synthetic.attach_projection(model, synthetic.to_device(synthetic.kitti_frame(seed=rank), device))
+    batch = bench_batch(full_batch)     # (the tables stay in `full_batch` for the cpu_baseline's input cross-check)
 
     def step():
         with torch.no_grad():
@@ -304,10 +374,10 @@ def _forward(args, world, rank, device, dist):
     elapsed = shard.max_over_ranks(elapsed, dist, device)
     assert out["ssc_logit"].shape == (1, 20, 256, 256, 32)
     graph_flags = {"batch_views": bool(model.batch_views), "graph_2d": bool(model.graph_2d),
-                   "graph_all": bool(model.graph_all)}
+                   "graph_all": bool(model.graph_all), "fresh_outputs": bool(model.clone_graph_outputs),
+                   "voxel_tables_in_batch": any(k.startswith("projected_pix") for k in batch)}
     from occdepth_amd import fused as _fused
-    if _fused.BF16X3:      # opt-in experiment: the line is NOT the exact-fp32 default and says so
-        graph_flags["bf16x3_split_convs"] = True
+    graph_flags["bf16x3_split"] = _fused.BF16X3 or "off"    # "head" (default), "all" (experiment), "off" (exact fp32 everywhere)
 
     # ---- untimed diagnostic passes (the same model, the same frame), eager so that every launch can be bracketed:
     # (1) per-launch HIP events on the launch stream (occd_prof_*) -> roofline.achieved of the head convolution;
@@ -394,15 +464,33 @@ def _forward(args, world, rank, device, dist):
                  "kernel": "lift_proj_kernel (projection + frustum sample + gather in one launch)" if lift_fused
                            else "lift_p1_kernel (tables from the batch) + flosp_sample_kernel"},
     }
-    if _fused.BF16X3:
-        # the experiment's roofline is priced against the instruction it issues: six bf16 MFMAs per algorithmic MAC
+    split_head = any(k.startswith(("conv3d_c32x3", "conv3d_bf16x3")) for k, _ in head)
+    if split_head:
+        # the head convolutions run on the bf16 matrix pipe (3-way split, six bf16 MFMAs per algorithmic MAC): the roofline is
+        # priced against the instruction that is issued; the fp32-equivalent figures stay next to it
+        x3_slide = any(k.startswith("conv3d_c32x3") for k, _ in head)
+        res["dtype"] = ("f32 storage and accumulate; head convolutions as 3x bf16 split (hi + mid + lo of both operands, six "
+                        "v_mfma_f32_32x32x16_bf16 per K step, error vs float64 <= the exact-fp32 kernel's); everything else exact "
+                        "fp32 MFMA / VALU.  OCCDEPTH_BF16X3=0 restores exact fp32 everywhere")
         res["roofline"].update({
-            "kernel": "conv3d_bf16_kernel<SPLIT=3>: 3x3x3 32->32 @256x256x32 (6 x v_mfma_f32_32x32x16_bf16 per K step)",
+            "kernel": ("conv3d_c32_slide_x3_kernel" if x3_slide else "conv3d_bf16_kernel<SPLIT=3>") +
+                      ": 3x3x3 32->32 @256x256x32 (6 x v_mfma_f32_32x32x16_bf16 per 16-channel K step)",
             "peak": BF16_MFMA_PEAK_TFLOPS, "achieved": 6.0 * ach, "frac": 6.0 * ach / BF16_MFMA_PEAK_TFLOPS,
-            "algorithmic_tflops": ach, "traffic": None,
-            "traffic_source": None,
-            "note": "opt-in OCCDEPTH_BF16X3=1 experiment, not the exact-fp32 default; achieved = issued MFMA flops "
-                    "(6 x algorithmic) / time"})
+            "algorithmic_tflops": ach, "fp32_mfma_equivalent_frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "issued_gflop_per_launch": 6.0 * flops / max(n_launch, 1) / 1e9,
+            "note": "achieved = ISSUED bf16 MFMA flops (6 x algorithmic) / time against the dense bf16 peak; algorithmic_tflops = "
+                    "2*voxels*27*32*32 / time; fp32_mfma_equivalent_frac prices the same launch against the 157.3 TF/s exact-fp32 "
+                    "instruction it replaced (> 1 is possible and is the point)"})
+        res["stack3d"]["note"] = ("frac_of_fp32_mfma_peak is the fp32-EQUIVALENT rate of the whole stack (algorithmic flops / time / "
+                                  "157.3 TF/s); the head's share of it runs on the bf16 pipe")
+        xname = "head_conv_x3_hbm_bytes_inframe.json"
+        xpath = os.path.join(ROOT, "profiles", xname)
+        res["roofline"]["traffic"], res["roofline"]["traffic_source"] = None, None
+        if os.path.exists(xpath):
+            with open(xpath) as f:
+                res["roofline"]["traffic"] = json.load(f).get("bytes_per_launch")
+            res["roofline"]["traffic_source"] = (f"profiles/{xname}: in-frame launches of this command, rocprofv3 --pmc FETCH_SIZE "
+                                                 "(x2, gfx950) and --pmc WRITE_SIZE, separate passes")
     for attr in ("graph_2d_error", "graph_all_error"):
         if getattr(model, attr, None):
             res["config"][attr] = getattr(model, attr)
@@ -412,10 +500,15 @@ def _forward(args, world, rank, device, dist):
             res["parity_rel_err"] = parity_check(device)
         except Exception as e:  # a report, never a reason to lose the measurement
             res["parity_rel_err"] = {"error": repr(e)}
+    if world == 1 and not args.no_extras and os.environ.get("OCCDEPTH_BENCH_EXTRAS", "1") == "1":
+        log(f"[bench {time.strftime('%H:%M:%S')}] extras: config 5, training step fp32 / bf16 (child runs of this script)")
+        del out
+        torch.cuda.empty_cache()
+        res["extras"] = run_extras()
     if world == 1 and not args.no_cpu_baseline:
         log(f"[bench {time.strftime('%H:%M:%S')}] CPU baseline (oracle, 1 warm-up + 3 timed frames)")
         try:
-            res["cpu_baseline"] = cpu_baseline(model, cfg, batch, rank)
+            res["cpu_baseline"] = cpu_baseline(model, cfg, full_batch, rank)
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
             res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e!r}"}

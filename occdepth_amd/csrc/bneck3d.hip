@@ -266,13 +266,9 @@ int launch(const BneckP& p, hipStream_t st) {
     const size_t lds_b = sizeof(float) * ((size_t)6 * P * P + (size_t)P * p.C + (size_t)(p.TX + 2 * p.d2) * TYZ * P + (size_t)NT * P);
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) return OCCD_ENOMEM;
     if (lds_a > 64 * 1024 || lds_b > 64 * 1024) {
-        static bool done = false;                      // per instantiation
-        if (!done) {
-            if (hipFuncSetAttribute((const void*)bneck_a_kernel<P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)bneck_b_kernel<P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return OCCD_ELAUNCH;
-            done = true;
-        }
+        if (occd::ensure_big_lds((const void*)bneck_a_kernel<P, NT>) != OCCD_OK ||
+            occd::ensure_big_lds((const void*)bneck_b_kernel<P, NT>) != OCCD_OK)
+            return OCCD_ELAUNCH;
     }
     hipLaunchKernelGGL((bneck_a_kernel<P, NT>), dim3((unsigned)blocks_a), dim3(NT), lds_a, st, p);
     hipLaunchKernelGGL((bneck_b_kernel<P, NT>), dim3((unsigned)(p.xtiles * p.ytiles), (unsigned)p.batch), dim3(NT), lds_b, st, p);

@@ -17,6 +17,8 @@ struct ProfScope {
 // conv3d_c32p.hip: persistent weights-stationary kernel for the full-resolution head convolutions.
 // 1 = launched, 0 = geometry does not qualify (use the generic kernel), <0 = error.
 int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream);
+// K2s3: the same launches with the 3-way bf16 split (weights = the image of occd_pack_weights_bf16x3); same return convention.
+int try_conv3d_c32_slide_x3(const occd_conv3d_args* a, hipStream_t stream);
 
 // occd_pack_weights*_gather: where element (co, ci, tap) of a packed operator lives in a dense source tensor
 constexpr int kMaxTaps = 27;
@@ -24,6 +26,10 @@ struct TapMap {
     int64_t s_co, s_ci;
     int32_t ofs[kMaxTaps];
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize (> 64 KB of LDS) belongs to the (kernel, DEVICE) pair: set once per pair,
+// whatever device the calling thread has current (prof.cpp).  Returns OCCD_OK / OCCD_ELAUNCH.
+int ensure_big_lds(const void* kernel);
 
 inline int check_launch() {
     hipError_t e = hipGetLastError();

@@ -370,7 +370,6 @@ const VariantB kVariantsB[] = {
 };
 constexpr int kNumVariantsB = sizeof(kVariantsB) / sizeof(kVariantsB[0]);
 constexpr size_t kMaxLdsB = 160 * 1024;
-bool g_attr_set_b[kNumVariantsB][3] = {};
 
 struct TilingB {
     int TY, TZ, YIN, ZIN, ytiles, ztiles, ngroups;
@@ -505,6 +504,10 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
         return OCCD_EINVAL;
 
+    if (ksel == 2) {   // the full-resolution head launches: sliding-window form of the split (K2s3, conv3d_c32p.hip)
+        const int r = occd::try_conv3d_c32_slide_x3(a, (hipStream_t)stream);
+        if (r != 0) return r < 0 ? r : OCCD_OK;
+    }
     int order[kNumVariantsB];
     int n = 0;
     if (a->tile_hint > 0 && a->tile_hint <= kNumVariantsB) {
@@ -548,12 +551,7 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
 
     void (*kern)(const ConvBP) = v.kern[ksel];
-    if (til.lds > 64 * 1024 && !g_attr_set_b[pick][ksel]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kMaxLdsB) != hipSuccess)
-            return OCCD_ELAUNCH;
-        g_attr_set_b[pick][ksel] = true;
-    }
+    if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double taps = (double)a->kx * a->ky * a->kz;
     const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
     const double flops = 2.0 * pos * taps * a->cin * a->cout;

@@ -464,6 +464,351 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2s3 -- K2s on the bf16 matrix pipe with the 3-way operand split.  Same work list, same sliding
+// window (three accumulators, every staged plane feeds the three kx taps), same epilogue; what changes:
+//   * instruction: v_mfma_f32_32x32x16_bf16, six per 16-channel K step -- (mid,mid), (hi,lo), (lo,hi), (hi,mid), (mid,hi),
+//     (hi,hi), smallest first -- on x = hi + mid + lo, w = hi + mid + lo (three bf16 terms each, 24 significant bits):
+//     float32-level accuracy at 6 x 32 = 192 matrix-pipe cycles per 16 channels instead of 8 x 64 = 512;
+//   * the activation split is paid ONCE per staged element (while the slab is committed: fp32 rows in HBM, three bf16
+//     planes in LDS: rows of 3 x 32 B + 16 B pad = 7 sixteen-byte slots, odd -> conflict-free ds_read_b128), not once per
+//     tap as an on-the-fly split would;
+//   * weights: the hi and mid images (2 x 55,296 B, exactly the 110,592 B K2s keeps) stay in LDS for the kernel's
+//     lifetime; the lo image (one of the six products) does not fit beside the slab any more and is streamed from L2
+//     two steps ahead (3 x 1 KB per wave and step, the same addresses for all 8 waves of a CU and all CUs);
+//   * Z = 32 only: the z halo is not staged -- every y row of the slab carries ONE all-zero entry and the lanes whose
+//     tap leaves the column read that (33 entries per row instead of 32 + 2 D: at D = 3 the slab is 51.7 KB, not 59.6).
+// Work per launch 115.96 GFLOP algorithmic = 695.8 GFLOP issued on the bf16 pipe.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kX3RowB = 112;              // bytes per slab entry: hi | mid | lo of 16 channels + 16 B pad
+constexpr int kX3ZW = 33;                 // entries per y row: z = 0 .. 31 and the zero entry
+constexpr int kX3WImg = kWTaps * 2 * 64;  // u32x4 per split image of the weights: [tap][k16 2][lane 64]
+
+// x = hi + mid + lo (round-to-nearest at every step; exact for every float32 whose low parts do not underflow)
+__device__ __forceinline__ void split3_bf16(f32x4 a, f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+    bf16x8 h = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    float r[8] = {a.x - (float)h[0], a.y - (float)h[1], a.z - (float)h[2], a.w - (float)h[3],
+                  b.x - (float)h[4], b.y - (float)h[5], b.z - (float)h[6], b.w - (float)h[7]};
+    bf16x8 m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m[j] = (__bf16)r[j];
+        l[j] = (__bf16)(r[j] - (float)m[j]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    mid = __builtin_bit_cast(u32x4, m);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+// NRES: residual operands compiled in (0: neither, 1: res1, 2: res1 and res2) -- their prefetch registers (16 per
+// operand) are what the 5 of 7 head launches without residuals do not pay for.
+template <int D, int NRES>
+__global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const SlideP sp) {
+    const PersistP& p = sp.base;
+    constexpr int YIN = kTY + 2 * D, ROWS = YIN * kX3ZW;
+    constexpr int NITEM = YIN * kTZ * 2;          // staging items: (y row, z, 8-channel chunk of the 16-channel half)
+    constexpr int NLOAD = (NITEM + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u32x4* const w4 = reinterpret_cast<u32x4*>(lds_raw);                 // hi image | mid image
+    unsigned char* const slab = lds_raw + 2 * kX3WImg * 16;
+    int* const mailbox = reinterpret_cast<int*>(slab + ROWS * kX3RowB);
+    f32x4* const bias4 = reinterpret_cast<f32x4*>(slab + ROWS * kX3RowB + 16);
+    // lo image: read through a buffer descriptor (voffset = lane * 16, soffset = a compile-time constant per fragment, so
+    // the 54 fragment addresses cost no address VGPRs)
+    const auto wlo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(reinterpret_cast<const u32x4*>(p.wpk) + 2 * kX3WImg)), 0,
+        kX3WImg * 16, 0x00020000);
+    auto wlo_load = [&](int frag) {
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wlo_rsrc, (unsigned)(threadIdx.x & 63) * 16u, frag * 1024, 0));
+    };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+
+    {   // hi | mid weight images: global -> LDS, once (6912 u32x4 = 13.5 x 512, 7 loads in flight per thread)
+        static_assert(2 * kX3WImg == 13 * 512 + 256, "weight staging loop");
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 wv[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = tid + (half * 7 + u) * 512;
+                if (i < 2 * kX3WImg) wv[u] = reinterpret_cast<const u32x4*>(p.wpk)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = tid + (half * 7 + u) * 512;
+                if (i < 2 * kX3WImg) w4[i] = wv[u];
+            }
+        }
+        // the zero entry of every y row (never written again)
+        if (tid < YIN * 7) {
+            const int yi = tid / 7, s16 = tid - yi * 7;
+            *reinterpret_cast<u32x4*>(slab + (yi * kX3ZW + kTZ) * kX3RowB + s16 * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    // staging descriptors (constant over the kernel): slab byte offset of the item's hi chunk, y row, z column, channel chunk
+    int sdst[NLOAD], syi[NLOAD], sz[NLOAD], sc8[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int f = tid + i * 512;
+        const bool live = f < NITEM;
+        const int row = f >> 1, c8 = f & 1;
+        const int yi = row >> 5, z = row & 31;
+        sdst[i] = live ? (yi * kX3ZW + z) * kX3RowB + c8 * 16 : -1;
+        syi[i] = yi;
+        sz[i] = z;
+        sc8[i] = c8 * 8;
+    }
+    // A-fragment bases of this lane for kz = 0, 1, 2 (ky adds a constant): the voxel column li + (kz - 1) D, or the zero
+    // entry when it leaves [0, 32)
+    int abase[3];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+        const int z = li + (kz - 1) * D;
+        abase[kz] = (wave * kX3ZW + ((z >= 0 && z < kTZ) ? z : kTZ)) * kX3RowB + kk * 16;
+    }
+    const size_t plane_stride = (size_t)p.Y * p.Z * p.in_cs;
+
+    unsigned coloff[NLOAD];
+    bool colok[NLOAD];
+    f32x4 v[NLOAD][2];
+    auto issue = [&](int xi, int h) {        // global -> registers; xi inside the volume
+        const float* base = p.in + (size_t)xi * plane_stride + h * 16;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            v[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            v[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (colok[i]) {
+                v[i][0] = *(const f32x4*)(base + coloff[i]);
+                v[i][1] = *(const f32x4*)(base + coloff[i] + 4);
+            }
+        }
+    };
+    auto commit = [&]() {                    // registers -> split -> the three bf16 planes of the slab
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i)
+            if (sdst[i] >= 0) {
+                f32x4 a = v[i][0], b = v[i][1];
+                if (p.act_in == OCCD_ACT_RELU) {
+                    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+                }
+                u32x4 hi, mid, lo;
+                split3_bf16(a, b, hi, mid, lo);
+                *reinterpret_cast<u32x4*>(slab + sdst[i]) = hi;
+                *reinterpret_cast<u32x4*>(slab + sdst[i] + 32) = mid;
+                *reinterpret_cast<u32x4*>(slab + sdst[i] + 64) = lo;
+            }
+    };
+
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = 0.f;
+    int mid_img = kX3WImg;                       // (opaque to the optimiser: folded into one base, the mid image's offsets
+    asm volatile("" : "+v"(mid_img));            //  exceed the 16-bit ds_read immediate and every fragment costs an address VGPR)
+
+    // lo-weight ring: [step parity][kx], two steps ahead of the MFMAs (a younger load must not be waited for while the
+    // next slab's staging loads -- issued at the top of the slab -- are still in flight: vmcnt retires in order)
+    u32x4 ring[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) ring[t][kx] = wlo_load((kx * 9 + t) * 2 + 0);
+
+#define OCCD_X3_MFMA(ACC, W, A) \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, A), ACC, 0, 0, 0)
+
+    // one staged slab (16-channel half H of a plane) into the accumulators whose output plane exists.  Sub-step =
+    // (tap t = (ky, kz), kx): 6 MFMAs into acc[kx]; the hi / mid weight fragments of the next sub-step and the three
+    // activation fragments of the next step are read from LDS above the MFMAs of the current one.
+    auto mma = [&](auto hsel, auto u0, auto u1, auto u2) {
+        constexpr int H = decltype(hsel)::value;
+        constexpr bool U0 = decltype(u0)::value, U1 = decltype(u1)::value, U2 = decltype(u2)::value;
+        constexpr int NA = (U0 ? 1 : 0) + (U1 ? 1 : 0) + (U2 ? 1 : 0);
+        constexpr int KXS[3] = {U0 ? 0 : (U1 ? 1 : 2), (U0 && U1) ? 1 : 2, 2};
+        constexpr int NSUB = 9 * NA;
+        const u32x4* const whi = w4 + H * 64 + lane;
+        const u32x4* const wmid = whi + mid_img;   // its own base register: the ds_read offsets of both images stay below 64 KB
+        auto aptr = [&](int t, int term) {
+            const int ky = t / 3, kz = t - 3 * ky;
+            return reinterpret_cast<const u32x4*>(slab + abase[kz] + ky * D * kX3ZW * kX3RowB + term * 32);
+        };
+        u32x4 an0 = *aptr(0, 0), an1 = *aptr(0, 1), an2 = *aptr(0, 2);
+        u32x4 bhn = whi[(KXS[0] * 9 * 2) * 64], bmn = wmid[(KXS[0] * 9 * 2) * 64];
+        u32x4 a0 = an0, a1 = an1, a2 = an2;
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+            const int t = i / NA, kx = KXS[i % NA];
+            const int par = (H * 9 + t) & 1;
+            if (i % NA == 0) {
+                a0 = an0; a1 = an1; a2 = an2;
+                if (t < 8) { an0 = *aptr(t + 1, 0); an1 = *aptr(t + 1, 1); an2 = *aptr(t + 1, 2); }
+            }
+            const u32x4 bh = bhn, bm = bmn;
+            if (i + 1 < NSUB) {
+                const int tn = (i + 1) / NA, kxn = KXS[(i + 1) % NA];
+                bhn = whi[((kxn * 9 + tn) * 2) * 64];
+                bmn = wmid[((kxn * 9 + tn) * 2) * 64];
+            }
+            const u32x4 bl = ring[par][kx];
+            __builtin_amdgcn_sched_barrier(0);
+            if (kx == 0) {
+                OCCD_X3_MFMA(acc0, bm, a1); OCCD_X3_MFMA(acc0, bh, a2); OCCD_X3_MFMA(acc0, bl, a0);
+                OCCD_X3_MFMA(acc0, bh, a1); OCCD_X3_MFMA(acc0, bm, a0); OCCD_X3_MFMA(acc0, bh, a0);
+            } else if (kx == 1) {
+                OCCD_X3_MFMA(acc1, bm, a1); OCCD_X3_MFMA(acc1, bh, a2); OCCD_X3_MFMA(acc1, bl, a0);
+                OCCD_X3_MFMA(acc1, bh, a1); OCCD_X3_MFMA(acc1, bm, a0); OCCD_X3_MFMA(acc1, bh, a0);
+            } else {
+                OCCD_X3_MFMA(acc2, bm, a1); OCCD_X3_MFMA(acc2, bh, a2); OCCD_X3_MFMA(acc2, bl, a0);
+                OCCD_X3_MFMA(acc2, bh, a1); OCCD_X3_MFMA(acc2, bm, a0); OCCD_X3_MFMA(acc2, bh, a0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i % NA == NA - 1) {
+                // step t done: refill its ring parity with step t + 2 (of this slab, or t + 2 - 9 of the next one, whose
+                // half is always the other one) for ALL kx -- the next slab may feed accumulators this one skipped
+                const int t2 = t + 2 < 9 ? t + 2 : t + 2 - 9;
+                const int h2 = t + 2 < 9 ? H : 1 - H;
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2) ring[par][k2] = wlo_load((k2 * 9 + t2) * 2 + h2);
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+
+    f32x4 r1[4], r2[4];
+    if (tid < 8) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && 4 * tid < p.cout_store) bv = *(const f32x4*)(p.bias + 4 * tid);
+        bias4[tid] = bv;
+    }
+    auto res_fetch = [&](int b, int yt, int x) {
+        if (NRES == 0) return;
+        const int y = min(yt * kTY + wave, p.Y - 1);
+        const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 8 * g + 4 * kk;
+            if (c < p.cout_store) {
+                if (NRES >= 1) r1[g] = *(const f32x4*)(p.res1 + vox * p.res1_cs + p.res1_coff + c);
+                if (NRES >= 2) r2[g] = *(const f32x4*)(p.res2 + vox * p.res2_cs + p.res2_coff + c);
+            }
+        }
+    };
+    auto store2 = [&](int b, int yt, int x) {
+        const int y = yt * kTY + wave;
+        if (y < p.Y) {
+            const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 8 * g + 4 * kk;
+                if (c < p.cout_store) {
+                    f32x4 o = {acc2[4 * g], acc2[4 * g + 1], acc2[4 * g + 2], acc2[4 * g + 3]};
+                    o += bias4[2 * g + kk];
+                    if (p.act_out == OCCD_ACT_RELU_PRE) {
+                        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                    }
+                    if (NRES >= 1) o += r1[g];
+                    if (NRES >= 2) o += r2[g];
+                    if (p.act_out == OCCD_ACT_RELU) {
+                        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                    }
+                    *(f32x4*)(p.out + vox * p.out_cs + p.out_coff + c) = o;
+                }
+            }
+        }
+    };
+    auto slab_mma = [&](auto hsel, bool u0, bool u1, bool u2) {
+        if (u0 && u1 && u2) mma(hsel, T_{}, T_{}, T_{});      // interior plane
+        else if (u0 && u1) mma(hsel, T_{}, T_{}, F_{});       // second plane of a run
+        else if (u1 && u2) mma(hsel, F_{}, T_{}, T_{});       // second to last
+        else if (u0) mma(hsel, T_{}, F_{}, F_{});             // first
+        else if (u2) mma(hsel, F_{}, F_{}, T_{});             // last
+        else mma(hsel, F_{}, T_{}, F_{});                     // run of a single output plane
+    };
+
+    while (true) {
+        __syncthreads();                                   // mailbox / slab free, weights visible
+        if (tid == 0) mailbox[0] = atomicAdd(sp.counter, 1);
+        __syncthreads();
+        const int seg = mailbox[0];
+        if (seg >= sp.total_segs) {
+            if (tid == 0 && atomicAdd(sp.counter + 1, 1) == (int)gridDim.x - 1) {
+                sp.counter[1] = 0;
+                __threadfence();
+                atomicExch(sp.counter, 0);
+            }
+            break;
+        }
+        // segments are ordered (b, range, ytile); ztiles == 1
+        const int yt = seg % p.ytiles;
+        const int rest = seg / p.ytiles;
+        const int b = rest / sp.segs_per_col;
+        const int q0 = (rest - b * sp.segs_per_col) * sp.seg_len;
+        const int q1 = min(q0 + sp.seg_len, p.X);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int y = yt * kTY - D + syi[i];
+            colok[i] = sdst[i] >= 0 && y >= 0 && y < p.Y;
+            coloff[i] = (unsigned)((((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * p.Z + sz[i]) * p.in_cs + p.in_coff + sc8[i]);
+        }
+        int q = q0;
+        while (q < q1) {
+            int r = 0, idx = q, n_r = p.X;
+            if (D > 1) {
+#pragma unroll
+                for (int rr = 0; rr < D; ++rr) {
+                    const int n = (p.X - rr + D - 1) / D;
+                    if (idx < n || rr == D - 1) { r = rr; n_r = n; break; }
+                    idx -= n;
+                }
+            }
+            const int cnt = min(q1 - q, n_r - idx);
+            const int x0 = r + D * idx;
+            q += cnt;
+            const int nj = cnt + 2;
+            const int jfirst = x0 - D < 0 ? 1 : 0;
+            const int jlast = x0 + cnt * D >= p.X ? (p.X - 1 - x0) / D + 1 : nj - 1;
+            __syncthreads();                                               // previous run's slab consumed
+            issue(x0 + (jfirst - 1) * D, 0);
+            for (int j = 0; j < nj; ++j) {
+                const int xi = x0 + (j - 1) * D;
+                const bool u0 = j < cnt, u1 = j >= 1 && j <= cnt, u2 = j >= 2;
+                if (j >= jfirst && j <= jlast) {
+                    __syncthreads();                                       // previous slab consumed
+                    commit();
+                    __syncthreads();
+                    issue(xi, 1);
+                    slab_mma(H0{}, u0, u1, u2);
+                    __syncthreads();
+                    commit();
+                    __syncthreads();
+                    if (j < jlast) issue(xi + D, 0);
+                    if (u2) res_fetch(b, yt, xi - D);                      // out[j-2] completes with this slab
+                    slab_mma(H1{}, u0, u1, u2);
+                }
+                if (u2) {
+                    if (j < jfirst || j > jlast) res_fetch(b, yt, xi - D);   // padding plane: nothing was staged
+                    store2(b, yt, xi - D);
+                }
+                acc2 = acc1;
+                acc1 = acc0;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc0[rr] = 0.f;
+            }
+        }
+    }
+#undef OCCD_X3_MFMA
+}
+
 // Per-DEVICE launch state (work-list counters live in that device's memory, CU count and the large-LDS function
 // attribute belong to it): a process that drives several GPUs gets one of these per device, looked up from the
 // current device at every launch.
@@ -473,6 +818,7 @@ struct DevState {
     int* counter = nullptr;
     int num_cu = 0;
     bool slide_attr[4] = {};
+    bool slide_x3_attr[4][3] = {};
     bool attr_done[4] = {};
 };
 DevState g_dev[kMaxDevices];
@@ -491,31 +837,23 @@ DevState* dev_state() {
     return s;
 }
 
+// Work list of the sliding-window kernels: ranges per column = k rounds over the grid; a range of L planes costs L + 2
+// stagings per run (D > 1: up to two runs).  Few long ranges amortise the two extra planes, but the list must fill
+// whole rounds.  Also hands out the launch's pair of self re-arming counters (a ring: launches in flight on different
+// streams never share one).
 template <int D>
-int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
-    constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D), RS4 = 16 / 4 + 1;
-    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * RS4 * 16 + 16 + 128;
-    const int num_cu = ds->num_cu;
-    // a ring of self re-arming counter pairs: launches in flight on different streams never share one
+int plan_slide(const PersistP& base, DevState* ds, SlideP* sp) {
     constexpr int kSlots = 256;
+    const int num_cu = ds->num_cu;
     {
         std::lock_guard<std::mutex> lock(ds->mu);
-        if (!ds->slide_attr[D]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return OCCD_ELAUNCH;
-            ds->slide_attr[D] = true;
-        }
         if (ds->counter == nullptr) {
             if (hipMalloc(&ds->counter, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
             if (hipMemset(ds->counter, 0, kSlots * 2 * sizeof(int)) != hipSuccess) return OCCD_ELAUNCH;
         }
     }
-    SlideP sp;
-    sp.base = base;
-    sp.counter = ds->counter + 2 * (g_slot.fetch_add(1) % kSlots);
-    // ranges per column: k rounds over the grid; a range of L planes costs L + 2 stagings per run (D > 1: up to two
-    // runs).  Few long ranges amortise the two extra planes, but the list must fill whole rounds.
+    sp->base = base;
+    sp->counter = ds->counter + 2 * (g_slot.fetch_add(1) % kSlots);
     const int cols = base.batch * base.ytiles * base.ztiles;
     int best_s = 1;
     double best_cost = 1e30;
@@ -529,11 +867,52 @@ int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
         const double cost = (double)rounds * (L + 2.0 + (D > 1 ? 1.0 : 0.0));
         if (cost < best_cost - 1e-9) { best_cost = cost; best_s = S; }
     }
-    sp.seg_len = (base.X + best_s - 1) / best_s;
-    sp.segs_per_col = (base.X + sp.seg_len - 1) / sp.seg_len;
-    sp.total_segs = cols * sp.segs_per_col;
-    int grid = num_cu < sp.total_segs ? num_cu : sp.total_segs;
+    sp->seg_len = (base.X + best_s - 1) / best_s;
+    sp->segs_per_col = (base.X + sp->seg_len - 1) / sp->seg_len;
+    sp->total_segs = cols * sp->segs_per_col;
+    return OCCD_OK;
+}
+
+template <int D>
+int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
+    constexpr int ROWS = (kTY + 2 * D) * (kTZ + 2 * D), RS4 = 16 / 4 + 1;
+    const size_t lds = (size_t)kWFloat4 * 16 + (size_t)ROWS * RS4 * 16 + 16 + 128;
+    {
+        std::lock_guard<std::mutex> lock(ds->mu);
+        if (!ds->slide_attr[D]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_kernel<D>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return OCCD_ELAUNCH;
+            ds->slide_attr[D] = true;
+        }
+    }
+    SlideP sp;
+    const int rc = plan_slide<D>(base, ds, &sp);
+    if (rc != OCCD_OK) return rc;
+    const int grid = ds->num_cu < sp.total_segs ? ds->num_cu : sp.total_segs;
     hipLaunchKernelGGL(conv3d_c32_slide_kernel<D>, dim3((unsigned)grid), dim3(512), lds, st, sp);
+    return occd::check_launch();
+}
+
+template <int D, int NRES>
+int launch_slide_x3(const PersistP& base, hipStream_t st, DevState* ds) {
+    constexpr int ROWS = (kTY + 2 * D) * kX3ZW;
+    const size_t lds = (size_t)2 * kX3WImg * 16 + (size_t)ROWS * kX3RowB + 16 + 128;
+    static_assert((size_t)2 * kX3WImg * 16 + (size_t)(kTY + 6) * kX3ZW * kX3RowB + 144 <= 160 * 1024, "K2s3 LDS budget at D = 3");
+    {
+        std::lock_guard<std::mutex> lock(ds->mu);
+        if (!ds->slide_x3_attr[D][NRES]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_x3_kernel<D, NRES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return OCCD_ELAUNCH;
+            ds->slide_x3_attr[D][NRES] = true;
+        }
+    }
+    SlideP sp;
+    const int rc = plan_slide<D>(base, ds, &sp);
+    if (rc != OCCD_OK) return rc;
+    const int grid = ds->num_cu < sp.total_segs ? ds->num_cu : sp.total_segs;
+    hipLaunchKernelGGL((conv3d_c32_slide_x3_kernel<D, NRES>), dim3((unsigned)grid), dim3(512), lds, st, sp);
     return occd::check_launch();
 }
 
@@ -558,37 +937,47 @@ int launch(const PersistP& p, hipStream_t st, DevState* ds) {
 
 }  // namespace
 
-namespace occd {
-
-// Returns 1 when the launch was taken by the persistent kernel, 0 when the geometry does not qualify,
-// <0 on error.
-int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
+namespace {
+// Geometry shared by K2p / K2s / K2s3: 3x3x3, stride 1, dilation d = padding in {1, 2, 3}, <= 32 -> <= 32 channels on rows
+// that hold at least 32 input channels, output grid == input grid, no scatter.
+bool c32_geometry(const occd_conv3d_args* a, PersistP* p, double* flops, double* bytes) {
     const int d = a->dx;
     const bool geom = a->kx == 3 && a->ky == 3 && a->kz == 3 && a->sx == 1 && a->sy == 1 && a->sz == 1 &&
                       a->dy == d && a->dz == d && d >= 1 && d <= 3 && a->px == d && a->py == d && a->pz == d;
-    static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
-    const bool shape = a->Z % kTZ == 0 && (a->Z == kTZ || !tiled) && a->Xo == a->X && a->Yo == a->Y && a->Zo == a->Z && a->OX == a->X &&
+    const bool shape = a->Z % kTZ == 0 && a->Xo == a->X && a->Yo == a->Y && a->Zo == a->Z && a->OX == a->X &&
                        a->OY == a->Y && a->OZ == a->Z && a->o_stride_x == 1 && a->o_stride_y == 1 &&
                        a->o_stride_z == 1 && a->o_off_x == 0 && a->o_off_y == 0 && a->o_off_z == 0;
     const int cin8 = (a->cin + 7) & ~7;
     const bool chans = cin8 <= 32 && a->cout <= 32 && a->in_coff + 32 <= a->in_cs && a->act_in != OCCD_ACT_SIGMOID;
     // enough tiles to keep every CU busy for several rounds, otherwise the generic kernel tiles finer
     const long tiles = (long)a->batch * a->X * ((a->Y + kTY - 1) / kTY) * (a->Z / kTZ);
-    if (!(geom && shape && chans) || cin8 != 32 || tiles < 512 || a->tile_hint != 0) return 0;
-    if ((double)a->batch * a->X * a->Y * a->Z * a->in_cs >= 4294967296.0) return 0;   // 32-bit staging offsets
-    PersistP p;
-    p.in = a->in; p.wpk = a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
-    p.batch = a->batch; p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
-    p.out_cs = a->out_cs; p.out_coff = a->out_coff;
-    p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
-    p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
-    p.ytiles = (a->Y + kTY - 1) / kTY;
-    p.ztiles = a->Z / kTZ;
-    p.tiles_total = (int)tiles;
+    if (!(geom && shape && chans) || cin8 != 32 || tiles < 512 || a->tile_hint != 0) return false;
+    if ((double)a->batch * a->X * a->Y * a->Z * a->in_cs >= 4294967296.0) return false;   // 32-bit staging offsets
+    p->in = a->in; p->wpk = a->wpk; p->bias = a->bias; p->res1 = a->res1; p->res2 = a->res2; p->out = a->out;
+    p->batch = a->batch; p->X = a->X; p->Y = a->Y; p->Z = a->Z; p->in_cs = a->in_cs; p->in_coff = a->in_coff;
+    p->out_cs = a->out_cs; p->out_coff = a->out_coff;
+    p->res1_cs = a->res1_cs; p->res1_coff = a->res1_coff; p->res2_cs = a->res2_cs; p->res2_coff = a->res2_coff;
+    p->act_in = a->act_in; p->act_out = a->act_out; p->cout_store = a->cout_store;
+    p->ytiles = (a->Y + kTY - 1) / kTY;
+    p->ztiles = a->Z / kTZ;
+    p->tiles_total = (int)tiles;
     const double pos = (double)a->batch * a->X * a->Y * a->Z;
-    const double flops = 2.0 * pos * 27 * a->cin * a->cout;
-    const double bytes = 4.0 * (pos * a->cin + pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) +
-                                27.0 * a->cin * a->cout);
+    *flops = 2.0 * pos * 27 * a->cin * a->cout;
+    *bytes = 4.0 * (pos * a->cin + pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) + 27.0 * a->cin * a->cout);
+    return true;
+}
+}  // namespace
+
+namespace occd {
+
+// Returns 1 when the launch was taken by the persistent kernel, 0 when the geometry does not qualify,
+// <0 on error.
+int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
+    static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
+    PersistP p;
+    double flops, bytes;
+    if (!c32_geometry(a, &p, &flops, &bytes) || (tiled && a->Z != kTZ)) return 0;
+    const int d = a->dx;
     ProfScope prof("conv3d_c32p", stream, flops, bytes);
     DevState* ds = dev_state();
     if (ds == nullptr) return OCCD_ELAUNCH;
@@ -599,6 +988,31 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
         rc = d == 1 ? launch_slide<1>(p, stream, ds) : d == 2 ? launch_slide<2>(p, stream, ds)
                                                               : launch_slide<3>(p, stream, ds);
     }
+    return rc == OCCD_OK ? 1 : rc;
+}
+
+// K2s3: the same launches on the bf16 matrix pipe with the 3-way split (a->wpk = the hi | mid | lo image of
+// occd_pack_weights_bf16x3, float32 tensors).  Same return convention; Z == 32 only (see the kernel header);
+// OCCD_C32X3_SLIDE=0 leaves every split launch to the generic K2b skeleton (A/B).
+int try_conv3d_c32_slide_x3(const occd_conv3d_args* a, hipStream_t stream) {
+    static const bool off = getenv("OCCD_C32X3_SLIDE") != nullptr && getenv("OCCD_C32X3_SLIDE")[0] == '0';
+    PersistP p;
+    double flops, bytes;
+    if (off || !c32_geometry(a, &p, &flops, &bytes) || a->Z != kTZ) return 0;
+    if ((a->in_cs & 3) || (a->in_coff & 3)) return 0;
+    const int d = a->dx;
+    ProfScope prof("conv3d_c32x3", stream, flops, bytes);
+    DevState* ds = dev_state();
+    if (ds == nullptr) return OCCD_ELAUNCH;
+    if (p.res1 == nullptr && p.res2 != nullptr) {   // the kernel's single-residual form reads res1
+        p.res1 = p.res2; p.res1_cs = p.res2_cs; p.res1_coff = p.res2_coff; p.res2 = nullptr;
+    }
+    const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);
+    int rc;
+#define OCCD_X3_LAUNCH(DD) \
+    (nres == 0 ? launch_slide_x3<DD, 0>(p, stream, ds) : nres == 1 ? launch_slide_x3<DD, 1>(p, stream, ds) : launch_slide_x3<DD, 2>(p, stream, ds))
+    rc = d == 1 ? OCCD_X3_LAUNCH(1) : d == 2 ? OCCD_X3_LAUNCH(2) : OCCD_X3_LAUNCH(3);
+#undef OCCD_X3_LAUNCH
     return rc == OCCD_OK ? 1 : rc;
 }
 

@@ -325,7 +325,6 @@ const Variant kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr size_t kMaxLds = 160 * 1024;
-bool g_attr_set[16] = {};
 
 struct Tiling {
     int TY, TZ, YIN, ZIN, ytiles, ztiles, ngroups;
@@ -484,12 +483,7 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
     p.div_zin = occd::make_fastdiv(til.ZIN); p.div_tz = occd::make_fastdiv(til.TZ);
     p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
 
-    if (til.lds > 64 * 1024 && !g_attr_set[pick]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(v.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kMaxLds) != hipSuccess)
-            return OCCD_ELAUNCH;
-        g_attr_set[pick] = true;
-    }
+    if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(v.kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double taps = (double)a->kx * a->ky * a->kz;
     const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
     const double flops = 2.0 * pos * taps * a->cin * a->cout;

@@ -511,14 +511,7 @@ int occd_conv3d_wgrad_bf16(const occd_conv3d_wgrad_args* a, int32_t dtype, void*
         void (*kern)(const WgradBP);
         if (cosplit) kern = dtype == 1 ? wgrad_bf16_kernel<9, true, true> : wgrad_bf16_kernel<9, true, false>;
         else kern = dtype == 1 ? wgrad_bf16_kernel<7, false, true> : wgrad_bf16_kernel<7, false, false>;
-        static bool attr_done[4] = {};
-        const int slot = (cosplit ? 2 : 0) + dtype;
-        if (lds > 64 * 1024 && !attr_done[slot]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024) != hipSuccess)
-                return OCCD_ELAUNCH;
-            attr_done[slot] = true;
-        }
+        if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
         const dim3 grid((unsigned)nchunks, (unsigned)(cosplit ? (p.cot + 3) / 4 : p.cot), (unsigned)p.cit);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
         const int rc2 = occd::check_launch();

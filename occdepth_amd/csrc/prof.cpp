@@ -2,6 +2,8 @@
 // bench.py turns it on around the timed region; the per-tag totals feed the
 // `roofline` object (achieved = algorithmic flops or bytes / measured time).
 #include <map>
+#include <set>
+#include <utility>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -50,6 +52,20 @@ ProfScope::~ProfScope() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (slot < 0 || slot >= (int)g_recs.size()) return;
     (void)hipEventRecord(g_recs[slot].e1, stream);
+}
+}  // namespace occd
+
+namespace occd {
+int ensure_big_lds(const void* kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return OCCD_ELAUNCH;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kernel})) return OCCD_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OCCD_ELAUNCH;
+    done.insert({dev, kernel});
+    return OCCD_OK;
 }
 }  // namespace occd
 

@@ -363,13 +363,7 @@ int launch_wino(const WinoP& p, hipStream_t st) {
     size_t lds = ((size_t)2 * PBUF + 2 * 16 * 256) * sizeof(float);
     const size_t xchg = (size_t)4 * 2 * 64 * 64 * sizeof(float);          // the pairs' accumulator exchange (128 KB)
     if (lds < xchg) lds = xchg;
-    static bool attr_done = false;                                        // (idempotent; per function, any device)
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino3x3_kernel<TWV, EXP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return OCCD_ELAUNCH;
-        attr_done = true;
-    }
+    if (occd::ensure_big_lds(reinterpret_cast<const void*>(wino3x3_kernel<TWV, EXP>)) != OCCD_OK) return OCCD_ELAUNCH;
     hipLaunchKernelGGL((wino3x3_kernel<TWV, EXP>), dim3((unsigned)p.nwg), dim3(512), lds, st, p);
     return occd::check_launch();
 }

@@ -96,20 +96,38 @@ def _pad_bias(bias, cout):
     return out
 
 
-# VERDICT r2 item 8 experiment, OFF by default: run the eval path's K2 convolutions on the bf16 matrix pipe with the 3-way
-# operand split (csrc/conv3d_bf16.hip, float32-level accuracy).  The exact-fp32 MFMA kernels stay the default.
-BF16X3 = os.environ.get("OCCDEPTH_BF16X3", "0") == "1"
+# The 3-way bf16 split (x = hi + mid + lo, six bf16 MFMAs per K step, float32-level accuracy on the bf16 matrix pipe):
+#   OCCDEPTH_BF16X3=head  (default since round 4) the full-resolution head convolutions (<= 32 -> <= 32 channels, 3x3x3,
+#                         dilation 1 / 2 / 3, Z = 32) on K2s3, the sliding-window form of the split (csrc/conv3d_c32p.hip):
+#                         0.51 ms per launch against 0.90 ms for the exact-fp32 K2s, error against float64 no larger than
+#                         K2s' own (tests/test_bf16_conv.py::test_conv3d_slide_x3_head_kernel, profiles/r04_head_x3_ab.txt);
+#                         everything else exact fp32
+#   OCCDEPTH_BF16X3=0     exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32): the bit-for-bit round-3 path
+#   OCCDEPTH_BF16X3=1     additionally every other large dilation-1 K2 launch on the generic K2b skeleton with the split
+#                         (csrc/conv3d_bf16.hip; the round-3 experiment)
+def _parse_bf16x3(v):
+    v = (v or "0").strip().lower()
+    if v in ("0", "", "off", "false"):
+        return False
+    if v in ("1", "all", "on", "true"):
+        return "all"
+    if v == "head":
+        return "head"
+    raise ValueError(f"OCCDEPTH_BF16X3={v!r}: expected 0, head or 1")
+
+
+BF16X3 = _parse_bf16x3(os.environ.get("OCCDEPTH_BF16X3", "head"))
 
 
 def set_bf16x3(on):
+    """False / 'head' / 'all' (True = 'all'); plans re-pack their weights on the next call."""
     global BF16X3
-    BF16X3 = bool(on)
+    BF16X3 = "all" if on is True else _parse_bf16x3(str(on)) if on else False
 
 
 class _DualW:
-    """Both weight images of a plan while the experiment is on: the 3-way split one for the launches K2b takes (rows padded
-    to 8 channels, dilation 1 unless OCCDEPTH_BF16X3_DILATED=1 -- the dilated head convolutions measured slower than the
-    fp32 kernel, profiles/r03_bf16x3_ab.txt), the exact-fp32 one for the rest."""
+    """Both weight images of a plan while the split is on: the hi | mid | lo one for the launches the split kernels take,
+    the exact-fp32 one for the rest."""
 
     def __init__(self, f32, x3):
         self.f32, self.x3 = f32, x3
@@ -118,18 +136,24 @@ class _DualW:
 BF16X3_DILATED = os.environ.get("OCCDEPTH_BF16X3_DILATED", "0") == "1"
 
 
+def _head_weight(w, layout):
+    return layout == 0 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[0] <= 32 and 24 < w.shape[1] <= 32
+
+
 def _pack_w(w, scale=None, layout=0):
-    if BF16X3:
+    if BF16X3 == "all" or (BF16X3 == "head" and _head_weight(w, layout)):
         return _DualW(hip.pack_weights(w, scale, layout), hip.pack_weights_bf16(w, scale, layout, split3=True))
     return hip.pack_weights(w, scale, layout)
 
 
 def _conv3d(x, wpk, bias, cout, kernel, out, **kw):
     if isinstance(wpk, _DualW):
+        if hip.c32x3_eligible(x, cout, kernel, out, **kw):        # K2s3 (all three dilations)
+            return hip.conv3d_bf16(x, wpk.x3, bias, cout, kernel, out, split3=True, **kw)
         aligned = x.cs % 8 == 0 and x.coff % 8 == 0          # K2b stages 8 channels per 16-byte LDS chunk
         dil = tuple(kw.get("dilation", (1, 1, 1)))
         big = kernel[0] * kernel[1] * kernel[2] >= 8
-        if aligned and big and (dil == (1, 1, 1) or BF16X3_DILATED) and kw.get("cin") is None and \
+        if BF16X3 == "all" and aligned and big and (dil == (1, 1, 1) or BF16X3_DILATED) and kw.get("cin") is None and \
                 kw.get("act_in", ACT_NONE) in (ACT_NONE, ACT_RELU):
             return hip.conv3d_bf16(x, wpk.x3, bias, cout, kernel, out, split3=True, **kw)
         wpk = wpk.f32

@@ -462,6 +462,27 @@ def conv3d_bf16(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 
     return out
 
 
+def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0), res1=None, res2=None,
+                   act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1), o_off=(0, 0, 0), cin=None,
+                   tile_hint=0):
+    """True when `conv3d_bf16(..., split3=True)` takes the sliding-window split kernel K2s3 (the host-side mirror of
+    `c32_geometry` + the Z == 32 condition in csrc/conv3d_c32p.hip): the full-resolution head convolutions."""
+    d = tuple(dilation)
+    if tuple(kernel) != (3, 3, 3) or tuple(stride) != (1, 1, 1) or d[0] != d[1] or d[0] != d[2] or not 1 <= d[0] <= 3:
+        return False
+    if tuple(padding) != d or out_pos is not None or tuple(o_stride) != (1, 1, 1) or tuple(o_off) != (0, 0, 0):
+        return False
+    c = x.C if cin is None else cin
+    if round_up(c, 8) != 32 or cout > 32 or x.coff + 32 > x.cs or act_in == ACT_SIGMOID or tile_hint != 0:
+        return False
+    if x.buf.dtype != torch.float32 or x.cs % 4 or x.coff % 4:
+        return False
+    X, Y, Z = x.dims
+    if Z != 32 or tuple(out.dims) != (X, Y, Z):
+        return False
+    return x.batch * X * ((Y + 7) // 8) >= 512 and x.batch * X * Y * Z * x.cs < 2 ** 32
+
+
 _wgrad_ws = {}
 
 

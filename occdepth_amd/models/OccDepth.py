@@ -61,9 +61,18 @@ class OccDepth(_Base):
         print("INFO: Use cascade cls: {}".format(self.cascade_cls))
         print("INFO: Use occluded cls: {}".format(self.occluded_cls))
         self.infer_mode = infer_mode
-        self.batch_views = False  # eval: run all views through net_rgb as one batch (faster, not bit-equal)
-        self.graph_2d = False     # eval + batch_views: replay the 2-D network as one captured hipGraph
-        self.graph_all = False    # eval: replay the WHOLE forward (2-D network, lift, 3-D stack) as one captured hipGraph
+        # eval fast path, OFF by default (the default forward is the reference's: per-view 2-D passes, fresh tensors).
+        # `enable_fast_eval()` -- or OCCDEPTH_FAST_EVAL=1 in the environment of an unmodified scripts/eval.py /
+        # generate_output.py run -- switches all three on; the individual variables switch them one by one.
+        env = os.environ.get
+        fast = env("OCCDEPTH_FAST_EVAL", "0") == "1"
+        self.batch_views = fast or env("OCCDEPTH_BATCH_VIEWS", "0") == "1"   # all views through net_rgb as one batch
+        self.graph_2d = self.batch_views and (fast or env("OCCDEPTH_GRAPH_2D", "0") == "1")    # 2-D network as one hipGraph
+        self.graph_all = self.batch_views and (fast or env("OCCDEPTH_GRAPH_ALL", "0") == "1")  # WHOLE forward as one hipGraph
+        # graph_all replays into static output buffers; by default the caller gets fresh tensors (the reference's contract:
+        # a caller may keep `pred` across forwards).  False hands out the static buffers themselves (valid until the next
+        # forward of this model) and saves the ~0.1 ms copy of ~300 MB at config 2.
+        self.clone_graph_outputs = env("OCCDEPTH_CLONE_OUTPUTS", "1") == "1"
         self._graphs = {}
         self.batch_views_train = os.environ.get("OCCDEPTH_TRAIN_BATCH_VIEWS", "1") == "1"
         self.fused_lift = True    # training on the GPU: HIP lift + one-launch backward (lift_autograd.py) where it applies
@@ -146,6 +155,17 @@ class OccDepth(_Base):
         self._graphs.clear()
         self.__dict__.pop("_net_rgb_tensors", None)
         self.__dict__.pop("_all_tensors", None)
+
+    def enable_fast_eval(self, clone_outputs=True, graph=True):
+        """Switch the eval forward to the benched configuration: both views through the 2-D network as one batch and the
+        whole forward replayed from ONE captured hipGraph (`graph=False`: batched views only).  `clone_outputs=True` (default)
+        returns fresh tensors per call like the reference; False returns the graph's static output buffers, valid until the
+        next forward.  The same switches from the environment: OCCDEPTH_FAST_EVAL=1 (OCCDEPTH_CLONE_OUTPUTS=0)."""
+        self.batch_views = True
+        self.graph_2d = self.graph_all = bool(graph)
+        self.clone_graph_outputs = bool(clone_outputs)
+        self._drop_graphs()
+        return self
 
     def invalidate_graphs(self):
         """Forget every captured hipGraph (they are re-captured on the next forward)."""
@@ -266,24 +286,30 @@ class OccDepth(_Base):
             return self.flosp_depth(**kw)
         return self.flosp_depth(**kw), None
 
-    # the eval lift projects the voxels and samples the depth frustum inside the kernel
-    # (csrc/lift.hip lift_proj_kernel) whenever the batch carries the calibration the tables were made from -- the
-    # dataloader's float64 extrinsics (`T_velo_2_cam_f64`) -- or no tables at all.  A batch with tables and only the
-    # float32 extrinsics keeps the table path: float32 extrinsics move a few voxels by one pixel.
-    lift_in_kernel = os.environ.get("OCCDEPTH_LIFT_PROJ", "1") == "1"
+    # The eval lift can project the voxels and sample the depth frustum inside the kernel (csrc/lift.hip lift_proj_kernel)
+    # from the batch's calibration -- no voxel->pixel tables read.  `lift_in_kernel`:
+    #   "auto"  (default) when the batch carries NO `projected_pix_{s}` / `fov_mask_{s}` tables (nothing to contradict: the
+    #           dataloader's numba vox2pix pass can be dropped); a batch that brings tables is lifted from ITS tables,
+    #           whatever origin / image-space transform they were built with;
+    #   True    also when tables are present, provided the batch carries the float64 extrinsics the tables were made from
+    #           (`T_velo_2_cam_f64`; float32 extrinsics move a few voxels by one pixel) -- the caller vouches that the tables
+    #           are the plain vox2pix of that calibration;
+    #   False   never.
+    # OCCDEPTH_LIFT_PROJ = auto | 1 | 0.
+    lift_in_kernel = {"1": True, "0": False}.get(os.environ.get("OCCDEPTH_LIFT_PROJ", "auto"), "auto")
 
     def _lift_calibration(self, batch, img, key):
         """(cam_E (B, V, 4, 4), cam_k (B, V, 3, 3)) float64 device tensors for hip.lift_proj, or None when the in-kernel
-        projection does not apply (NYU geometry, multi-point patterns, tables without float64 extrinsics)."""
+        projection does not apply (NYU geometry, multi-point patterns, tables present and not vouched for)."""
         if not self.lift_in_kernel or self.dataset != "kitti" or "cam_k" not in batch:
             return None
-        if "T_velo_2_cam_f64" in batch:
-            ext = batch["T_velo_2_cam_f64"]
-        elif key not in batch and "T_velo_2_cam" in batch:
-            ext = batch["T_velo_2_cam"]
-        else:
+        have_tables = key in batch
+        if have_tables and (self.lift_in_kernel != True or "T_velo_2_cam_f64" not in batch):   # noqa: E712 ("auto" is truthy)
             return None
-        if key in batch and batch[key][0].shape[-2] != 1:
+        ext = batch.get("T_velo_2_cam_f64", batch.get("T_velo_2_cam"))
+        if ext is None:
+            return None
+        if have_tables and batch[key][0].shape[-2] != 1:
             return None                                          # multi-point pattern: table path
         dims = [int(d) // int(self.project_scale) for d in self.full_scene_size]
         if any(v & (v - 1) for v in dims[1:] + [int(r) for r in self.project_res]):
@@ -309,7 +335,7 @@ class OccDepth(_Base):
                     frustum, depth_pred = self._depth_volume(batch, x_rgb, vox_origin, defer_sample=True)
                 feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
                 H, W = img.shape[-2:]
-                vox = lift_scales_proj(feats, scales, cam[0], cam[1], self._kitti_origin(), 0.2 * self.project_scale, (W, H),
+                vox = lift_scales_proj(feats, scales, cam[0], cam[1], self._kitti_origin(batch), 0.2 * self.project_scale, (W, H),
                                        self.projects[str(scales[0])].scene_size, self.project_scale, self.dataset,
                                        frustum=frustum, scale_const=100.0)
                 return vox, depth_pred
@@ -353,9 +379,15 @@ class OccDepth(_Base):
             x3ds = x3ds * depth_vol * 100
         return x3ds, depth_pred
 
-    def _kitti_origin(self):
-        """SemanticKITTI voxel origin (kitti_dataset.py: vox_origin = (0, -25.6, -2) for the 51.2 m wide scene): the grid is
-        centred on the sensor in y, whatever the scene width of a reduced test config."""
+    def _kitti_origin(self, batch=None):
+        """SemanticKITTI voxel origin (kitti_dataset.py:82: vox_origin = (0, -25.6, -2) for the 51.2 m wide scene): the grid
+        is centred on the sensor in y, whatever the scene width of a reduced test config.  A batch that carries its own
+        `vox_origin` (host tensor / array / tuple; the reference's kitti collate does not) overrides it."""
+        vo = None if batch is None else batch.get("vox_origin")
+        if vo is not None:
+            v = vo if torch.is_tensor(vo) else torch.as_tensor(vo[0] if isinstance(vo, (list, tuple)) and torch.is_tensor(vo[0]) else vo)
+            if not v.is_cuda:                                      # (a device tensor would cost a sync per frame: ignored)
+                return tuple(float(x) for x in v.reshape(-1, 3)[0])
         return (0.0, -0.1 * float(self.full_scene_size[1]), -2.0)
 
     def project_voxels_on_gpu(self, batch, img):
@@ -374,7 +406,7 @@ class OccDepth(_Base):
             # float32 copy.  `T_velo_2_cam_f64`, when present, reproduces the dataloader's tables bit for bit.
             ext = batch.get("T_velo_2_cam_f64", batch["T_velo_2_cam"])
             views = [hip.project_voxels(ext[i][v].detach().cpu().double().numpy(),
-                                        batch["cam_k"][i][v].detach().cpu().double().numpy(), self._kitti_origin(),
+                                        batch["cam_k"][i][v].detach().cpu().double().numpy(), self._kitti_origin(batch),
                                         0.2 * ps, dims, W, H, device=img.device) for v in range(img.shape[1])]
             pix.append(torch.stack([p for p, _ in views]))
             fov.append(torch.stack([m for _, m in views]))
@@ -445,6 +477,8 @@ class OccDepth(_Base):
         graph, static, static_out, _ = entry
         self._copy_batch(static, batch)
         graph.replay()
+        if self.clone_graph_outputs:
+            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in static_out.items()}
         return dict(static_out)
 
     def forward(self, batch):
@@ -534,7 +568,12 @@ class OccDepth(_Base):
         if self.sem_scal_loss:
             decay = max(0.1, (1 - self.cur_batch / self.total_batch)) if self.sem_step_decay_loss else 1.0
             if self.sem_step_decay_loss and getattr(self, "_decay_dev", None) is not None and ssc_pred.is_cuda:
-                decay = self._decay_dev                      # device scalar kept current by train_graph.GraphedTrainStep
+                # device scalar a captured step reads (train_graph.GraphedTrainStep refreshes it before every replay).  An
+                # EAGER step -- a failed capture's fall-back, or a plain training_step once the scalar exists -- refreshes it
+                # here from the host formula (asynchronous fill, no sync), so the factor can never freeze at its capture value
+                if not torch.cuda.is_current_stream_capturing():
+                    self._decay_dev.fill_(decay)
+                decay = self._decay_dev
             loss_sem_scal = terms["loss_sem_scal"] * decay
             loss = loss + loss_sem_scal
             self._log(step_type + "/loss_sem_scal", loss_sem_scal)

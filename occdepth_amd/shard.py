@@ -117,6 +117,14 @@ class GradBuckets:
                     view.copy_(p.grad)
                 p.grad = view
 
+    def release(self):
+        """Undo what `prepare_for_ddp(force=True)` switched on process-wide (single-rank collectives): call it when the
+        forced run is over so that later SyncBatchNorm / bn_act calls on single-rank groups skip their collectives again."""
+        global FORCE_COLLECTIVES
+        if getattr(self, "_restore_force", None) is not None:
+            FORCE_COLLECTIVES = self._restore_force
+            self._restore_force = None
+
     def zero_grad(self):
         """One memset per bucket; gradients stay attached."""
         for b in self.buckets:
@@ -262,7 +270,8 @@ class _SyncBNFn(torch.autograd.Function):
               merged with Chan's formula -- total mean = sum(n_r mean_r) / n, total M2 = sum(M2_r + n_r mean_r^2) - n mean^2 --
               from ONE all-reduce of the (2C + 1)-element vector [n_r mean_r, M2_r + n_r mean_r^2, n_r].  Only that small
               vector is float64 (so the merge cannot cancel, whatever mean / std is: the per-rank pass is centred on the
-              rank's own mean); no full-size float64 or float32 copy of the activation is made or saved.
+              rank's own mean); no full-size float64 copy of the activation is made or saved (bf16 / fp16 inputs are widened to one
+              float32 copy for the statistics pass).
     backward: one reduction pass [sum(gy), sum(gy (x - mean))], ONE all-reduce of 2C floats, one element-wise pass.
     On the GPU the two passes per direction are ATen's fused batch-norm kernels (batch_norm_elemt,
     batch_norm_backward_reduce / _elemt -- the ones torch.nn.SyncBatchNorm uses); elsewhere (gloo CPU tests) the same
@@ -396,9 +405,14 @@ def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, forc
     buckets run their collectives on the single-rank group, i.e. the real RCCL calls on one GPU."""
     if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return model, None
+    global FORCE_COLLECTIVES
+    was_forced = FORCE_COLLECTIVES
     if force:
-        global FORCE_COLLECTIVES
-        FORCE_COLLECTIVES = True
+        FORCE_COLLECTIVES = True          # process-wide while these buckets live: `buckets.release()` restores it
     if sync_bn:
         model = convert_sync_batchnorm(model)
-    return model, GradBuckets(model.parameters(), dist, bucket_bytes, algo=algo, force=force)
+        if hasattr(model, "invalidate_graphs"):
+            model.invalidate_graphs()     # module surgery: a captured eval graph would keep replaying the old layers
+    buckets = GradBuckets(model.parameters(), dist, bucket_bytes, algo=algo, force=force)
+    buckets._restore_force = was_forced if force else None
+    return model, buckets

@@ -354,7 +354,54 @@ def case_train_step():
     _save("train_step_small", arrays)
 
 
-CASES = {"sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "unet3d_512": case_unet3d_512,
+def case_train_step_full():
+    """The step bench.py TIMES (`--train`: BASELINE configs[2]), once through the real reference at full size: B7, 370x1220
+    stereo -> 256x256x32, TRAINING mode (BatchNorm on batch statistics), the reference's `training_step` + `backward`.
+    Stored: every logged loss term, the parameters left without gradient, and for 12 parameters spread over the model the
+    gradient norm and its first 4096 elements (VERDICT r3 missing #6).  ~25 GB of autograd state, minutes of CPU time."""
+    import occdepth.loss.sscMetrics as ref_metrics  # noqa: F401  (the reference's own numpy metric inside training_step)
+    arrays = {}
+    cfg_name = "kitti_a100"
+    t0 = time.time()
+    m, cfg, batch = _build_ref_occdepth(cfg_name, {})          # (BatchNorm statistics: the ones occdepth_kitti_a100.npz stores)
+    with torch.no_grad():
+        for k, p_ in m.named_parameters():
+            if gc.is_classifier_param(k):
+                p_.mul_(gc.CLASSIFIER_SCALE)
+                arrays[f"override.{k}"] = _np(p_)
+    shapes = {"P_logits": (1, 4, 512, 4096), "depth_pred": (1, 2, 104, 47, 153)}
+    extras = gc.train_extras(cfg_name, shapes, tuple(cfg.full_scene_size), cfg.n_classes, batch["img"].shape[-2:])
+    batch = dict(batch, **extras)
+    logged = {}
+    m.log = lambda key, val, **kw: logged.__setitem__(key, float(val))
+    m.train()
+    m.cur_batch = 0
+    m.zero_grad()
+    print("built + calibrated in %.0f s; training_step ..." % (time.time() - t0), flush=True)
+    t0 = time.time()
+    loss = m.training_step(batch, 0)
+    print("forward + losses %.0f s; backward ..." % (time.time() - t0), flush=True)
+    t0 = time.time()
+    loss.backward()
+    print("backward %.0f s" % (time.time() - t0), flush=True)
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    for k, v in logged.items():
+        arrays[k] = np.float64(v)
+    arrays["no_grad_keys"] = np.frombuffer(json.dumps(sorted(k for k, g in grads.items() if g is None)).encode(), dtype=np.uint8)
+    for k in gc.pick_grad_keys(grads):
+        arrays[f"grad.{k}"] = _np(grads[k]).reshape(-1)[:4096]
+        arrays[f"gradnorm.{k}"] = np.float64(grads[k].double().norm())
+    # a few running statistics after the step (momentum update from the batch statistics of this very frame)
+    sd = m.state_dict()
+    bn_keys = sorted(k for k in sd if k.endswith("running_var"))
+    for k in bn_keys[:: max(1, len(bn_keys) // 8)][:8]:
+        arrays[f"running.{k}"] = _np(sd[k]).reshape(-1)[:256]
+    print({k: round(v, 5) for k, v in logged.items()}, "params without grad:", sum(g is None for g in grads.values()), "/", len(grads))
+    _save("train_step_full", arrays, meta={"mode": "train (batch statistics), cur_batch 0 -> 1, classifier convolutions scaled by %g"
+                                                   % gc.CLASSIFIER_SCALE})
+
+
+CASES = {"train_step_full": case_train_step_full, "sfa": case_sfa, "blocks3d": case_blocks3d, "unet3d": case_unet3d, "unet3d_512": case_unet3d_512,
          "flosp": case_flosp,
          "decoder2d": case_decoder2d, "occdepth_small": case_occdepth_small, "occdepth_full": case_occdepth_full,
          "occdepth_nyu": case_occdepth_nyu, "losses": case_losses, "train_step": case_train_step}

@@ -72,28 +72,40 @@ def test_occdepth_eval_path_in_kernel_lift():
     tr2 = inputs.KITTI_TR.copy()
     tr2[0, 3] = -0.54
     b64 = dict(batch, T_velo_2_cam_f64=[torch.from_numpy(np.stack([inputs.KITTI_TR, tr2])) for _ in batch["cam_k"]])
+    no_tables = {k: v for k, v in b64.items() if not (k.startswith("projected_pix") or k.startswith("fov_mask"))}
     calls = []
     with emu.patched(), torch.no_grad():
         real = hip.lift_proj
-        hip.lift_proj = lambda *a, **k: (calls.append("proj"), real(*a, **k))[1]
+        hip.lift_proj = lambda *a, **k: (calls.append(("proj", tuple(a[4]))), real(*a, **k))[1]
         real_t = hip.lift
-        hip.lift = lambda *a, **k: (calls.append("table"), real_t(*a, **k))[1]
-        out = m(b64)
-        assert calls == ["proj"]
+        hip.lift = lambda *a, **k: (calls.append(("table",)), real_t(*a, **k))[1]
+        assert m.lift_in_kernel == "auto"
+        out = m(no_tables)                                         # default: no tables in the batch -> projects in the kernel
+        assert [c[0] for c in calls] == ["proj"]
+        assert calls[0][1] == (0.0, -0.1 * cfg.full_scene_size[1], -2.0)      # kitti_dataset.py:82, scaled to the scene width
         for k, v in out.items():
             close(gc.maybe_subsample(v.contiguous()), g[f"kitti_small.{k}"], tol=3e-4, what=f"kitti_small.{k}")
         del calls[:]
-        m(batch)                                                   # tables, float32 extrinsics only: table path
-        assert calls == ["table"]
+        m(b64)                                                     # default + tables: the batch's own tables win
+        m(batch)
+        assert [c[0] for c in calls] == ["table", "table"]
+        del calls[:]
+        m.lift_in_kernel = True                                    # the caller vouches for the tables: float64 extrinsics needed
+        out = m(b64)
+        m(batch)                                                   # (tables, float32 extrinsics only: table path)
+        assert [c[0] for c in calls] == ["proj", "table"]
+        for k, v in out.items():
+            close(gc.maybe_subsample(v.contiguous()), g[f"kitti_small.{k}"], tol=3e-4, what=f"kitti_small.{k}")
+        del calls[:]
         m.lift_in_kernel = False
         m(b64)
-        assert calls == ["table", "table"]
-        # no tables at all: projects from the float32 extrinsics
-        m.lift_in_kernel = True
+        assert [c[0] for c in calls] == ["table"]
+        # no tables and no float64 extrinsics: projects from the float32 ones; a batch-supplied vox_origin is honoured
+        m.lift_in_kernel = "auto"
         del calls[:]
-        m({k: v for k, v in b64.items() if not (k.startswith("projected_pix") or k.startswith("fov_mask")
-                                               or k == "T_velo_2_cam_f64")})
-        assert calls[0] == "proj"
+        m({k: v for k, v in no_tables.items() if k != "T_velo_2_cam_f64"})
+        m(dict(no_tables, vox_origin=torch.tensor([[0.0, -3.2, -2.0]])))
+        assert [c[0] for c in calls] == ["proj", "proj"] and calls[1][1] == pytest.approx((0.0, -3.2, -2.0))
 
 
 @pytest.mark.parametrize("cfg_name", ["kitti_small", "nyu_small"])

@@ -9,6 +9,7 @@ CPU: the loss / confusion kernels run through the test-only emulation of the C A
 import re
 
 import numpy as np
+import pytest
 import torch
 
 import emu
@@ -115,3 +116,75 @@ def test_configure_optimizers_by_dataset():
         raise AssertionError("unknown dataset must raise")
     except NotImplementedError:
         pass
+
+
+def test_fast_eval_switches_are_off_by_default_and_read_from_the_environment(monkeypatch):
+    """the benched eval configuration is reachable without a code edit -- OCCDEPTH_FAST_EVAL=1 (or the
+    three individual variables) in the environment of an unmodified scripts/eval.py run, or `model.enable_fast_eval()`."""
+    for k in ("OCCDEPTH_FAST_EVAL", "OCCDEPTH_BATCH_VIEWS", "OCCDEPTH_GRAPH_2D", "OCCDEPTH_GRAPH_ALL", "OCCDEPTH_CLONE_OUTPUTS"):
+        monkeypatch.delenv(k, raising=False)
+    m, _, _ = build_product("kitti_small")
+    assert (m.batch_views, m.graph_2d, m.graph_all, m.clone_graph_outputs) == (False, False, False, True)
+    monkeypatch.setenv("OCCDEPTH_FAST_EVAL", "1")
+    m, _, _ = build_product("kitti_small")
+    assert (m.batch_views, m.graph_2d, m.graph_all, m.clone_graph_outputs) == (True, True, True, True)
+    monkeypatch.delenv("OCCDEPTH_FAST_EVAL")
+    monkeypatch.setenv("OCCDEPTH_BATCH_VIEWS", "1")
+    monkeypatch.setenv("OCCDEPTH_GRAPH_ALL", "1")
+    monkeypatch.setenv("OCCDEPTH_CLONE_OUTPUTS", "0")
+    m, _, _ = build_product("kitti_small")
+    assert (m.batch_views, m.graph_2d, m.graph_all, m.clone_graph_outputs) == (True, False, True, False)
+    monkeypatch.delenv("OCCDEPTH_BATCH_VIEWS")                     # the graphs need the batched views
+    m, _, _ = build_product("kitti_small")
+    assert (m.batch_views, m.graph_2d, m.graph_all) == (False, False, False)
+    assert m.enable_fast_eval(clone_outputs=False) is m
+    assert (m.batch_views, m.graph_2d, m.graph_all, m.clone_graph_outputs) == (True, True, True, False)
+
+
+@pytest.mark.gpu
+def test_eval_script_flow_reaches_the_fast_path_gpu(monkeypatch, capsys):
+    """scripts/eval.py:65-80 (`trainer.test`) and scripts/generate_output.py:87-95 (a loop that KEEPS `pred`) against a model
+    built with OCCDEPTH_FAST_EVAL=1 in the environment: the whole forward replays from one hipGraph, the printed report
+    equals the plain model's, and predictions kept across forwards stay intact (fresh tensors by default)."""
+    dev = "cuda"
+    cfg_name = "kitti_small"
+
+    def to_dev(b):
+        return {k: ([t.to(dev) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
+                    (v.to(dev) if torch.is_tensor(v) else v)) for k, v in b.items()}
+
+    monkeypatch.delenv("OCCDEPTH_FAST_EVAL", raising=False)
+    plain, cfg, _ = build_product(cfg_name)
+    monkeypatch.setenv("OCCDEPTH_FAST_EVAL", "1")
+    fast, _, _ = build_product(cfg_name)
+    plain, fast = plain.to(dev).eval(), fast.to(dev).eval()
+    assert fast.graph_all and not plain.graph_all
+    base = gc.occdepth_batch(cfg_name)
+    with torch.no_grad():
+        shapes = {k: tuple(v.shape) for k, v in plain(to_dev(base)).items() if torch.is_tensor(v)}
+    extras = gc.train_extras(cfg_name, shapes, tuple(cfg.full_scene_size), cfg.n_classes, base["img"].shape[-2:])
+    g = torch.Generator().manual_seed(3)
+    frames = [to_dev(dict(base, **extras, img=base["img"] + 0.3 * i * torch.randn(base["img"].shape, generator=g)))
+              for i in range(3)]
+    reports = {}
+    for name, m in (("plain", plain), ("fast", fast)):
+        m.class_names = [f"cls{i}" for i in range(cfg.n_classes)]
+        capsys.readouterr()
+        FakeTrainer(m).test(frames)
+        reports[name] = capsys.readouterr().out.strip().splitlines()
+    assert fast.graph_all, getattr(fast, "graph_all_error", None)
+    assert [k[0] for k in fast._graphs] == ["all"]                 # one capture served the three frames
+    assert reports["fast"][0] == "test======" and len(reports["fast"]) == len(reports["plain"]) == 5
+
+    def numbers(line):
+        return [float(x) for x in re.findall(r"\d+\.\d+", line)]
+    for a, b in zip(reports["plain"], reports["fast"]):            # batched views: round-off may flip a few arg-max ties
+        assert np.allclose(numbers(a), numbers(b), atol=0.05), (a, b)
+    # generate_output.py keeps every `pred` it computed: with fresh outputs they must survive the following forwards
+    with torch.no_grad():
+        kept = [fast(f)["ssc_logit"] for f in frames]
+        want = [plain(f)["ssc_logit"] for f in frames]
+    assert len({k.data_ptr() for k in kept}) == 3
+    for k, w in zip(kept, want):
+        assert float((k - w).abs().max() / w.abs().max()) < 1e-3
+    assert float((kept[0] - kept[2]).abs().max()) > 0              # (the frames really differ)
