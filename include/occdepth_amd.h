@@ -218,6 +218,40 @@ int occd_rows_gemm_fwd(const occd_rows_gemm_args* a, void* stream);
 int64_t occd_rows_gemm_packed_floats(int32_t K, int32_t N);
 int occd_rows_gemm_pack(const float* w, float* wpk, int32_t K, int32_t N, int32_t w_stride, void* stream);
 
+/* K16 (csrc/gemm_x3.hip): row-major float32 GEMM with the 3-way bf16 split of both operands (float32-level accuracy on the
+ * bf16 matrix pipe):  C[b][m][n] = act(sum_k A[b][m][k] B[b][k][n] + bias[m]).  Replaces the library GEMMs behind the
+ * reference's 2-D network call sites as this repo restates them (occdepth/models/unet2d.py:24-46 -- the first convolution of
+ * a decoder level as nine low-resolution tap GEMMs --, :137-165 -- the Winograd-domain products of the second convolutions
+ * at 1/8 and 1/16 --, and the geffnet MBConv expand 1x1 convolutions): torch.matmul / torch.bmm / F.conv2d there.
+ * A: M x K with k contiguous (lda >= K, K % 8 == 0, 16-byte aligned rows); B: K x N with n contiguous (ldb >= N, N >= 4, any
+ * dword alignment); C: M x N (ldc >= N).  stride_a == 0 shares A over the batch (weights).  bias: M floats or NULL.
+ * act: OCCD_GEMM_ACT_NONE / _SWISH / _LEAKY (slope).  tile_hint: 0 = choose, 1 .. 4 = force a tile variant (tests).        */
+#define OCCD_GEMM_ACT_NONE 0
+#define OCCD_GEMM_ACT_SWISH 1
+#define OCCD_GEMM_ACT_LEAKY 2
+typedef struct occd_gemm_args {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int32_t M, N, K, batch;
+    int64_t lda, ldb, ldc;                 /* elements */
+    int64_t stride_a, stride_b, stride_c;  /* elements between consecutive batch items */
+    int32_t act;
+    float slope;
+    int32_t tile_hint;
+    int32_t pre;                           /* 0: A, B float32; 1: A = occd_gemm_x3_pack(role 0) image; 2: B = role-1 image */
+} occd_gemm_args;
+int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
+/* A static operand (weights) split once into its three bf16 terms in MFMA fragment order, so the GEMM reads it straight
+ * from L2 (no LDS, no split arithmetic): role 0 = an A operand (rows x K, k contiguous, ld >= K), role 1 = a B operand
+ * (K x rows, "row" = column index contiguous, ld >= rows).  `out`: occd_gemm_x3_packed_elems(rows, K) bf16 per batch item,
+ * consecutive; in_stride: float elements between the batch items of `w`.  With pre = 1 / 2 the packed operand's lda / ldb is
+ * ignored and stride_a / stride_b counts bf16 elements (0 = shared over the batch).                                          */
+int64_t occd_gemm_x3_packed_elems(int32_t rows, int32_t K);
+int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_t K, int64_t ld, int32_t role, int32_t batch,
+                      int64_t in_stride, void* stream);
+
 /* The eval lift without its tables (SURVEY 8(f) N2 fused into K1b): the kernel projects every voxel
  * centroid itself (the arithmetic of occd_project_voxels: occdepth/data/utils/helpers.py:94-169, integer-exact), samples the
  * FLoSP depth frustum for the voxel (the arithmetic of occd_flosp_sample_fwd: flosp_depth.py:561-602) and applies

@@ -1,0 +1,431 @@
+// K16 -- row-major float32 GEMM on the bf16 matrix pipe with the 3-way operand split (the library GEMMs
+// of the 2-D network -- tap GEMMs of the decoder levels, Winograd-domain products at 1/8 and 1/16, expand 1x1 convolutions of
+// the 1/16 and 1/32 encoder stages -- out of the eval path):
+//
+//   C[b][m][n] = act( sum_k A[b][m][k] * B[b][k][n] + bias[m] )        A: M x K, k contiguous;  B: K x N, n contiguous
+//
+// Both operands are float32 in memory and are split x = hi + mid + lo (three bf16 terms, 24 significant bits) WHILE they
+// are staged into LDS; six v_mfma_f32_32x32x16_bf16 per 16-k step -- (mid,mid), (hi,lo), (lo,hi), (hi,mid), (mid,hi),
+// (hi,hi), smallest first -- reproduce the float32 product to ~2^-24 relative (the same arithmetic as K2s3 / K2b SPLIT=3):
+// float32-level accuracy at 6/16 of the fp32-MFMA time, so nothing needs pre-packing and weights stay the plain tensors.
+// Layout in LDS: A rows [hi 32 k | mid | lo | 16 B pad] = 208 B (13 sixteen-byte slots, odd: conflict-free ds_read_b128
+// of 8 consecutive k per lane); B as it lies in memory, [term][k][n] with rows of TN bf16 + 64 B pad (row stride = 64 mod
+// 128 B), read with the transposing ds_read_b64_tr_b16 of gfx950 (lane <- 4 consecutive k of ONE column; layout pinned on
+// hardware by tools/probe_bf16.hip and used by K8b): no transposition pass, no 2-byte scatter.
+// One K step = 32 k: global -> registers (prefetched under the MFMAs of the previous step) -> split -> LDS, two barriers.
+// Workgroup = WM x WN waves, a wave owns MT x NT tiles of 32 x 32; D layout: lane -> column n, registers -> rows m, so every
+// store instruction writes two 128-byte row segments.  Block order is XCD-aware: an XCD walks a contiguous range of tiles
+// with the index over the SMALLER operand's reuse dimension fastest, so the larger operand's tile is fetched once per L2.
+//
+// Reference semantics replaced: torch.matmul / torch.bmm / F.conv2d(1x1) call sites of occdepth/models/unet2d.py:24-46,137-165
+// (through the tap-GEMM / Winograd-domain forms of this repo's unet2d.py) and the geffnet MBConv expand convolutions.
+#include <type_traits>
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // rows of odd length: dword-aligned 16-byte loads
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;   // (as K8b, csrc/conv3d_wgrad.hip)
+
+namespace {
+
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc, sA, sB, sC;     // elements
+    int act;                            // 0 none, 1 swish, 2 leaky relu (slope)
+    float slope;
+    int mtiles, ntiles, n_fast;         // n_fast: the N-tile index runs fastest in the block order (A tile reused), else M
+    unsigned nwg;
+};
+
+constexpr int kARow = 208;              // bytes per A row in LDS: 3 x 64 B (32 k of one term) + 16 B pad
+
+__device__ __forceinline__ void split8(f32x4 a, f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+    bf16x8 h = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    float r[8] = {a.x - (float)h[0], a.y - (float)h[1], a.z - (float)h[2], a.w - (float)h[3],
+                  b.x - (float)h[4], b.y - (float)h[5], b.z - (float)h[6], b.w - (float)h[7]};
+    bf16x8 m, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m[j] = (__bf16)r[j];
+        l[j] = (__bf16)(r[j] - (float)m[j]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    mid = __builtin_bit_cast(u32x4, m);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ void split4(f32x4 a, u32x2& hi, u32x2& mid, u32x2& lo) {
+    bf16x4 h = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w};
+    float r[4] = {a.x - (float)h[0], a.y - (float)h[1], a.z - (float)h[2], a.w - (float)h[3]};
+    bf16x4 m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[j] = (__bf16)r[j];
+        l[j] = (__bf16)(r[j] - (float)m[j]);
+    }
+    hi = __builtin_bit_cast(u32x2, h);
+    mid = __builtin_bit_cast(u32x2, m);
+    lo = __builtin_bit_cast(u32x2, l);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, int step_bytes) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p0);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(p0 + step_bytes));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// PRE: 0 = both operands float32 in memory (split while staged); 1 = A is the pre-split fragment image of
+// occd_gemm_x3_pack (weights: [row tile 32][k16][term][lane][8 bf16], read straight from L2 like K2b's weights -- no LDS,
+// no split arithmetic, no ds_write for that operand); 2 = B is (role 1 image: [column tile 32][k16][term][lane][8]).
+template <int MT, int NT, int WM, int WN, int PRE>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
+    constexpr int NTH = WM * WN * 64, TM = WM * MT * 32, TN = WN * NT * 32;
+    constexpr int SB = TN * 2 + 64;                 // bytes per B row (one k, one term): = 64 mod 128
+    constexpr int BTERM = 32 * SB;                  // bytes per term of the B tile
+    constexpr int NA = TM * 4 / NTH;                // A staging items per thread: (row, 8-k chunk), 2 float4 each
+    constexpr int NB = 8 * TN / NTH;                // B staging items per thread: (k row, 4-column chunk), 1 float4 each
+    static_assert(TM * 4 % NTH == 0 && 8 * TN % NTH == 0, "staging split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
+    unsigned char* const lA = glds;
+    unsigned char* const lB = glds + (PRE == 1 ? 0 : TM * kARow);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g1 = (lane >> 4) & 1;
+
+    uint32_t bid = blockIdx.x;   // XCD-aware bijective remap: an XCD walks a contiguous run of tiles
+    {
+        const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int mt_i, nt_i;
+    if (p.n_fast) { nt_i = bid % p.ntiles; mt_i = bid / p.ntiles; }
+    else { mt_i = bid % p.mtiles; nt_i = bid / p.mtiles; }
+    const int bz = blockIdx.y;
+    const int m0 = mt_i * TM, n0 = nt_i * TN;
+    const float* const Ab = p.A + (size_t)bz * p.sA;
+    const float* const Bb = p.B + (size_t)bz * p.sB;
+
+    // staging descriptors
+    size_t a_off[NA];
+    int a_dst[NA], a_k[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + i * NTH;
+        const int row = f >> 2, c8 = f & 3;
+        a_off[i] = (size_t)min(m0 + row, p.M - 1) * p.lda + c8 * 8;
+        a_dst[i] = row * kARow + c8 * 16;
+        a_k[i] = c8 * 8;
+    }
+    size_t b_col[NB];
+    int b_dst[NB], b_k[NB], b_sh[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = tid + i * NTH;
+        const int k = f / (TN / 4), c4 = f - k * (TN / 4);
+        // a chunk that crosses the end of the row loads the row's LAST four columns instead and is shifted into place
+        // while it is committed (no read beyond the tensor, no branch around the load)
+        b_col[i] = (size_t)min(n0 + c4 * 4, p.N - 4);
+        b_sh[i] = n0 + c4 * 4 - (int)b_col[i];                     // 0, or 1 .. 3 (partial chunk), or >= 4 (columns >= N: never stored)
+        b_dst[i] = k * SB + c4 * 8;
+        b_k[i] = k;
+    }
+
+    f32x4 ra[NA][2], rb[NB];
+    auto issue = [&](int k0) {          // global -> registers for the K step starting at k0 (clamped addresses, masked later)
+        if (PRE != 1) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int k = min(k0 + a_k[i], p.K - 8);
+                const float* src = Ab + a_off[i] - a_k[i] + k;
+                ra[i][0] = *(const f32x4*)src;
+                ra[i][1] = *(const f32x4*)(src + 4);
+            }
+        }
+        if (PRE != 2) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int k = min(k0 + b_k[i], p.K - 1);
+                rb[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + b_col[i]);
+            }
+        }
+    };
+    auto commit = [&](int k0) {         // registers -> split -> LDS
+#pragma unroll
+        for (int i = 0; i < (PRE == 1 ? 0 : NA); ++i) {
+            const bool ok = k0 + a_k[i] < p.K;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            u32x4 hi, mid, lo;
+            split8(ok ? ra[i][0] : z, ok ? ra[i][1] : z, hi, mid, lo);
+            *(u32x4*)(lA + a_dst[i]) = hi;
+            *(u32x4*)(lA + a_dst[i] + 64) = mid;
+            *(u32x4*)(lA + a_dst[i] + 128) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < (PRE == 2 ? 0 : NB); ++i) {
+            const bool ok = k0 + b_k[i] < p.K;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 w = ok ? rb[i] : z;
+            const int sh = b_sh[i];                  // (selects, not branches: the shift is lane-dependent)
+            f32x4 v;
+            v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
+            v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
+            v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
+            v.w = sh == 0 ? w.w : 0.f;
+            u32x2 hi, mid, lo;
+            split4(v, hi, mid, lo);
+            *(u32x2*)(lB + b_dst[i]) = hi;
+            *(u32x2*)(lB + BTERM + b_dst[i]) = mid;
+            *(u32x2*)(lB + 2 * BTERM + b_dst[i]) = lo;
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // lane-constant LDS offsets: A row of this lane (8 consecutive k of half h); B transposed read (row 8 h + (i16 >> 2),
+    // 4 columns 16 g1 + 4 (i16 & 3) of the 32-column tile; second read 4 rows further)
+    int a_lane[MT], b_lane[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_lane[mt] = ((wm * MT + mt) * 32 + li) * kARow + h * 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        b_lane[nt] = (8 * h + (i16 >> 2)) * SB + ((wn * NT + nt) * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
+
+#define OCCD_GX3(WT, XT)                                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] =  \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][WT]), bf[nt][XT], acc[mt][nt], 0, 0, 0)
+
+    // pre-split operand: fragment records of this wave's tiles, one K16 sub-step ahead of the MFMAs
+    const int K16tot = (p.K + 15) >> 4;
+    const u32x4* pk[PRE == 1 ? MT : PRE == 2 ? NT : 1];
+    if (PRE == 1) {
+        const u32x4* base = reinterpret_cast<const u32x4*>(p.A) + (size_t)bz * p.sA + lane;       // sA: u32x4 per batch item
+        const int last = (p.M + 31) / 32 - 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pk[mt] = base + (size_t)min(m0 / 32 + wm * MT + mt, last) * K16tot * 192;
+    } else if (PRE == 2) {
+        const u32x4* base = reinterpret_cast<const u32x4*>(p.B) + (size_t)bz * p.sB + lane;
+        const int last = (p.N + 31) / 32 - 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pk[nt] = base + (size_t)min(n0 / 32 + wn * NT + nt, last) * K16tot * 192;
+    }
+    constexpr int NPK = PRE == 1 ? MT : PRE == 2 ? NT : 1;
+    u32x4 pn[NPK][3];
+    auto fetch_pk = [&](int k16) {
+        const int kc = min(k16, K16tot - 1);      // (a step past K multiplies the other operand's zeros)
+#pragma unroll
+        for (int i = 0; i < NPK; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) pn[i][t] = pk[i][(kc * 3 + t) * 64];
+    };
+
+    const int ksteps = (p.K + 31) >> 5;
+    issue(0);
+    if (PRE != 0) fetch_pk(0);
+    for (int s = 0; s < ksteps; ++s) {
+        __syncthreads();                // previous tile consumed
+        commit(s * 32);
+        __syncthreads();
+        if (s + 1 < ksteps) issue((s + 1) * 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[MT][3];
+            bf16x8 bf[NT][3];
+            if (PRE == 1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) af[mt][t] = pn[mt][t];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(lA + a_lane[mt] + t * 64 + ks * 32);
+            }
+            if (PRE == 2) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bf[nt][t] = __builtin_bit_cast(bf16x8, pn[nt][t]);
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) bf[nt][t] = tr_frag(lB + t * BTERM + b_lane[nt] + ks * 16 * SB, 4 * SB);
+            }
+            if (PRE != 0) fetch_pk(s * 2 + ks + 1);
+            OCCD_GX3(1, 1);
+            OCCD_GX3(0, 2);
+            OCCD_GX3(2, 0);
+            OCCD_GX3(0, 1);
+            OCCD_GX3(1, 0);
+            OCCD_GX3(0, 0);
+        }
+    }
+#undef OCCD_GX3
+
+    // epilogue: lane -> column n, registers -> rows (r & 3) + 8 (r >> 2) + 4 h.  Bias / activation are uniform over the
+    // launch: one straight-line store sequence per combination
+    float* const Cb = p.C + (size_t)bz * p.sC;
+    auto store_all = [&](auto has_bias, auto act_sel) {
+        constexpr bool BIAS = decltype(has_bias)::value;
+        constexpr int ACT = decltype(act_sel)::value;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + (wn * NT + nt) * 32 + li;
+            const bool n_ok = n < p.N;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int mb = m0 + (wm * MT + mt) * 32 + 4 * h;
+                float bv[16];
+                if (BIAS) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bv[r] = p.bias[min(mb + (r & 3) + 8 * (r >> 2), p.M - 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    float v = acc[mt][nt][r];
+                    if (BIAS) v += bv[r];
+                    if (ACT == 1) v = occd::swish_fast(v);
+                    else if (ACT == 2) v = v > 0.f ? v : v * p.slope;
+                    if (n_ok && m < p.M) Cb[(size_t)m * p.ldc + n] = v;
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (p.bias == nullptr && p.act == 0) store_all(F_{}, std::integral_constant<int, 0>{});
+    else if (p.bias != nullptr && p.act == 1) store_all(T_{}, std::integral_constant<int, 1>{});
+    else if (p.bias != nullptr && p.act == 2) store_all(T_{}, std::integral_constant<int, 2>{});
+    else if (p.bias != nullptr) store_all(T_{}, std::integral_constant<int, 0>{});
+    else if (p.act == 1) store_all(F_{}, std::integral_constant<int, 1>{});
+    else store_all(F_{}, std::integral_constant<int, 2>{});
+}
+
+struct VariantG {
+    int MT, NT, WM, WN;
+    void (*kern[3])(const GemmP);
+};
+#define OCCD_VARIANT_G(MT, NT, WM, WN) \
+    VariantG{MT, NT, WM, WN, {gemm_x3_kernel<MT, NT, WM, WN, 0>, gemm_x3_kernel<MT, NT, WM, WN, 1>, gemm_x3_kernel<MT, NT, WM, WN, 2>}}
+const VariantG kVariantsG[] = {
+    OCCD_VARIANT_G(2, 2, 4, 2),   // 0: 256 x 128, 512 threads
+    OCCD_VARIANT_G(2, 2, 2, 2),   // 1: 128 x 128, 256 threads
+    OCCD_VARIANT_G(2, 1, 2, 2),   // 2: 128 x 64
+    OCCD_VARIANT_G(1, 1, 2, 2),   // 3: 64 x 64
+};
+constexpr int kNumVariantsG = sizeof(kVariantsG) / sizeof(kVariantsG[0]);
+
+// role 0: the A operand (rows x K, k contiguous) -> [row tile 32][k16][term][lane][8]: lane = (row & 31) + 32 ((k & 15) >> 3)
+// role 1: the B operand (K x cols, column contiguous) -> the same image with "row" = column
+__global__ void gemm_x3_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int rows, int K, long ld,
+                                    int role, long in_stride, long out_stride, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = i & 7, lane = (i >> 3) & 63;
+    long t = i >> 9;
+    const int K16 = (K + 15) >> 4;
+    const int k16 = t % K16;
+    const int rt = t / K16;
+    const int r = rt * 32 + (lane & 31), k = k16 * 16 + (lane >> 5) * 8 + j;
+    const float* src = w + (size_t)blockIdx.y * in_stride;
+    float v = 0.f;
+    if (r < rows && k < K) v = role == 0 ? src[(size_t)r * ld + k] : src[(size_t)k * ld + r];
+    const __bf16 hi = (__bf16)v;
+    const float r1 = v - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    uint16_t* dst = out + (size_t)blockIdx.y * out_stride + ((size_t)(rt * K16 + k16) * 3) * 512 + lane * 8 + j;
+    dst[0] = __builtin_bit_cast(uint16_t, hi);
+    dst[512] = __builtin_bit_cast(uint16_t, mid);
+    dst[1024] = __builtin_bit_cast(uint16_t, lo);
+}
+
+}  // namespace
+
+extern "C" int64_t occd_gemm_x3_packed_elems(int32_t rows, int32_t K) {
+    if (rows <= 0 || K <= 0) return OCCD_EINVAL;
+    return (int64_t)((rows + 31) / 32) * ((K + 15) / 16) * 3 * 512;
+}
+
+extern "C" int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_t K, int64_t ld, int32_t role, int32_t batch,
+                                 int64_t in_stride, void* stream) {
+    if (!w || !out || rows <= 0 || K <= 0 || role < 0 || role > 1 || batch <= 0 || batch > 65535) return OCCD_EINVAL;
+    if (ld < (role == 0 ? K : rows)) return OCCD_EINVAL;
+    const int64_t per = occd_gemm_x3_packed_elems(rows, K);
+    const long total = per / 3;
+    occd::ProfScope prof("gemm_x3_pack", (hipStream_t)stream, 0.0, (double)per * 2 * batch);
+    hipLaunchKernelGGL(gemm_x3_pack_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, w, (uint16_t*)out, rows, K, (long)ld, role, (long)in_stride, (long)per, total);
+    return occd::check_launch();
+}
+
+// a->tile_hint: 0 = pick (the largest tile that still gives >= 160 workgroups, else the finest), 1 .. 4 = force a variant.
+// a->pre: 0 = A and B float32; 1 = a->A is the role-0 image of occd_gemm_x3_pack (lda ignored, stride_a = bf16 elements
+// between batch items, 0 = shared); 2 = a->B is the role-1 image (ldb ignored, stride_b likewise).
+extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
+    if (a->pre < 0 || a->pre > 2) return OCCD_EINVAL;
+    if ((a->K & 7) || a->ldc < a->N || a->N < 4) return OCCD_EINVAL;
+    if (a->pre != 1 && ((a->lda & 3) || a->lda < a->K || (reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 3)))
+        return OCCD_EINVAL;
+    if (a->pre != 2 && (a->ldb < a->N || (reinterpret_cast<uintptr_t>(a->B) & 3))) return OCCD_EINVAL;
+    if (a->pre == 1 && ((reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 7))) return OCCD_EINVAL;
+    if (a->pre == 2 && ((reinterpret_cast<uintptr_t>(a->B) & 15) || (a->stride_b & 7))) return OCCD_EINVAL;
+    if (reinterpret_cast<uintptr_t>(a->C) & 3) return OCCD_EINVAL;
+    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG) return OCCD_EINVAL;
+    int pick = a->tile_hint - 1;
+    if (pick < 0) {
+        pick = kNumVariantsG - 1;
+        for (int i = 0; i < kNumVariantsG; ++i) {
+            const VariantG& v = kVariantsG[i];
+            const long tm = v.MT * v.WM * 32, tn = v.NT * v.WN * 32;
+            const long wgs = ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
+            if (wgs >= 160) { pick = i; break; }   // measured (profiles/r04_gemm_x3.txt): the large tiles win down to ~0.6 workgroups per CU
+        }
+    }
+    const VariantG& v = kVariantsG[pick];
+    const int TM = v.MT * v.WM * 32, TN = v.NT * v.WN * 32;
+    GemmP p;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a; p.sB = a->stride_b; p.sC = a->stride_c;
+    if (a->pre == 1) p.sA = a->stride_a / 8;        // bf16 elements -> u32x4 records
+    if (a->pre == 2) p.sB = a->stride_b / 8;
+    p.act = a->act; p.slope = a->slope;
+    p.mtiles = (a->M + TM - 1) / TM;
+    p.ntiles = (a->N + TN - 1) / TN;
+    // the tile of the LARGER operand is the one worth fetching once per L2: iterate over the other dimension fastest
+    p.n_fast = (double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) >= (double)a->K * a->N * a->batch ? 1 : 0;
+    const long nwg = (long)p.mtiles * p.ntiles;
+    if (nwg >= (1L << 31)) return OCCD_EINVAL;
+    p.nwg = (unsigned)nwg;
+    const size_t lds = (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
+    void (*kern)(const GemmP) = v.kern[a->pre];
+    if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
+    const double flops = 2.0 * a->M * a->N * a->K * a->batch;
+    const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
+    occd::ProfScope prof(a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : "gemm_f32x3_preB", (hipStream_t)stream, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(v.WM * v.WN * 64), lds, (hipStream_t)stream, p);
+    return occd::check_launch();
+}

@@ -261,26 +261,35 @@ __global__ void __launch_bounds__(512, 2) wino3x3_kernel(const WinoP p) {
     else k_loop(std::integral_constant<int, 1>{});
     __syncthreads();                                       // every wave is done with the staging buffers
 
+    // The exchange and the epilogue are instantiated once per domain half, like the K loop: with a run-time `h` the
+    // accumulator registers are picked by a wave-uniform but DYNAMIC index, which hipcc lowers to s_set_gpr_idx moves
+    // through a 16-register VGPR copy of each tile -- that copy was the kernel's 16 - 50 spilled VGPRs.
+    auto finish = [&](auto hc) {
+    constexpr int H = decltype(hc)::value;
+    constexpr bool h0 = H == 0;
     // ---------------- pair exchange: wave half h finishes the cout registers r in [8h, 8h + 8) and needs the partner's
     // 8 xi for them.  xchg[pair][writer half][k * 8 + (r & 7)][lane]  (the staging buffers are dead: last barrier above)
     float* xchg = lds;
     {
-        float* mine = xchg + ((pr * 2 + h) * 64) * 64 + lane;
+        float* mine = xchg + ((pr * 2 + H) * 64) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8) mine[(k * 8 + r8) * 64] = h0 ? acc[k][8 + r8] : acc[k][r8];
     }
     __syncthreads();
-    const float* theirs = xchg + ((pr * 2 + (1 - h)) * 64) * 64 + lane;
+    const float* theirs = xchg + ((pr * 2 + (1 - H)) * 64) * 64 + lane;
 
     // ---------------- epilogue: Y = A^T m A (A^T = [1 1 1 0; 0 1 -1 -1]), shift, activation, residual, NCHW store.
     // D = U^T-rows x tile-columns: this lane is tile `li` of the pair and register r is cout 8 (r >> 2) + 4 kk + (r & 3).
     const int oy0 = 2 * (ty0 + lr), ox = 2 * (tx0 + lc);
     const bool pair = ox + 1 < p.W && (p.W & 1) == 0;      // 8-byte aligned 2-pixel store
+    // One cout register per iteration, fenced by scheduling barriers: left alone, hipcc hoists the 64 exchange reads of
+    // all eight unrolled iterations above the first store and spills 16 - 50 VGPRs beside the 128 live accumulators.
 #pragma unroll
     for (int r8 = 0; r8 < 8; ++r8) {
-        const int r = h * 8 + r8;
+        __builtin_amdgcn_sched_barrier(0);
+        const int r = H * 8 + r8;
         const int co = nb * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
         float m[4][4];                                     // m[i][j], xi = 4 i + j; rows 2h, 2h + 1 are this wave's
 #pragma unroll
@@ -322,6 +331,9 @@ __global__ void __launch_bounds__(512, 2) wino3x3_kernel(const WinoP p) {
             }
         }
     }
+    };
+    if (h0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
 }
 
 // upk[chunk][r = 4 q + 2 h + part][cout/32][lane][j]: the A operands of cin 8 chunk + 4 (lane >> 5) + q for the four
@@ -415,8 +427,12 @@ int occd_wino_conv3x3_fwd(const occd_wino_args* a, void* stream) {
     const double tiles = (double)p.B * th * tw;
     occd::ProfScope prof("wino_conv3x3", (hipStream_t)stream, 2.0 * 16 * tiles * p.chunks * 8 * p.nblk * 32,
                          4.0 * p.B * ((double)p.Cin + p.Cout) * p.H * p.W);
+#ifdef OCCD_WINO_DEV_VARIANTS   // development A/B switches (wrong results by design): not compiled into the library
     if (exp_mode == 1) return twv == 16 ? launch_wino<16, 1>(p, (hipStream_t)stream) : launch_wino<32, 1>(p, (hipStream_t)stream);
     if (exp_mode == 2) return twv == 16 ? launch_wino<16, 2>(p, (hipStream_t)stream) : launch_wino<32, 2>(p, (hipStream_t)stream);
+#else
+    (void)exp_mode;
+#endif
     return twv == 16 ? launch_wino<16>(p, (hipStream_t)stream) : launch_wino<32>(p, (hipStream_t)stream);
 }
 

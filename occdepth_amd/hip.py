@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 7   # 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 8   # 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -95,6 +95,13 @@ class RowsGemmArgs(Structure):
                                 "act_out")]
 
 
+class GemmArgs(Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p)] + \
+        [(n, c_int32) for n in ("M", "N", "K", "batch")] + \
+        [(n, c_int64) for n in ("lda", "ldb", "ldc", "stride_a", "stride_b", "stride_c")] + \
+        [("act", c_int32), ("slope", c_float), ("tile_hint", c_int32), ("pre", c_int32)]
+
+
 class WinoArgs(Structure):
     _fields_ = [("x", c_void_p), ("upk", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("y", c_void_p)] + \
         [(n, c_int32) for n in ("batch", "cin", "cout", "H", "W", "act", "res_first", "tile_hint")] + [("slope", c_float)]
@@ -134,6 +141,9 @@ EXPORTS = {
                                     c_int32, c_void_p]),
     "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
     "occd_rows_gemm_fwd": (c_int32, [POINTER(RowsGemmArgs), c_void_p]),
+    "occd_gemm_f32x3": (c_int32, [POINTER(GemmArgs), c_void_p]),
+    "occd_gemm_x3_packed_elems": (c_int64, [c_int32, c_int32]),
+    "occd_gemm_x3_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_int64, c_void_p]),
     "occd_rows_gemm_packed_floats": (c_int64, [c_int32, c_int32]),
     "occd_rows_gemm_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "occd_bottleneck3d_weight_floats": (c_int64, [c_int32, c_int32]),
@@ -460,6 +470,143 @@ def conv3d_bf16(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 
     _check(load().occd_conv3d_bf16_fwd(ctypes.byref(a), 2 if split3 else _storage_code(x.buf.dtype), _stream()),
            "occd_conv3d_bf16_fwd")
     return out
+
+
+GEMM_ACT = {None: 0, "none": 0, "swish": 1, "leaky": 2}
+
+
+class GemmPacked:
+    """A static GEMM operand (weights) split once into its three bf16 terms in MFMA fragment order (occd_gemm_x3_pack):
+    role "a" = the left operand (M, K) / (batch, M, K), role "b" = the right operand (K, N) / (batch, K, N)."""
+
+    def __init__(self, w, role):
+        if role not in ("a", "b") or w.dim() not in (2, 3) or w.dtype != torch.float32 or not w.is_cuda:
+            raise RuntimeError("GemmPacked: a 2-D / 3-D float32 GPU tensor and role 'a' or 'b'")
+        w = w.detach().contiguous()
+        self.role, self.batch = role, (w.shape[0] if w.dim() == 3 else None)
+        if role == "a":
+            self.rows, self.K = w.shape[-2], w.shape[-1]
+        else:
+            self.K, self.rows = w.shape[-2], w.shape[-1]
+        self.shape = tuple(w.shape)
+        self.per = load().occd_gemm_x3_packed_elems(self.rows, self.K)
+        if self.per <= 0:
+            raise RuntimeError("occd_gemm_x3_packed_elems: bad shape")
+        nb = self.batch or 1
+        self.buf = torch.empty(nb * self.per, device=w.device, dtype=torch.bfloat16)
+        _check(load().occd_gemm_x3_pack(w.data_ptr(), self.buf.data_ptr(), self.rows, self.K, w.shape[-1], 0 if role == "a" else 1,
+                                        nb, w.shape[-2] * w.shape[-1], _stream()), "occd_gemm_x3_pack")
+
+    def dim(self):
+        return len(self.shape)
+
+
+def gemm_x3_supported(a, b):
+    """Shapes / layouts K16 takes: a (M, K) or (batch, M, K), b (batch, K, N) or (K, N); float32, innermost stride 1,
+    K % 8 == 0, 16-byte aligned rows of a, N >= 4.  Either operand may be a `GemmPacked` (pre-split weights)."""
+    if isinstance(a, GemmPacked) and isinstance(b, GemmPacked):
+        return False
+    for t, role in ((a, "a"), (b, "b")):
+        if isinstance(t, GemmPacked):
+            if t.role != role:
+                return False
+        elif t.dtype != torch.float32 or not t.is_cuda or t.dim() not in (2, 3) or t.stride(-1) != 1:
+            return False
+    K = a.K if isinstance(a, GemmPacked) else a.shape[-1]
+    Kb = b.K if isinstance(b, GemmPacked) else b.shape[-2]
+    N = b.rows if isinstance(b, GemmPacked) else b.shape[-1]
+    if K != Kb or K % 8 or N < 4:
+        return False
+    if not isinstance(a, GemmPacked):
+        if a.stride(-2) % 4 or a.stride(-2) < K or a.data_ptr() % 16 or (a.dim() == 3 and a.stride(0) % 4):
+            return False
+    if not isinstance(b, GemmPacked) and b.stride(-2) < N:
+        return False
+    nb_a = (a.batch if isinstance(a, GemmPacked) else (a.shape[0] if a.dim() == 3 else None))
+    nb_b = (b.batch if isinstance(b, GemmPacked) else (b.shape[0] if b.dim() == 3 else None))
+    return nb_a is None or nb_b is None or nb_a == nb_b
+
+
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
+    """K16 (occd_gemm_f32x3): out[i] = act(a[i] @ b[i] + bias[:, None]) in float32-level accuracy on the bf16 matrix pipe.
+    a: (M, K) shared over the batch, or (batch, M, K); b: (K, N) or (batch, K, N); out: (batch, M, N) ((M, N) when neither
+    operand is batched).  Tensor operands may be strided views as long as the innermost stride is 1; a static operand may be
+    given as `GemmPacked(w, "a" / "b")` (split once, read straight from L2)."""
+    if not gemm_x3_supported(a, b):
+        raise RuntimeError("gemm_x3: unsupported operands")
+    pa, pb = isinstance(a, GemmPacked), isinstance(b, GemmPacked)
+    nb_a = a.batch if pa else (a.shape[0] if a.dim() == 3 else None)
+    nb_b = b.batch if pb else (b.shape[0] if b.dim() == 3 else None)
+    batch = nb_a or nb_b or 1
+    M = a.rows if pa else a.shape[-2]
+    K = a.K if pa else a.shape[-1]
+    N = b.rows if pb else b.shape[-1]
+    squeeze = nb_a is None and nb_b is None
+    dev = a.buf.device if pa else a.device
+    if out is None:
+        out = torch.empty((batch, M, N), device=dev, dtype=torch.float32)
+    elif out.dtype != torch.float32 or out.stride(-1) != 1 or out.shape[-2:] != (M, N) or not out.is_cuda:
+        raise RuntimeError("gemm_x3: bad output tensor")
+    q = GemmArgs()
+    q.A = a.buf.data_ptr() if pa else a.data_ptr()       # (strided views: the strides travel as lda / ldb / ldc)
+    q.B = b.buf.data_ptr() if pb else b.data_ptr()
+    q.C = out.data_ptr()
+    q.bias = _f32(bias, "bias") if bias is not None else None
+    if bias is not None and (bias.numel() != M or not bias.is_contiguous()):
+        raise RuntimeError("gemm_x3: bias must be M contiguous floats")
+    q.M, q.N, q.K, q.batch = M, N, K, batch
+    q.lda = K if pa else a.stride(-2)
+    q.ldb = N if pb else b.stride(-2)
+    q.ldc = out.stride(-2)
+    q.stride_a = (a.per if nb_a else 0) if pa else (a.stride(0) if a.dim() == 3 else 0)
+    q.stride_b = (b.per if nb_b else 0) if pb else (b.stride(0) if b.dim() == 3 else 0)
+    q.stride_c = out.stride(0) if out.dim() == 3 else 0
+    q.act, q.slope, q.tile_hint = GEMM_ACT[act], slope, tile_hint
+    q.pre = 1 if pa else 2 if pb else 0
+    if _PROFILING:
+        set_tag("%dx%dx%d b%d" % (M, N, K, batch))
+    _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
+    return out[0] if squeeze and out.dim() == 3 else out
+
+
+# K16 instead of the library GEMMs in the eval path of the 2-D network (tap GEMMs, Winograd-domain products, expand 1x1
+# convolutions, the merged conv_head o conv2).  OCCDEPTH_GEMM_X3=0 restores torch.matmul / torch.bmm / F.conv2d for A/B.
+GEMM_X3 = os.environ.get("OCCDEPTH_GEMM_X3", "1") == "1"
+
+
+# static operands pre-split once (GemmPacked) instead of split on the fly: measured NO gain (tap GEMMs +-3 %, Winograd domain
+# 122 against 140 TF/s, frame 21.77 against 21.48 ms; profiles/r04_gemm_x3_v2_presplit.txt) -- the fragment stream from L2 costs
+# what the split arithmetic saved -- so it stays an option (tested), off by default
+GEMM_X3_PACK = os.environ.get("OCCDEPTH_GEMM_X3_PACK", "0") == "1"
+
+
+def matmul_operand(w, role):
+    """A static operand (weights) in the form hip.matmul wants it: (the float32 tensor, its GemmPacked image or None)."""
+    w = w.detach().float().contiguous()
+    if GEMM_X3 and GEMM_X3_PACK and w.is_cuda:
+        return w, GemmPacked(w, role)
+    return w, None
+
+
+def matmul(a, b, bias=None, act=None, slope=0.01):
+    """a @ b (+ bias[:, None], activation) for the eval path: K16 when it applies, else the library + plain tensor ops.
+    a / b may be the (tensor, GemmPacked or None) pair of `matmul_operand`."""
+    ta, pa = a if isinstance(a, tuple) else (a, None)
+    tb, pb = b if isinstance(b, tuple) else (b, None)
+    if GEMM_X3:
+        xa, xb = (pa if pa is not None else ta), (pb if pb is not None else tb)
+        if gemm_x3_supported(xa, xb):
+            return gemm_x3(xa, xb, bias=bias, act=act, slope=slope)
+        if gemm_x3_supported(ta, tb):
+            return gemm_x3(ta, tb, bias=bias, act=act, slope=slope)
+    y = torch.matmul(ta, tb)
+    if bias is not None:
+        y = y + bias.view(-1, 1)
+    if act == "swish":
+        y = y * torch.sigmoid(y)
+    elif act == "leaky":
+        y = torch.nn.functional.leaky_relu(y, slope)
+    return y
 
 
 def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0), res1=None, res2=None,
@@ -850,18 +997,20 @@ def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01
 
 
 def conv2d_3x3_winograd(x, U, scale=None, shift=None, act=None, slope=0.01, res=None, res_first=False, strip_rows=None):
-    """act(scale * conv3x3(x, g, pad 1) + shift) (+res) with U = winograd_weights(g): HIP transforms around 16 batched
-    fp32 GEMMs on the MFMA pipe (hipBLASLt).  `strip_rows` tile rows per pass keep V / M cache-sized on big images."""
+    """act(scale * conv3x3(x, g, pad 1) + shift) (+res) with U = winograd_weights(g) (or the `matmul_operand(U, "b")` pair):
+    HIP transforms around 16 batched GEMMs (K16; the library with OCCDEPTH_GEMM_X3=0).  `strip_rows` tile rows per pass keep
+    V / M cache-sized on big images."""
     B, Cin, H, W = x.shape
+    cout = (U[0] if isinstance(U, tuple) else U).shape[2]
     th = (H + 1) // 2
     if strip_rows is None or strip_rows >= th:
         V = wino_input_transform(x)
-        return wino_output_transform(torch.bmm(V, U), (B, U.shape[2], H, W), scale, shift, act, slope, res, res_first)
-    y = torch.empty((B, U.shape[2], H, W), device=x.device, dtype=torch.float32)
+        return wino_output_transform(matmul(V, U), (B, cout, H, W), scale, shift, act, slope, res, res_first)
+    y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
     xc = x if x.is_contiguous() else x.contiguous()
     for ty0 in range(0, th, strip_rows):
         ths = min(strip_rows, th - ty0)
-        M = torch.bmm(wino_input_transform(xc, ty0, ths), U)
+        M = matmul(wino_input_transform(xc, ty0, ths), U)
         wino_output_transform(M, tuple(y.shape), scale, shift, act, slope, res, res_first, out=y, ty0=ty0, ths=ths)
     return y
 

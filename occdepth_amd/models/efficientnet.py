@@ -64,6 +64,32 @@ def pw_operands(owner, conv, bn=None):
     return hit[1], hit[2]
 
 
+def gemm_operands(owner, conv, bn):
+    """(W * BatchNorm scale as a (Cout, Cin) matrix, shift) of a 1x1 convolution + BatchNorm for K16 (hip.matmul), cached on
+    `owner` until a source tensor changes."""
+    key = _stamp(conv, bn)
+    cache = owner.__dict__.setdefault("_gemm_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        scale, shift = bn_affine_cached(bn)
+        w = conv.weight.detach().float().flatten(1) * scale.view(-1, 1)
+        if conv.bias is not None:
+            shift = conv.bias.detach().float() * scale + shift
+        hit = (key, hip.matmul_operand(w, "a"), shift.contiguous())
+        cache[id(conv)] = hit
+    return hit[1], hit[2]
+
+
+def expand_gemm(owner, conv, bn, x, act):
+    """act(bn(conv1x1(x))) of the few-pixel stages: ONE K16 launch (BatchNorm folded, shift + swish in the epilogue) where
+    the library path is a GEMM + an elementwise pass; falls back to that path when K16 does not apply."""
+    B, C, H, W = x.shape
+    if hip.GEMM_X3 and C % 8 == 0 and H * W >= 4 and x.is_contiguous():
+        w, shift = gemm_operands(owner, conv, bn)
+        return hip.matmul(w, x.view(B, C, H * W), bias=shift, act=act).view(B, -1, H, W)
+    return hip.affine_act(F.conv2d(x, conv.weight), *bn_affine_cached(bn), act)
+
+
 def _fast(x, module):
     """eval-mode CUDA tensors take the fused HIP elementwise / depthwise kernels (occdepth_amd/csrc/nchw2d.hip)."""
     return _fused.on_gpu(x) and not needs_autograd(module) and x.dtype == torch.float32
@@ -191,7 +217,7 @@ class InvertedResidual(nn.Module):
             # 4 launches instead of 11: expand GEMM + BN + swish, depthwise + BN + swish + SE pooling, SE gate,
             # project GEMM with the gate on its input channels + BN + skip
             if expand_on_library(x):
-                y = hip.affine_act(F.conv2d(x, self.conv_pw.weight), *bn_affine_cached(self.bn1), "swish")
+                y = expand_gemm(self, self.conv_pw, self.bn1, x, "swish")
             else:
                 wpk, shift = pw_operands(self, self.conv_pw, self.bn1)
                 y = hip.conv1x1(x, wpk, self.conv_pw.out_channels, shift, "swish")

@@ -60,7 +60,7 @@ class UpSampleBN(nn.Module):
             scale, shift = bn_affine_cached(bn)
             if conv.bias is not None:
                 shift = shift + scale * conv.bias.detach().float()
-            hit = (key, hip.winograd_weights(conv.weight), scale.contiguous(), shift.contiguous())
+            hit = (key, hip.matmul_operand(hip.winograd_weights(conv.weight), "b"), scale.contiguous(), shift.contiguous())
             cache[id(conv)] = hit
         return hit[1:]
 
@@ -89,7 +89,7 @@ class UpSampleBN(nn.Module):
             return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope)
         if self.WINOGRAD and C >= self.WINOGRAD_HIRES_MIN_CIN and B * H * W <= self.WINOGRAD_HIRES_PIXELS:
             U, scale, shift = self._wino_operands(conv, bn)
-            per_row = 16.0 * B * ((W + 1) // 2) * (C + U.shape[2]) * 4
+            per_row = 16.0 * B * ((W + 1) // 2) * (C + conv.out_channels) * 4
             rows = max(1, int(self.WINOGRAD_STRIP_MB * 2 ** 20 / per_row))
             return hip.conv2d_3x3_winograd(f, U, scale, shift, "leaky", act.negative_slope, strip_rows=rows)
         return hip.affine_act(conv(f), *bn_affine_cached(bn), "leaky", slope=act.negative_slope)
@@ -118,7 +118,7 @@ class UpSampleBN(nn.Module):
             # rows t * Cout + co (t = ky * 3 + kx) of the tap GEMM, BatchNorm scale folded in
             w9 = (w[:, :cup] * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(9 * cout, cup).contiguous()
             wskip = (w[:, cup:] * scale.view(-1, 1, 1, 1)).contiguous()
-            hit = (key, hip.pw_pack_weights(w9), w9,
+            hit = (key, hip.pw_pack_weights(w9), hip.matmul_operand(w9, "a"),
                    hip.wino_pack_weights(w[:, cup:].contiguous(), scale), shift.contiguous(), wskip)
             self.__dict__["_upconv_cache"] = hit
         return hit[1:]
@@ -129,13 +129,13 @@ class UpSampleBN(nn.Module):
         B, cup, h, w = x.shape
         if B > 1 and B * h * w <= self.UPCONV_FOLD_BELOW:
             # few pixels per image: ONE GEMM over the pixels of all images (the operand copy is small here)
-            z = torch.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w)).view(9 * cout, B, h, w)
+            z = hip.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w)).view(9 * cout, B, h, w)
             batch_inner = True
         else:
             batch_inner = False
             if B * h * w < self.UPCONV_LIB_BELOW:
                 xc = x if x.is_contiguous() else x.contiguous()
-                z = torch.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)
+                z = hip.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)     # K16 (csrc/gemm_x3.hip)
             else:
                 z = hip.conv1x1(x, wpk9, 9 * cout)
         rw = (w - 1) / max(skip.shape[3] - 1, 1)
@@ -230,9 +230,18 @@ class DecoderBN(nn.Module):
         if hit is None or hit[0] != key:
             w2 = self.conv2.weight.detach().double().flatten(1)
             wh = conv_head.weight.detach().double().flatten(1)
-            hit = (key, (w2 @ wh).float().reshape(w2.shape[0], wh.shape[1], 1, 1).contiguous())
+            w = (w2 @ wh).float().reshape(w2.shape[0], wh.shape[1], 1, 1).contiguous()
+            hit = (key, w, hip.matmul_operand(w.view(w.shape[0], -1), "a") if w.is_cuda else None)
             self.__dict__["_merged_head"] = hit
-        return F.conv2d(f, hit[1], self.conv2.bias, self.conv2.stride, self.conv2.padding)
+        pad = self.conv2.padding
+        if (hip.GEMM_X3 and _fused.on_gpu(f) and self.conv2.stride == (1, 1) and self.conv2.bias is not None
+                and f.shape[1] % 8 == 0):
+            # a 1x1 convolution with padding: the frame is bias only -- pad the (small) input with zeros and run ONE GEMM (K16)
+            fp = F.pad(f, (pad[1], pad[1], pad[0], pad[0]))
+            B, C, H, W = fp.shape
+            w2d = hit[2] if hit[2] is not None else hit[1].view(hit[1].shape[0], C)
+            return hip.matmul(w2d, fp.view(B, C, H * W), bias=self.conv2.bias.detach().float().contiguous()).view(B, -1, H, W)
+        return F.conv2d(f, hit[1], self.conv2.bias, self.conv2.stride, pad)
 
     def forward(self, features, merged_head=None):
         taps = {16: features[8], 8: features[6], 4: features[5], 2: features[4], 1: features[0]}

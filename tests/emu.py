@@ -525,6 +525,30 @@ def softmax_nchw(x):
     return torch.softmax(x.double(), 1).float()
 
 
+def gemm_x3_supported(a, b):
+    """hip.gemm_x3_supported without the device check (the layout rules are the kernel's own)."""
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        return False
+    if a.dim() not in (2, 3) or b.dim() not in (2, 3) or a.stride(-1) != 1 or b.stride(-1) != 1:
+        return False
+    K, N = b.shape[-2], b.shape[-1]
+    if a.shape[-1] != K or K % 8 or N < 4 or a.stride(-2) % 4 or a.stride(-2) < K or b.stride(-2) < N:
+        return False
+    return a.dim() == 2 or b.dim() == 2 or a.shape[0] == b.shape[0]
+
+
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
+    """occd_gemm_f32x3: float32-level GEMM + bias[:, None] + activation (evaluated in float64 here)."""
+    y = torch.matmul(a.double(), b.double())
+    if bias is not None:
+        y = y + bias.double().view(-1, 1)
+    y = _act2d(y, act, slope).float()
+    if out is not None:
+        out.copy_(y if y.dim() == out.dim() else y.unsqueeze(0))
+        return out
+    return y if (a.dim() == 3 or b.dim() == 3) else y
+
+
 @contextlib.contextmanager
 def patched(fast2d=False):
     """fast2d: also route the 2-D eval fast paths (fused.on_gpu gates) through the emulation on CPU tensors."""
@@ -533,9 +557,10 @@ def patched(fast2d=False):
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "pack_weights_gather", "conv3d_bf16",
-                                          "conv3d_wgrad_bf16")}
+                                          "conv3d_wgrad_bf16", "gemm_x3", "gemm_x3_supported")}
     hip.pack_weights_bf16, hip.conv3d_bf16, hip.conv3d_wgrad_bf16 = pack_weights_bf16, conv3d_bf16, conv3d_wgrad_bf16
     hip.pack_weights_gather = pack_weights_gather
+    hip.gemm_x3, hip.gemm_x3_supported = gemm_x3, gemm_x3_supported
     hip.upconv_gather = upconv_gather
     hip.affine_act, hip.dwconv2d_same = affine_act, dwconv2d_same
     hip.upsample_bilinear_cat, hip.softmax_nchw = upsample_bilinear_cat, softmax_nchw

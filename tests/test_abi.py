@@ -49,7 +49,7 @@ def test_ctypes_structs_match_c_layout(tmp_path):
                "occd_prof_row": hip.ProfRow, "occd_conv3d_wgrad_args": hip.WgradArgs, "occd_wino_args": hip.WinoArgs,
                "occd_pw_args": hip.PwArgs, "occd_lift_bwd_args": hip.LiftBwdArgs, "occd_bn_args": hip.BnArgs,
                "occd_lift_proj_args": hip.LiftProjArgs, "occd_bneck_args": hip.BneckArgs,
-               "occd_rows_gemm_args": hip.RowsGemmArgs}
+               "occd_rows_gemm_args": hip.RowsGemmArgs, "occd_gemm_args": hip.GemmArgs}
     rename = {"inp": "in"}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():

@@ -1,0 +1,107 @@
+"""K16 (csrc/gemm_x3.hip, occd_gemm_f32x3): the row-major float32 GEMM with the 3-way bf16 split against float64 on the
+UN-rounded operands -- float32 level (bound 2e-6 of the output maximum; torch.matmul's float32 result is measured beside it) --
+on the shapes the 2-D network uses it for (tap GEMMs of the decoder levels, Winograd-domain products, expand 1x1
+convolutions; reduced in the long dimension so the float64 reference stays cheap) and on the ragged ones: rows of odd
+length (dword-aligned 16-byte loads, a last chunk that crosses the end of the row), M / N / K tails, strided views,
+every tile variant, bias + activation epilogues."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from occdepth_amd import hip as h
+    h.load()
+    return h
+
+
+# name: (batch or None, M, N, K, A batched?)
+SHAPES = {
+    "tap_1_16": (2, 11520 // 8, 574, 2560, False),        # 9 Cout x Cup at 14 x 41 pixels (M cut to 1/8)
+    "tap_1_4": (2, 2880, 7191 // 4, 640, False),          # N odd
+    "tap_1_1": (2, 720, 225700 // 64, 160, False),        # short K, M = 2.8 tiles of 256
+    "wino_1_16": (16, 936, 1280 // 4, 1280, True),        # V[xi] (T x Cin) . U[xi] (Cin x Cout)
+    "expand_1_32": (2, 3840 // 4, 468, 640, False),
+    "expand_k48": (2, 288, 1848, 48, False),              # K tail: 48 = 32 + 16
+    "tiny": (None, 40, 7, 8, False),                      # single partial tile everywhere, N % 4 = 3
+    "n_tail_1": (1, 70, 133, 24, False),                  # N % 4 = 1, K tail of 8
+    "n_tail_2": (3, 33, 130, 104, True),                  # N % 4 = 2
+}
+
+
+def run(hip, a, b, **kw):
+    return hip.gemm_x3(a, b, **kw)
+
+
+@pytest.mark.parametrize("packed", [None, "a", "b"], ids=["split_on_the_fly", "A_presplit", "B_presplit"])
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_gemm_x3_vs_float64(hip, name, packed):
+    """packed: the static operand split once into its fragment image (hip.GemmPacked, occd_gemm_x3_pack) and read straight
+    from L2 -- what the model does with its weights (A for the tap GEMMs / expand convolutions, B for the Winograd domain)."""
+    batch, M, N, K, a_batched = SHAPES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    bshape = (K, N) if batch is None else (batch, K, N)
+    ashape = (batch, M, K) if a_batched else (M, K)
+    a = torch.randn(*ashape, generator=g) * (1.0 / K ** 0.5)
+    b = torch.randn(*bshape, generator=g) * 3.0
+    ref = torch.matmul(a.double(), b.double())
+    ad, bd = a.to(DEV), b.to(DEV)
+    xa = hip.GemmPacked(ad, "a") if packed == "a" else ad
+    xb = hip.GemmPacked(bd, "b") if packed == "b" else bd
+    got = run(hip, xa, xb).cpu().double()
+    assert got.shape == ref.shape
+    scale = ref.abs().max()
+    err = float((got - ref).abs().max() / scale)
+    err32 = float((torch.matmul(ad, bd).cpu().double() - ref).abs().max() / scale)
+    print(f"gemm_x3 {name} ({packed or 'no'} pre-split): max err {err:.2e} (torch.matmul fp32 {err32:.2e})")
+    # float32 accumulation over K terms: the bound grows with sqrt(K) (measured 1.9e-6 at K = 2560, the library's 2.0e-6)
+    assert err < max(2e-6, 1.25 * err32), (name, err, err32)
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3, 4])
+def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
+    g = torch.Generator().manual_seed(hint)
+    batch, M, N, K = 2, 300, 333, 72                       # M, N tails in every variant; K = 2 steps + a tail of 8
+    a = torch.randn(M, K, generator=g) / K ** 0.5
+    b = torch.randn(batch, K, N, generator=g)
+    bias = torch.randn(M, generator=g)
+    lin = torch.matmul(a.double(), b.double()) + bias.double().view(1, -1, 1)
+    for act, ref in ((None, lin), ("swish", lin * torch.sigmoid(lin)), ("leaky", torch.where(lin > 0, lin, lin * 0.2))):
+        got = run(hip, a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=act, slope=0.2, tile_hint=hint).cpu().double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < (3e-6 if act == "swish" else 2e-6), (hint, act, err)      # (swish: hardware exp2 / rcp, ~3 ulp)
+    for xa, xb in ((a.to(DEV), b.to(DEV)), (hip.GemmPacked(a.to(DEV), "a"), b.to(DEV)), (a.to(DEV), hip.GemmPacked(b.to(DEV), "b"))):
+        got = run(hip, xa, xb, tile_hint=hint).cpu().double()
+        assert float((got - (lin - bias.double().view(1, -1, 1))).abs().max() / lin.abs().max()) < 2e-6
+
+
+def test_gemm_x3_strided_views_and_output(hip):
+    """Operands as views (leading dimensions larger than the logical sizes) and a caller-provided strided output: the
+    forms the decoder uses -- x[b] planes of an NCHW tensor as (K, N) with ldb = H W, weights as a slice of a wider matrix."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K, batch = 96, 150, 64, 2
+    abig = torch.randn(M + 5, K + 24, generator=g).to(DEV)
+    bbig = torch.randn(batch, K + 3, N + 9, generator=g).to(DEV)
+    a, b = abig[2:2 + M, 8:8 + K], bbig[:, 1:1 + K, 3:3 + N]
+    assert not a.is_contiguous() and not b.is_contiguous() and hip.gemm_x3_supported(a, b)
+    obig = torch.full((batch, M + 2, N + 6), 7.0, device=DEV)
+    out = obig[:, 1:1 + M, 2:2 + N]
+    hip.gemm_x3(a, b, out=out)
+    ref = torch.matmul(a.double().cpu(), b.double().cpu())
+    assert float((out.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    border = obig.clone()
+    border[:, 1:1 + M, 2:2 + N] = 7.0
+    assert torch.equal(border, torch.full_like(obig, 7.0))          # nothing written outside the view
+    assert not hip.gemm_x3_supported(a[:, :63], b[:, :63])          # K % 8
+    assert not hip.gemm_x3_supported(abig[:, 1:1 + K], bbig[:, :K]) # rows of A not 16-byte aligned
+
+
+def test_gemm_x3_rejects_bad_arguments(hip):
+    import ctypes
+    lib = hip.load()
+    assert lib.occd_gemm_f32x3(None, None) == -1
+    q = hip.GemmArgs()
+    assert lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1

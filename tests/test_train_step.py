@@ -120,9 +120,10 @@ def test_train_step_full_config2_matches_reference_gpu(mode, hip_lib):
     """VERDICT r3 missing #6: the step `bench.py --train [--bf16]` TIMES -- B7, 370x1220 stereo -> 256x256x32, training mode
     (BatchNorm on batch statistics), `training_step` + backward -- against the REAL reference's step on the same weights
     and frame (tests/golden/train_step_full.npz, tests/golden/make_golden.py train_step_full: 46 s forward + 212 s backward
-    on the build container's CPU).  fp32: every loss term within 3e-3, the same parameters left without gradient, 12
-    gradient norms within 5e-2 (the round-off of ~270 BatchNorm-normalised layers; the kernels are pinned one by one at
-    2e-5 elsewhere).  bf16-MFMA mode (configs[3]): loss terms within 2e-2, gradient norms within 0.25."""
+    on the build container's CPU).  fp32: every loss term within 5e-4 (measured 1.5e-5), the same parameters left without gradient,
+    11 gradient norms within 3e-2 (measured 1.2e-2) and their stored slices at cosine > 0.99 (0.9987): the round-off of ~270
+    BatchNorm-normalised layers; the kernels are pinned one by one at 2e-5 elsewhere.  bf16-MFMA mode (configs[3]): loss
+    terms within 3e-3 (1.2e-4), gradient norms within 0.15 (7.3e-2), cosine > 0.85 (0.93)."""
     from occdepth_amd import autograd3d
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
@@ -148,7 +149,7 @@ def test_train_step_full_config2_matches_reference_gpu(mode, hip_lib):
         torch.cuda.synchronize()
     finally:
         autograd3d.set_bf16_mfma(saved)
-    rel, nrel = (3e-3, 5e-2) if mode == "fp32" else (2e-2, 0.25)
+    rel, nrel = (5e-4, 3e-2) if mode == "fp32" else (3e-3, 0.15)      # measured: 1.5e-5 / 1.2e-2 and 1.2e-4 / 7.3e-2
     terms = [f for f in g.files if f.startswith("train/")]
     assert len(terms) == 8
     report = {}
@@ -160,19 +161,28 @@ def test_train_step_full_config2_matches_reference_gpu(mode, hip_lib):
     assert sorted(k for k, v in grads.items() if v is None) == want_none
     keys = [f[len("gradnorm."):] for f in g.files if f.startswith("gradnorm.")]
     assert len(keys) >= 8
-    worst_norm, worst_cos = 0.0, 1.0
+    worst_norm, worst_cos, rows = 0.0, 1.0, []
     for k in keys:
         ref_n = float(g[f"gradnorm.{k}"])
         got_n = float(grads[k].double().norm())
-        worst_norm = max(worst_norm, abs(got_n - ref_n) / ref_n)
+        if ref_n < 1e-5:
+            # a bias in front of a training-mode BatchNorm: its gradient is EXACTLY zero (the batch mean absorbs it); both
+            # sides hold round-off only (reference 1.5e-7, here ~1e-9)
+            assert got_n < 1e-5, (k, got_n, ref_n)
+            continue
         ref_e = torch.from_numpy(g[f"grad.{k}"]).double()
         got_e = grads[k].detach().reshape(-1)[:4096].double().cpu()
-        if ref_e.numel() >= 64:
-            worst_cos = min(worst_cos, float(torch.dot(ref_e, got_e) / (ref_e.norm() * got_e.norm() + 1e-300)))
-        assert got_n == pytest.approx(ref_n, rel=nrel), (k, got_n, ref_n)
+        cos = float(torch.dot(ref_e, got_e) / (ref_e.norm() * got_e.norm() + 1e-300)) if ref_e.numel() >= 64 else 1.0
+        rows.append((k, got_n, ref_n, cos))
+        worst_norm = max(worst_norm, abs(got_n - ref_n) / ref_n)
+        worst_cos = min(worst_cos, cos)
     print(f"config-2 training step ({mode}) vs the real reference: loss terms {report}; worst gradient-norm deviation "
-          f"{worst_norm:.2e}, worst cosine of the stored gradient slices {worst_cos:.4f}")
-    assert worst_cos > (0.98 if mode == "fp32" else 0.8)
+          f"{worst_norm:.2e}, worst cosine of the stored gradient slices {worst_cos:.4f}; per parameter (norm here, reference, "
+          f"cosine): {[(k.split('.')[-3:], round(a, 5), round(b, 5), round(c, 4)) for k, a, b, c in rows]}")
+    assert len(rows) >= 8
+    for k, got_n, ref_n, cos in rows:
+        assert got_n == pytest.approx(ref_n, rel=nrel), (k, got_n, ref_n)
+    assert worst_cos > (0.99 if mode == "fp32" else 0.85)                 # measured 0.9987 / 0.9301
 
 
 # The HIP-vs-ATen comparison of the 3-D stack's backward lives in tests/test_stack3d_backward.py: the stack alone,
