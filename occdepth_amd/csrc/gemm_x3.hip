@@ -19,6 +19,7 @@
 //
 // Reference semantics replaced: torch.matmul / torch.bmm / F.conv2d(1x1) call sites of occdepth/models/unet2d.py:24-46,137-165
 // (through the tap-GEMM / Winograd-domain forms of this repo's unet2d.py) and the geffnet MBConv expand convolutions.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -321,6 +322,195 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     else store_all(F_{}, std::integral_constant<int, 2>{});
 }
 
+// ------------------------------------------------------------------------------------------------
+// K16w -- the same GEMM, wave-specialised (PRE = 0 only): 256 x 128 tile, 8 waves = 4 MFMA waves (one per SIMD, each owns
+// 64 rows x all 128 columns: 2 x 4 tiles, 128 accumulator registers) + 4 LOADER waves (one per SIMD) that do nothing but
+// global -> split -> LDS for the NEXT 16-k step into the other half of a double-buffered LDS tile.  In the barrier-phased
+// kernel above every wave splits, then every wave multiplies: the matrix pipe idles through ~55 % of a K step
+// (profiles/r04_gemm_x3_v1.txt: 150 TF/s = 36 % of the bf16 peak issued).  Here the split arithmetic and the ds_writes of
+// a loader wave issue in the shadow of the MFMAs of the wave it shares a SIMD with; one barrier per 16-k step.
+constexpr int kWsTM = 256, kWsTN = 128;
+constexpr int kWsARow = 112;                         // A row of ONE 16-k step: 3 x 32 B + 16 B pad (7 slots, odd)
+constexpr int kWsSB = kWsTN * 2 + 64;                // B row (one k, one term)
+constexpr int kWsBTerm = 16 * kWsSB;
+constexpr int kWsStage = kWsTM * kWsARow + 3 * kWsBTerm;   // 28,672 + 15,360 = 44,032 B per buffer
+
+__global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;                   // waves 0-3 multiply, 4-7 load (one of each per SIMD)
+    const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g1 = (lane >> 4) & 1;
+
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int mt_i, nt_i;
+    if (p.n_fast) { nt_i = bid % p.ntiles; mt_i = bid / p.ntiles; }
+    else { mt_i = bid % p.mtiles; nt_i = bid / p.mtiles; }
+    const int bz = blockIdx.y;
+    const int m0 = mt_i * kWsTM, n0 = nt_i * kWsTN;
+    const int K16tot = (p.K + 15) >> 4;
+
+    if (loader) {
+        // ---------------------------------------------------------------- loader waves: 256 threads
+        const int lt = tid - 256;
+        const float* const Ab = p.A + (size_t)bz * p.sA;
+        const float* const Bb = p.B + (size_t)bz * p.sB;
+        // A: 256 rows x 2 chunks of 8 k = 512 items -> 2 per thread; B: 16 k rows x 32 column chunks = 512 items -> 2 per thread
+        size_t a_off[2], b_col[2];
+        int a_dst[2], a_k[2], b_dst[2], b_k[2], b_sh[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = lt + i * 256;
+            const int row = f >> 1, c8 = f & 1;
+            a_off[i] = (size_t)min(m0 + row, p.M - 1) * p.lda;
+            a_dst[i] = row * kWsARow + c8 * 16;
+            a_k[i] = c8 * 8;
+            const int k = f >> 5, c4 = f & 31;
+            b_col[i] = (size_t)min(n0 + c4 * 4, p.N - 4);
+            b_sh[i] = n0 + c4 * 4 - (int)b_col[i];
+            b_dst[i] = k * kWsSB + c4 * 8;
+            b_k[i] = k;
+        }
+        // TWO register sets: the loads of step s + 3 are issued while step s + 1 is committed, so every load has two full
+        // steps (~2 x 1.8k cycles) to come back -- one step was not enough once the B panel of an XCD's tile run stops fitting
+        // its 4 MB L2 (PMC, profiles/r04_pmc_gemm_head_v1.txt: 417 MB fetched for 48 MB of operands, MFMA pipe busy 40 %)
+        f32x4 ra[2][2][2], rb[2][2];
+        auto issue = [&](int k0, int set) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = Ab + a_off[i] + min(k0 + a_k[i], p.K - 8);
+                ra[set][i][0] = *(const f32x4*)src;
+                ra[set][i][1] = *(const f32x4*)(src + 4);
+                rb[set][i] = *(const f32x4u*)(Bb + (size_t)min(k0 + b_k[i], p.K - 1) * p.ldb + b_col[i]);
+            }
+        };
+        auto commit = [&](int k0, int set, unsigned char* buf) {
+            unsigned char* const lB = buf + kWsTM * kWsARow;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool oka = k0 + a_k[i] < p.K;
+                u32x4 hi, mid, lo;
+                split8(oka ? ra[set][i][0] : z, oka ? ra[set][i][1] : z, hi, mid, lo);
+                *(u32x4*)(buf + a_dst[i]) = hi;
+                *(u32x4*)(buf + a_dst[i] + 32) = mid;
+                *(u32x4*)(buf + a_dst[i] + 64) = lo;
+                const bool okb = k0 + b_k[i] < p.K;
+                const f32x4 w = okb ? rb[set][i] : z;
+                const int sh = b_sh[i];
+                f32x4 v;
+                v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
+                v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
+                v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
+                v.w = sh == 0 ? w.w : 0.f;
+                u32x2 h2, m2, l2;
+                split4(v, h2, m2, l2);
+                *(u32x2*)(lB + b_dst[i]) = h2;
+                *(u32x2*)(lB + kWsBTerm + b_dst[i]) = m2;
+                *(u32x2*)(lB + 2 * kWsBTerm + b_dst[i]) = l2;
+            }
+        };
+        // step t lives in register set t & 1 and LDS buffer t & 1
+        issue(0, 0);
+        if (K16tot > 1) issue(16, 1);
+        commit(0, 0, glds);                          // step 0 -> buffer 0
+        if (K16tot > 2) issue(32, 0);
+        __syncthreads();
+        for (int s = 0; s < K16tot; s += 2) {        // unrolled by two: the register-set index is a compile-time constant
+            if (s + 1 < K16tot) {
+                commit((s + 1) * 16, 1, glds + kWsStage);
+                if (s + 3 < K16tot) issue((s + 3) * 16, 1);
+            }
+            __syncthreads();                         // buffer 1 published, buffer 0 consumed
+            if (s + 1 >= K16tot) break;
+            if (s + 2 < K16tot) {
+                commit((s + 2) * 16, 0, glds);
+                if (s + 4 < K16tot) issue((s + 4) * 16, 0);
+            }
+            __syncthreads();                         // buffer 0 published, buffer 1 consumed
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- MFMA waves: wave w owns rows 64 w .. 64 w + 63
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    int a_lane[2], b_lane[4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a_lane[mt] = ((wave * 2 + mt) * 32 + li) * kWsARow + h * 16;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b_lane[nt] = kWsTM * kWsARow + (8 * h + (i16 >> 2)) * kWsSB + (nt * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
+
+#define OCCD_WS(WT, XT)                                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][WT]), bf[nt][XT], acc[mt][nt], 0, 0, 0)
+
+    __syncthreads();                                 // buffer 0 published
+    for (int s = 0; s < K16tot; ++s) {
+        const unsigned char* buf = glds + (s & 1) * kWsStage;
+        u32x4 af[2][3];
+        bf16x8 bf[4][3];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(buf + a_lane[mt] + t * 32);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bf[nt][t] = tr_frag(buf + t * kWsBTerm + b_lane[nt], 4 * kWsSB);
+        OCCD_WS(1, 1);
+        OCCD_WS(0, 2);
+        OCCD_WS(2, 0);
+        OCCD_WS(0, 1);
+        OCCD_WS(1, 0);
+        OCCD_WS(0, 0);
+        __syncthreads();
+    }
+#undef OCCD_WS
+
+    float* const Cb = p.C + (size_t)bz * p.sC;
+    auto store_all = [&](auto has_bias, auto act_sel) {
+        constexpr bool BIAS = decltype(has_bias)::value;
+        constexpr int ACT = decltype(act_sel)::value;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + nt * 32 + li;
+            const bool n_ok = n < p.N;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int mb = m0 + (wave * 2 + mt) * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    float v = acc[mt][nt][r];
+                    if (BIAS) v += p.bias[min(m, p.M - 1)];
+                    if (ACT == 1) v = occd::swish_fast(v);
+                    else if (ACT == 2) v = v > 0.f ? v : v * p.slope;
+                    if (n_ok && m < p.M) Cb[(size_t)m * p.ldc + n] = v;
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (p.bias == nullptr && p.act == 0) store_all(F_{}, std::integral_constant<int, 0>{});
+    else if (p.bias != nullptr && p.act == 1) store_all(T_{}, std::integral_constant<int, 1>{});
+    else if (p.bias != nullptr && p.act == 2) store_all(T_{}, std::integral_constant<int, 2>{});
+    else if (p.bias != nullptr) store_all(T_{}, std::integral_constant<int, 0>{});
+    else if (p.act == 1) store_all(F_{}, std::integral_constant<int, 1>{});
+    else store_all(F_{}, std::integral_constant<int, 2>{});
+}
+
 struct VariantG {
     int MT, NT, WM, WN;
     void (*kern[3])(const GemmP);
@@ -393,7 +583,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (a->pre == 1 && ((reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 7))) return OCCD_EINVAL;
     if (a->pre == 2 && ((reinterpret_cast<uintptr_t>(a->B) & 15) || (a->stride_b & 7))) return OCCD_EINVAL;
     if (reinterpret_cast<uintptr_t>(a->C) & 3) return OCCD_EINVAL;
-    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG) return OCCD_EINVAL;
+    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 1) return OCCD_EINVAL;
     int pick = a->tile_hint - 1;
     if (pick < 0) {
         pick = kNumVariantsG - 1;
@@ -403,6 +593,16 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
             const long wgs = ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
             if (wgs >= 160) { pick = i; break; }   // measured (profiles/r04_gemm_x3.txt): the large tiles win down to ~0.6 workgroups per CU
         }
+    }
+    // the wave-specialised 256 x 128 kernel takes the launches the 256 x 128 tile would (float32 operands): hint 5 forces it,
+    // hint 0 picks it (OCCD_GEMM_WS=0 in the environment keeps the barrier-phased kernels for A/B)
+    static const bool ws_off = getenv("OCCD_GEMM_WS") != nullptr && getenv("OCCD_GEMM_WS")[0] == '0';
+    // measured (profiles/r04_gemm_x3_v3_ws.txt): the two forms are within 5 % of each other; K16w leads on the long-K launches
+    // (1/16, 1/8 levels), the barrier-phased kernel on the short-K ones (K = 160 / 320)
+    const bool ws = a->pre == 0 && (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 512));
+    if (a->tile_hint == kNumVariantsG + 1) {
+        if (a->pre != 0) return OCCD_EINVAL;
+        pick = 0;
     }
     const VariantG& v = kVariantsG[pick];
     const int TM = v.MT * v.WM * 32, TN = v.NT * v.WN * 32;
@@ -420,12 +620,13 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     const long nwg = (long)p.mtiles * p.ntiles;
     if (nwg >= (1L << 31)) return OCCD_EINVAL;
     p.nwg = (unsigned)nwg;
-    const size_t lds = (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
-    void (*kern)(const GemmP) = v.kern[a->pre];
+    const size_t lds = ws ? (size_t)2 * kWsStage
+                          : (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
+    void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel : v.kern[a->pre];
     if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double flops = 2.0 * a->M * a->N * a->K * a->batch;
     const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
-    occd::ProfScope prof(a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : "gemm_f32x3_preB", (hipStream_t)stream, flops, bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(v.WM * v.WN * 64), lds, (hipStream_t)stream, p);
+    occd::ProfScope prof(ws ? "gemm_f32x3_ws" : a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : "gemm_f32x3_preB", (hipStream_t)stream, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(ws ? 512 : v.WM * v.WN * 64), lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }

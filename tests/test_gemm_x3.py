@@ -53,6 +53,10 @@ def test_gemm_x3_vs_float64(hip, name, packed):
     xb = hip.GemmPacked(bd, "b") if packed == "b" else bd
     got = run(hip, xa, xb).cpu().double()
     assert got.shape == ref.shape
+    if packed is None:                                     # the wave-specialised kernel on the same operands
+        got_ws = run(hip, xa, xb, tile_hint=5).cpu().double()
+        assert float((got_ws - ref).abs().max() / ref.abs().max()) < max(2e-6, 1.25 * float(
+            (torch.matmul(ad, bd).cpu().double() - ref).abs().max() / ref.abs().max())), name
     scale = ref.abs().max()
     err = float((got - ref).abs().max() / scale)
     err32 = float((torch.matmul(ad, bd).cpu().double() - ref).abs().max() / scale)
@@ -61,7 +65,7 @@ def test_gemm_x3_vs_float64(hip, name, packed):
     assert err < max(2e-6, 1.25 * err32), (name, err, err32)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5])          # 5 = the wave-specialised 256 x 128 kernel (K16w)
 def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
     g = torch.Generator().manual_seed(hint)
     batch, M, N, K = 2, 300, 333, 72                       # M, N tails in every variant; K = 2 steps + a tail of 8
@@ -73,7 +77,10 @@ def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
         got = run(hip, a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=act, slope=0.2, tile_hint=hint).cpu().double()
         err = float((got - ref).abs().max() / ref.abs().max())
         assert err < (3e-6 if act == "swish" else 2e-6), (hint, act, err)      # (swish: hardware exp2 / rcp, ~3 ulp)
-    for xa, xb in ((a.to(DEV), b.to(DEV)), (hip.GemmPacked(a.to(DEV), "a"), b.to(DEV)), (a.to(DEV), hip.GemmPacked(b.to(DEV), "b"))):
+    forms = [(a.to(DEV), b.to(DEV))]
+    if hint != 5:                                          # (K16w takes float32 operands only)
+        forms += [(hip.GemmPacked(a.to(DEV), "a"), b.to(DEV)), (a.to(DEV), hip.GemmPacked(b.to(DEV), "b"))]
+    for xa, xb in forms:
         got = run(hip, xa, xb, tile_hint=hint).cpu().double()
         assert float((got - (lin - bias.double().view(1, -1, 1))).abs().max() / lin.abs().max()) < 2e-6
 

@@ -31,11 +31,8 @@ def main():
         b = torch.randn(batch, K, N, device="cuda")
         out = torch.empty(batch, M, N, device="cuda")
         fns = {"torch.matmul fp32": lambda: torch.matmul(a, b, out=out)}
-        pk = hip.GemmPacked(a, "a") if not ab else hip.GemmPacked(b, "b")        # the static operand (weights) pre-split
-        for hint in (0, 1, 2):
-            fns[f"K16 v{hint}"] = lambda hint=hint: hip.gemm_x3(a, b, out=out, tile_hint=hint)
-            fns[f"K16pre v{hint}"] = (lambda hint=hint: hip.gemm_x3(pk, b, out=out, tile_hint=hint)) if not ab else \
-                (lambda hint=hint: hip.gemm_x3(a, pk, out=out, tile_hint=hint))
+        for hint, nm in ((1, "K16 256x128"), (2, "K16 128x128"), (5, "K16w 256x128 wave-specialised"), (0, "K16 auto")):
+            fns[nm] = lambda hint=hint: hip.gemm_x3(a, b, out=out, tile_hint=hint)
         ms = time_many(fns, rounds=3, iters=5)
         fl = 2.0 * M * N * K * batch
         line = "  ".join(f"{k}: {t:7.3f} ms {fl / t / 1e9:6.1f} TF/s" for k, t in ms.items())

@@ -42,7 +42,9 @@ def train_main(path, out):
 def main(path, out, n_fwd=5):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "conv3d_c32_slide_kernel<1>" in r["Kernel_Name"]]
+    # (the dilation-1 head launches: conv3d_c32_slide_kernel<1> in the exact-fp32 mode, conv3d_c32_slide_x3_kernel<1, NRES> in the
+    # default split mode -- 4 per forward either way)
+    marks = [i for i, r in enumerate(rows) if re.search(r"conv3d_c32_slide(_x3)?_kernel<1[,>]", r["Kernel_Name"])]
     assert len(marks) >= 4 * (n_fwd + 1), "not enough forwards in the trace"
     # a forward ends with its 4th <1> launch (+ the cascade tail right after); start after forward (F - n_fwd)'s end
     fwd_ends = marks[3::4]
