@@ -335,6 +335,10 @@ constexpr int kWsSB = kWsTN * 2 + 64;                // B row (one k, one term)
 constexpr int kWsBTerm = 16 * kWsSB;
 constexpr int kWsStage = kWsTM * kWsARow + 3 * kWsBTerm;   // 28,672 + 15,360 = 44,032 B per buffer
 
+// DBG (development A/B, wrong results, only with -DOCCD_GEMM_DEV_VARIANTS): 1 = truncate instead of split (what does the split
+// arithmetic cost?), 2 = loaders skip the global loads (what does memory cost?), 3 = MFMA waves read LDS in step 0 only (what do
+// the fragment reads cost?), 4 = loaders only keep the barriers (what does the whole loader cost?), 5 = no barriers at all in the K loop (what do the barriers cost?)
+template <int DBG>
 __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
     const int tid = threadIdx.x;
@@ -381,6 +385,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
         // its 4 MB L2 (PMC, profiles/r04_pmc_gemm_head_v1.txt: 417 MB fetched for 48 MB of operands, MFMA pipe busy 40 %)
         f32x4 ra[2][2][2], rb[2][2];
         auto issue = [&](int k0, int set) {
+            if (DBG == 2 && k0 > 16) return;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float* src = Ab + a_off[i] + min(k0 + a_k[i], p.K - 8);
@@ -396,7 +401,16 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
             for (int i = 0; i < 2; ++i) {
                 const bool oka = k0 + a_k[i] < p.K;
                 u32x4 hi, mid, lo;
-                split8(oka ? ra[set][i][0] : z, oka ? ra[set][i][1] : z, hi, mid, lo);
+                if (DBG == 1) {
+                    const f32x4 x0 = ra[set][i][0], x1 = ra[set][i][1];
+                    hi = u32x4{__builtin_amdgcn_perm(__float_as_uint(x0.y), __float_as_uint(x0.x), 0x07060302u),
+                               __builtin_amdgcn_perm(__float_as_uint(x0.w), __float_as_uint(x0.z), 0x07060302u),
+                               __builtin_amdgcn_perm(__float_as_uint(x1.y), __float_as_uint(x1.x), 0x07060302u),
+                               __builtin_amdgcn_perm(__float_as_uint(x1.w), __float_as_uint(x1.z), 0x07060302u)};
+                    mid = hi; lo = hi;
+                } else {
+                    split8(oka ? ra[set][i][0] : z, oka ? ra[set][i][1] : z, hi, mid, lo);
+                }
                 *(u32x4*)(buf + a_dst[i]) = hi;
                 *(u32x4*)(buf + a_dst[i] + 32) = mid;
                 *(u32x4*)(buf + a_dst[i] + 64) = lo;
@@ -409,7 +423,13 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
                 v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
                 v.w = sh == 0 ? w.w : 0.f;
                 u32x2 h2, m2, l2;
-                split4(v, h2, m2, l2);
+                if (DBG == 1) {
+                    h2 = u32x2{__builtin_amdgcn_perm(__float_as_uint(w.y), __float_as_uint(w.x), 0x07060302u),
+                               __builtin_amdgcn_perm(__float_as_uint(w.w), __float_as_uint(w.z), 0x07060302u)};
+                    m2 = h2; l2 = h2;
+                } else {
+                    split4(v, h2, m2, l2);
+                }
                 *(u32x2*)(lB + b_dst[i]) = h2;
                 *(u32x2*)(lB + kWsBTerm + b_dst[i]) = m2;
                 *(u32x2*)(lB + 2 * kWsBTerm + b_dst[i]) = l2;
@@ -422,6 +442,13 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
         if (K16tot > 2) issue(32, 0);
         __syncthreads();
         for (int s = 0; s < K16tot; s += 2) {        // unrolled by two: the register-set index is a compile-time constant
+            if (DBG == 4) {
+                __syncthreads();
+                if (s + 1 >= K16tot) break;
+                __syncthreads();
+                continue;
+            }
+            if (DBG == 5) continue;
             if (s + 1 < K16tot) {
                 commit((s + 1) * 16, 1, glds + kWsStage);
                 if (s + 3 < K16tot) issue((s + 3) * 16, 1);
@@ -456,25 +483,27 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][WT]), bf[nt][XT], acc[mt][nt], 0, 0, 0)
 
     __syncthreads();                                 // buffer 0 published
+    u32x4 af[2][3];
+    bf16x8 bf[4][3];
     for (int s = 0; s < K16tot; ++s) {
         const unsigned char* buf = glds + (s & 1) * kWsStage;
-        u32x4 af[2][3];
-        bf16x8 bf[4][3];
+        if (DBG != 3 || s == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(buf + a_lane[mt] + t * 32);
+                for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(buf + a_lane[mt] + t * 32);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) bf[nt][t] = tr_frag(buf + t * kWsBTerm + b_lane[nt], 4 * kWsSB);
+                for (int t = 0; t < 3; ++t) bf[nt][t] = tr_frag(buf + t * kWsBTerm + b_lane[nt], 4 * kWsSB);
+        }
         OCCD_WS(1, 1);
         OCCD_WS(0, 2);
         OCCD_WS(2, 0);
         OCCD_WS(0, 1);
         OCCD_WS(1, 0);
         OCCD_WS(0, 0);
-        __syncthreads();
+        if (DBG != 5) __syncthreads();
     }
 #undef OCCD_WS
 
@@ -622,7 +651,13 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     p.nwg = (unsigned)nwg;
     const size_t lds = ws ? (size_t)2 * kWsStage
                           : (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
-    void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel : v.kern[a->pre];
+    void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel<0> : v.kern[a->pre];
+#ifdef OCCD_GEMM_DEV_VARIANTS
+    if (ws && getenv("OCCD_GEMM_DBG") != nullptr)
+        kern = getenv("OCCD_GEMM_DBG")[0] == '1' ? gemm_x3_ws_kernel<1> : getenv("OCCD_GEMM_DBG")[0] == '2' ? gemm_x3_ws_kernel<2> :
+               getenv("OCCD_GEMM_DBG")[0] == '3' ? gemm_x3_ws_kernel<3> : getenv("OCCD_GEMM_DBG")[0] == '4' ? gemm_x3_ws_kernel<4> :
+               getenv("OCCD_GEMM_DBG")[0] == '5' ? gemm_x3_ws_kernel<5> : kern;
+#endif
     if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double flops = 2.0 * a->M * a->N * a->K * a->batch;
     const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
