@@ -243,6 +243,10 @@ typedef struct occd_gemm_args {
     int32_t pre;                           /* 0: A, B float32; 1: A = occd_gemm_x3_pack(role 0) image; 2: B = role-1 image */
 } occd_gemm_args;
 int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
+/* K16t, the "NT" form: C[b][m][n] = sum_k A[b][m][k] B[b][n][k], BOTH operands with k contiguous (lda, ldb >= K), any dword
+ * alignment, any K: autograd's weight gradient of a pointwise convolution, dW = gy (Cout x HW) . x^T, on NCHW tensors as they
+ * lie (training step, the geffnet MBConv 1x1 convolutions).  bias / act / pre must be NULL / 0 / 0; tile_hint 0 / 1 / 2.    */
+int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream);
 /* A static operand (weights) split once into its three bf16 terms in MFMA fragment order, so the GEMM reads it straight
  * from L2 (no LDS, no split arithmetic): role 0 = an A operand (rows x K, k contiguous, ld >= K), role 1 = a B operand
  * (K x rows, "row" = column index contiguous, ld >= rows).  `out`: occd_gemm_x3_packed_elems(rows, K) bf16 per batch item,

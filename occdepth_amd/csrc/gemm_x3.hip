@@ -540,6 +540,144 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
     else store_all(F_{}, std::integral_constant<int, 2>{});
 }
 
+// ------------------------------------------------------------------------------------------------
+// K16t -- "NT" form for weight gradients: C[b][m][n] = sum_k A[b][m][k] * B[b][n][k], BOTH operands with k contiguous and
+// of ANY dword alignment and any K (rows of H*W pixels: odd lengths are the rule).  dW of a pointwise convolution is
+// gy (Cout x HW) . x^T (HW x Cin): both tensors lie k(= pixel)-contiguous in NCHW memory, so both are staged like K16's A
+// operand (rows of [hi | mid | lo] 32 k, conflict-free ds_read_b128 fragments) -- no transposing reads, no transposed copy.
+// The last K step masks element-wise (a per-lane branch that only the tail step takes).
+template <int MT, int NT, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) {
+    constexpr int NTH = WM * WN * 64, TM = WM * MT * 32, TN = WN * NT * 32;
+    constexpr int NA = TM * 4 / NTH, NB = TN * 4 / NTH;
+    static_assert(TM * 4 % NTH == 0 && TN * 4 % NTH == 0, "staging split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
+    unsigned char* const lA = glds;
+    unsigned char* const lB = glds + TM * kARow;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, h = lane >> 5;
+    const int mt_i = blockIdx.x % p.mtiles, nt_i = blockIdx.x / p.mtiles;
+    const int bz = blockIdx.y;
+    const int m0 = mt_i * TM, n0 = nt_i * TN;
+    const float* const Ab = p.A + (size_t)bz * p.sA;
+    const float* const Bb = p.B + (size_t)bz * p.sB;
+
+    const float* a_src[NA];
+    const float* b_src[NB];
+    int a_dst[NA], b_dst[NB];
+    const int kc = (tid & 3) * 8;                          // this thread's 8-k chunk inside a 32-k step (same for all its items)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid + i * NTH) >> 2;
+        a_src[i] = Ab + (size_t)min(m0 + row, p.M - 1) * p.lda + kc;
+        a_dst[i] = row * kARow + (tid & 3) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (tid + i * NTH) >> 2;
+        b_src[i] = Bb + (size_t)min(n0 + row, p.N - 1) * p.ldb + kc;
+        b_dst[i] = row * kARow + (tid & 3) * 16;
+    }
+    f32x4 ra[NA][2], rb[NB][2];
+    auto load8 = [&](const float* src, int k0, f32x4 (&v)[2]) {
+        const int rem = p.K - (k0 + kc);
+        if (rem >= 8) {
+            v[0] = *(const f32x4u*)(src + k0);
+            v[1] = *(const f32x4u*)(src + k0 + 4);
+        } else {                                           // tail step only
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = j < rem ? src[k0 + j] : 0.f;
+            v[0] = f32x4{t[0], t[1], t[2], t[3]};
+            v[1] = f32x4{t[4], t[5], t[6], t[7]};
+        }
+    };
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) load8(a_src[i], k0, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) load8(b_src[i], k0, rb[i]);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x4 hi, mid, lo;
+            split8(ra[i][0], ra[i][1], hi, mid, lo);
+            *(u32x4*)(lA + a_dst[i]) = hi;
+            *(u32x4*)(lA + a_dst[i] + 64) = mid;
+            *(u32x4*)(lA + a_dst[i] + 128) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            u32x4 hi, mid, lo;
+            split8(rb[i][0], rb[i][1], hi, mid, lo);
+            *(u32x4*)(lB + b_dst[i]) = hi;
+            *(u32x4*)(lB + b_dst[i] + 64) = mid;
+            *(u32x4*)(lB + b_dst[i] + 128) = lo;
+        }
+    };
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    int a_lane[MT], b_lane[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_lane[mt] = ((wm * MT + mt) * 32 + li) * kARow + h * 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b_lane[nt] = ((wn * NT + nt) * 32 + li) * kARow + h * 16;
+
+#define OCCD_GNT(WT, XT)                                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][WT]), __builtin_bit_cast(bf16x8, bf[nt][XT]), acc[mt][nt], 0, 0, 0)
+    const int ksteps = (p.K + 31) >> 5;
+    issue(0);
+    for (int s = 0; s < ksteps; ++s) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (s + 1 < ksteps) issue((s + 1) * 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[MT][3], bf[NT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(lA + a_lane[mt] + t * 64 + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bf[nt][t] = *(const u32x4*)(lB + b_lane[nt] + t * 64 + ks * 32);
+            OCCD_GNT(1, 1);
+            OCCD_GNT(0, 2);
+            OCCD_GNT(2, 0);
+            OCCD_GNT(0, 1);
+            OCCD_GNT(1, 0);
+            OCCD_GNT(0, 0);
+        }
+    }
+#undef OCCD_GNT
+    float* const Cb = p.C + (size_t)bz * p.sC;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + li;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mb = m0 + (wm * MT + mt) * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (n < p.N && m < p.M) Cb[(size_t)m * p.ldc + n] = acc[mt][nt][r];
+            }
+        }
+    }
+}
+
 struct VariantG {
     int MT, NT, WM, WN;
     void (*kern[3])(const GemmP);
@@ -665,3 +803,37 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(ws ? 512 : v.WM * v.WN * 64), lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }
+
+// K16t: C[b] = A[b] . B[b]^T with both operands k-contiguous (lda, ldb >= K; any dword alignment; any K >= 1): the weight
+// gradient of a pointwise convolution, dW = gy (Cout x HW) . x^T.  a->act / bias / pre must be 0 / NULL / 0.
+extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
+    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || a->pre != 0 || a->act != 0 || a->bias != nullptr) return OCCD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->A) & 3) || (reinterpret_cast<uintptr_t>(a->B) & 3) || (reinterpret_cast<uintptr_t>(a->C) & 3))
+        return OCCD_EINVAL;
+    if (a->tile_hint < 0 || a->tile_hint > 2) return OCCD_EINVAL;
+    // 128 x 128 tiles unless that leaves too few workgroups (weight matrices are small: M x N = Cout x Cin)
+    const long wg128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
+    const bool small = a->tile_hint == 2 || (a->tile_hint == 0 && wg128 < 128);
+    const int TM = small ? 64 : 128, TN = small ? 64 : 128;
+    GemmP p;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = nullptr;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a; p.sB = a->stride_b; p.sC = a->stride_c;
+    p.act = 0; p.slope = 0.f;
+    p.mtiles = (a->M + TM - 1) / TM;
+    p.ntiles = (a->N + TN - 1) / TN;
+    p.n_fast = 0;
+    const long nwg = (long)p.mtiles * p.ntiles;
+    if (nwg >= (1L << 31)) return OCCD_EINVAL;
+    p.nwg = (unsigned)nwg;
+    const size_t lds = (size_t)(TM + TN) * kARow;
+    void (*kern)(const GemmP) = small ? gemm_x3_nt_kernel<1, 1, 2, 2> : gemm_x3_nt_kernel<2, 2, 2, 2>;
+    if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
+    const double flops = 2.0 * a->M * a->N * a->K * a->batch;
+    occd::ProfScope prof("gemm_f32x3_nt", (hipStream_t)stream, flops, 4.0 * a->batch * ((double)(a->M + a->N) * a->K + (double)a->M * a->N));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(256), lds, (hipStream_t)stream, p);
+    return occd::check_launch();
+}
+

@@ -142,6 +142,7 @@ EXPORTS = {
     "occd_flosp_sample_fwd": (c_int32, [POINTER(FlospArgs), c_void_p]),
     "occd_rows_gemm_fwd": (c_int32, [POINTER(RowsGemmArgs), c_void_p]),
     "occd_gemm_f32x3": (c_int32, [POINTER(GemmArgs), c_void_p]),
+    "occd_gemm_f32x3_nt": (c_int32, [POINTER(GemmArgs), c_void_p]),
     "occd_gemm_x3_packed_elems": (c_int64, [c_int32, c_int32]),
     "occd_gemm_x3_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_int64, c_void_p]),
     "occd_rows_gemm_packed_floats": (c_int64, [c_int32, c_int32]),
@@ -567,6 +568,75 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
     return out[0] if squeeze and out.dim() == 3 else out
+
+
+def gemm_x3_nt(a, b, out=None, tile_hint=0):
+    """K16t (occd_gemm_f32x3_nt): out[i] = a[i] @ b[i].T for a (batch, M, K), b (batch, N, K) -- both k-contiguous, any
+    alignment / K: the weight gradient of a pointwise convolution (gy (Cout, HW) x (Cin, HW))."""
+    for t, nm in ((a, "a"), (b, "b")):
+        if t.dim() != 3 or t.dtype != torch.float32 or not t.is_cuda or t.stride(-1) != 1:
+            raise RuntimeError(f"gemm_x3_nt: {nm} must be a (batch, rows, K) float32 GPU tensor with unit innermost stride")
+    batch, M, K = a.shape
+    if b.shape[0] != batch or b.shape[2] != K:
+        raise RuntimeError("gemm_x3_nt: operand shapes do not match")
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty((batch, M, N), device=a.device, dtype=torch.float32)
+    q = GemmArgs()
+    q.A, q.B, q.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    q.M, q.N, q.K, q.batch = M, N, K, batch
+    q.lda, q.ldb, q.ldc = a.stride(1), b.stride(1), out.stride(1)
+    q.stride_a, q.stride_b, q.stride_c = a.stride(0), b.stride(0), out.stride(0)
+    q.tile_hint = tile_hint
+    if _PROFILING:
+        set_tag("%dx%dx%d b%d" % (M, N, K, batch))
+    _check(load().occd_gemm_f32x3_nt(ctypes.byref(q), _stream()), "occd_gemm_f32x3_nt")
+    return out
+
+
+class _PwConvFn(torch.autograd.Function):
+    """Training: a pointwise (1x1, stride 1, no bias) convolution of an NCHW tensor on K16 / K16t -- forward W . x, data
+    gradient W^T . gy (both the NN kernel, float32-level accuracy on the bf16 matrix pipe) and weight gradient gy . x^T (the
+    NT kernel, on the tensors as they lie) -- instead of MIOpen / rocBLAS behind `aten::convolution_backward`: the 55 MBConv
+    blocks' expand / project convolutions were 13 ms of the 106 ms bf16-mode step (profiles/r04_train_step_bf16_aten_ops.txt)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w):
+        B, C, H, W = x.shape
+        xc = x if x.is_contiguous() else x.contiguous()
+        ctx.save_for_backward(xc, w)
+        return gemm_x3(w.detach().reshape(w.shape[0], C), xc.view(B, C, H * W)).view(B, w.shape[0], H, W)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, C, H, W = x.shape
+        Co = w.shape[0]
+        g = gy.float()
+        g = (g if g.is_contiguous() else g.contiguous()).view(B, Co, H * W)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_x3(w.detach().reshape(Co, C).t().contiguous(), g).view(B, C, H, W)
+        if ctx.needs_input_grad[1]:
+            gw = gemm_x3_nt(g, x.view(B, C, H * W)).sum(0).view(Co, C, 1, 1)
+        return gx, gw
+
+
+PW_TRAIN = os.environ.get("OCCDEPTH_TRAIN_PW_GEMM", "1") == "1"
+
+
+def pw_conv_autograd_ok(conv, x):
+    """The pointwise convolutions `_PwConvFn` takes: 1x1, stride 1, one group, no bias, channel counts K16 accepts."""
+    return (PW_TRAIN and GEMM_X3 and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.dilation == (1, 1) and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
+            and x.shape[2] * x.shape[3] >= 4 and x.shape[0] <= 65535)
+
+
+def pw_conv_autograd(x, w):
+    return _PwConvFn.apply(x, w)
 
 
 # K16 instead of the library GEMMs in the eval path of the 2-D network (tap GEMMs, Winograd-domain products, expand 1x1

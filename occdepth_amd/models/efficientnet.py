@@ -124,6 +124,9 @@ class Conv2dSame(nn.Conv2d):
             # training: depthwise forward / data gradient / weight gradient on the HIP kernels (MIOpen's fp32 depthwise
             # path is the naive fallback: 17.5 ms of a config-2 step)
             return hip.dwconv2d_same_autograd(x, self.weight, self.stride[0])
+        if needs_autograd(self) and hip.pw_conv_autograd_ok(self, x):
+            # training: expand / project convolutions forward, data gradient and weight gradient on K16 / K16t
+            return hip.pw_conv_autograd(x, self.weight)
         pads = []
         for size, k, s, d in zip(x.shape[-2:], self.kernel_size, self.stride, self.dilation):
             total = max((math.ceil(size / s) - 1) * s + (k - 1) * d + 1 - size, 0)

@@ -112,3 +112,49 @@ def test_gemm_x3_rejects_bad_arguments(hip):
     assert lib.occd_gemm_f32x3(None, None) == -1
     q = hip.GemmArgs()
     assert lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+
+
+NT_SHAPES = {
+    "dw_project_1_32": (2, 384, 2304, 468),          # dW of 2304 -> 384 at 12 x 39 pixels: (Cout, HW) x (Cin, HW)
+    "dw_expand_1_4": (2, 288, 48, 28365 // 8),       # K odd, rows of odd length
+    "dw_tiny": (3, 40, 24, 7),                       # K < 8: the element-wise tail only
+    "dw_tail_5": (1, 70, 130, 37),                   # K = 32 + 5
+}
+
+
+@pytest.mark.parametrize("name", list(NT_SHAPES))
+@pytest.mark.parametrize("hint", [0, 1, 2])
+def test_gemm_x3_nt_vs_float64(hip, name, hint):
+    """K16t (occd_gemm_f32x3_nt): C = A . B^T with both operands k-contiguous, any alignment, any K (weight gradients of
+    pointwise convolutions) against float64, incl. operands that are views into wider buffers (odd row strides)."""
+    batch, M, N, K = NT_SHAPES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    abig = torch.randn(batch, M, K + 3, generator=g).to(DEV)
+    bbig = torch.randn(batch, N, K + 1, generator=g).to(DEV)
+    a, b = abig[:, :, 2:2 + K], bbig[:, :, 1:1 + K]
+    ref = torch.matmul(a.double().cpu(), b.double().cpu().transpose(1, 2))
+    got = hip.gemm_x3_nt(a, b, tile_hint=hint).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    err32 = float((torch.matmul(a, b.transpose(1, 2)).cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"gemm_x3_nt {name} hint {hint}: max err {err:.2e} (torch.matmul fp32 {err32:.2e})")
+    assert err < max(2e-6, 1.25 * err32), (name, hint, err, err32)
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 288, 23, 77), (2, 2304, 384, 12, 39), (1, 32, 32, 31, 45)])
+def test_pointwise_conv_autograd_matches_aten(hip, shape):
+    """hip._PwConvFn (training path of the MBConv 1x1 convolutions): forward, data gradient and weight gradient against
+    ATen float64 on the CPU."""
+    import torch.nn.functional as F
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    gy = torch.randn(B, cout, H, W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(xr, wr).backward(gy.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = hip.pw_conv_autograd(xd, wd)
+    y.backward(gy.to(DEV))
+    for got, ref, what in ((y, F.conv2d(x.double(), w.double()), "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
+        err = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        assert err < 3e-6, (shape, what, err)
