@@ -225,7 +225,8 @@ int occd_rows_gemm_pack(const float* w, float* wpk, int32_t K, int32_t N, int32_
  * at 1/8 and 1/16 --, and the geffnet MBConv expand 1x1 convolutions): torch.matmul / torch.bmm / F.conv2d there.
  * A: M x K with k contiguous (lda >= K, K % 8 == 0, 16-byte aligned rows); B: K x N with n contiguous (ldb >= N, N >= 4, any
  * dword alignment); C: M x N (ldc >= N).  stride_a == 0 shares A over the batch (weights).  bias: M floats or NULL.
- * act: OCCD_GEMM_ACT_NONE / _SWISH / _LEAKY (slope).  tile_hint: 0 = choose, 1 .. 4 = force a tile variant (tests).        */
+ * act: OCCD_GEMM_ACT_NONE / _SWISH / _LEAKY (slope).  tile_hint: 0 = choose, 1 .. 5 = force a tile variant, 6 = the
+ * wave-specialised 256 x 128 kernel (tests / A-B).                                                                           */
 #define OCCD_GEMM_ACT_NONE 0
 #define OCCD_GEMM_ACT_SWISH 1
 #define OCCD_GEMM_ACT_LEAKY 2
@@ -245,8 +246,12 @@ typedef struct occd_gemm_args {
 int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
 /* K16t, the "NT" form: C[b][m][n] = sum_k A[b][m][k] B[b][n][k], BOTH operands with k contiguous (lda, ldb >= K), any dword
  * alignment, any K: autograd's weight gradient of a pointwise convolution, dW = gy (Cout x HW) . x^T, on NCHW tensors as they
- * lie (training step, the geffnet MBConv 1x1 convolutions).  bias / act / pre must be NULL / 0 / 0; tile_hint 0 / 1 / 2.    */
+ * lie (training step, the geffnet MBConv 1x1 convolutions).  The reduction dimension is split over `act` (>= 1) workgroup
+ * groups -- a weight gradient is a small matrix reduced over many pixels --: C receives batch x act partial matrices
+ * (batch-major, stride_c elements apart) which the caller sums; occd_gemm_f32x3_nt_splits proposes `act` (every split must own
+ * at least one 32-k step: pass exactly what it returns, or 1).  bias / pre must be NULL / 0; tile_hint 0 / 1 / 2.            */
 int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream);
+int32_t occd_gemm_f32x3_nt_splits(int32_t M, int32_t N, int32_t K, int32_t batch);
 /* A static operand (weights) split once into its three bf16 terms in MFMA fragment order, so the GEMM reads it straight
  * from L2 (no LDS, no split arithmetic): role 0 = an A operand (rows x K, k contiguous, ld >= K), role 1 = a B operand
  * (K x rows, "row" = column index contiguous, ld >= rows).  `out`: occd_gemm_x3_packed_elems(rows, K) bf16 per batch item,

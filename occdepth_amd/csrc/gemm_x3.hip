@@ -564,6 +564,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) 
     const int m0 = mt_i * TM, n0 = nt_i * TN;
     const float* const Ab = p.A + (size_t)bz * p.sA;
     const float* const Bb = p.B + (size_t)bz * p.sB;
+    // split-K over blockIdx.z: a weight gradient is a SMALL matrix (Cout x Cin) reduced over MANY pixels -- without the
+    // split a 288 x 48 gradient at 93 x 305 pixels is 6 workgroups walking K = 28,365 alone.  Split z owns the 32-k steps
+    // [z * p.act, (z + 1) * p.act) (p.act = steps per split) and writes its own partial C (summed by the caller).
+    const int step0 = blockIdx.z * p.act;
+    const int step1 = min(step0 + p.act, (p.K + 31) >> 5);
 
     const float* a_src[NA];
     const float* b_src[NB];
@@ -635,13 +640,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) 
 #define OCCD_GNT(WT, XT)                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt][WT]), __builtin_bit_cast(bf16x8, bf[nt][XT]), acc[mt][nt], 0, 0, 0)
-    const int ksteps = (p.K + 31) >> 5;
-    issue(0);
-    for (int s = 0; s < ksteps; ++s) {
+    issue(step0 * 32);
+    for (int s = step0; s < step1; ++s) {
         __syncthreads();
         commit();
         __syncthreads();
-        if (s + 1 < ksteps) issue((s + 1) * 32);
+        if (s + 1 < step1) issue((s + 1) * 32);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 af[MT][3], bf[NT][3];
@@ -662,7 +666,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) 
         }
     }
 #undef OCCD_GNT
-    float* const Cb = p.C + (size_t)bz * p.sC;
+    float* const Cb = p.C + ((size_t)bz * gridDim.z + blockIdx.z) * p.sC;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + (wn * NT + nt) * 32 + li;
@@ -689,7 +693,10 @@ const VariantG kVariantsG[] = {
     OCCD_VARIANT_G(2, 2, 2, 2),   // 1: 128 x 128, 256 threads
     OCCD_VARIANT_G(2, 1, 2, 2),   // 2: 128 x 64
     OCCD_VARIANT_G(1, 1, 2, 2),   // 3: 64 x 64
+    OCCD_VARIANT_G(2, 2, 1, 4),   // 4: 64 x 256 (few rows, many columns: project convolutions at high resolution, M = 48 ... 64)
 };
+// relative throughput of a FULL tile of each variant (profiles/r04_gemm_x3_v3_ws.txt; the 64-row shapes are LDS-read bound)
+const double kVariantEff[] = {1.0, 0.75, 0.6, 0.45, 0.7};
 constexpr int kNumVariantsG = sizeof(kVariantsG) / sizeof(kVariantsG[0]);
 
 // role 0: the A operand (rows x K, k contiguous) -> [row tile 32][k16][term][lane][8]: lane = (row & 31) + 32 ((k & 15) >> 3)
@@ -736,7 +743,7 @@ extern "C" int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_
     return occd::check_launch();
 }
 
-// a->tile_hint: 0 = pick (the largest tile that still gives >= 160 workgroups, else the finest), 1 .. 4 = force a variant.
+// a->tile_hint: 0 = pick (cheapest variant by padded work / throughput), 1 .. 5 = force a tile variant, 6 = force K16w.
 // a->pre: 0 = A and B float32; 1 = a->A is the role-0 image of occd_gemm_x3_pack (lda ignored, stride_a = bf16 elements
 // between batch items, 0 = shared); 2 = a->B is the role-1 image (ldb ignored, stride_b likewise).
 extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
@@ -752,13 +759,19 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (reinterpret_cast<uintptr_t>(a->C) & 3) return OCCD_EINVAL;
     if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 1) return OCCD_EINVAL;
     int pick = a->tile_hint - 1;
+    if (a->tile_hint == kNumVariantsG + 1) pick = 0;
     if (pick < 0) {
-        pick = kNumVariantsG - 1;
+        // cheapest variant: padded work (tile quantisation in M and N) / the variant's throughput, with a penalty when fewer
+        // than ~160 workgroups are left for 256 CUs
+        double best = 1e300;
         for (int i = 0; i < kNumVariantsG; ++i) {
             const VariantG& v = kVariantsG[i];
             const long tm = v.MT * v.WM * 32, tn = v.NT * v.WN * 32;
-            const long wgs = ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
-            if (wgs >= 160) { pick = i; break; }   // measured (profiles/r04_gemm_x3.txt): the large tiles win down to ~0.6 workgroups per CU
+            const long mt = (a->M + tm - 1) / tm, nt = (a->N + tn - 1) / tn;
+            const double wgs = (double)mt * nt * a->batch;
+            double cost = (double)(mt * tm) * (double)(nt * tn) / kVariantEff[i];
+            if (wgs < 160.0) cost *= 160.0 / wgs;
+            if (cost < best) { best = cost; pick = i; }
         }
     }
     // the wave-specialised 256 x 128 kernel takes the launches the 256 x 128 tile would (float32 operands): hint 5 forces it,
@@ -767,10 +780,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     // measured (profiles/r04_gemm_x3_v3_ws.txt): the two forms are within 5 % of each other; K16w leads on the long-K launches
     // (1/16, 1/8 levels), the barrier-phased kernel on the short-K ones (K = 160 / 320)
     const bool ws = a->pre == 0 && (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 512));
-    if (a->tile_hint == kNumVariantsG + 1) {
-        if (a->pre != 0) return OCCD_EINVAL;
-        pick = 0;
-    }
+    if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
     const int TM = v.MT * v.WM * 32, TN = v.NT * v.WN * 32;
     GemmP p;
@@ -804,36 +814,55 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     return occd::check_launch();
 }
 
-// K16t: C[b] = A[b] . B[b]^T with both operands k-contiguous (lda, ldb >= K; any dword alignment; any K >= 1): the weight
-// gradient of a pointwise convolution, dW = gy (Cout x HW) . x^T.  a->act / bias / pre must be 0 / NULL / 0.
+// K16t: C[b][z] = A[b] . B[b]^T over the z-th K range, with both operands k-contiguous (lda, ldb >= K; any dword alignment;
+// any K >= 1): the weight gradient of a pointwise convolution, dW = gy (Cout x HW) . x^T.  a->act carries the number of
+// K splits (>= 1; occd_gemm_f32x3_nt_splits proposes one): C holds batch x splits partial matrices, stride_c elements apart
+// (batch-major), which the caller sums.  bias / pre must be NULL / 0.
+extern "C" int32_t occd_gemm_f32x3_nt_splits(int32_t M, int32_t N, int32_t K, int32_t batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return OCCD_EINVAL;
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    const bool small = tiles128 < 32;
+    const long tiles = small ? (long)((M + 63) / 64) * ((N + 63) / 64) * batch : tiles128;
+    const int steps = (K + 31) / 32;
+    long want = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU
+    if (want > steps / 4) want = steps / 4;          // at least 4 K steps (128 k) per split
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    return (int32_t)want;
+}
+
 extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
-    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || a->pre != 0 || a->act != 0 || a->bias != nullptr) return OCCD_EINVAL;
+    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || a->pre != 0 || a->bias != nullptr) return OCCD_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->A) & 3) || (reinterpret_cast<uintptr_t>(a->B) & 3) || (reinterpret_cast<uintptr_t>(a->C) & 3))
         return OCCD_EINVAL;
-    if (a->tile_hint < 0 || a->tile_hint > 2) return OCCD_EINVAL;
-    // 128 x 128 tiles unless that leaves too few workgroups (weight matrices are small: M x N = Cout x Cin)
+    const int steps = (a->K + 31) / 32;
+    const int splits = a->act;
+    if (a->tile_hint < 0 || a->tile_hint > 2 || splits < 1 || splits > 65535 || splits > steps) return OCCD_EINVAL;
+    // 128 x 128 tiles unless that leaves too few of them (weight matrices are small: M x N = Cout x Cin)
     const long wg128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->batch;
-    const bool small = a->tile_hint == 2 || (a->tile_hint == 0 && wg128 < 128);
+    const bool small = a->tile_hint == 2 || (a->tile_hint == 0 && wg128 < 32);
     const int TM = small ? 64 : 128, TN = small ? 64 : 128;
     GemmP p;
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = nullptr;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a; p.sB = a->stride_b; p.sC = a->stride_c;
-    p.act = 0; p.slope = 0.f;
+    p.act = (steps + splits - 1) / splits;            // (the kernel reads p.act as "32-k steps per split")
+    p.slope = 0.f;
     p.mtiles = (a->M + TM - 1) / TM;
     p.ntiles = (a->N + TN - 1) / TN;
     p.n_fast = 0;
     const long nwg = (long)p.mtiles * p.ntiles;
     if (nwg >= (1L << 31)) return OCCD_EINVAL;
     p.nwg = (unsigned)nwg;
+    const int zsplits = (steps + p.act - 1) / p.act;  // splits that own at least one step
+    if (zsplits != splits) return OCCD_EINVAL;        // (the caller sized C for `splits` partials: every one must be written)
     const size_t lds = (size_t)(TM + TN) * kARow;
     void (*kern)(const GemmP) = small ? gemm_x3_nt_kernel<1, 1, 2, 2> : gemm_x3_nt_kernel<2, 2, 2, 2>;
     if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double flops = 2.0 * a->M * a->N * a->K * a->batch;
-    occd::ProfScope prof("gemm_f32x3_nt", (hipStream_t)stream, flops, 4.0 * a->batch * ((double)(a->M + a->N) * a->K + (double)a->M * a->N));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(256), lds, (hipStream_t)stream, p);
+    occd::ProfScope prof("gemm_f32x3_nt", (hipStream_t)stream, flops, 4.0 * a->batch * ((double)(a->M + a->N) * a->K + (double)a->M * a->N * splits));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch, (unsigned)splits), dim3(256), lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }
-

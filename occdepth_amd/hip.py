@@ -143,6 +143,7 @@ EXPORTS = {
     "occd_rows_gemm_fwd": (c_int32, [POINTER(RowsGemmArgs), c_void_p]),
     "occd_gemm_f32x3": (c_int32, [POINTER(GemmArgs), c_void_p]),
     "occd_gemm_f32x3_nt": (c_int32, [POINTER(GemmArgs), c_void_p]),
+    "occd_gemm_f32x3_nt_splits": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     "occd_gemm_x3_packed_elems": (c_int64, [c_int32, c_int32]),
     "occd_gemm_x3_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_int64, c_void_p]),
     "occd_rows_gemm_packed_floats": (c_int64, [c_int32, c_int32]),
@@ -570,9 +571,11 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
     return out[0] if squeeze and out.dim() == 3 else out
 
 
-def gemm_x3_nt(a, b, out=None, tile_hint=0):
-    """K16t (occd_gemm_f32x3_nt): out[i] = a[i] @ b[i].T for a (batch, M, K), b (batch, N, K) -- both k-contiguous, any
-    alignment / K: the weight gradient of a pointwise convolution (gy (Cout, HW) x (Cin, HW))."""
+def gemm_x3_nt(a, b, tile_hint=0, splits=None, reduce=True):
+    """K16t (occd_gemm_f32x3_nt): a[i] @ b[i].T for a (batch, M, K), b (batch, N, K) -- both k-contiguous, any alignment /
+    K: the weight gradient of a pointwise convolution (gy (Cout, HW) x (Cin, HW)).  The reduction dimension is split over
+    `splits` workgroup groups (default: the library's proposal); reduce=True returns the (M, N) sum over batch and splits
+    (what a weight gradient is), reduce=False the (batch, splits, M, N) partial products."""
     for t, nm in ((a, "a"), (b, "b")):
         if t.dim() != 3 or t.dtype != torch.float32 or not t.is_cuda or t.stride(-1) != 1:
             raise RuntimeError(f"gemm_x3_nt: {nm} must be a (batch, rows, K) float32 GPU tensor with unit innermost stride")
@@ -580,18 +583,22 @@ def gemm_x3_nt(a, b, out=None, tile_hint=0):
     if b.shape[0] != batch or b.shape[2] != K:
         raise RuntimeError("gemm_x3_nt: operand shapes do not match")
     N = b.shape[1]
-    if out is None:
-        out = torch.empty((batch, M, N), device=a.device, dtype=torch.float32)
+    if splits is None:
+        splits = load().occd_gemm_f32x3_nt_splits(M, N, K, batch)
+    steps = (K + 31) // 32
+    per = (steps + splits - 1) // splits
+    splits = (steps + per - 1) // per                 # every split owns at least one K step
+    out = torch.empty((batch, splits, M, N), device=a.device, dtype=torch.float32)
     q = GemmArgs()
     q.A, q.B, q.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
     q.M, q.N, q.K, q.batch = M, N, K, batch
-    q.lda, q.ldb, q.ldc = a.stride(1), b.stride(1), out.stride(1)
-    q.stride_a, q.stride_b, q.stride_c = a.stride(0), b.stride(0), out.stride(0)
-    q.tile_hint = tile_hint
+    q.lda, q.ldb, q.ldc = a.stride(1), b.stride(1), N
+    q.stride_a, q.stride_b, q.stride_c = a.stride(0), b.stride(0), M * N
+    q.tile_hint, q.act = tile_hint, splits
     if _PROFILING:
-        set_tag("%dx%dx%d b%d" % (M, N, K, batch))
+        set_tag("%dx%dx%d b%d z%d" % (M, N, K, batch, splits))
     _check(load().occd_gemm_f32x3_nt(ctypes.byref(q), _stream()), "occd_gemm_f32x3_nt")
-    return out
+    return out.sum((0, 1)) if reduce else out
 
 
 class _PwConvFn(torch.autograd.Function):
@@ -620,7 +627,7 @@ class _PwConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gemm_x3(w.detach().reshape(Co, C).t().contiguous(), g).view(B, C, H, W)
         if ctx.needs_input_grad[1]:
-            gw = gemm_x3_nt(g, x.view(B, C, H * W)).sum(0).view(Co, C, 1, 1)
+            gw = gemm_x3_nt(g, x.view(B, C, H * W)).view(Co, C, 1, 1)
         return gx, gw
 
 

@@ -54,7 +54,7 @@ def test_gemm_x3_vs_float64(hip, name, packed):
     got = run(hip, xa, xb).cpu().double()
     assert got.shape == ref.shape
     if packed is None:                                     # the wave-specialised kernel on the same operands
-        got_ws = run(hip, xa, xb, tile_hint=5).cpu().double()
+        got_ws = run(hip, xa, xb, tile_hint=6).cpu().double()
         assert float((got_ws - ref).abs().max() / ref.abs().max()) < max(2e-6, 1.25 * float(
             (torch.matmul(ad, bd).cpu().double() - ref).abs().max() / ref.abs().max())), name
     scale = ref.abs().max()
@@ -65,7 +65,7 @@ def test_gemm_x3_vs_float64(hip, name, packed):
     assert err < max(2e-6, 1.25 * err32), (name, err, err32)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5])          # 5 = the wave-specialised 256 x 128 kernel (K16w)
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6])       # 5 = 64 x 256 tile, 6 = the wave-specialised 256 x 128 kernel (K16w)
 def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
     g = torch.Generator().manual_seed(hint)
     batch, M, N, K = 2, 300, 333, 72                       # M, N tails in every variant; K = 2 steps + a tail of 8
@@ -78,7 +78,7 @@ def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
         err = float((got - ref).abs().max() / ref.abs().max())
         assert err < (3e-6 if act == "swish" else 2e-6), (hint, act, err)      # (swish: hardware exp2 / rcp, ~3 ulp)
     forms = [(a.to(DEV), b.to(DEV))]
-    if hint != 5:                                          # (K16w takes float32 operands only)
+    if hint != 6:                                          # (K16w takes float32 operands only)
         forms += [(hip.GemmPacked(a.to(DEV), "a"), b.to(DEV)), (a.to(DEV), hip.GemmPacked(b.to(DEV), "b"))]
     for xa, xb in forms:
         got = run(hip, xa, xb, tile_hint=hint).cpu().double()
@@ -133,8 +133,12 @@ def test_gemm_x3_nt_vs_float64(hip, name, hint):
     bbig = torch.randn(batch, N, K + 1, generator=g).to(DEV)
     a, b = abig[:, :, 2:2 + K], bbig[:, :, 1:1 + K]
     ref = torch.matmul(a.double().cpu(), b.double().cpu().transpose(1, 2))
-    got = hip.gemm_x3_nt(a, b, tile_hint=hint).cpu().double()
+    got = hip.gemm_x3_nt(a, b, tile_hint=hint, splits=1, reduce=False)[:, 0].cpu().double()
     err = float((got - ref).abs().max() / ref.abs().max())
+    # split-K (the default: a small matrix reduced over many pixels) and the batch sum
+    for splits in (None, 3):
+        summed = hip.gemm_x3_nt(a, b, tile_hint=hint, splits=splits).cpu().double()
+        assert float((summed - ref.sum(0)).abs().max() / ref.sum(0).abs().max()) < 3e-6, (name, hint, splits)
     err32 = float((torch.matmul(a, b.transpose(1, 2)).cpu().double() - ref).abs().max() / ref.abs().max())
     print(f"gemm_x3_nt {name} hint {hint}: max err {err:.2e} (torch.matmul fp32 {err32:.2e})")
     assert err < max(2e-6, 1.25 * err32), (name, hint, err, err32)

@@ -31,7 +31,7 @@ def main():
         b = torch.randn(batch, K, N, device="cuda")
         out = torch.empty(batch, M, N, device="cuda")
         fns = {"torch.matmul fp32": lambda: torch.matmul(a, b, out=out)}
-        for hint, nm in ((1, "K16 256x128"), (2, "K16 128x128"), (5, "K16w 256x128 wave-specialised"), (0, "K16 auto")):
+        for hint, nm in ((1, "K16 256x128"), (2, "K16 128x128"), (6, "K16w 256x128 wave-specialised"), (0, "K16 auto")):
             fns[nm] = lambda hint=hint: hip.gemm_x3(a, b, out=out, tile_hint=hint)
         ms = time_many(fns, rounds=3, iters=5)
         fl = 2.0 * M * N * K * batch

@@ -15,7 +15,7 @@ for (batch, M, N, K, ab) in ((2, 5760, 1848, 1280, False), (16, 3696, 640, 640, 
     a = torch.randn(*((batch, M, K) if ab else (M, K)), device="cuda") / K ** 0.5
     b = torch.randn(batch, K, N, device="cuda")
     out = torch.empty(batch, M, N, device="cuda")
-    for hint in (1, 5):
+    for hint in (1, 6):
         for _ in range(3):
             hip.gemm_x3(a, b, out=out, tile_hint=hint)
     for _ in range(3):

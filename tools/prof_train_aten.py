@@ -39,23 +39,20 @@ def main(bf16):
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    agg = {}
-    for ev in prof.events():
+    rows = []
+    for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
         t = getattr(ev, "self_device_time_total", 0) or getattr(ev, "self_cuda_time_total", 0)
-        if t <= 0 or not ev.name.startswith("aten::"):
+        if t <= 0 or not ev.key.startswith("aten::"):
             continue
         where = "?"
         for fr in (ev.stack or []):
-            if repo in fr and "/tools/" not in fr:
+            if repo in fr and "/tools/" not in fr and "bench.py" not in fr:
                 where = fr.replace(repo + "/", "").strip()
                 break
-        key = (ev.name, str(ev.input_shapes)[:90], where[:110])
-        a = agg.setdefault(key, [0, 0.0])
-        a[0] += 1
-        a[1] += t
-    print("\n== ATen operators with device time, by (op, shapes, innermost repo frame), top 60 ==")
-    for (name, shapes, where), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
-        print(f"{t / 1e3:8.3f} ms  x{n:<4d} {name:32s} {shapes:92s} {where}")
+        rows.append((t, ev.count, ev.key, str(ev.input_shapes)[:80], where[:120]))
+    print("\n== ATen operators with device time, by (op, shapes, innermost repo frame), top 70 ==")
+    for t, n, name, shapes, where in sorted(rows, reverse=True)[:70]:
+        print(f"{t / 1e3:8.3f} ms  x{n:<4d} {name:30s} {shapes:82s} {where}")
 
 
 if __name__ == "__main__":
