@@ -87,7 +87,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, int step_byte
 // PRE: 0 = both operands float32 in memory (split while staged); 1 = A is the pre-split fragment image of
 // occd_gemm_x3_pack (weights: [row tile 32][k16][term][lane][8 bf16], read straight from L2 like K2b's weights -- no LDS,
 // no split arithmetic, no ds_write for that operand); 2 = B is (role 1 image: [column tile 32][k16][term][lane][8]).
-template <int MT, int NT, int WM, int WN, int PRE>
+// TERMS: 3 = the split (float32-level accuracy); 1 = plain bf16 operands, ONE MFMA per 16-k step (the bf16 training mode,
+// BASELINE configs[3]: "bf16 MFMA, fp32 storage and accumulate" like K2b): same staging and layout, only the hi plane is
+// written and read.
+template <int MT, int NT, int WM, int WN, int PRE, int TERMS = 3>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     constexpr int NTH = WM * WN * 64, TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int SB = TN * 2 + 64;                 // bytes per B row (one k, one term): = 64 mod 128
@@ -170,8 +173,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
             u32x4 hi, mid, lo;
             split8(ok ? ra[i][0] : z, ok ? ra[i][1] : z, hi, mid, lo);
             *(u32x4*)(lA + a_dst[i]) = hi;
-            *(u32x4*)(lA + a_dst[i] + 64) = mid;
-            *(u32x4*)(lA + a_dst[i] + 128) = lo;
+            if (TERMS == 3) {
+                *(u32x4*)(lA + a_dst[i] + 64) = mid;
+                *(u32x4*)(lA + a_dst[i] + 128) = lo;
+            }
         }
 #pragma unroll
         for (int i = 0; i < (PRE == 2 ? 0 : NB); ++i) {
@@ -187,8 +192,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
             u32x2 hi, mid, lo;
             split4(v, hi, mid, lo);
             *(u32x2*)(lB + b_dst[i]) = hi;
-            *(u32x2*)(lB + BTERM + b_dst[i]) = mid;
-            *(u32x2*)(lB + 2 * BTERM + b_dst[i]) = lo;
+            if (TERMS == 3) {
+                *(u32x2*)(lB + BTERM + b_dst[i]) = mid;
+                *(u32x2*)(lB + 2 * BTERM + b_dst[i]) = lo;
+            }
         }
     };
 
@@ -258,7 +265,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(lA + a_lane[mt] + t * 64 + ks * 32);
+                    for (int t = 0; t < TERMS; ++t) af[mt][t] = *(const u32x4*)(lA + a_lane[mt] + t * 64 + ks * 32);
             }
             if (PRE == 2) {
 #pragma unroll
@@ -269,14 +276,16 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) bf[nt][t] = tr_frag(lB + t * BTERM + b_lane[nt] + ks * 16 * SB, 4 * SB);
+                    for (int t = 0; t < TERMS; ++t) bf[nt][t] = tr_frag(lB + t * BTERM + b_lane[nt] + ks * 16 * SB, 4 * SB);
             }
             if (PRE != 0) fetch_pk(s * 2 + ks + 1);
-            OCCD_GX3(1, 1);
-            OCCD_GX3(0, 2);
-            OCCD_GX3(2, 0);
-            OCCD_GX3(0, 1);
-            OCCD_GX3(1, 0);
+            if (TERMS == 3) {
+                OCCD_GX3(1, 1);
+                OCCD_GX3(0, TERMS == 3 ? 2 : 0);
+                OCCD_GX3(TERMS == 3 ? 2 : 0, 0);
+                OCCD_GX3(0, 1);
+                OCCD_GX3(1, 0);
+            }
             OCCD_GX3(0, 0);
         }
     }
@@ -546,7 +555,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
 // gy (Cout x HW) . x^T (HW x Cin): both tensors lie k(= pixel)-contiguous in NCHW memory, so both are staged like K16's A
 // operand (rows of [hi | mid | lo] 32 k, conflict-free ds_read_b128 fragments) -- no transposing reads, no transposed copy.
 // The last K step masks element-wise (a per-lane branch that only the tail step takes).
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int TERMS = 3>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) {
     constexpr int NTH = WM * WN * 64, TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int NA = TM * 4 / NTH, NB = TN * 4 / NTH;
@@ -612,16 +621,20 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) 
             u32x4 hi, mid, lo;
             split8(ra[i][0], ra[i][1], hi, mid, lo);
             *(u32x4*)(lA + a_dst[i]) = hi;
-            *(u32x4*)(lA + a_dst[i] + 64) = mid;
-            *(u32x4*)(lA + a_dst[i] + 128) = lo;
+            if (TERMS == 3) {
+                *(u32x4*)(lA + a_dst[i] + 64) = mid;
+                *(u32x4*)(lA + a_dst[i] + 128) = lo;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             u32x4 hi, mid, lo;
             split8(rb[i][0], rb[i][1], hi, mid, lo);
             *(u32x4*)(lB + b_dst[i]) = hi;
-            *(u32x4*)(lB + b_dst[i] + 64) = mid;
-            *(u32x4*)(lB + b_dst[i] + 128) = lo;
+            if (TERMS == 3) {
+                *(u32x4*)(lB + b_dst[i] + 64) = mid;
+                *(u32x4*)(lB + b_dst[i] + 128) = lo;
+            }
         }
     };
     f32x16 acc[MT][NT];
@@ -652,16 +665,18 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) af[mt][t] = *(const u32x4*)(lA + a_lane[mt] + t * 64 + ks * 32);
+                for (int t = 0; t < TERMS; ++t) af[mt][t] = *(const u32x4*)(lA + a_lane[mt] + t * 64 + ks * 32);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bf[nt][t] = *(const u32x4*)(lB + b_lane[nt] + t * 64 + ks * 32);
-            OCCD_GNT(1, 1);
-            OCCD_GNT(0, 2);
-            OCCD_GNT(2, 0);
-            OCCD_GNT(0, 1);
-            OCCD_GNT(1, 0);
+                for (int t = 0; t < TERMS; ++t) bf[nt][t] = *(const u32x4*)(lB + b_lane[nt] + t * 64 + ks * 32);
+            if (TERMS == 3) {
+                OCCD_GNT(1, 1);
+                OCCD_GNT(0, TERMS == 3 ? 2 : 0);
+                OCCD_GNT(TERMS == 3 ? 2 : 0, 0);
+                OCCD_GNT(0, 1);
+                OCCD_GNT(1, 0);
+            }
             OCCD_GNT(0, 0);
         }
     }
@@ -684,10 +699,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_nt_kernel(const GemmP p) 
 
 struct VariantG {
     int MT, NT, WM, WN;
-    void (*kern[3])(const GemmP);
+    void (*kern[4])(const GemmP);     // [pre 0 / 1 / 2] with the split; [3] = float32 operands rounded to ONE bf16 term
 };
 #define OCCD_VARIANT_G(MT, NT, WM, WN) \
-    VariantG{MT, NT, WM, WN, {gemm_x3_kernel<MT, NT, WM, WN, 0>, gemm_x3_kernel<MT, NT, WM, WN, 1>, gemm_x3_kernel<MT, NT, WM, WN, 2>}}
+    VariantG{MT, NT, WM, WN, {gemm_x3_kernel<MT, NT, WM, WN, 0>, gemm_x3_kernel<MT, NT, WM, WN, 1>, gemm_x3_kernel<MT, NT, WM, WN, 2>, \
+                              gemm_x3_kernel<MT, NT, WM, WN, 0, 1>}}
 const VariantG kVariantsG[] = {
     OCCD_VARIANT_G(2, 2, 4, 2),   // 0: 256 x 128, 512 threads
     OCCD_VARIANT_G(2, 2, 2, 2),   // 1: 128 x 128, 256 threads
@@ -695,8 +711,6 @@ const VariantG kVariantsG[] = {
     OCCD_VARIANT_G(1, 1, 2, 2),   // 3: 64 x 64
     OCCD_VARIANT_G(2, 2, 1, 4),   // 4: 64 x 256 (few rows, many columns: project convolutions at high resolution, M = 48 ... 64)
 };
-// relative throughput of a FULL tile of each variant (profiles/r04_gemm_x3_v3_ws.txt; the 64-row shapes are LDS-read bound)
-const double kVariantEff[] = {1.0, 0.75, 0.6, 0.45, 0.7};
 constexpr int kNumVariantsG = sizeof(kVariantsG) / sizeof(kVariantsG[0]);
 
 // role 0: the A operand (rows x K, k contiguous) -> [row tile 32][k16][term][lane][8]: lane = (row & 31) + 32 ((k & 15) >> 3)
@@ -743,13 +757,14 @@ extern "C" int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_
     return occd::check_launch();
 }
 
-// a->tile_hint: 0 = pick (cheapest variant by padded work / throughput), 1 .. 5 = force a tile variant, 6 = force K16w.
+// a->tile_hint: 0 = pick (the largest tile that leaves >= 160 workgroups; 64-row tiles for M <= 64), 1 .. 5 = force a tile
+// variant, 6 = force K16w.
 // a->pre: 0 = A and B float32; 1 = a->A is the role-0 image of occd_gemm_x3_pack (lda ignored, stride_a = bf16 elements
 // between batch items, 0 = shared); 2 = a->B is the role-1 image (ldb ignored, stride_b likewise).
 extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
-    if (a->pre < 0 || a->pre > 2) return OCCD_EINVAL;
+    if (a->pre < 0 || a->pre > 3) return OCCD_EINVAL;      // 3: float32 operands, plain bf16 arithmetic (one term)
     if ((a->K & 7) || a->ldc < a->N || a->N < 4) return OCCD_EINVAL;
     if (a->pre != 1 && ((a->lda & 3) || a->lda < a->K || (reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 3)))
         return OCCD_EINVAL;
@@ -761,17 +776,19 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     int pick = a->tile_hint - 1;
     if (a->tile_hint == kNumVariantsG + 1) pick = 0;
     if (pick < 0) {
-        // cheapest variant: padded work (tile quantisation in M and N) / the variant's throughput, with a penalty when fewer
-        // than ~160 workgroups are left for 256 CUs
-        double best = 1e300;
-        for (int i = 0; i < kNumVariantsG; ++i) {
-            const VariantG& v = kVariantsG[i];
-            const long tm = v.MT * v.WM * 32, tn = v.NT * v.WN * 32;
-            const long mt = (a->M + tm - 1) / tm, nt = (a->N + tn - 1) / tn;
-            const double wgs = (double)mt * nt * a->batch;
-            double cost = (double)(mt * tm) * (double)(nt * tn) / kVariantEff[i];
-            if (wgs < 160.0) cost *= 160.0 / wgs;
-            if (cost < best) { best = cost; pick = i; }
+        // the largest tile that still leaves >= 160 workgroups (measured, profiles/r04_gemm_x3_v3_ws.txt: the large tiles win
+        // down to ~0.6 workgroups per CU), else the finest; a matrix of <= 64 rows (project convolutions of the high-resolution
+        // stages in training: M = 32 ... 64, N = 10^4 ... 10^5 pixels) takes the 64-row tiles instead of wasting 3/4 of a 256-row one
+        if (a->M <= 64) {
+            pick = ((long)((a->N + 255) / 256) * a->batch >= 160) ? 4 : 3;
+        } else {
+            pick = 3;
+            for (int i = 0; i < 4; ++i) {
+                const VariantG& v = kVariantsG[i];
+                const long tm = v.MT * v.WM * 32, tn = v.NT * v.WN * 32;
+                const long wgs = ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
+                if (wgs >= 160) { pick = i; break; }
+            }
         }
     }
     // the wave-specialised 256 x 128 kernel takes the launches the 256 x 128 tile would (float32 operands): hint 5 forces it,
@@ -779,6 +796,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     static const bool ws_off = getenv("OCCD_GEMM_WS") != nullptr && getenv("OCCD_GEMM_WS")[0] == '0';
     // measured (profiles/r04_gemm_x3_v3_ws.txt): the two forms are within 5 % of each other; K16w leads on the long-K launches
     // (1/16, 1/8 levels), the barrier-phased kernel on the short-K ones (K = 160 / 320)
+    const bool plain = a->pre == 3;
     const bool ws = a->pre == 0 && (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 512));
     if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
@@ -799,6 +817,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     p.nwg = (unsigned)nwg;
     const size_t lds = ws ? (size_t)2 * kWsStage
                           : (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
+    (void)plain;
     void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel<0> : v.kern[a->pre];
 #ifdef OCCD_GEMM_DEV_VARIANTS
     if (ws && getenv("OCCD_GEMM_DBG") != nullptr)
@@ -809,7 +828,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double flops = 2.0 * a->M * a->N * a->K * a->batch;
     const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
-    occd::ProfScope prof(ws ? "gemm_f32x3_ws" : a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : "gemm_f32x3_preB", (hipStream_t)stream, flops, bytes);
+    occd::ProfScope prof(ws ? "gemm_f32x3_ws" : a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : a->pre == 2 ? "gemm_f32x3_preB" : "gemm_bf16", (hipStream_t)stream, flops, bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(ws ? 512 : v.WM * v.WN * 64), lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }
@@ -834,7 +853,7 @@ extern "C" int32_t occd_gemm_f32x3_nt_splits(int32_t M, int32_t N, int32_t K, in
 extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
-    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || a->pre != 0 || a->bias != nullptr) return OCCD_EINVAL;
+    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || (a->pre != 0 && a->pre != 3) || a->bias != nullptr) return OCCD_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->A) & 3) || (reinterpret_cast<uintptr_t>(a->B) & 3) || (reinterpret_cast<uintptr_t>(a->C) & 3))
         return OCCD_EINVAL;
     const int steps = (a->K + 31) / 32;
@@ -859,10 +878,11 @@ extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
     const int zsplits = (steps + p.act - 1) / p.act;  // splits that own at least one step
     if (zsplits != splits) return OCCD_EINVAL;        // (the caller sized C for `splits` partials: every one must be written)
     const size_t lds = (size_t)(TM + TN) * kARow;
-    void (*kern)(const GemmP) = small ? gemm_x3_nt_kernel<1, 1, 2, 2> : gemm_x3_nt_kernel<2, 2, 2, 2>;
+    void (*kern)(const GemmP) = a->pre == 3 ? (small ? gemm_x3_nt_kernel<1, 1, 2, 2, 1> : gemm_x3_nt_kernel<2, 2, 2, 2, 1>)
+                                            : (small ? gemm_x3_nt_kernel<1, 1, 2, 2> : gemm_x3_nt_kernel<2, 2, 2, 2>);
     if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     const double flops = 2.0 * a->M * a->N * a->K * a->batch;
-    occd::ProfScope prof("gemm_f32x3_nt", (hipStream_t)stream, flops, 4.0 * a->batch * ((double)(a->M + a->N) * a->K + (double)a->M * a->N * splits));
+    occd::ProfScope prof(a->pre == 3 ? "gemm_bf16_nt" : "gemm_f32x3_nt", (hipStream_t)stream, flops, 4.0 * a->batch * ((double)(a->M + a->N) * a->K + (double)a->M * a->N * splits));
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch, (unsigned)splits), dim3(256), lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }

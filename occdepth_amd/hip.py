@@ -529,11 +529,12 @@ def gemm_x3_supported(a, b):
     return nb_a is None or nb_b is None or nb_a == nb_b
 
 
-def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_bf16=False):
     """K16 (occd_gemm_f32x3): out[i] = act(a[i] @ b[i] + bias[:, None]) in float32-level accuracy on the bf16 matrix pipe.
     a: (M, K) shared over the batch, or (batch, M, K); b: (K, N) or (batch, K, N); out: (batch, M, N) ((M, N) when neither
     operand is batched).  Tensor operands may be strided views as long as the innermost stride is 1; a static operand may be
-    given as `GemmPacked(w, "a" / "b")` (split once, read straight from L2)."""
+    given as `GemmPacked(w, "a" / "b")` (split once, read straight from L2).  plain_bf16: operands rounded to ONE bf16 term
+    (the bf16 training mode: bf16 MFMA, fp32 storage and accumulate) instead of the split."""
     if not gemm_x3_supported(a, b):
         raise RuntimeError("gemm_x3: unsupported operands")
     pa, pb = isinstance(a, GemmPacked), isinstance(b, GemmPacked)
@@ -564,14 +565,16 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
     q.stride_b = (b.per if nb_b else 0) if pb else (b.stride(0) if b.dim() == 3 else 0)
     q.stride_c = out.stride(0) if out.dim() == 3 else 0
     q.act, q.slope, q.tile_hint = GEMM_ACT[act], slope, tile_hint
-    q.pre = 1 if pa else 2 if pb else 0
+    q.pre = 1 if pa else 2 if pb else (3 if plain_bf16 else 0)
+    if plain_bf16 and (pa or pb):
+        raise RuntimeError("gemm_x3: plain_bf16 takes float32 tensor operands")
     if _PROFILING:
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
     return out[0] if squeeze and out.dim() == 3 else out
 
 
-def gemm_x3_nt(a, b, tile_hint=0, splits=None, reduce=True):
+def gemm_x3_nt(a, b, tile_hint=0, splits=None, reduce=True, plain_bf16=False):
     """K16t (occd_gemm_f32x3_nt): a[i] @ b[i].T for a (batch, M, K), b (batch, N, K) -- both k-contiguous, any alignment /
     K: the weight gradient of a pointwise convolution (gy (Cout, HW) x (Cin, HW)).  The reduction dimension is split over
     `splits` workgroup groups (default: the library's proposal); reduce=True returns the (M, N) sum over batch and splits
@@ -594,7 +597,7 @@ def gemm_x3_nt(a, b, tile_hint=0, splits=None, reduce=True):
     q.M, q.N, q.K, q.batch = M, N, K, batch
     q.lda, q.ldb, q.ldc = a.stride(1), b.stride(1), N
     q.stride_a, q.stride_b, q.stride_c = a.stride(0), b.stride(0), M * N
-    q.tile_hint, q.act = tile_hint, splits
+    q.tile_hint, q.act, q.pre = tile_hint, splits, (3 if plain_bf16 else 0)
     if _PROFILING:
         set_tag("%dx%dx%d b%d z%d" % (M, N, K, batch, splits))
     _check(load().occd_gemm_f32x3_nt(ctypes.byref(q), _stream()), "occd_gemm_f32x3_nt")
@@ -610,10 +613,12 @@ class _PwConvFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, w):
+        from . import autograd3d
         B, C, H, W = x.shape
         xc = x if x.is_contiguous() else x.contiguous()
         ctx.save_for_backward(xc, w)
-        return gemm_x3(w.detach().reshape(w.shape[0], C), xc.view(B, C, H * W)).view(B, w.shape[0], H, W)
+        ctx.plain = bool(autograd3d.BF16_MFMA)          # bf16 training mode: one bf16 product instead of the 3-way split
+        return gemm_x3(w.detach().reshape(w.shape[0], C), xc.view(B, C, H * W), plain_bf16=ctx.plain).view(B, w.shape[0], H, W)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -625,18 +630,28 @@ class _PwConvFn(torch.autograd.Function):
         g = (g if g.is_contiguous() else g.contiguous()).view(B, Co, H * W)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_x3(w.detach().reshape(Co, C).t().contiguous(), g).view(B, C, H, W)
+            gx = gemm_x3(w.detach().reshape(Co, C).t().contiguous(), g, plain_bf16=ctx.plain).view(B, C, H, W)
         if ctx.needs_input_grad[1]:
-            gw = gemm_x3_nt(g, x.view(B, C, H * W)).view(Co, C, 1, 1)
+            gw = gemm_x3_nt(g, x.view(B, C, H * W), plain_bf16=ctx.plain).view(Co, C, 1, 1)
         return gx, gw
 
 
-PW_TRAIN = os.environ.get("OCCDEPTH_TRAIN_PW_GEMM", "1") == "1"
+# OCCDEPTH_TRAIN_PW_GEMM: "auto" (default) = in the bf16-MFMA training mode only -- there the GEMMs run on plain bf16 operands
+# and the step gains 1.2 ms (105.5 against 106.7 ms) while ~12 ms of MIOpen / rocBLAS work moves in-repo; in the fp32 mode the
+# 3-way split GEMMs are a wash against the libraries on these small shapes (153.1 against 152 ms), so ATen keeps them; 1 / 0
+# force it on / off in both modes.
+PW_TRAIN = os.environ.get("OCCDEPTH_TRAIN_PW_GEMM", "auto")
 
 
 def pw_conv_autograd_ok(conv, x):
     """The pointwise convolutions `_PwConvFn` takes: 1x1, stride 1, one group, no bias, channel counts K16 accepts."""
-    return (PW_TRAIN and GEMM_X3 and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+    if PW_TRAIN == "0":
+        return False
+    if PW_TRAIN != "1":
+        from . import autograd3d
+        if not autograd3d.BF16_MFMA:
+            return False
+    return (GEMM_X3 and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
             and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.dilation == (1, 1) and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
             and x.shape[2] * x.shape[3] >= 4 and x.shape[0] <= 65535)

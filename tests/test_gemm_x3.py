@@ -162,3 +162,23 @@ def test_pointwise_conv_autograd_matches_aten(hip, shape):
     for got, ref, what in ((y, F.conv2d(x.double(), w.double()), "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
         err = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
         assert err < 3e-6, (shape, what, err)
+
+
+def test_gemm_plain_bf16_mode_equals_float64_on_rounded_operands(hip):
+    """`plain_bf16` (the bf16 training mode of K16 / K16t: operands rounded to ONE bf16 term, fp32 accumulate): against float64
+    evaluated on the SAME bf16-rounded operands the products are exact, so the bound is float32 accumulation (2e-6), i.e. an
+    index / layout bug cannot hide behind 2^-8."""
+    g = torch.Generator().manual_seed(5)
+    batch, M, N, K = 2, 200, 333, 104
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    a = r(torch.randn(M, K, generator=g) / K ** 0.5)
+    b = r(torch.randn(batch, K, N, generator=g))
+    ref = torch.matmul(a.double(), b.double())
+    for hint in (0, 2, 4):
+        got = hip.gemm_x3(a.to(DEV), b.to(DEV), tile_hint=hint, plain_bf16=True).cpu().double()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6, hint
+    a3 = r(torch.randn(batch, 72, 517, generator=g))
+    b3 = r(torch.randn(batch, 40, 517, generator=g))
+    ref = torch.matmul(a3.double(), b3.double().transpose(1, 2)).sum(0)
+    got = hip.gemm_x3_nt(a3.to(DEV), b3.to(DEV), plain_bf16=True).cpu().double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
