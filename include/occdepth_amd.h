@@ -603,6 +603,10 @@ int occd_pack_weights_gather(const float* w, const float* scale, float* wpk, int
                              int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, void* stream);
 int occd_pack_weights_bf16_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
                                   int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, void* stream);
+/* the same view as three images hi | mid | lo (3 x occd_packed_weight_bf16_elems elements): data-gradient operators of the 3-way
+ * split (occd_conv3d_bf16_fwd dtype 2) */
+int occd_pack_weights_bf16x3_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
+                                  int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, void* stream);
 /* Opt-in experiment: dtype 2 of occd_conv3d_bf16_fwd = float32 tensors, both operands split into three
  * bf16 terms (x = hi + mid + lo), six bf16 MFMAs per K step (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid), fp32
  * accumulate: float32-level accuracy at 6/16 of the fp32-MFMA time.  Its weight image (3 x

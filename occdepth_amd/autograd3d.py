@@ -53,10 +53,19 @@ def _to_vox(x):
     return v
 
 
+def _x3_head(x, cout, kernel, out, kw):
+    """fp32 training mode: the full-resolution head convolutions (forward and data gradient) take K2s3 -- the 3-way bf16 split,
+    float32-level accuracy, 0.51 against 0.90 ms per launch -- whenever the eval path's default does (fused.BF16X3)."""
+    from . import fused
+    return (not BF16_MFMA) and bool(fused.BF16X3) and x.buf.dtype == torch.float32 and hip.c32x3_eligible(x, cout, kernel, out, **kw)
+
+
 def _conv(x, w, bias, cout, kernel, out, **kw):
     """One forward-kernel launch with the weights packed for the active matrix pipe."""
     if BF16_MFMA:
         return hip.conv3d_bf16(x, hip.pack_weights_bf16(w), bias, cout, kernel, out, **kw)
+    if _x3_head(x, cout, kernel, out, kw):
+        return hip.conv3d_bf16(x, hip.pack_weights_bf16(w, split3=True), bias, cout, kernel, out, split3=True, **kw)
     return hip.conv3d(x, hip.pack_weights(w), bias, cout, kernel, out, **kw)
 
 
@@ -66,6 +75,9 @@ def _conv_view(x, w, n_out, n_in, s_out, s_in, tap_ofs, kernel, out, **kw):
     if BF16_MFMA:
         return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16=True), None, n_out,
                                kernel, out, **kw)
+    if _x3_head(x, n_out, kernel, out, kw):
+        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16="x3"), None, n_out,
+                               kernel, out, split3=True, **kw)
     return hip.conv3d(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel), None, n_out, kernel, out, **kw)
 
 

@@ -448,9 +448,25 @@ static int pack_bf16(const float* w, const float* scale, void* wpk, int32_t cout
     return occd::check_launch();
 }
 
+static int pack_bf16_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin, int32_t ntaps,
+                            int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, int nsplit, void* stream);
+
 extern "C" int occd_pack_weights_bf16_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
                                              int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs,
                                              void* stream) {
+    return pack_bf16_gather(w, scale, wpk, cout, cin, ntaps, s_co, s_ci, tap_ofs, 1, stream);
+}
+
+// the hi | mid | lo images of the gathered operator (3 * occd_packed_weight_bf16_elems() elements): the 3-way split of the
+// data-gradient operators (float32-accurate dgrad of the head convolutions on K2s3 in the fp32 training mode)
+extern "C" int occd_pack_weights_bf16x3_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin,
+                                               int32_t ntaps, int64_t s_co, int64_t s_ci, const int32_t* tap_ofs,
+                                               void* stream) {
+    return pack_bf16_gather(w, scale, wpk, cout, cin, ntaps, s_co, s_ci, tap_ofs, 3, stream);
+}
+
+static int pack_bf16_gather(const float* w, const float* scale, void* wpk, int32_t cout, int32_t cin, int32_t ntaps,
+                            int64_t s_co, int64_t s_ci, const int32_t* tap_ofs, int nsplit, void* stream) {
     if (!w || !wpk || !tap_ofs || ntaps <= 0 || ntaps > occd::kMaxTaps) return OCCD_EINVAL;
     const int64_t total = occd_packed_weight_bf16_elems(cout, cin, ntaps);
     if (total <= 0) return OCCD_EINVAL;
@@ -462,7 +478,7 @@ extern "C" int occd_pack_weights_bf16_gather(const float* w, const float* scale,
     const long blocks = (total + th - 1) / th;
     occd::ProfScope prof("pack_weights_bf16", (hipStream_t)stream, 0.0, (double)total * 6);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)blocks), dim3(th), 0, (hipStream_t)stream, w, scale,
-                       (uint16_t*)wpk, cout, cin, ntaps, K16, NT, 3, (long)total, 1, tm);
+                       (uint16_t*)wpk, cout, cin, ntaps, K16, NT, 3, (long)total, nsplit, tm);
     return occd::check_launch();
 }
 

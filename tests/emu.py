@@ -108,6 +108,8 @@ def pack_weights_gather(w, cout, cin, s_co, s_ci, tap_ofs, kernel=None, bf16=Fal
     ci = torch.arange(cin).view(1, -1, 1) * s_ci
     idx = co + ci + torch.tensor([int(o) for o in tap_ofs]).view(1, 1, -1)
     sub = flat[idx].reshape(cout, cin, *kernel)
+    if bf16 == "x3":
+        return pack_weights_bf16(sub, split3=True)
     return pack_weights_bf16(sub) if bf16 else pack_weights(sub)
 
 

@@ -224,3 +224,31 @@ def test_autocast_and_bf16_mode_dtypes(hip_lib):
         assert conv.weight.grad.dtype == torch.float32 and torch.isfinite(conv.weight.grad).all()
     finally:
         ag.set_bf16_mfma(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_head_conv_forward_and_dgrad_take_k2s3_in_fp32_training_mode(d, hip_lib):
+    """fp32 training mode: the full-resolution head convolutions run forward AND data gradient on K2s3 (3-way bf16 split,
+    float32-level accuracy) when the eval default does (fused.BF16X3 = "head"); against ATen float64 on the CPU at the bound of
+    the exact-fp32 kernels (2e-5), and the profile shows which kernel ran."""
+    import torch.nn as nn
+    from occdepth_amd import autograd3d, fused, hip
+    assert fused.BF16X3 == "head" and not autograd3d.BF16_MFMA
+    torch.manual_seed(d)
+    conv = autograd3d.Conv3d(32, 32, 3, padding=d, dilation=d, bias=False).cuda()
+    x = torch.randn(1, 32, 16, 256, 32, device="cuda").contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    gy = torch.randn(1, 32, 16, 256, 32, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    with hip.profile() as prof:
+        y = conv(x)
+        y.backward(gy)
+        torch.cuda.synchronize()
+    tags = sorted({k.split(":")[0] for k in prof.rows})
+    assert sum(v["launches"] for k, v in prof.rows.items() if k.startswith("conv3d_c32x3")) == 2, tags     # forward + dgrad
+    xr = x.detach().cpu().double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    yr = torch.nn.functional.conv3d(xr, wr, padding=d, dilation=d)
+    yr.backward(gy.cpu().double())
+    for got, ref, what in ((y, yr, "y"), (x.grad, xr.grad, "dx"), (conv.weight.grad, wr.grad, "dw")):
+        err = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        assert err < 2e-5, (d, what, err)

@@ -123,9 +123,9 @@ def test_train_step_full_config2_matches_reference_gpu(mode, hip_lib):
     on the build container's CPU).  fp32: every loss term within 5e-4 (measured 1.5e-5), the same parameters left without gradient,
     11 gradient norms within 3e-2 (measured 1.2e-2) and their stored slices at cosine > 0.99 (0.9987): the round-off of ~270
     BatchNorm-normalised layers; the kernels are pinned one by one at 2e-5 elsewhere.  bf16-MFMA mode (configs[3]: every
-    convolution of the 3-D stack and the 2-D decoder AND, since round 4, the encoder's pointwise convolutions on plain bf16
-    operands): loss terms within 1e-2 (measured 3.2e-3; 1.2e-4 with the encoder still in fp32), gradient norms within 0.25,
-    cosine > 0.8."""
+    convolution of the 3-D stack and the 2-D decoder on bf16 operands, the encoder in fp32): loss terms within 3e-3 (1.2e-4),
+    gradient norms within 0.15 (7.3e-2), cosine > 0.85 (0.93).  (This test is what kept the encoder's pointwise convolutions
+    OUT of the bf16 pipe: with them on plain bf16 operands the cosines of the encoder gradients fall to 0.2 - 0.35.)"""
     from occdepth_amd import autograd3d
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
@@ -151,7 +151,7 @@ def test_train_step_full_config2_matches_reference_gpu(mode, hip_lib):
         torch.cuda.synchronize()
     finally:
         autograd3d.set_bf16_mfma(saved)
-    rel, nrel = (5e-4, 3e-2) if mode == "fp32" else (1e-2, 0.25)      # measured: 1.5e-5 / 1.2e-2; bf16 mode 3.2e-3 / see the printed table
+    rel, nrel = (5e-4, 3e-2) if mode == "fp32" else (3e-3, 0.15)      # measured: 1.5e-5 / 1.2e-2 and 1.2e-4 / 7.3e-2
     terms = [f for f in g.files if f.startswith("train/")]
     assert len(terms) == 8
     report = {}
@@ -184,7 +184,7 @@ def test_train_step_full_config2_matches_reference_gpu(mode, hip_lib):
     assert len(rows) >= 8
     for k, got_n, ref_n, cos in rows:
         assert got_n == pytest.approx(ref_n, rel=nrel), (k, got_n, ref_n)
-    assert worst_cos > (0.99 if mode == "fp32" else 0.8)                  # measured 0.9987 / 0.93 (encoder fp32)
+    assert worst_cos > (0.99 if mode == "fp32" else 0.85)                 # measured 0.9987 / 0.9301
 
 
 # The HIP-vs-ATen comparison of the 3-D stack's backward lives in tests/test_stack3d_backward.py: the stack alone,
