@@ -147,11 +147,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     }
 
     f32x4 ra[NA][2], rb[NB];
-    auto issue = [&](int k0) {          // global -> registers for the K step starting at k0 (clamped addresses, masked later)
+    // FAST (interior tiles of a K % 32 == 0 problem -- all but the last column of tiles): no address clamps, no K / N tail
+    // selects; the general form pays ~2 extra VALU instructions per MFMA for them (PMC: 5.8 VALU per MFMA)
+    auto issue = [&](int k0, auto fast_c) {          // global -> registers for the K step starting at k0
+        constexpr bool FAST = decltype(fast_c)::value;
         if (PRE != 1) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int k = min(k0 + a_k[i], p.K - 8);
+                const int k = FAST ? k0 + a_k[i] : min(k0 + a_k[i], p.K - 8);
                 const float* src = Ab + a_off[i] - a_k[i] + k;
                 ra[i][0] = *(const f32x4*)src;
                 ra[i][1] = *(const f32x4*)(src + 4);
@@ -160,15 +163,16 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
         if (PRE != 2) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int k = min(k0 + b_k[i], p.K - 1);
+                const int k = FAST ? k0 + b_k[i] : min(k0 + b_k[i], p.K - 1);
                 rb[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + b_col[i]);
             }
         }
     };
-    auto commit = [&](int k0) {         // registers -> split -> LDS
+    auto commit = [&](int k0, auto fast_c) {         // registers -> split -> LDS
+        constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
         for (int i = 0; i < (PRE == 1 ? 0 : NA); ++i) {
-            const bool ok = k0 + a_k[i] < p.K;
+            const bool ok = FAST || k0 + a_k[i] < p.K;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             u32x4 hi, mid, lo;
             split8(ok ? ra[i][0] : z, ok ? ra[i][1] : z, hi, mid, lo);
@@ -180,15 +184,19 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
         }
 #pragma unroll
         for (int i = 0; i < (PRE == 2 ? 0 : NB); ++i) {
-            const bool ok = k0 + b_k[i] < p.K;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 w = ok ? rb[i] : z;
-            const int sh = b_sh[i];                  // (selects, not branches: the shift is lane-dependent)
             f32x4 v;
-            v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
-            v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
-            v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
-            v.w = sh == 0 ? w.w : 0.f;
+            if (FAST) {
+                v = rb[i];
+            } else {
+                const bool ok = k0 + b_k[i] < p.K;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 w = ok ? rb[i] : z;
+                const int sh = b_sh[i];                  // (selects, not branches: the shift is lane-dependent)
+                v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
+                v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
+                v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
+                v.w = sh == 0 ? w.w : 0.f;
+            }
             u32x2 hi, mid, lo;
             split4(v, hi, mid, lo);
             *(u32x2*)(lB + b_dst[i]) = hi;
@@ -245,13 +253,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     };
 
     const int ksteps = (p.K + 31) >> 5;
-    issue(0);
+    auto kloop = [&](auto fast_c) {
+    issue(0, fast_c);
     if (PRE != 0) fetch_pk(0);
     for (int s = 0; s < ksteps; ++s) {
         __syncthreads();                // previous tile consumed
-        commit(s * 32);
+        commit(s * 32, fast_c);
         __syncthreads();
-        if (s + 1 < ksteps) issue((s + 1) * 32);
+        if (s + 1 < ksteps) issue((s + 1) * 32, fast_c);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 af[MT][3];
@@ -289,6 +298,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
             OCCD_GX3(0, 0);
         }
     }
+    };
+    if ((p.K & 31) == 0 && n0 + TN <= p.N) kloop(std::true_type{});
+    else kloop(std::false_type{});
 #undef OCCD_GX3
 
     // epilogue: lane -> column n, registers -> rows (r & 3) + 8 (r >> 2) + 4 h.  Bias / activation are uniform over the
@@ -393,14 +405,16 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
         // steps (~2 x 1.8k cycles) to come back -- one step was not enough once the B panel of an XCD's tile run stops fitting
         // its 4 MB L2 (PMC, profiles/r04_pmc_gemm_head_v1.txt: 417 MB fetched for 48 MB of operands, MFMA pipe busy 40 %)
         f32x4 ra[2][2][2], rb[2][2];
+        auto loader = [&](auto fast_c) {             // FAST: interior tile of a K % 16 == 0 problem (no clamps, no tail selects)
+        constexpr bool FAST = decltype(fast_c)::value;
         auto issue = [&](int k0, int set) {
             if (DBG == 2 && k0 > 16) return;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float* src = Ab + a_off[i] + min(k0 + a_k[i], p.K - 8);
+                const float* src = Ab + a_off[i] + (FAST ? k0 + a_k[i] : min(k0 + a_k[i], p.K - 8));
                 ra[set][i][0] = *(const f32x4*)src;
                 ra[set][i][1] = *(const f32x4*)(src + 4);
-                rb[set][i] = *(const f32x4u*)(Bb + (size_t)min(k0 + b_k[i], p.K - 1) * p.ldb + b_col[i]);
+                rb[set][i] = *(const f32x4u*)(Bb + (size_t)(FAST ? k0 + b_k[i] : min(k0 + b_k[i], p.K - 1)) * p.ldb + b_col[i]);
             }
         };
         auto commit = [&](int k0, int set, unsigned char* buf) {
@@ -408,7 +422,7 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const bool oka = k0 + a_k[i] < p.K;
+                const bool oka = FAST || k0 + a_k[i] < p.K;
                 u32x4 hi, mid, lo;
                 if (DBG == 1) {
                     const f32x4 x0 = ra[set][i][0], x1 = ra[set][i][1];
@@ -423,14 +437,17 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
                 *(u32x4*)(buf + a_dst[i]) = hi;
                 *(u32x4*)(buf + a_dst[i] + 32) = mid;
                 *(u32x4*)(buf + a_dst[i] + 64) = lo;
-                const bool okb = k0 + b_k[i] < p.K;
-                const f32x4 w = okb ? rb[set][i] : z;
-                const int sh = b_sh[i];
                 f32x4 v;
-                v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
-                v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
-                v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
-                v.w = sh == 0 ? w.w : 0.f;
+                const f32x4 w = (FAST || k0 + b_k[i] < p.K) ? rb[set][i] : z;
+                if (FAST) {
+                    v = w;
+                } else {
+                    const int sh = b_sh[i];
+                    v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
+                    v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
+                    v.z = sh == 0 ? w.z : sh == 1 ? w.w : 0.f;
+                    v.w = sh == 0 ? w.w : 0.f;
+                }
                 u32x2 h2, m2, l2;
                 if (DBG == 1) {
                     h2 = u32x2{__builtin_amdgcn_perm(__float_as_uint(w.y), __float_as_uint(w.x), 0x07060302u),
@@ -470,6 +487,9 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
             }
             __syncthreads();                         // buffer 0 published, buffer 1 consumed
         }
+        };
+        if ((p.K & 15) == 0 && n0 + kWsTN <= p.N) loader(std::true_type{});
+        else loader(std::false_type{});
         return;
     }
 
@@ -794,10 +814,9 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     // the wave-specialised 256 x 128 kernel takes the launches the 256 x 128 tile would (float32 operands): hint 5 forces it,
     // hint 0 picks it (OCCD_GEMM_WS=0 in the environment keeps the barrier-phased kernels for A/B)
     static const bool ws_off = getenv("OCCD_GEMM_WS") != nullptr && getenv("OCCD_GEMM_WS")[0] == '0';
-    // measured (profiles/r04_gemm_x3_v3_ws.txt): the two forms are within 5 % of each other; K16w leads on the long-K launches
-    // (1/16, 1/8 levels), the barrier-phased kernel on the short-K ones (K = 160 / 320)
-    const bool plain = a->pre == 3;
-    const bool ws = a->pre == 0 && (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 512));
+    // measured (profiles/r04_gemm_x3_v4_fast.txt): with the tail-free fast path the barrier-phased kernel leads everywhere but on
+    // the longest K (tap GEMM of the 1/16 level, K = 2560: 0.438 against 0.462 ms); K16w keeps that launch
+    const bool ws = a->pre == 0 && (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 2048));
     if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
     const int TM = v.MT * v.WM * 32, TN = v.NT * v.WN * 32;
