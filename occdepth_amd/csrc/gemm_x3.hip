@@ -836,7 +836,6 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     p.nwg = (unsigned)nwg;
     const size_t lds = ws ? (size_t)2 * kWsStage
                           : (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
-    (void)plain;
     void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel<0> : v.kern[a->pre];
 #ifdef OCCD_GEMM_DEV_VARIANTS
     if (ws && getenv("OCCD_GEMM_DBG") != nullptr)
