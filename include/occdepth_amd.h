@@ -95,6 +95,12 @@ typedef struct occd_conv3d_args {
 
 int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream);
 
+/* The n in {1, 2, 4, 8} sub-pixel phases of ONE transposed convolution as one launch
+ * (ConvTranspose3d(k3, s2, p1, op1) of the reference's Upsample blocks, occdepth/models/modules.py:278-296,
+ * = 8 phase convolutions over tap subsets scattering to interleaved voxels).  a[0..n) may differ ONLY in
+ * wpk, kx / ky / kz and o_off_*; OCCD_EINVAL otherwise.  Same arithmetic as n calls of occd_conv3d_fwd.   */
+int occd_conv3d_fwd_phases(const occd_conv3d_args* a, int32_t n, void* stream);
+
 /* Pack PyTorch-layout conv weights (Cout, Cin, KX, KY, KZ) [transposed=0] or
  * conv-transpose weights (Cin, Cout, KX, KY, KZ) [transposed=1] into `wpk`,
  * multiplying output channel c by scale[c] when scale != NULL (BN fold).

@@ -21,6 +21,10 @@
 // occdepth/models/modules.py:40-46,158-175,278-296, occdepth/models/CRP3D.py:54-97.
 #include "common.h"
 
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+
 using occd::FastDiv;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,9 +32,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// What differs between the sub-pixel phases of one transposed convolution (occd_conv3d_fwd_phases): the tap subset (its
+// packed weights and extent), where the phase's voxels land in the output, and the staged slab that follows from the extent.
+// A plain launch is the one-phase case.
+struct PhaseP {
+    const float* wpk;
+    int KX, KY, KZ, oox, ooy, ooz, YIN, ZIN;
+    FastDiv div_zin;
+};
+constexpr int kMaxPhases = 8;
+
 struct ConvP {
     const float* in;
-    const float* wpk;
     const float* bias;
     const float* res1;
     const float* res2;
@@ -38,11 +51,13 @@ struct ConvP {
     int X, Y, Z, cin8, in_cs, in_coff;
     int KTtot, NTtot;
     int out_cs, out_coff, res1_cs, res1_coff, res2_cs, res2_coff;
-    int KX, KY, KZ, SX, SY, SZ, DX, DY, DZ, PX, PY, PZ;
-    int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz, oox, ooy, ooz;
+    int SX, SY, SZ, DX, DY, DZ, PX, PY, PZ;
+    int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz;
     int act_in, act_out, cout_store;
-    int TY, TZ, YIN, ZIN, ytiles, ztiles, nwg;
-    FastDiv div_zin, div_tz, div_ztiles, div_ytiles;
+    int TY, TZ, ytiles, ztiles, nwg;
+    int nph_log2;           // blockIdx.y = (batch index << nph_log2) | phase
+    FastDiv div_tz, div_ztiles, div_ytiles;
+    PhaseP ph[kMaxPhases];
 };
 
 __device__ __forceinline__ f32x4 apply_act(f32x4 v, int act) {
@@ -88,7 +103,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
     const uint32_t t2 = occd_fastdiv(t1, p.div_ytiles);
     const int yt = t1 - t2 * p.ytiles;
     const int xo = t2;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y >> p.nph_log2;
+    const PhaseP& ph = p.ph[blockIdx.y & ((1u << p.nph_log2) - 1u)];
     const int nt0 = (blockIdx.z * WN + wn) * NT;
 
     // LDS float4 index of this lane's A row for each M tile.
@@ -101,7 +117,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
         const bool in_tile = yl < (uint32_t)p.TY;
         yl = in_tile ? yl : 0u;
         zl = in_tile ? zl : 0u;
-        rowbase[mt] = (int)((yl * p.SY) * p.ZIN + zl * p.SZ) * RS4 + kk;
+        rowbase[mt] = (int)((yl * p.SY) * ph.ZIN + zl * p.SZ) * RS4 + kk;
     }
     // float offset of each owned N tile inside one (tap, kt) weight record;
     // N tiles past the layer's last one alias it (their results are never stored).
@@ -120,8 +136,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
     const int y_in0 = yt * p.TY * p.SY - p.PY;
     const int z_in0 = zt * p.TZ * p.SZ - p.PZ;
     const size_t w_step = (size_t)p.NTtot * 256;  // floats per (tap, kt)
-    const float* const wlane = p.wpk + lane * 4;
-    const int rows = p.YIN * p.ZIN;
+    const float* const wlane = ph.wpk + lane * 4;
+    const int rows = ph.YIN * ph.ZIN;
     const int F = rows * C4;
     f32x4* const slab4 = lds_all + (size_t)kg * rows * RS4;   // this K group's slab
     const int n_chunks = (p.cin8 + CK - 1) / CK;
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] =                               \
             __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[nt][q], a_cur[mt][q], acc[mt][nt], 0, 0, 0)
 
-    for (int kx = 0; kx < p.KX; ++kx) {
+    for (int kx = 0; kx < ph.KX; ++kx) {
         const int xi = xo * p.SX - p.PX + kx * p.DX;
         if (xi < 0 || xi >= p.X) continue;  // workgroup-uniform
         const float* const in_plane =
@@ -142,8 +158,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
             const bool active = c0 < p.cin8;      // uniform per K group; every group still joins the barriers
             const int ck = active ? min(CK, p.cin8 - c0) : 8;
             const int ktn = ck >> 3;
-            const int S = active ? p.KY * p.KZ * ktn : 0;
-            const float* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.KTtot + (c0 >> 3)) * w_step;
+            const int S = active ? ph.KY * ph.KZ * ktn : 0;
+            const float* wp = wlane + ((size_t)(kx * ph.KY * ph.KZ) * p.KTtot + (c0 >> 3)) * w_step;
 
             // first B fragments fly while the slab is staged
             f32x4 b_cur[NT];
@@ -162,8 +178,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
                     const int fc = min(f, F - 1);
                     const uint32_t row = (uint32_t)fc / C4;
                     const int c4 = fc - (int)row * C4;
-                    const uint32_t yi = occd_fastdiv(row, p.div_zin);
-                    const int zi = (int)row - (int)yi * p.ZIN;
+                    const uint32_t yi = occd_fastdiv(row, ph.div_zin);
+                    const int zi = (int)row - (int)yi * ph.ZIN;
                     const int y = y_in0 + (int)yi, z = z_in0 + zi;
                     okv[u] = f < F && c4 * 4 < ck && (unsigned)y < (unsigned)p.Y && (unsigned)z < (unsigned)p.Z;
                     const int yc = min(max(y, 0), p.Y - 1), zc = min(max(z, 0), p.Z - 1);
@@ -193,8 +209,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
                 if (ktl == ktn) {
                     ktl = 0;
                     wp += (size_t)(p.KTtot - ktn) * w_step;
-                    if (++kz == p.KZ) { kz = 0; ++ky; }
-                    lds_off = (ky * p.DY * p.ZIN + kz * p.DZ) * RS4;
+                    if (++kz == ph.KZ) { kz = 0; ++ky; }
+                    lds_off = (ky * p.DY * ph.ZIN + kz * p.DZ) * RS4;
                 }
                 f32x4 a_nxt[MT], b_nxt[NT];
 #pragma unroll
@@ -249,8 +265,8 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
         const uint32_t zl = m - yl * p.TZ;
         const int yo = yt * p.TY + (int)yl, zo = zt * p.TZ + (int)zl;
         const bool ok = yl < (uint32_t)p.TY && yo < p.Yo && zo < p.Zo;
-        const size_t vox = ((size_t)(b * p.OX + xo * p.osx + p.oox) * p.OY + (yo * p.osy + p.ooy)) * p.OZ +
-                           (zo * p.osz + p.ooz);
+        const size_t vox = ((size_t)(b * p.OX + xo * p.osx + ph.oox) * p.OY + (yo * p.osy + ph.ooy)) * p.OZ +
+                           (zo * p.osz + ph.ooz);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -395,7 +411,9 @@ extern "C" int occd_pack_weights_gather(const float* w, const float* scale, floa
     return occd::check_launch();
 }
 
-extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
+namespace {
+
+int validate(const occd_conv3d_args* a) {
     if (!a || !a->in || !a->wpk || !a->out) return OCCD_EINVAL;
     if (a->batch <= 0 || a->X <= 0 || a->Y <= 0 || a->Z <= 0 || a->cin <= 0 || a->cout <= 0) return OCCD_EINVAL;
     if (a->kx <= 0 || a->ky <= 0 || a->kz <= 0 || a->sx <= 0 || a->sy <= 0 || a->sz <= 0) return OCCD_EINVAL;
@@ -422,14 +440,14 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
         return OCCD_EINVAL;
     if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
         return OCCD_EINVAL;
+    return OCCD_OK;
+}
 
-    {
-        const int taken = occd::try_conv3d_c32_persist(a, (hipStream_t)stream);
-        if (taken != 0) return taken > 0 ? OCCD_OK : taken;
-    }
-
-    // ---- variant choice: widest N tile the layer fills, then the largest M
-    // tile that fits LDS and still yields >= 2 workgroups per CU.
+// ---- variant choice: widest N tile the layer fills, then the largest M tile that fits LDS and still yields >= 2
+// workgroups per CU.  `copies` = launches' worth of workgroups that share the grid (batch x phases).
+int choose(const occd_conv3d_args* a, long copies, Tiling* til) {
+    const int cin8 = (a->cin + 7) & ~7;
+    const int NTtot = (a->cout + 31) / 32;
     int order[kNumVariants];
     int n = 0;
     if (a->tile_hint > 0 && a->tile_hint <= kNumVariants) {
@@ -442,56 +460,146 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
         order[n++] = 2; order[n++] = 3; order[n++] = 6;
     }
     int pick = -1;
-    Tiling til{};
     for (int i = 0; i < n; ++i) {
         Tiling t{};
         if (!plan(a, kVariants[order[i]], NTtot, &t)) continue;
         pick = order[i];
-        til = t;
-        if (t.nwg * t.ngroups * a->batch >= 512) break;  // else keep refining to the finest fit
+        *til = t;
+        if (t.nwg * t.ngroups * copies >= 512) break;  // else keep refining to the finest fit
     }
-    if (pick < 0) return OCCD_ENOMEM;
-    if (a->tile_hint == 0 && til.nwg * til.ngroups * a->batch <= 320 && cin8 >= 128) {
+    if (pick < 0) return -1;
+    if (a->tile_hint == 0 && til->nwg * til->ngroups * copies <= 320 && cin8 >= 128) {
         // too few output tiles to fill 1024 SIMDs with one wave each: multiply the waves by splitting K
         for (int cand : {7, 8}) {
             Tiling t{};
             const int nwn = kVariants[cand].NT * kVariants[cand].WN;
             if (NTtot % nwn != 0 && NTtot > nwn) continue;
             if (!plan(a, kVariants[cand], NTtot, &t)) continue;
-            if (t.nwg * t.ngroups * a->batch > 1024) continue;
+            if (t.nwg * t.ngroups * copies > 1024) continue;
             pick = cand;
-            til = t;
+            *til = t;
             break;
         }
     }
-    const Variant& v = kVariants[pick];
+    return pick;
+}
 
-    ConvP p;
-    p.in = a->in; p.wpk = a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
-    p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.cin8 = cin8; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
-    p.KTtot = cin8 / 8; p.NTtot = NTtot;
-    p.out_cs = a->out_cs; p.out_coff = a->out_coff;
-    p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
-    p.KX = a->kx; p.KY = a->ky; p.KZ = a->kz; p.SX = a->sx; p.SY = a->sy; p.SZ = a->sz;
-    p.DX = a->dx; p.DY = a->dy; p.DZ = a->dz; p.PX = a->px; p.PY = a->py; p.PZ = a->pz;
-    p.Xo = a->Xo; p.Yo = a->Yo; p.Zo = a->Zo; p.OX = a->OX; p.OY = a->OY; p.OZ = a->OZ;
-    p.osx = a->o_stride_x; p.osy = a->o_stride_y; p.osz = a->o_stride_z;
-    p.oox = a->o_off_x; p.ooy = a->o_off_y; p.ooz = a->o_off_z;
-    p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
-    p.TY = til.TY; p.TZ = til.TZ; p.YIN = til.YIN; p.ZIN = til.ZIN;
-    p.ytiles = til.ytiles; p.ztiles = til.ztiles; p.nwg = (int)til.nwg;
-    p.div_zin = occd::make_fastdiv(til.ZIN); p.div_tz = occd::make_fastdiv(til.TZ);
-    p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
+void fill_shared(const occd_conv3d_args* a, const Tiling& til, ConvP* p) {
+    const int cin8 = (a->cin + 7) & ~7;
+    p->in = a->in; p->bias = a->bias; p->res1 = a->res1; p->res2 = a->res2; p->out = a->out;
+    p->X = a->X; p->Y = a->Y; p->Z = a->Z; p->cin8 = cin8; p->in_cs = a->in_cs; p->in_coff = a->in_coff;
+    p->KTtot = cin8 / 8; p->NTtot = (a->cout + 31) / 32;
+    p->out_cs = a->out_cs; p->out_coff = a->out_coff;
+    p->res1_cs = a->res1_cs; p->res1_coff = a->res1_coff; p->res2_cs = a->res2_cs; p->res2_coff = a->res2_coff;
+    p->SX = a->sx; p->SY = a->sy; p->SZ = a->sz;
+    p->DX = a->dx; p->DY = a->dy; p->DZ = a->dz; p->PX = a->px; p->PY = a->py; p->PZ = a->pz;
+    p->Xo = a->Xo; p->Yo = a->Yo; p->Zo = a->Zo; p->OX = a->OX; p->OY = a->OY; p->OZ = a->OZ;
+    p->osx = a->o_stride_x; p->osy = a->o_stride_y; p->osz = a->o_stride_z;
+    p->act_in = a->act_in; p->act_out = a->act_out; p->cout_store = a->cout_store;
+    p->TY = til.TY; p->TZ = til.TZ;
+    p->ytiles = til.ytiles; p->ztiles = til.ztiles; p->nwg = (int)til.nwg;
+    p->div_tz = occd::make_fastdiv(til.TZ);
+    p->div_ztiles = occd::make_fastdiv(til.ztiles); p->div_ytiles = occd::make_fastdiv(til.ytiles);
+}
 
-    if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(v.kern)) != OCCD_OK) return OCCD_ELAUNCH;
+void fill_phase(const occd_conv3d_args* a, const Tiling& til, PhaseP* ph) {
+    ph->wpk = a->wpk;
+    ph->KX = a->kx; ph->KY = a->ky; ph->KZ = a->kz;
+    ph->oox = a->o_off_x; ph->ooy = a->o_off_y; ph->ooz = a->o_off_z;
+    ph->YIN = til.YIN; ph->ZIN = til.ZIN;
+    ph->div_zin = occd::make_fastdiv(til.ZIN);
+}
+
+void cost(const occd_conv3d_args* a, double* flops, double* bytes, bool first) {
     const double taps = (double)a->kx * a->ky * a->kz;
     const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
-    const double flops = 2.0 * pos * taps * a->cin * a->cout;
-    const double bytes = 4.0 * ((double)a->batch * a->X * a->Y * a->Z * a->cin +
-                                pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) +
-                                taps * a->cin * a->cout);
+    *flops += 2.0 * pos * taps * a->cin * a->cout;
+    *bytes += 4.0 * ((first ? (double)a->batch * a->X * a->Y * a->Z * a->cin : 0.0) +
+                     pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr)) + taps * a->cin * a->cout);
+}
+
+}  // namespace
+
+extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
+    const int bad = validate(a);
+    if (bad != OCCD_OK) return bad;
+    {
+        const int taken = occd::try_conv3d_c32_persist(a, (hipStream_t)stream);
+        if (taken != 0) return taken > 0 ? OCCD_OK : taken;
+    }
+    Tiling til{};
+    const int pick = choose(a, a->batch, &til);
+    if (pick < 0) return OCCD_ENOMEM;
+    const Variant& v = kVariants[pick];
+    ConvP p{};
+    fill_shared(a, til, &p);
+    fill_phase(a, til, &p.ph[0]);
+    p.nph_log2 = 0;
+    if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(v.kern)) != OCCD_OK) return OCCD_ELAUNCH;
+    double flops = 0.0, bytes = 0.0;
+    cost(a, &flops, &bytes, true);
     occd::ProfScope prof("conv3d_igemm", (hipStream_t)stream, flops, bytes);
     hipLaunchKernelGGL(v.kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
+                       dim3(v.WM * v.WN * v.KS * 64), til.lds, (hipStream_t)stream, p);
+    return occd::check_launch();
+}
+
+// The sub-pixel phases of ONE transposed convolution (ConvTranspose3d(k3, s2, p1, op1) = 8 phase convolutions over tap
+// subsets that scatter to interleaved voxels, occdepth/models/modules.py:278-296) as ONE launch: the phase is the low bits
+// of blockIdx.y, every phase walks the same output tiling of the (shared) input volume, and the heaviest phase comes first in
+// dispatch order so that the single-tap ones fill the tail.  a[0..n): n in {1, 2, 4, 8} descriptors that may differ ONLY
+// in wpk, kx / ky / kz and o_off_*; anything else must match a[0].  Replaces n launches of occd_conv3d_fwd (24 per frame
+// at config 2, the smallest 16 us long).
+extern "C" int occd_conv3d_fwd_phases(const occd_conv3d_args* a, int32_t n, void* stream) {
+    if (!a || (n != 1 && n != 2 && n != 4 && n != 8)) return OCCD_EINVAL;
+    int heavy = 0;
+    for (int i = 0; i < n; ++i) {
+        const int bad = validate(a + i);
+        if (bad != OCCD_OK) return bad;
+        occd_conv3d_args t = a[i];
+        t.wpk = a[0].wpk; t.kx = a[0].kx; t.ky = a[0].ky; t.kz = a[0].kz;
+        t.o_off_x = a[0].o_off_x; t.o_off_y = a[0].o_off_y; t.o_off_z = a[0].o_off_z;
+        if (memcmp(&t, &a[0], offsetof(occd_conv3d_args, tile_hint) + sizeof(int32_t)) != 0) return OCCD_EINVAL;
+        if (a[i].kx * a[i].ky * a[i].kz > a[heavy].kx * a[heavy].ky * a[heavy].kz) heavy = i;
+    }
+    if (a[0].cin <= 32 && n > 1) {             // (the <= 32-channel sliding-window kernels are single-phase: issue them one by one)
+        for (int i = 0; i < n; ++i) {
+            const int rc = occd_conv3d_fwd(a + i, stream);
+            if (rc != OCCD_OK) return rc;
+        }
+        return OCCD_OK;
+    }
+    // one variant / output tiling for all phases: the one the heaviest phase would take with n x batch copies in the grid
+    occd_conv3d_args big = a[heavy];
+    for (int i = 0; i < n; ++i) {               // (slab extents: the largest ky / kz over the phases)
+        big.ky = a[i].ky > big.ky ? a[i].ky : big.ky;
+        big.kz = a[i].kz > big.kz ? a[i].kz : big.kz;
+    }
+    Tiling til{};
+    const int pick = choose(&big, (long)a[0].batch * n, &til);
+    if (pick < 0) return OCCD_ENOMEM;
+    const Variant& v = kVariants[pick];
+    const int NTtot = (a[0].cout + 31) / 32;
+    ConvP p{};
+    fill_shared(&a[0], til, &p);
+    int order[kMaxPhases];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order, order + n, [&](int l, int r) {
+        return a[l].kx * a[l].ky * a[l].kz > a[r].kx * a[r].ky * a[r].kz;
+    });
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const occd_conv3d_args* ai = a + order[i];
+        Tiling ti{};
+        if (!plan(ai, v, NTtot, &ti) || ti.TY != til.TY || ti.TZ != til.TZ || ti.lds > til.lds) return OCCD_EINVAL;
+        fill_phase(ai, ti, &p.ph[i]);
+        cost(ai, &flops, &bytes, i == 0);
+    }
+    p.nph_log2 = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
+    if ((long)a[0].batch * n > 65535) return OCCD_EINVAL;
+    if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(v.kern)) != OCCD_OK) return OCCD_ELAUNCH;
+    occd::ProfScope prof("conv3d_igemm_phases", (hipStream_t)stream, flops, bytes);
+    hipLaunchKernelGGL(v.kern, dim3((unsigned)til.nwg, (unsigned)(a[0].batch * n), (unsigned)til.ngroups),
                        dim3(v.WM * v.WN * v.KS * 64), til.lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }

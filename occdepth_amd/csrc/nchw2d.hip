@@ -458,12 +458,20 @@ __global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* 
 
 // Staged form of the kernel above (the product path).  The direct form issues 144 four-byte gathers per thread (9 taps x
 // 4 outputs x 4 bilinear corners) and is bound by the texture-address path (0.58 ms per decoder level).  Here the
-// workgroup (4 output rows x 256 output columns of one (b, co) plane) first builds, for every tap plane t and each of its
-// 4 output rows, the VERTICALLY interpolated low-resolution row segment its columns can touch -- coalesced loads along
-// the row, 2 per element, zero for rows outside the output grid -- in LDS: L[t][r][c] = hy z_t[y0][xlo + c] + ly z_t[y1][xlo + c]
-// for the output row oy0 + r + ky - 1.  A thread then needs 2 LDS reads per (tap, output): 72 instead of 144 global ones.
-// Same arithmetic as the direct form up to the order of the two interpolations (vertical first here).
+// workgroup (256 output columns of one (b, co) plane, a strip of kUpGroups x 4 output rows walked 4 rows at a time) first
+// builds, for every tap plane t and each of the 4 output rows, the VERTICALLY interpolated low-resolution row segment its
+// columns can touch -- coalesced loads along the row, 2 per element, zero for rows outside the output grid -- in LDS:
+// L[t][r][c] = hy z_t[y0][xlo + c] + ly z_t[y1][xlo + c] for the output row oy0 + r + ky - 1.  A thread then needs 2 LDS
+// reads per (tap, output): 72 instead of 144 global ones.  Same arithmetic as the direct form up to the order of the two
+// interpolations (vertical first here).
+// Round 4: (a) wave r stages exactly the 9 segments of ITS output row r (lane = column, 3 column chunks), so all four waves
+// load and every load of a row group is independent of the others: 54 loads in flight per lane instead of three dependent
+// batches of 24 on 130 of the 256 threads; (b) the loads of row group g + 1 are issued before the arithmetic of group g
+// (register double buffer), so a workgroup pays one memory round trip per strip instead of ~7 per 4 rows -- the kernel was
+// latency bound at 1.9 TB/s; (c) consecutive row groups share 2 of their ~4 low-resolution source rows, which the SAME CU
+// has just loaded: the PMC showed 1.9x the z tensor fetched from HBM with one group per workgroup.
 constexpr int kUpNC = 192;                                   // LDS row length: low-resolution columns a workgroup can touch
+constexpr int kUpGroups = 4;                                 // 4-row groups per workgroup (a strip of 16 output rows)
 // SKIP: the convolution over the (few: <= kUpSkipC) skip channels, the BatchNorm shift and the LeakyReLU are applied here
 // too, i.e. the kernel emits the finished first convolution of the level (the 1/1 level: 3 raw image channels).  K10 is
 // the wrong tool for K = 3: its per-workgroup prologue / exchange / epilogue is fixed and it ran the 3 -> 80 convolution
@@ -476,16 +484,33 @@ struct UpSkipP {
     float slope;
 };
 constexpr int kUpSkipC = 4, kUpSkipW = 260;                  // skip tile: [Cs][6 rows][258 columns (+2 pad)]
+
+// one row group's worth of global loads, held in registers until the LDS tile of the previous group has been consumed
+template <bool SKIP>
+struct UpStage {
+    float a0[9][3], a1[9][3];      // [tap][column chunk]: the two source rows of this wave's output row
+    float ly[3], ok[3];            // per ky (wave-uniform)
+    float s[SKIP ? kUpSkipC * 6 : 1];
+    float sx;                      // the two extra tile columns (256, 257): one (channel, row, column) element on threads < 12 Cs
+};
+
+// a wave-uniform value that the vector ALU produced, as an SGPR (the compiler folds __builtin_amdgcn_readfirstlane of a
+// value it can prove uniform, and then legalises buffer descriptors / scalar offsets held in VGPRs with waterfall loops)
+__device__ __forceinline__ int to_sgpr(int v) {
+    int s;
+    asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
+    return s;
+}
+
 template <bool SKIP>
 __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
                                                             int h, int w, int H, int W, float rh, float rw, long zcs,
                                                             long zbs, const UpSkipP sk) {
     __shared__ float L[9 * 4 * kUpNC];
     __shared__ __attribute__((aligned(16))) float S[SKIP ? kUpSkipC * 6 * kUpSkipW : 4];
-    // Workgroup -> tile mapping.  Vertically adjacent tiles share 2 of their ~4 low-resolution source rows; the
-    // dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2), so in launch order
-    // those rows came back from HBM twice (PMC: 2.2x the z tensor fetched).  XCD-aware bijective remap of the linear id,
-    // then column-major tiles inside a plane: every XCD walks a contiguous run of vertically adjacent tiles.
+    // Workgroup -> tile mapping.  Vertically adjacent strips share low-resolution source rows; the dispatcher deals
+    // consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2).  XCD-aware bijective remap of the linear
+    // id, then column-major strips inside a plane: every XCD walks a contiguous run of vertically adjacent strips.
     const uint32_t gx = gridDim.x, gy = gridDim.y, per_plane = gx * gy;
     uint32_t bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     {
@@ -496,71 +521,117 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     const uint32_t local = bid - plane * per_plane;
     const int bx = local / gy, by = local - bx * gy;
     const int b = plane / Cout, co = plane - b * Cout;
-    const int X0 = bx * 256, oy0 = by * 4;
+    const int X0 = bx * 256;
+    const int g0 = by * kUpGroups, ng = min(kUpGroups, (H + 3) / 4 - g0);
     // low-resolution column window of the hi-res columns X0 - 1 .. X0 + 256 (clamped): [xlo, xlo + nc)
-    const int xlo = (int)(rw * max(X0 - 1, 0));
-    const int xe = (int)(rw * min(X0 + 256, W - 1));
+    // (float-derived integers come out of the vector ALU; to_sgpr moves them, and with them the buffer descriptor and the
+    //  scalar offsets built from them, into SGPRs -- otherwise every buffer load is wrapped in a waterfall loop)
+    const int xlo = to_sgpr((int)(rw * max(X0 - 1, 0)));
+    const int xe = to_sgpr((int)(rw * min(X0 + 256, W - 1)));
     const int nc = min(xe + 1, w - 1) - xlo + 1;              // (the host guarantees nc <= kUpNC)
     const size_t tap_stride = (size_t)Cout * zcs;            // z[b][ch][y][x] at b * zbs + ch * zcs + y * w + x
-    const float* zb = z + (size_t)b * zbs + (size_t)co * zcs;
-    // thread c stages column xlo + c of all 36 (tap, row) segments: the row arithmetic is wave-uniform, the loads of a
-    // wave are consecutive floats, and 12 segments (24 loads) are in flight per thread before any is used
-    if ((int)threadIdx.x < nc) {
-        const float* pc = zb + xlo + threadIdx.x;
+    const float* zb = z + (size_t)b * zbs + (size_t)co * zcs + xlo;
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // output row of this wave inside a group
+    const bool third = lane + 128 < nc;                       // (2x upsampling: nc = 131, three lanes)
+    const int cA = min(lane, nc - 1), cB = min(lane + 64, nc - 1), cC = min(lane + 128, nc - 1);
+    const float* sb = SKIP ? sk.skip + (size_t)b * sk.Cs * H * W : nullptr;
+    const int cx0 = min(max(X0 - 1 + (int)threadIdx.x, 0), W - 1);
+    const bool okx0 = (unsigned)(X0 - 1 + (int)threadIdx.x) < (unsigned)W;
+    // (extra columns 256 / 257 of the skip tile: thread e -> channel e / 12, row (e % 12) / 2, column 256 + (e & 1))
+    const int ec = threadIdx.x / 12, er = (threadIdx.x % 12) >> 1, ecol = 256 + (threadIdx.x & 1);
+    const bool extra = SKIP && (int)threadIdx.x < 12 * sk.Cs;
+
+    // buffer loads: one descriptor per tensor (SGPRs), the (tap, source row) part of the address as the scalar offset and the
+    // column as a loop-invariant 32-bit vector offset -- no 64-bit address registers for the 54 + 19 loads of a row group
+    const auto zr = __builtin_amdgcn_make_buffer_rsrc((void*)zb, 0, 0x7fffffff, 0x00020000);
+    const auto sr = __builtin_amdgcn_make_buffer_rsrc((void*)(SKIP ? sb : z), 0, 0x7fffffff, 0x00020000);
+    const unsigned vA = (unsigned)cA * 4u, vB = (unsigned)cB * 4u, vC = (unsigned)cC * 4u, vS = (unsigned)cx0 * 4u;
+    const unsigned tap_bytes = (unsigned)tap_stride * 4u;
+    auto ldz = [&](unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, voff, soff, 0));
+    };
+    auto issue = [&](int g, UpStage<SKIP>& st) {
+        const int oy = (g0 + g) * 4 + r;
+        unsigned o0[3], o1[3];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            float a0[12], a1[12], wy[12], rowok[12];
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ry = oy + ky - 1;
+            const bool ok = (unsigned)ry < (unsigned)H;
+            const float sy = rh * (ok ? ry : 0);
+            const int y0 = to_sgpr((int)sy);
+            const int y1 = y0 + (y0 < h - 1);
+            st.ly[ky] = sy - y0;                               // (may round a hair below 0 when contracted into an fma:
+            st.ok[ky] = ok ? 1.f : 0.f;                        //  never use its sign as the "outside the grid" marker)
+            o0[ky] = (unsigned)(y0 * w) * 4u;
+            o1[ky] = (unsigned)(y1 * w) * 4u;
+        }
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const int tr = g * 12 + u, t = tr >> 2, r = tr & 3;
-                const int ry = oy0 + r + t / 3 - 1;
-                const bool ok = (unsigned)ry < (unsigned)H;
-                const float sy = rh * (ok ? ry : 0);
-                const int y0 = (int)sy;
-                const int y1 = y0 + (y0 < h - 1);
-                wy[u] = sy - y0;                               // (may round a hair below 0 when contracted into an fma:
-                rowok[u] = ok ? 1.f : 0.f;                     //  never use its sign as the "outside the grid" marker)
-                a0[u] = pc[(size_t)t * tap_stride + (size_t)y0 * w];
-                a1[u] = pc[(size_t)t * tap_stride + (size_t)y1 * w];
-            }
+        for (int t = 0; t < 9; ++t) {
+            const unsigned s0 = (unsigned)t * tap_bytes + o0[t / 3], s1 = (unsigned)t * tap_bytes + o1[t / 3];
+            st.a0[t][0] = ldz(vA, s0);
+            st.a1[t][0] = ldz(vA, s1);
+            st.a0[t][1] = ldz(vB, s0);
+            st.a1[t][1] = ldz(vB, s1);
+        }
+        if (third) {
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const float ly = wy[u];
-                L[(g * 12 + u) * kUpNC + threadIdx.x] = rowok[u] * ((1.f - ly) * a0[u] + ly * a1[u]);
+            for (int t = 0; t < 9; ++t) {
+                st.a0[t][2] = ldz(vC, (unsigned)t * tap_bytes + o0[t / 3]);
+                st.a1[t][2] = ldz(vC, (unsigned)t * tap_bytes + o1[t / 3]);
             }
         }
-    }
-    if (SKIP) {
-        // skip tile: rows oy0 - 1 .. oy0 + 4, columns X0 - 1 .. X0 + 256 of every skip channel, zero outside the image
-        // (thread = tile column, channels x rows unrolled: no index divisions, all loads of a thread independent)
-        const float* sb = sk.skip + (size_t)b * sk.Cs * H * W;
-        const int cc0 = threadIdx.x;
-        const int ix0 = X0 - 1 + cc0, ix1 = ix0 + 256;                     // second column only for the first 2 threads
-        const bool okx0 = (unsigned)ix0 < (unsigned)W, okx1 = cc0 < 2 && (unsigned)ix1 < (unsigned)W;
-        const int cx0 = min(max(ix0, 0), W - 1), cx1 = min(max(ix1, 0), W - 1);
+        if (SKIP) {
+            // skip tile: rows oy0 - 1 .. oy0 + 4, columns X0 - 1 .. X0 + 256 of every skip channel, zero outside the image
+            // (thread = tile column, channels x rows unrolled: no index divisions, all loads of a thread independent)
+            const int oy0 = (g0 + g) * 4;
 #pragma unroll
-        for (int c = 0; c < kUpSkipC; ++c) {
-            if (c < sk.Cs) {                                                 // (uniform)
-                float v0[6], v1[6];
+            for (int c = 0; c < kUpSkipC; ++c) {
+                if (c < sk.Cs) {                                                 // (uniform)
 #pragma unroll
-                for (int rr = 0; rr < 6; ++rr) {
-                    const int iy = min(max(oy0 - 1 + rr, 0), H - 1);
-                    v0[rr] = sb[((size_t)c * H + iy) * W + cx0];
-                    v1[rr] = sb[((size_t)c * H + iy) * W + cx1];
-                }
-#pragma unroll
-                for (int rr = 0; rr < 6; ++rr) {
-                    const bool oky = (unsigned)(oy0 - 1 + rr) < (unsigned)H;
-                    S[(c * 6 + rr) * kUpSkipW + cc0] = oky && okx0 ? v0[rr] : 0.f;
-                    if (cc0 < 2) S[(c * 6 + rr) * kUpSkipW + cc0 + 256] = oky && okx1 ? v1[rr] : 0.f;
+                    for (int rr = 0; rr < 6; ++rr) {
+                        const int iy = min(max(oy0 - 1 + rr, 0), H - 1);
+                        st.s[SKIP ? c * 6 + rr : 0] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(sr, vS, (unsigned)((c * H + iy) * W) * 4u, 0));
+                    }
                 }
             }
+            if (extra) {
+                const int iy = min(max(oy0 - 1 + er, 0), H - 1), ix = min(X0 - 1 + ecol, W - 1);
+                st.sx = sb[((size_t)ec * H + iy) * W + ix];
+            }
         }
-    }
-    __syncthreads();
-    const int r = threadIdx.x >> 6;
-    const int ox0 = X0 + (threadIdx.x & 63) * 4, oy = oy0 + r;
-    if (ox0 >= W || oy >= H) return;
+    };
+    auto commit = [&](int g, const UpStage<SKIP>& st) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float ly = st.ly[t / 3], ok = st.ok[t / 3];
+            float* row = L + (t * 4 + r) * kUpNC + lane;
+            row[0] = ok * ((1.f - ly) * st.a0[t][0] + ly * st.a1[t][0]);
+            row[64] = ok * ((1.f - ly) * st.a0[t][1] + ly * st.a1[t][1]);
+            row[128] = ok * ((1.f - ly) * st.a0[t][2] + ly * st.a1[t][2]);   // (columns >= nc: never read)
+        }
+        if (SKIP) {
+            const int oy0 = (g0 + g) * 4;
+#pragma unroll
+            for (int c = 0; c < kUpSkipC; ++c) {
+                if (c < sk.Cs) {
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+                        const bool oky = (unsigned)(oy0 - 1 + rr) < (unsigned)H;
+                        S[(c * 6 + rr) * kUpSkipW + threadIdx.x] = oky && okx0 ? st.s[SKIP ? c * 6 + rr : 0] : 0.f;
+                    }
+                }
+            }
+            if (extra) {
+                const bool oky = (unsigned)(oy0 - 1 + er) < (unsigned)H, okx = X0 - 1 + ecol < W;
+                S[(ec * 6 + er) * kUpSkipW + ecol] = oky && okx ? st.sx : 0.f;
+            }
+        }
+    };
+
+    // per-thread column arithmetic of the 4 outputs (the same for every row group)
+    const int ox0 = X0 + lane * 4;
     int x0[6], x1[6];
     float lx[6], cm[6];
 #pragma unroll
@@ -573,52 +644,68 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
         x1[j] = xa + (xa < w - 1) - xlo;
         lx[j] = sx - xa;
     }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* wk = SKIP ? sk.wskip + (size_t)co * sk.Cs * 9 : nullptr;     // (uniform: scalar loads at the point of use)
+    const float sh = SKIP ? sk.shift[co] : 0.f;
+
+    UpStage<SKIP> st;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float* row = L + (t * 4 + r) * kUpNC;
-        const int kx = t % 3;
+    for (int t = 0; t < 9; ++t) st.a0[t][2] = st.a1[t][2] = 0.f;  // (only lanes with a third column ever load them)
+    st.sx = 0.f;
+    issue(0, st);
+    for (int g = 0; g < ng; ++g) {
+        commit(g, st);
+        __syncthreads();
+        if (g + 1 < ng) issue(g + 1, st);                     // in flight during the arithmetic below
+        const int oy = (g0 + g) * 4 + r;
+        if (ox0 < W && oy < H) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = i + kx;
-            acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
-        }
-    }
-    if (SKIP) {
-        const float* wk = sk.wskip + (size_t)co * sk.Cs * 9;
-        const int lc = ox0 - X0;                              // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
+            for (int t = 0; t < 9; ++t) {
+                const float* row = L + (t * 4 + r) * kUpNC;
+                const int kx = t % 3;
 #pragma unroll
-        for (int c = 0; c < kUpSkipC; ++c) {
-            if (c >= sk.Cs) break;                                           // (uniform)
+                for (int i = 0; i < 4; ++i) {
+                    const int j = i + kx;
+                    acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
+                }
+                if (kx == 2) __builtin_amdgcn_sched_barrier(0);   // (24 LDS reads in flight, not 72: registers)
+            }
+            if (SKIP) {
+                const int lc = ox0 - X0;                      // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* srow = S + (c * 6 + r + ky) * kUpSkipW + lc;
-                // (tile rows are 1040 bytes and lc = 4 * lane: one aligned 16-byte + one 8-byte LDS read per row)
-                const f32x4 va = *(const f32x4*)srow;
-                const f32x2 vb = *(const f32x2*)(srow + 4);
-                const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
+                for (int c = 0; c < kUpSkipC; ++c) {
+                    if (c >= sk.Cs) break;                                       // (uniform)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = wk[(c * 3 + ky) * 3 + kx];
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float* srow = S + (c * 6 + r + ky) * kUpSkipW + lc;
+                        // (tile rows are 1040 bytes and lc = 4 * lane: one aligned 16-byte + one 8-byte LDS read per row)
+                        const f32x4 va = *(const f32x4*)srow;
+                        const f32x2 vb = *(const f32x2*)(srow + 4);
+                        const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] += v[i + kx] * wv;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float wv = wk[(c * 3 + ky) * 3 + kx];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i] += v[i + kx] * wv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = acc[i] + sh;
+                    acc[i] = t > 0.f ? t : t * sk.slope;
                 }
             }
-        }
-        const float sh = sk.shift[co];
+            float* op = out + ((size_t)plane * H + oy) * W + ox0;
+            if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+                *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t = acc[i] + sh;
-            acc[i] = t > 0.f ? t : t * sk.slope;
+                for (int i = 0; i < 4; ++i)
+                    if (ox0 + i < W) op[i] = acc[i];
+            }
         }
-    }
-    float* op = out + ((size_t)plane * H + oy) * W + ox0;
-    if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
-        *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (ox0 + i < W) op[i] = acc[i];
+        __syncthreads();                                      // tile consumed before the next group's commit
     }
 }
 
@@ -927,12 +1014,15 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     if (zcs < (long)h * w) return OCCD_EINVAL;
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
+    // (the staged kernel addresses one image's z with 32-bit buffer offsets; OCCD_UPCONV_DIRECT: A/B switch)
+    const bool staged = getenv("OCCD_UPCONV_DIRECT") == nullptr && rw * 258.f + 3.f <= (float)kUpNC &&
+                        9L * Cout * zcs * 4 < (1L << 31);
+    const unsigned groups = (unsigned)((H + 3) / 4);
+    const dim3 grid((unsigned)((W + 255) / 256), staged ? (groups + kUpGroups - 1) / kUpGroups : groups, (unsigned)(batch * Cout));
     occd::ProfScope prof("upconv_gather_nchw", (hipStream_t)stream, 2.0 * 36 * batch * Cout * (double)H * W,
                          4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
-    static const bool force_direct = getenv("OCCD_UPCONV_DIRECT") != nullptr;        // A/B switch
-    if (!force_direct && rw * 258.f + 3.f <= (float)kUpNC)
+    if (staged)
         hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh,
                            rw, zcs, zbs, UpSkipP{});
     else
@@ -954,7 +1044,8 @@ extern "C" int occd_upconv_gather_skip_nchw(const float* z, const float* skip, c
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     if (rw * 258.f + 3.f > (float)kUpNC) return OCCD_EINVAL;          // (upsampling ratios below ~1.4: use the two-kernel form)
-    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
+    if (9L * Cout * zcs * 4 >= (1L << 31) || (long)Cs * H * W * 4 >= (1L << 31)) return OCCD_EINVAL;   // 32-bit buffer offsets
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(((H + 3) / 4 + kUpGroups - 1) / kUpGroups), (unsigned)(batch * Cout));
     occd::ProfScope prof("upconv_gather_skip_nchw", (hipStream_t)stream, 2.0 * (36 + 9.0 * Cs) * batch * Cout * (double)H * W,
                          4.0 * batch * (Cout * (9.0 * h * w + (double)H * W) + (double)Cs * H * W));
     UpSkipP sk{skip, wskip, shift, Cs, slope};

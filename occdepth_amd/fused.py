@@ -254,6 +254,10 @@ class DerivedConvPlan:
                           act_out=act_out)
 
 
+# the 8 sub-pixel phases of a stride-2 transposed convolution as one launch (occd_conv3d_fwd_phases); 0 = eight launches
+PHASES_ONE_LAUNCH = os.environ.get("OCCDEPTH_PHASES_ONE_LAUNCH", "1") == "1"
+
+
 class ConvTransposePlan:
     """ConvTranspose3d(k=3, s=2, p=1, output_padding=1) (+BN) as 8 sub-pixel phase convolutions,
     or ConvTranspose3d(k=3, s=1, p=1) (+BN) as one flipped convolution."""
@@ -315,6 +319,10 @@ class ConvTransposePlan:
             return lambda: _conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
                                    out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
 
+        if PHASES_ONE_LAUNCH and len(self._phases) > 1 and not any(isinstance(ph[3], _DualW) for ph in self._phases):
+            # one K2 launch for the 8 phases (phase = low bits of blockIdx.y, heaviest tap subset first)
+            return hip.conv3d_phases(x, [(wpk, kern, off) for off, kern, _, wpk in self._phases], self._bias, self.cout, out,
+                                     res1=res1, act_out=act_out, out_pos=x.dims, o_stride=(self.up,) * 3)
         thunks = [phase(*ph) for ph in self._phases]
         if x.buf.is_cuda and len(thunks) > 1:
             run_parallel(thunks)                     # the phases write disjoint voxels of `out`

@@ -88,6 +88,12 @@ def pack_weights_bf16(w, scale=None, layout=0, split3=False):
     return pk
 
 
+def conv3d_phases(x, phases, bias, cout, out, res1=None, act_out=0, out_pos=None, o_stride=(1, 1, 1)):
+    for wpk, kernel, o_off in phases:
+        conv3d(x, wpk, bias, cout, kernel, out, res1=res1, act_out=act_out, out_pos=out_pos, o_stride=o_stride, o_off=o_off)
+    return out
+
+
 def conv3d_bf16(x, wpk, bias, cout, kernel, out, **kw):
     """bf16 operands, exact products, float32 accumulation == the float32 emulation on bf16-rounded inputs."""
     assert getattr(wpk, "bf16", False), "conv3d_bf16 needs pack_weights_bf16's image"
@@ -559,7 +565,8 @@ def patched(fast2d=False):
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "pack_weights_gather", "conv3d_bf16",
-                                          "conv3d_wgrad_bf16", "gemm_x3", "gemm_x3_supported")}
+                                          "conv3d_wgrad_bf16", "gemm_x3", "gemm_x3_supported", "conv3d_phases")}
+    hip.conv3d_phases = conv3d_phases
     hip.pack_weights_bf16, hip.conv3d_bf16, hip.conv3d_wgrad_bf16 = pack_weights_bf16, conv3d_bf16, conv3d_wgrad_bf16
     hip.pack_weights_gather = pack_weights_gather
     hip.gemm_x3, hip.gemm_x3_supported = gemm_x3, gemm_x3_supported

@@ -229,6 +229,34 @@ def test_module_hip_vs_aten(hip, name):
     compare(got, ref, 2e-4, name)
 
 
+@pytest.mark.parametrize("case", [(2, 128, 64, (8, 8, 4)), (1, 64, 32, (16, 12, 8)), (1, 40, 20, (5, 3, 5)), (1, 256, 128, (8, 8, 2))])
+def test_transposed_conv_phases_one_launch_equals_eight(hip, case):
+    """occd_conv3d_fwd_phases (phase = low bits of blockIdx.y, one shared tiling) against the eight separate launches it
+    replaces -- the same kernel and K order, so bit for bit unless the merged grid picks another tile variant -- and against
+    ATen's ConvTranspose3d + BatchNorm (+ the residual and ReLU of the Upsample block)."""
+    from occdepth_amd import fused
+    B, cin, cout, dims = case
+    torch.manual_seed(cin)
+    convt = nn.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1).to(DEV)
+    bn = randomize_bn(nn.BatchNorm3d(cout)).to(DEV).eval()
+    x = torch.randn(B, cin, *dims, device=DEV)
+    res = torch.randn(B, cout, *(2 * n for n in dims), device=DEV)
+    with torch.no_grad():
+        ref = F.relu(bn(convt(x)) + res)
+        plan = fused.ConvTransposePlan(convt, bn)
+        vx, vr = hip.Vox.from_ncdhw(x), hip.Vox.from_ncdhw(res)
+        saved = fused.PHASES_ONE_LAUNCH
+        try:
+            fused.PHASES_ONE_LAUNCH = True
+            one = plan(vx, res1=vr, act_out=hip.ACT_RELU).ncdhw()
+            fused.PHASES_ONE_LAUNCH = False
+            eight = plan(vx, res1=vr, act_out=hip.ACT_RELU).ncdhw()
+        finally:
+            fused.PHASES_ONE_LAUNCH = saved
+    assert rel_err(one, ref) < 2e-5 and rel_err(eight, ref) < 2e-5
+    assert rel_err(one, eight) < 1e-6
+
+
 @pytest.mark.parametrize("cfg", ["kitti_ps2", "kitti_ps1", "nyu"])
 def test_unet3d_hip_vs_aten(hip, cfg):
     torch.manual_seed(2)
