@@ -458,20 +458,19 @@ __global__ void __launch_bounds__(256) upconv_gather_direct_kernel(const float* 
 
 // Staged form of the kernel above (the product path).  The direct form issues 144 four-byte gathers per thread (9 taps x
 // 4 outputs x 4 bilinear corners) and is bound by the texture-address path (0.58 ms per decoder level).  Here the
-// workgroup (256 output columns of one (b, co) plane, a strip of kUpGroups x 4 output rows walked 4 rows at a time) first
-// builds, for every tap plane t and each of the 4 output rows, the VERTICALLY interpolated low-resolution row segment its
+// workgroup (4 output rows x 256 output columns of one (b, co) plane) first builds, for every tap plane t and each of its
+// 4 output rows, the VERTICALLY interpolated low-resolution row segment its
 // columns can touch -- coalesced loads along the row, 2 per element, zero for rows outside the output grid -- in LDS:
 // L[t][r][c] = hy z_t[y0][xlo + c] + ly z_t[y1][xlo + c] for the output row oy0 + r + ky - 1.  A thread then needs 2 LDS
 // reads per (tap, output): 72 instead of 144 global ones.  Same arithmetic as the direct form up to the order of the two
 // interpolations (vertical first here).
-// Round 4: (a) wave r stages exactly the 9 segments of ITS output row r (lane = column, 3 column chunks), so all four waves
-// load and every load of a row group is independent of the others: 54 loads in flight per lane instead of three dependent
-// batches of 24 on 130 of the 256 threads; (b) the loads of row group g + 1 are issued before the arithmetic of group g
-// (register double buffer), so a workgroup pays one memory round trip per strip instead of ~7 per 4 rows -- the kernel was
-// latency bound at 1.9 TB/s; (c) consecutive row groups share 2 of their ~4 low-resolution source rows, which the SAME CU
-// has just loaded: the PMC showed 1.9x the z tensor fetched from HBM with one group per workgroup.
+// Round 4: wave r stages exactly the 9 segments of ITS output row r (lane = column, 3 column chunks) through buffer loads
+// (descriptor + scalar (tap, row) offset + a loop-invariant column offset: no 64-bit address registers), so all four waves
+// load and every load of the tile is independent of the others: 54 loads in flight per lane instead of three dependent
+// batches of 24 on 130 of the 256 threads -- the kernel was latency bound at 1.9 TB/s.  The 1/1 level with the fused skip
+// convolution: 0.81 -> 0.55 ms.  (Measured and dropped: strips of 2 / 4 / 8 row groups per workgroup with the next
+// group's loads issued before the arithmetic of the current one -- 184 VGPRs, 2 workgroups per CU, 0.64 ms.)
 constexpr int kUpNC = 192;                                   // LDS row length: low-resolution columns a workgroup can touch
-constexpr int kUpGroups = 4;                                 // 4-row groups per workgroup (a strip of 16 output rows)
 // SKIP: the convolution over the (few: <= kUpSkipC) skip channels, the BatchNorm shift and the LeakyReLU are applied here
 // too, i.e. the kernel emits the finished first convolution of the level (the 1/1 level: 3 raw image channels).  K10 is
 // the wrong tool for K = 3: its per-workgroup prologue / exchange / epilogue is fixed and it ran the 3 -> 80 convolution
@@ -485,7 +484,7 @@ struct UpSkipP {
 };
 constexpr int kUpSkipC = 4, kUpSkipW = 260;                  // skip tile: [Cs][6 rows][258 columns (+2 pad)]
 
-// one row group's worth of global loads, held in registers until the LDS tile of the previous group has been consumed
+// the tile's global loads
 template <bool SKIP>
 struct UpStage {
     float a0[9][3], a1[9][3];      // [tap][column chunk]: the two source rows of this wave's output row
@@ -494,12 +493,13 @@ struct UpStage {
     float sx;                      // the two extra tile columns (256, 257): one (channel, row, column) element on threads < 12 Cs
 };
 
-// a wave-uniform value that the vector ALU produced, as an SGPR (the compiler folds __builtin_amdgcn_readfirstlane of a
-// value it can prove uniform, and then legalises buffer descriptors / scalar offsets held in VGPRs with waterfall loops)
+// A wave-uniform value that the vector ALU produced, as an SGPR.  A bare __builtin_amdgcn_readfirstlane is commuted by the
+// optimiser to the operand side of the float -> int conversion (whose result is a VGPR again, and buffer descriptors /
+// scalar offsets held in VGPRs are legalised with waterfall loops); the empty asm makes the converted value opaque first.
+// (Not the instruction itself as inline asm: that form faulted on gfx950 -- the compiler cannot see a hazard inside asm.)
 __device__ __forceinline__ int to_sgpr(int v) {
-    int s;
-    asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
-    return s;
+    asm volatile("" : "+v"(v));
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 template <bool SKIP>
@@ -508,9 +508,10 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
                                                             long zbs, const UpSkipP sk) {
     __shared__ float L[9 * 4 * kUpNC];
     __shared__ __attribute__((aligned(16))) float S[SKIP ? kUpSkipC * 6 * kUpSkipW : 4];
-    // Workgroup -> tile mapping.  Vertically adjacent strips share low-resolution source rows; the dispatcher deals
-    // consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2).  XCD-aware bijective remap of the linear
-    // id, then column-major strips inside a plane: every XCD walks a contiguous run of vertically adjacent strips.
+    // Workgroup -> tile mapping.  Vertically adjacent tiles share 2 of their ~4 low-resolution source rows; the
+    // dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2), so in launch order
+    // those rows came back from HBM twice (PMC: 2.2x the z tensor fetched).  XCD-aware bijective remap of the linear id,
+    // then column-major tiles inside a plane: every XCD walks a contiguous run of vertically adjacent tiles.
     const uint32_t gx = gridDim.x, gy = gridDim.y, per_plane = gx * gy;
     uint32_t bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     {
@@ -521,8 +522,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     const uint32_t local = bid - plane * per_plane;
     const int bx = local / gy, by = local - bx * gy;
     const int b = plane / Cout, co = plane - b * Cout;
-    const int X0 = bx * 256;
-    const int g0 = by * kUpGroups, ng = min(kUpGroups, (H + 3) / 4 - g0);
+    const int X0 = bx * 256, oy0 = by * 4;
     // low-resolution column window of the hi-res columns X0 - 1 .. X0 + 256 (clamped): [xlo, xlo + nc)
     // (float-derived integers come out of the vector ALU; to_sgpr moves them, and with them the buffer descriptor and the
     //  scalar offsets built from them, into SGPRs -- otherwise every buffer load is wrapped in a waterfall loop)
@@ -551,8 +551,8 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     auto ldz = [&](unsigned voff, unsigned soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, voff, soff, 0));
     };
-    auto issue = [&](int g, UpStage<SKIP>& st) {
-        const int oy = (g0 + g) * 4 + r;
+    auto issue = [&](UpStage<SKIP>& st) {
+        const int oy = oy0 + r;
         unsigned o0[3], o1[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -584,7 +584,6 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
         if (SKIP) {
             // skip tile: rows oy0 - 1 .. oy0 + 4, columns X0 - 1 .. X0 + 256 of every skip channel, zero outside the image
             // (thread = tile column, channels x rows unrolled: no index divisions, all loads of a thread independent)
-            const int oy0 = (g0 + g) * 4;
 #pragma unroll
             for (int c = 0; c < kUpSkipC; ++c) {
                 if (c < sk.Cs) {                                                 // (uniform)
@@ -602,7 +601,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
             }
         }
     };
-    auto commit = [&](int g, const UpStage<SKIP>& st) {
+    auto commit = [&](const UpStage<SKIP>& st) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float ly = st.ly[t / 3], ok = st.ok[t / 3];
@@ -612,7 +611,6 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
             row[128] = ok * ((1.f - ly) * st.a0[t][2] + ly * st.a1[t][2]);   // (columns >= nc: never read)
         }
         if (SKIP) {
-            const int oy0 = (g0 + g) * 4;
 #pragma unroll
             for (int c = 0; c < kUpSkipC; ++c) {
                 if (c < sk.Cs) {
@@ -630,7 +628,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
         }
     };
 
-    // per-thread column arithmetic of the 4 outputs (the same for every row group)
+    // per-thread column arithmetic of the 4 outputs
     const int ox0 = X0 + lane * 4;
     int x0[6], x1[6];
     float lx[6], cm[6];
@@ -649,63 +647,57 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
 
     UpStage<SKIP> st;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) st.a0[t][2] = st.a1[t][2] = 0.f;  // (only lanes with a third column ever load them)
+    for (int t = 0; t < 9; ++t) st.a0[t][2] = st.a1[t][2] = 0.f;  // (only lanes with a third column load them)
     st.sx = 0.f;
-    issue(0, st);
-    for (int g = 0; g < ng; ++g) {
-        commit(g, st);
-        __syncthreads();
-        if (g + 1 < ng) issue(g + 1, st);                     // in flight during the arithmetic below
-        const int oy = (g0 + g) * 4 + r;
-        if (ox0 < W && oy < H) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    issue(st);
+    commit(st);
+    __syncthreads();
+    const int oy = oy0 + r;
+    if (ox0 >= W || oy >= H) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float* row = L + (t * 4 + r) * kUpNC;
-                const int kx = t % 3;
+    for (int t = 0; t < 9; ++t) {
+        const float* row = L + (t * 4 + r) * kUpNC;
+        const int kx = t % 3;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = i + kx;
-                    acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
+        for (int i = 0; i < 4; ++i) {
+            const int j = i + kx;
+            acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
+        }
+    }
+    if (SKIP) {
+        const int lc = ox0 - X0;                              // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
+#pragma unroll
+        for (int c = 0; c < kUpSkipC; ++c) {
+            if (c >= sk.Cs) break;                                           // (uniform)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* srow = S + (c * 6 + r + ky) * kUpSkipW + lc;
+                // (tile rows are 1040 bytes and lc = 4 * lane: one aligned 16-byte + one 8-byte LDS read per row)
+                const f32x4 va = *(const f32x4*)srow;
+                const f32x2 vb = *(const f32x2*)(srow + 4);
+                const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = wk[(c * 3 + ky) * 3 + kx];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] += v[i + kx] * wv;
                 }
-                if (kx == 2) __builtin_amdgcn_sched_barrier(0);   // (24 LDS reads in flight, not 72: registers)
-            }
-            if (SKIP) {
-                const int lc = ox0 - X0;                      // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
-#pragma unroll
-                for (int c = 0; c < kUpSkipC; ++c) {
-                    if (c >= sk.Cs) break;                                       // (uniform)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const float* srow = S + (c * 6 + r + ky) * kUpSkipW + lc;
-                        // (tile rows are 1040 bytes and lc = 4 * lane: one aligned 16-byte + one 8-byte LDS read per row)
-                        const f32x4 va = *(const f32x4*)srow;
-                        const f32x2 vb = *(const f32x2*)(srow + 4);
-                        const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const float wv = wk[(c * 3 + ky) * 3 + kx];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i] += v[i + kx] * wv;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = acc[i] + sh;
-                    acc[i] = t > 0.f ? t : t * sk.slope;
-                }
-            }
-            float* op = out + ((size_t)plane * H + oy) * W + ox0;
-            if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
-                *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ox0 + i < W) op[i] = acc[i];
             }
         }
-        __syncthreads();                                      // tile consumed before the next group's commit
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = acc[i] + sh;
+            acc[i] = t > 0.f ? t : t * sk.slope;
+        }
+    }
+    float* op = out + ((size_t)plane * H + oy) * W + ox0;
+    if (ox0 + 3 < W && ((reinterpret_cast<uintptr_t>(op) & 15) == 0)) {
+        *(f32x4*)op = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ox0 + i < W) op[i] = acc[i];
     }
 }
 
@@ -1018,7 +1010,7 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     const bool staged = getenv("OCCD_UPCONV_DIRECT") == nullptr && rw * 258.f + 3.f <= (float)kUpNC &&
                         9L * Cout * zcs * 4 < (1L << 31);
     const unsigned groups = (unsigned)((H + 3) / 4);
-    const dim3 grid((unsigned)((W + 255) / 256), staged ? (groups + kUpGroups - 1) / kUpGroups : groups, (unsigned)(batch * Cout));
+    const dim3 grid((unsigned)((W + 255) / 256), groups, (unsigned)(batch * Cout));
     occd::ProfScope prof("upconv_gather_nchw", (hipStream_t)stream, 2.0 * 36 * batch * Cout * (double)H * W,
                          4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
@@ -1045,7 +1037,7 @@ extern "C" int occd_upconv_gather_skip_nchw(const float* z, const float* skip, c
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     if (rw * 258.f + 3.f > (float)kUpNC) return OCCD_EINVAL;          // (upsampling ratios below ~1.4: use the two-kernel form)
     if (9L * Cout * zcs * 4 >= (1L << 31) || (long)Cs * H * W * 4 >= (1L << 31)) return OCCD_EINVAL;   // 32-bit buffer offsets
-    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)(((H + 3) / 4 + kUpGroups - 1) / kUpGroups), (unsigned)(batch * Cout));
+    const dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(batch * Cout));
     occd::ProfScope prof("upconv_gather_skip_nchw", (hipStream_t)stream, 2.0 * (36 + 9.0 * Cs) * batch * Cout * (double)H * W,
                          4.0 * batch * (Cout * (9.0 * h * w + (double)H * W) + (double)Cs * H * W));
     UpSkipP sk{skip, wskip, shift, Cs, slope};

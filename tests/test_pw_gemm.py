@@ -90,7 +90,9 @@ def test_pointwise_conv_pixel_major_gpu(case, hip_lib):
 # ---------------------------------------------------------------------------------------------------------------
 # depthwise + SE pooling, SE gate, and whole EfficientNet blocks on the fused path
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 24, 37, 53, 3, 1), (1, 40, 30, 41, 5, 2), (2, 7, 9, 300, 5, 1)])
+@pytest.mark.parametrize("shape", [(2, 24, 37, 53, 3, 1), (1, 40, 30, 41, 5, 2), (2, 7, 9, 300, 5, 1),
+                                   # Cr % 4 == 0: the float4 expand kernel (3 chunks; 24 chunks > its 12-chunk preload x 4 lanes? no: 50 chunks)
+                                   (2, 48, 13, 17, 3, 1), (2, 96, 6, 9, 3, 1), (1, 800, 5, 7, 5, 1)])
 def test_dwconv_pool_and_se_gate_gpu(shape, hip_lib):
     from occdepth_amd import hip
     B, C, H, W, k, stride = shape
