@@ -248,6 +248,11 @@ typedef struct occd_gemm_args {
     float slope;
     int32_t tile_hint;
     int32_t pre;                           /* 0: A, B float32; 1: A = occd_gemm_x3_pack(role 0) image; 2: B = role-1 image */
+    const float* res;                      /* optional (ABI 9): C += res[b][m][n] after bias / activation, laid out like C
+                                              (ldc, stride_c): the skip connection of an MBConv project convolution      */
+    const float* scale_k;                  /* optional (ABI 9): (batch, K) floats, B[b][k][:] is multiplied by scale_k[b][k]
+                                              (rounded to float32, as the reference's x * gate) while it is staged: the
+                                              squeeze-excite gate in front of the project convolution; pre must not be 2   */
 } occd_gemm_args;
 int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
 /* K16t, the "NT" form: C[b][m][n] = sum_k A[b][m][k] B[b][n][k], BOTH operands with k contiguous (lda, ldb >= K), any dword

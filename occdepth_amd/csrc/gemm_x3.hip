@@ -39,6 +39,8 @@ struct GemmP {
     const float* B;
     float* C;
     const float* bias;
+    const float* res;                   // optional: + res[b][m][n] (laid out like C) after bias / activation
+    const float* kscale;                // optional: B[b][k][n] * kscale[b][k] (the squeeze-excite gate of a project convolution)
     int M, N, K;
     long lda, ldb, ldc, sA, sB, sC;     // elements
     int act;                            // 0 none, 1 swish, 2 leaky relu (slope)
@@ -147,6 +149,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     }
 
     f32x4 ra[NA][2], rb[NB];
+    float rg[NB];                                    // kscale of the staged B rows (1 without)
+    const float* const Gb = p.kscale != nullptr ? p.kscale + (size_t)bz * p.K : nullptr;
     // FAST (interior tiles of a K % 32 == 0 problem -- all but the last column of tiles): no address clamps, no K / N tail
     // selects; the general form pays ~2 extra VALU instructions per MFMA for them (PMC: 5.8 VALU per MFMA)
     auto issue = [&](int k0, auto fast_c) {          // global -> registers for the K step starting at k0
@@ -165,6 +169,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
             for (int i = 0; i < NB; ++i) {
                 const int k = FAST ? k0 + b_k[i] : min(k0 + b_k[i], p.K - 1);
                 rb[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + b_col[i]);
+                rg[i] = Gb != nullptr ? Gb[k] : 1.f;     // (uniform branch; the load rides with the tile's own)
             }
         }
     };
@@ -186,11 +191,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
         for (int i = 0; i < (PRE == 2 ? 0 : NB); ++i) {
             f32x4 v;
             if (FAST) {
-                v = rb[i];
+                v = rb[i] * rg[i];
             } else {
                 const bool ok = k0 + b_k[i] < p.K;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 w = ok ? rb[i] : z;
+                const f32x4 w = ok ? rb[i] * rg[i] : z;
                 const int sh = b_sh[i];                  // (selects, not branches: the shift is lane-dependent)
                 v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
                 v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
@@ -306,6 +311,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     // epilogue: lane -> column n, registers -> rows (r & 3) + 8 (r >> 2) + 4 h.  Bias / activation are uniform over the
     // launch: one straight-line store sequence per combination
     float* const Cb = p.C + (size_t)bz * p.sC;
+    const float* const Rb = p.res != nullptr ? p.res + (size_t)bz * p.sC : nullptr;
     auto store_all = [&](auto has_bias, auto act_sel) {
         constexpr bool BIAS = decltype(has_bias)::value;
         constexpr int ACT = decltype(act_sel)::value;
@@ -328,7 +334,10 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
                     if (BIAS) v += bv[r];
                     if (ACT == 1) v = occd::swish_fast(v);
                     else if (ACT == 2) v = v > 0.f ? v : v * p.slope;
-                    if (n_ok && m < p.M) Cb[(size_t)m * p.ldc + n] = v;
+                    if (n_ok && m < p.M) {
+                        if (Rb != nullptr) v += Rb[(size_t)m * p.ldc + n];       // (uniform branch)
+                        Cb[(size_t)m * p.ldc + n] = v;
+                    }
                 }
             }
         }
@@ -796,19 +805,29 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     int pick = a->tile_hint - 1;
     if (a->tile_hint == kNumVariantsG + 1) pick = 0;
     if (pick < 0) {
-        // the largest tile that still leaves >= 160 workgroups (measured, profiles/r04_gemm_x3_v3_ws.txt: the large tiles win
-        // down to ~0.6 workgroups per CU), else the finest; a matrix of <= 64 rows (project convolutions of the high-resolution
-        // stages in training: M = 32 ... 64, N = 10^4 ... 10^5 pixels) takes the 64-row tiles instead of wasting 3/4 of a 256-row one
+        // Long K (>= 1024: tap GEMMs, Winograd-domain products): the largest tile that still leaves >= 160 workgroups
+        // (measured, profiles/r04_gemm_x3_v3_ws.txt: the large tiles win down to ~0.6 workgroups per CU).  Short K (the MBConv
+        // expand convolutions, 32 ... 640 input channels = 1 ... 20 k-steps): a workgroup is mostly prologue + epilogue and only
+        // several resident workgroups per CU hide it -- 64 x 64 tiles unless the problem is so large that even 256 x 128 tiles
+        // give 8 workgroups per CU (profiles/r04_gemm_x3_v5_shortk.txt: 48 -> 288 on 28365 pixels 54 -> 34 us, 384 -> 2304 on
+        // 468 pixels 27 -> 23 us; the tap GEMMs of the 1/1 and 1/2 levels, K = 160 / 320, keep 256 x 128); in between
+        // (K = 512 ... 1023) the largest tile with >= 320 workgroups.  A matrix of <= 64 rows (project convolutions of the
+        // high-resolution stages in training: M = 32 ... 64, N = 10^4 ... 10^5 pixels) takes the 64-row tiles instead of
+        // wasting 3/4 of a 256-row one.
+        auto wgs_of = [&](int i) {
+            const VariantG& v = kVariantsG[i];
+            const long tm = v.MT * v.WM * 32, tn = v.NT * v.WN * 32;
+            return ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
+        };
         if (a->M <= 64) {
             pick = ((long)((a->N + 255) / 256) * a->batch >= 160) ? 4 : 3;
+        } else if (a->K < 512) {
+            pick = wgs_of(0) >= 2048 ? 0 : 3;
         } else {
+            const long need = a->K < 1024 ? 320 : 160;
             pick = 3;
-            for (int i = 0; i < 4; ++i) {
-                const VariantG& v = kVariantsG[i];
-                const long tm = v.MT * v.WM * 32, tn = v.NT * v.WN * 32;
-                const long wgs = ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
-                if (wgs >= 160) { pick = i; break; }
-            }
+            for (int i = 0; i < 4; ++i)
+                if (wgs_of(i) >= need) { pick = i; break; }
         }
     }
     // the wave-specialised 256 x 128 kernel takes the launches the 256 x 128 tile would (float32 operands): hint 5 forces it,
@@ -816,12 +835,15 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     static const bool ws_off = getenv("OCCD_GEMM_WS") != nullptr && getenv("OCCD_GEMM_WS")[0] == '0';
     // measured (profiles/r04_gemm_x3_v4_fast.txt): with the tail-free fast path the barrier-phased kernel leads everywhere but on
     // the longest K (tap GEMM of the 1/16 level, K = 2560: 0.438 against 0.462 ms); K16w keeps that launch
-    const bool ws = a->pre == 0 && (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 2048));
+    if ((a->res != nullptr || a->scale_k != nullptr) && (a->tile_hint == kNumVariantsG + 1 || a->pre == 2)) return OCCD_EINVAL;
+    if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
+    const bool ws = a->pre == 0 && a->res == nullptr && a->scale_k == nullptr &&
+                    (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 2048));
     if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
     const int TM = v.MT * v.WM * 32, TN = v.NT * v.WN * 32;
     GemmP p;
-    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.res = a->res; p.kscale = a->scale_k;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a; p.sB = a->stride_b; p.sC = a->stride_c;
     if (a->pre == 1) p.sA = a->stride_a / 8;        // bf16 elements -> u32x4 records
@@ -871,7 +893,9 @@ extern "C" int32_t occd_gemm_f32x3_nt_splits(int32_t M, int32_t N, int32_t K, in
 extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
-    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || (a->pre != 0 && a->pre != 3) || a->bias != nullptr) return OCCD_EINVAL;
+    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || (a->pre != 0 && a->pre != 3) || a->bias != nullptr || a->res != nullptr ||
+        a->scale_k != nullptr)
+        return OCCD_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->A) & 3) || (reinterpret_cast<uintptr_t>(a->B) & 3) || (reinterpret_cast<uintptr_t>(a->C) & 3))
         return OCCD_EINVAL;
     const int steps = (a->K + 31) / 32;
@@ -882,7 +906,7 @@ extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
     const bool small = a->tile_hint == 2 || (a->tile_hint == 0 && wg128 < 32);
     const int TM = small ? 64 : 128, TN = small ? 64 : 128;
     GemmP p;
-    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = nullptr;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = nullptr; p.res = nullptr; p.kscale = nullptr;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a; p.sB = a->stride_b; p.sC = a->stride_c;
     p.act = (steps + splits - 1) / splits;            // (the kernel reads p.act as "32-k steps per split")

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 8   # 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 9   # 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -99,7 +99,7 @@ class GemmArgs(Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p)] + \
         [(n, c_int32) for n in ("M", "N", "K", "batch")] + \
         [(n, c_int64) for n in ("lda", "ldb", "ldc", "stride_a", "stride_b", "stride_c")] + \
-        [("act", c_int32), ("slope", c_float), ("tile_hint", c_int32), ("pre", c_int32)]
+        [("act", c_int32), ("slope", c_float), ("tile_hint", c_int32), ("pre", c_int32), ("res", c_void_p), ("scale_k", c_void_p)]
 
 
 class WinoArgs(Structure):
@@ -552,8 +552,10 @@ def gemm_x3_supported(a, b):
     return nb_a is None or nb_b is None or nb_a == nb_b
 
 
-def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_bf16=False):
-    """K16 (occd_gemm_f32x3): out[i] = act(a[i] @ b[i] + bias[:, None]) in float32-level accuracy on the bf16 matrix pipe.
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_bf16=False, res=None, k_scale=None):
+    """K16 (occd_gemm_f32x3): out[i] = act(a[i] @ (b[i] * k_scale[i][:, None]) + bias[:, None]) + res[i] in float32-level
+    accuracy on the bf16 matrix pipe (k_scale: (batch, K), the squeeze-excite gate of a project convolution; res: laid out
+    like out, the block's skip connection).
     a: (M, K) shared over the batch, or (batch, M, K); b: (K, N) or (batch, K, N); out: (batch, M, N) ((M, N) when neither
     operand is batched).  Tensor operands may be strided views as long as the innermost stride is 1; a static operand may be
     given as `GemmPacked(w, "a" / "b")` (split once, read straight from L2).  plain_bf16: operands rounded to ONE bf16 term
@@ -591,6 +593,14 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
     q.pre = 1 if pa else 2 if pb else (3 if plain_bf16 else 0)
     if plain_bf16 and (pa or pb):
         raise RuntimeError("gemm_x3: plain_bf16 takes float32 tensor operands")
+    if res is not None:
+        if res.dtype != torch.float32 or res.shape != out.shape or res.stride() != out.stride():
+            raise RuntimeError("gemm_x3: res must be laid out like out")
+        q.res = res.data_ptr()
+    if k_scale is not None:
+        if pb or k_scale.dtype != torch.float32 or tuple(k_scale.shape) != (batch, K) or not k_scale.is_contiguous():
+            raise RuntimeError("gemm_x3: k_scale must be (batch, K) contiguous floats and b a float32 tensor")
+        q.scale_k = k_scale.data_ptr()
     if _PROFILING:
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
@@ -701,17 +711,19 @@ def matmul_operand(w, role):
     return w, None
 
 
-def matmul(a, b, bias=None, act=None, slope=0.01):
-    """a @ b (+ bias[:, None], activation) for the eval path: K16 when it applies, else the library + plain tensor ops.
-    a / b may be the (tensor, GemmPacked or None) pair of `matmul_operand`."""
+def matmul(a, b, bias=None, act=None, slope=0.01, res=None, k_scale=None):
+    """act(a @ (b * k_scale[..., None]) + bias[:, None]) + res for the eval path: K16 when it applies, else the library + plain
+    tensor ops.  a / b may be the (tensor, GemmPacked or None) pair of `matmul_operand`."""
     ta, pa = a if isinstance(a, tuple) else (a, None)
     tb, pb = b if isinstance(b, tuple) else (b, None)
     if GEMM_X3:
-        xa, xb = (pa if pa is not None else ta), (pb if pb is not None else tb)
+        xa, xb = (pa if pa is not None else ta), (pb if pb is not None and k_scale is None else tb)
         if gemm_x3_supported(xa, xb):
-            return gemm_x3(xa, xb, bias=bias, act=act, slope=slope)
+            return gemm_x3(xa, xb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale)
         if gemm_x3_supported(ta, tb):
-            return gemm_x3(ta, tb, bias=bias, act=act, slope=slope)
+            return gemm_x3(ta, tb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale)
+    if k_scale is not None:
+        tb = tb * k_scale.unsqueeze(-1)
     y = torch.matmul(ta, tb)
     if bias is not None:
         y = y + bias.view(-1, 1)
@@ -719,7 +731,7 @@ def matmul(a, b, bias=None, act=None, slope=0.01):
         y = y * torch.sigmoid(y)
     elif act == "leaky":
         y = torch.nn.functional.leaky_relu(y, slope)
-    return y
+    return y + res if res is not None else y
 
 
 def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0), res1=None, res2=None,

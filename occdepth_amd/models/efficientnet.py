@@ -36,14 +36,21 @@ def pw_wins(x):
     return PW_FUSED and x.shape[0] * x.shape[2] * x.shape[3] >= PW_MIN_PIXELS
 
 
-# Expand convolutions (short K, up to 3840 couts, no gate) on maps of fewer pixels than this go to the library GEMM + one
-# BN / swish pass: rocBLAS' LDS-tiled kernels run them at 70-90 TF/s where K11 / K11s reach 40-50
-# (profiles/r02_pw_gemm_layers.txt); the project convolutions (long K, SE gate + BN + skip fused) stay on K11s.
-PW_EXPAND_LIB_BELOW = int(os.environ.get("OCCDEPTH_PW_EXPAND_LIB_BELOW", "14000"))
+# Expand convolutions (short K, up to 3840 couts, no gate) on maps of fewer pixels than this go to K16 (hip.matmul: the LDS-tiled
+# GEMM with the 3-way bf16 split, BatchNorm shift + swish in its epilogue; round 2-3: the library GEMM + one BN / swish pass) --
+# since round 4 at EVERY resolution: with 64 x 64 tiles for short K (csrc/gemm_x3.hip) K16 runs 48 -> 288 on 2 x 28365 pixels in
+# 34 us against 61 for K11, 80 -> 480 on 2 x 7191 in 21 against 34, 32 -> 192 on 2 x 112850 in 55 against 104
+# (profiles/r04_gemm_x3_v5_shortk.txt).  The project convolutions (long K, SE gate + BN + skip fused) stay on K11 / K11s.
+# OCCDEPTH_PW_EXPAND_LIB_BELOW=14000 restores the round-3 split (K11 on the high-resolution stages).
+PW_EXPAND_LIB_BELOW = int(os.environ.get("OCCDEPTH_PW_EXPAND_LIB_BELOW", str(1 << 40)))
+# plain 1x1 convolutions outside the blocks (conv_head: 640 -> 2560 on the 1/32 map) below this many pixels: library GEMM
+PW_PLAIN_LIB_BELOW = 14000
 
 
 def expand_on_library(x):
-    return x.shape[0] * x.shape[2] * x.shape[3] < PW_EXPAND_LIB_BELOW
+    # (the exact-fp32 path, OCCDEPTH_GEMM_X3=0: K16 is off and hip.matmul is the library GEMM -- the round-3 split)
+    below = PW_EXPAND_LIB_BELOW if hip.GEMM_X3 else min(PW_EXPAND_LIB_BELOW, PW_PLAIN_LIB_BELOW)
+    return x.shape[1] % 8 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < below
 
 
 def pw_operands(owner, conv, bn=None):
@@ -90,6 +97,31 @@ def expand_gemm(owner, conv, bn, x, act):
     return hip.affine_act(F.conv2d(x, conv.weight), *bn_affine_cached(bn), act)
 
 
+# Project convolutions (the squeeze-excite gate on the input channels, BatchNorm, the block's skip) on K16 as well where it
+# wins: the gate is applied to the B rows while they are staged (occd_gemm_args.scale_k), the skip in the epilogue (.res).
+# Measured per launch, config 2 (profiles/r04_frame_per_launch.txt): 288 -> 48 on 2 x 28365 pixels 44 us against 59 on K11,
+# 480 -> 80 on 2 x 7191 29 against 40; but 2304 -> 384 on 2 x 468 82 against 35 on K11s, 3840 -> 640 130 against 92,
+# 1344 -> 224 on 2 x 1848 53 against 44 (K16 has no split-K: 96 workgroups walk K = 2304 alone) and 32 -> 32 on 2 x 112850
+# 64 against 49 (half of a 64-row tile is padding).  So: maps of >= 14000 pixels and >= 48 output channels.
+PW_PROJECT_K16 = os.environ.get("OCCDEPTH_PW_PROJECT_K16", "1") == "1"
+PW_PROJECT_K16_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_PIXELS", "14000"))
+PW_PROJECT_K16_MIN_COUT = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_COUT", "48"))
+
+
+def project_conv(owner, conv, bn, y, gate, res):
+    """bn(conv1x1(y * gate)) (+ res): one launch, K16 (hip.matmul) where it applies, else K11 / K11s."""
+    B, C, H, W = y.shape
+    cout = conv.out_channels
+    if (PW_PROJECT_K16 and hip.GEMM_X3 and C % 8 == 0 and B * H * W >= PW_PROJECT_K16_MIN_PIXELS and y.is_contiguous()
+            and cout >= PW_PROJECT_K16_MIN_COUT and gate.is_contiguous() and tuple(gate.shape) == (B, C) and (res is None or res.is_contiguous())):
+        w, shift = gemm_operands(owner, conv, bn)
+        out = hip.matmul(w, y.view(B, C, H * W), bias=shift, k_scale=gate,
+                         res=res.view(B, cout, H * W) if res is not None else None)
+        return out.view(B, cout, H, W)
+    wpk, shift = pw_operands(owner, conv, bn)
+    return hip.conv1x1(y, wpk, cout, shift, None, gate=gate, res=res)
+
+
 def _fast(x, module):
     """eval-mode CUDA tensors take the fused HIP elementwise / depthwise kernels (occdepth_amd/csrc/nchw2d.hip)."""
     return _fused.on_gpu(x) and not needs_autograd(module) and x.dtype == torch.float32
@@ -114,7 +146,7 @@ class Conv2dSame(nn.Conv2d):
 
     def forward(self, x):
         if (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.groups == 1 and _fast(x, self) and pw_wins(x)
-                and not expand_on_library(x)):
+                and x.shape[0] * x.shape[2] * x.shape[3] >= PW_PLAIN_LIB_BELOW):
             wpk, shift = pw_operands(self, self)            # e.g. conv_head: plain 1x1 convolution on the MFMA GEMM (K11)
             return hip.conv1x1(x, wpk, self.out_channels, shift)
         if (self.groups == self.in_channels == self.out_channels and self.groups > 1 and x.is_cuda and needs_autograd(self)
@@ -189,8 +221,7 @@ class DepthwiseSeparableConv(nn.Module):
             y, part, plane = hip.dwconv2d_same_pool(x, self.conv_dw.weight, *bn_affine_cached(self.bn1),
                                                     self.conv_dw.stride[0], "swish")
             gate = self.se.gate_from_pool(part, plane, x.shape[0])
-            wpk, shift = pw_operands(self, self.conv_pw, self.bn2)
-            return hip.conv1x1(y, wpk, self.conv_pw.out_channels, shift, None, gate=gate, res=x if self.skip else None)
+            return project_conv(self, self.conv_pw, self.bn2, y, gate, x if self.skip else None)
         if _fast(x, self):
             y = hip.dwconv2d_same(x, self.conv_dw.weight, *bn_affine_cached(self.bn1), self.conv_dw.stride[0], "swish")
             y = F.conv2d(self.se(y), self.conv_pw.weight)
@@ -227,8 +258,7 @@ class InvertedResidual(nn.Module):
             y, part, plane = hip.dwconv2d_same_pool(y, self.conv_dw.weight, *bn_affine_cached(self.bn2),
                                                     self.conv_dw.stride[0], "swish")
             gate = self.se.gate_from_pool(part, plane, x.shape[0])
-            wpk, shift = pw_operands(self, self.conv_pwl, self.bn3)
-            return hip.conv1x1(y, wpk, self.conv_pwl.out_channels, shift, None, gate=gate, res=x if self.skip else None)
+            return project_conv(self, self.conv_pwl, self.bn3, y, gate, x if self.skip else None)
         if _fast(x, self):
             y = hip.affine_act(F.conv2d(x, self.conv_pw.weight), *bn_affine_cached(self.bn1), "swish")
             y = hip.dwconv2d_same(y, self.conv_dw.weight, *bn_affine_cached(self.bn2), self.conv_dw.stride[0], "swish")

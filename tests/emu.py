@@ -545,12 +545,18 @@ def gemm_x3_supported(a, b):
     return a.dim() == 2 or b.dim() == 2 or a.shape[0] == b.shape[0]
 
 
-def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0):
-    """occd_gemm_f32x3: float32-level GEMM + bias[:, None] + activation (evaluated in float64 here)."""
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, res=None, k_scale=None):
+    """occd_gemm_f32x3: float32-level GEMM (B rows scaled by k_scale, rounded to float32 like the kernel's staging) + bias[:, None]
+    + activation + res (evaluated in float64 here)."""
+    if k_scale is not None:
+        b = b * k_scale.unsqueeze(-1)
     y = torch.matmul(a.double(), b.double())
     if bias is not None:
         y = y + bias.double().view(-1, 1)
-    y = _act2d(y, act, slope).float()
+    y = _act2d(y, act, slope)
+    if res is not None:
+        y = y + res.double()
+    y = y.float()
     if out is not None:
         out.copy_(y if y.dim() == out.dim() else y.unsqueeze(0))
         return out

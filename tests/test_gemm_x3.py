@@ -182,3 +182,29 @@ def test_gemm_plain_bf16_mode_equals_float64_on_rounded_operands(hip):
     ref = torch.matmul(a3.double(), b3.double().transpose(1, 2)).sum(0)
     got = hip.gemm_x3_nt(a3.to(DEV), b3.to(DEV), plain_bf16=True).cpu().double()
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+# project convolutions of the MBConv blocks on K16: squeeze-excite gate on the B rows (occd_gemm_args.scale_k), BatchNorm shift,
+# the block's skip in the epilogue (.res) -- (batch, Cout = M, pixels = N, Cin = K, skip?)
+@pytest.mark.parametrize("shape", [(2, 48, 2837, 288, True), (2, 384, 468, 2304, True), (2, 80, 1799, 480, False),
+                                   (1, 224, 463, 1344, True), (2, 32, 2001, 32, True), (3, 70, 131, 104, True)])
+@pytest.mark.parametrize("hint", [0, 4])
+def test_gemm_x3_gate_and_skip_epilogue(hip, shape, hint):
+    batch, M, N, K, skip = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    y = torch.randn(batch, K, N, generator=g) * 2.0
+    gate = torch.sigmoid(torch.randn(batch, K, generator=g))
+    shift = torch.randn(M, generator=g)
+    res = torch.randn(batch, M, N, generator=g) if skip else None
+    gated = (y * gate.unsqueeze(-1))                      # float32 rounding of the product, as the reference's x * gate
+    ref = torch.matmul(w.double(), gated.double()) + shift.double().view(-1, 1)
+    if skip:
+        ref = ref + res.double()
+    got = hip.gemm_x3(w.to(DEV), y.to(DEV), bias=shift.to(DEV), k_scale=gate.to(DEV), res=res.to(DEV) if skip else None,
+                      tile_hint=hint).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"gemm_x3 gate+skip {shape} hint {hint}: {err:.2e}")
+    assert got.shape == ref.shape and err < 2e-6, (shape, err)
+    with pytest.raises(RuntimeError):                      # the wave-specialised kernel has no gate / skip path
+        hip.gemm_x3(w.to(DEV), y.to(DEV), k_scale=gate.to(DEV), tile_hint=6)

@@ -134,20 +134,30 @@ def test_efficientnet_block_fused_path_gpu(kind, hip_lib):
             mod.bias.data.normal_(0, 0.2)
     m.eval()
     x = torch.randn(2, m.conv_dw.in_channels if kind == "ds_skip" else m.conv_pw.in_channels, 37, 61)
-    saved = E.PW_MIN_PIXELS
+    saved = (E.PW_MIN_PIXELS, E.PW_EXPAND_LIB_BELOW, E.PW_PROJECT_K16_MIN_PIXELS, E.PW_PROJECT_K16_MIN_COUT)
     E.PW_MIN_PIXELS = 0                                        # (the product only takes this path on large maps)
     try:
+        from occdepth_amd import hip
         with torch.no_grad():
             ref = copy.deepcopy(m).double()(x.double())
             assert E.PW_FUSED and E.pw_wins(x)
-            from occdepth_amd import hip
-            with hip.profile() as prof:
-                got = m.cuda()(x.cuda())
-        assert any(k.startswith("pw_conv") for k in prof.rows) and any(k.startswith("se_gate") for k in prof.rows)
+            mc = m.cuda()
+            # expand / project convolutions on K16 (gate on the staged B rows, skip in the epilogue) ...
+            E.PW_EXPAND_LIB_BELOW, E.PW_PROJECT_K16_MIN_PIXELS, E.PW_PROJECT_K16_MIN_COUT = 1 << 40, 0, 0
+            with hip.profile() as prof16:
+                got16 = mc(x.cuda())
+            # ... and on K11 (the exact-fp32 pointwise GEMM with the same fusions)
+            E.PW_EXPAND_LIB_BELOW, E.PW_PROJECT_K16_MIN_PIXELS = 0, 1 << 40
+            with hip.profile() as prof11:
+                got11 = mc(x.cuda())
+        assert any(k.startswith("gemm_f32x3") for k in prof16.rows) and not any(k.startswith("pw_conv") for k in prof16.rows)
+        assert any(k.startswith("pw_conv") for k in prof11.rows) and not any(k.startswith("gemm_f32x3") for k in prof11.rows)
+        assert any(k.startswith("se_gate") for k in prof16.rows) and any(k.startswith("se_gate") for k in prof11.rows)
     finally:
-        E.PW_MIN_PIXELS = saved
-    err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
-    assert got.shape == ref.shape and err < 2e-5, (kind, err)
+        E.PW_MIN_PIXELS, E.PW_EXPAND_LIB_BELOW, E.PW_PROJECT_K16_MIN_PIXELS, E.PW_PROJECT_K16_MIN_COUT = saved
+    for name, got in (("K16", got16), ("K11", got11)):
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert got.shape == ref.shape and err < 2e-5, (kind, name, err)
 
 
 @pytest.mark.gpu
