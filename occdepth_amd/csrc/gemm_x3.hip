@@ -100,6 +100,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     constexpr int NA = TM * 4 / NTH;                // A staging items per thread: (row, 8-k chunk), 2 float4 each
     constexpr int NB = 8 * TN / NTH;                // B staging items per thread: (k row, 4-column chunk), 1 float4 each
     static_assert(TM * 4 % NTH == 0 && 8 * TN % NTH == 0, "staging split");
+    // Register prefetch depth: K steps whose global loads are in flight while one is multiplied.  Measured with 4 steps on the
+    // 64 x 64 tile and 2 on 128 x 64 (round 4, session 31): SLOWER on every short-K launch (48 -> 288 on 28365 pixels 34 -> 38.5
+    // us, 384 -> 2304 on 468 pixels 23 -> 26 us; 160 VGPRs instead of 112), and the long-K project convolution on 96 workgroups
+    // stayed at 80 us: memory latency is not what a step of a small tile waits for (split arithmetic + LDS round trip + two
+    // barriers are).  So 1 everywhere; the loop keeps the general form.
+    constexpr int PF = 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
     unsigned char* const lA = glds;
     unsigned char* const lB = glds + (PRE == 1 ? 0 : TM * kARow);
@@ -148,39 +154,39 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
         b_k[i] = k;
     }
 
-    f32x4 ra[NA][2], rb[NB];
-    float rg[NB];                                    // kscale of the staged B rows (1 without)
+    f32x4 ra[PF][NA][2], rb[PF][NB];
+    float rg[PF][NB];                                // kscale of the staged B rows (1 without)
     const float* const Gb = p.kscale != nullptr ? p.kscale + (size_t)bz * p.K : nullptr;
     // FAST (interior tiles of a K % 32 == 0 problem -- all but the last column of tiles): no address clamps, no K / N tail
     // selects; the general form pays ~2 extra VALU instructions per MFMA for them (PMC: 5.8 VALU per MFMA)
-    auto issue = [&](int k0, auto fast_c) {          // global -> registers for the K step starting at k0
+    auto issue = [&](int u, int k0, auto fast_c) {   // global -> register set u for the K step starting at k0
         constexpr bool FAST = decltype(fast_c)::value;
         if (PRE != 1) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int k = FAST ? k0 + a_k[i] : min(k0 + a_k[i], p.K - 8);
                 const float* src = Ab + a_off[i] - a_k[i] + k;
-                ra[i][0] = *(const f32x4*)src;
-                ra[i][1] = *(const f32x4*)(src + 4);
+                ra[u][i][0] = *(const f32x4*)src;
+                ra[u][i][1] = *(const f32x4*)(src + 4);
             }
         }
         if (PRE != 2) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int k = FAST ? k0 + b_k[i] : min(k0 + b_k[i], p.K - 1);
-                rb[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + b_col[i]);
-                rg[i] = Gb != nullptr ? Gb[k] : 1.f;     // (uniform branch; the load rides with the tile's own)
+                rb[u][i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + b_col[i]);
+                rg[u][i] = Gb != nullptr ? Gb[k] : 1.f;     // (uniform branch; the load rides with the tile's own)
             }
         }
     };
-    auto commit = [&](int k0, auto fast_c) {         // registers -> split -> LDS
+    auto commit = [&](int u, int k0, auto fast_c) {  // register set u -> split -> LDS
         constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
         for (int i = 0; i < (PRE == 1 ? 0 : NA); ++i) {
             const bool ok = FAST || k0 + a_k[i] < p.K;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             u32x4 hi, mid, lo;
-            split8(ok ? ra[i][0] : z, ok ? ra[i][1] : z, hi, mid, lo);
+            split8(ok ? ra[u][i][0] : z, ok ? ra[u][i][1] : z, hi, mid, lo);
             *(u32x4*)(lA + a_dst[i]) = hi;
             if (TERMS == 3) {
                 *(u32x4*)(lA + a_dst[i] + 64) = mid;
@@ -191,11 +197,11 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
         for (int i = 0; i < (PRE == 2 ? 0 : NB); ++i) {
             f32x4 v;
             if (FAST) {
-                v = rb[i] * rg[i];
+                v = rb[u][i] * rg[u][i];
             } else {
                 const bool ok = k0 + b_k[i] < p.K;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 w = ok ? rb[i] * rg[i] : z;
+                const f32x4 w = ok ? rb[u][i] * rg[u][i] : z;
                 const int sh = b_sh[i];                  // (selects, not branches: the shift is lane-dependent)
                 v.x = sh == 0 ? w.x : sh == 1 ? w.y : sh == 2 ? w.z : w.w;
                 v.y = sh == 0 ? w.y : sh == 1 ? w.z : sh == 2 ? w.w : 0.f;
@@ -259,13 +265,19 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
 
     const int ksteps = (p.K + 31) >> 5;
     auto kloop = [&](auto fast_c) {
-    issue(0, fast_c);
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < ksteps) issue(u, u * 32, fast_c);
     if (PRE != 0) fetch_pk(0);
-    for (int s = 0; s < ksteps; ++s) {
+    for (int s0 = 0; s0 < ksteps; s0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {                  // (unrolled: the register set of a step is a compile-time index)
+        const int s = s0 + u;
+        if (s >= ksteps) continue;                  // (uniform)
         __syncthreads();                // previous tile consumed
-        commit(s * 32, fast_c);
+        commit(u, s * 32, fast_c);
         __syncthreads();
-        if (s + 1 < ksteps) issue((s + 1) * 32, fast_c);
+        if (s + PF < ksteps) issue(u, (s + PF) * 32, fast_c);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 af[MT][3];
@@ -302,6 +314,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
             }
             OCCD_GX3(0, 0);
         }
+    }
     }
     };
     if ((p.K & 31) == 0 && n0 + TN <= p.N) kloop(std::true_type{});
