@@ -6,10 +6,13 @@ O=$R/gpurun_out/r4ev
 mkdir -p $O
 cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-WHAT="${*:-bench prof pmc exact tests}"
+WHAT="${*:-bench frame prof pmc exact tests}"
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has bench; then
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json; echo
+fi
+if has frame; then
+  timeout 300 python tools/frame_table.py > $O/frame_per_launch.txt 2> $O/frame_per_launch.err; tail -2 $O/frame_per_launch.txt | cut -c1-300
 fi
 if has exact; then
   OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_exact_fp32.json 2> $O/bench_exact_fp32.err
