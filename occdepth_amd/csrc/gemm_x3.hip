@@ -92,8 +92,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, int step_byte
 // TERMS: 3 = the split (float32-level accuracy); 1 = plain bf16 operands, ONE MFMA per 16-k step (the bf16 training mode,
 // BASELINE configs[3]: "bf16 MFMA, fp32 storage and accumulate" like K2b): same staging and layout, only the hi plane is
 // written and read.
-template <int MT, int NT, int WM, int WN, int PRE, int TERMS = 3>
-__global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
+// KS > 1: in-workgroup split-K (the long-K / few-pixel project convolutions: 96 ... 230 output tiles for 256 CUs and K = 960 ...
+// 3840).  The KS wave groups of a workgroup own the same output tile, take interleaved 32-k steps (each group with its own LDS
+// stage), and their accumulators meet in LDS once, after the loop; group 0 runs the epilogue.  16 waves per CU instead of 4:
+// while one group waits at its split / LDS round trip, the others issue MFMAs.
+template <int MT, int NT, int WM, int WN, int PRE, int TERMS = 3, int KS = 1>
+__global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p) {
+    static_assert(KS == 1 || PRE == 0, "split-K stages both operands");
     constexpr int NTH = WM * WN * 64, TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int SB = TN * 2 + 64;                 // bytes per B row (one k, one term): = 64 mod 128
     constexpr int BTERM = 32 * SB;                  // bytes per term of the B tile
@@ -107,10 +112,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     // barriers are).  So 1 everywhere; the loop keeps the general form.
     constexpr int PF = 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
-    unsigned char* const lA = glds;
-    unsigned char* const lB = glds + (PRE == 1 ? 0 : TM * kARow);
+    constexpr int STAGE = (PRE == 1 ? 0 : TM * kARow) + (PRE == 2 ? 0 : 3 * BTERM);   // LDS bytes of one K group
+    const int kg = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTH);   // K group of this wave
+    unsigned char* const lA = glds + kg * STAGE;
+    unsigned char* const lB = lA + (PRE == 1 ? 0 : TM * kARow);
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x - kg * NTH;          // thread index inside the K group
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -265,19 +272,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
 
     const int ksteps = (p.K + 31) >> 5;
     auto kloop = [&](auto fast_c) {
+    // step s of the workgroup's walk belongs to K group s % KS; every group joins every barrier
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-        if (u < ksteps) issue(u, u * 32, fast_c);
+        if (u * KS + kg < ksteps) issue(u, (u * KS + kg) * 32, fast_c);
     if (PRE != 0) fetch_pk(0);
-    for (int s0 = 0; s0 < ksteps; s0 += PF) {
+    for (int s0 = 0; s0 < ksteps; s0 += PF * KS) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {                  // (unrolled: the register set of a step is a compile-time index)
-        const int s = s0 + u;
-        if (s >= ksteps) continue;                  // (uniform)
+        const int s = s0 + u * KS + kg;
+        if (s0 + u * KS >= ksteps) continue;        // (workgroup-uniform)
+        const bool active = KS == 1 || s < ksteps;  // (uniform per K group)
         __syncthreads();                // previous tile consumed
-        commit(u, s * 32, fast_c);
+        if (active) commit(u, s * 32, fast_c);
         __syncthreads();
-        if (s + PF < ksteps) issue(u, (s + PF) * 32, fast_c);
+        if (s + PF * KS < ksteps) issue(u, (s + PF * KS) * 32, fast_c);
+        if (!active) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 af[MT][3];
@@ -320,6 +330,32 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_x3_kernel(const GemmP p) {
     if ((p.K & 31) == 0 && n0 + TN <= p.N) kloop(std::true_type{});
     else kloop(std::false_type{});
 #undef OCCD_GX3
+
+    if (KS > 1) {
+        // sum the K groups' accumulators through LDS (the stages are dead after the barrier), group 0 stores
+        float* red = reinterpret_cast<float*>(glds);
+        __syncthreads();
+        if (kg > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((kg - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mt][nt][r] += red[((((g - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane];
+    }
 
     // epilogue: lane -> column n, registers -> rows (r & 3) + 8 (r >> 2) + 4 h.  Bias / activation are uniform over the
     // launch: one straight-line store sequence per combination
@@ -799,8 +835,7 @@ extern "C" int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_
     return occd::check_launch();
 }
 
-// a->tile_hint: 0 = pick (the largest tile that leaves >= 160 workgroups; 64-row tiles for M <= 64), 1 .. 5 = force a tile
-// variant, 6 = force K16w.
+// a->tile_hint: 0 = pick (see below), 1 .. 5 = force a tile variant, 6 = force K16w, 7 = force the 64 x 64 split-K form.
 // a->pre: 0 = A and B float32; 1 = a->A is the role-0 image of occd_gemm_x3_pack (lda ignored, stride_a = bf16 elements
 // between batch items, 0 = shared); 2 = a->B is the role-1 image (ldb ignored, stride_b likewise).
 extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
@@ -814,9 +849,13 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (a->pre == 1 && ((reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 7))) return OCCD_EINVAL;
     if (a->pre == 2 && ((reinterpret_cast<uintptr_t>(a->B) & 15) || (a->stride_b & 7))) return OCCD_EINVAL;
     if (reinterpret_cast<uintptr_t>(a->C) & 3) return OCCD_EINVAL;
-    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 1) return OCCD_EINVAL;
+    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 2) return OCCD_EINVAL;
     int pick = a->tile_hint - 1;
     if (a->tile_hint == kNumVariantsG + 1) pick = 0;
+    if (a->tile_hint == kNumVariantsG + 2) {
+        if (a->pre != 0) return OCCD_EINVAL;
+        pick = 3;
+    }
     if (pick < 0) {
         // Long K (>= 1024: tap GEMMs, Winograd-domain products): the largest tile that still leaves >= 160 workgroups
         // (measured, profiles/r04_gemm_x3_v3_ws.txt: the large tiles win down to ~0.6 workgroups per CU).  Short K (the MBConv
@@ -833,7 +872,8 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
             return ((a->M + tm - 1) / tm) * ((a->N + tn - 1) / tn) * a->batch;
         };
         if (a->M <= 64) {
-            pick = ((long)((a->N + 255) / 256) * a->batch >= 160) ? 4 : 3;
+            // (short K: 64 x 64 again -- 288 -> 48 on 2 x 28365 pixels 30 us against 42 with 64 x 256 tiles)
+            pick = (a->K >= 512 && (long)((a->N + 255) / 256) * a->batch >= 160) ? 4 : 3;
         } else if (a->K < 512) {
             pick = wgs_of(0) >= 2048 ? 0 : 3;
         } else {
@@ -855,6 +895,12 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
     const int TM = v.MT * v.WM * 32, TN = v.NT * v.WN * 32;
+    // in-workgroup split-K (64 x 64 tile, 4 K groups = 16 waves) when the 64 x 64 tiling leaves CUs without a workgroup and K is
+    // long: the project convolutions of the 1/16 and 1/32 stages (tile_hint 7 forces it; OCCD_GEMM_KS=0 disables it for A/B)
+    static const bool ks_off = getenv("OCCD_GEMM_KS") != nullptr && getenv("OCCD_GEMM_KS")[0] == '0';
+    const long wgs64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64) * a->batch;
+    const bool ksplit = a->pre == 0 && !ws && (a->tile_hint == kNumVariantsG + 2 ||
+                                               (a->tile_hint == 0 && pick == 3 && !ks_off && a->K >= 768 && wgs64 <= 320));
     GemmP p;
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.res = a->res; p.kscale = a->scale_k;
     p.M = a->M; p.N = a->N; p.K = a->K;
@@ -869,9 +915,10 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     const long nwg = (long)p.mtiles * p.ntiles;
     if (nwg >= (1L << 31)) return OCCD_EINVAL;
     p.nwg = (unsigned)nwg;
+    constexpr int kKS = 4;
     const size_t lds = ws ? (size_t)2 * kWsStage
-                          : (a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64));
-    void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel<0> : v.kern[a->pre];
+                          : ((a->pre == 1 ? 0 : (size_t)TM * kARow) + (a->pre == 2 ? 0 : (size_t)3 * 32 * (TN * 2 + 64))) * (ksplit ? kKS : 1);
+    void (*kern)(const GemmP) = ws ? gemm_x3_ws_kernel<0> : ksplit ? gemm_x3_kernel<1, 1, 2, 2, 0, 3, kKS> : v.kern[a->pre];
 #ifdef OCCD_GEMM_DEV_VARIANTS
     if (ws && getenv("OCCD_GEMM_DBG") != nullptr)
         kern = getenv("OCCD_GEMM_DBG")[0] == '1' ? gemm_x3_ws_kernel<1> : getenv("OCCD_GEMM_DBG")[0] == '2' ? gemm_x3_ws_kernel<2> :
@@ -882,7 +929,8 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     const double flops = 2.0 * a->M * a->N * a->K * a->batch;
     const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
     occd::ProfScope prof(ws ? "gemm_f32x3_ws" : a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : a->pre == 2 ? "gemm_f32x3_preB" : "gemm_bf16", (hipStream_t)stream, flops, bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(ws ? 512 : v.WM * v.WN * 64), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(ws ? 512 : v.WM * v.WN * 64 * (ksplit ? kKS : 1)), lds,
+                       (hipStream_t)stream, p);
     return occd::check_launch();
 }
 

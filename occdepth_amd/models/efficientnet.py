@@ -98,13 +98,14 @@ def expand_gemm(owner, conv, bn, x, act):
 
 
 # Project convolutions (the squeeze-excite gate on the input channels, BatchNorm, the block's skip) on K16 as well where it
-# wins: the gate is applied to the B rows while they are staged (occd_gemm_args.scale_k), the skip in the epilogue (.res).
-# Measured per launch, config 2 (profiles/r04_frame_per_launch.txt): 288 -> 48 on 2 x 28365 pixels 44 us against 59 on K11,
-# 480 -> 80 on 2 x 7191 29 against 40; but 2304 -> 384 on 2 x 468 82 against 35 on K11s, 3840 -> 640 130 against 92,
-# 1344 -> 224 on 2 x 1848 53 against 44 (K16 has no split-K: 96 workgroups walk K = 2304 alone) and 32 -> 32 on 2 x 112850
-# 64 against 49 (half of a 64-row tile is padding).  So: maps of >= 14000 pixels and >= 48 output channels.
+# wins: the gate is applied to the B rows while they are staged (occd_gemm_args.scale_k), the skip in the epilogue (.res); long K
+# on few output tiles takes K16's in-workgroup split-K form.  Measured per launch, config 2, K16 against K11 / K11s
+# (profiles/r04_gemm_x3_v6_project.txt): 288 -> 48 on 2 x 28365 pixels 30 against 54 us, 480 -> 80 on 2 x 7191 28 against 40,
+# 960 -> 160 on 2 x 1848 28 against 35, 1344 -> 224 39 against 44; but 2304 -> 384 on 2 x 468 56 against 37 and 3840 -> 640 88
+# against 94 (a 64 x 64 tile spends more on its split / LDS round trip per step than the exact-fp32 wave on its MFMAs), and
+# 32 -> 32 on 2 x 112850 64 against 49 (half of a 64-row tile is padding).  So: maps of >= 3000 pixels, >= 48 output channels.
 PW_PROJECT_K16 = os.environ.get("OCCDEPTH_PW_PROJECT_K16", "1") == "1"
-PW_PROJECT_K16_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_PIXELS", "14000"))
+PW_PROJECT_K16_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_PIXELS", "3000"))
 PW_PROJECT_K16_MIN_COUT = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_COUT", "48"))
 
 

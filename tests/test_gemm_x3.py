@@ -65,10 +65,12 @@ def test_gemm_x3_vs_float64(hip, name, packed):
     assert err < max(2e-6, 1.25 * err32), (name, err, err32)
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6])       # 5 = 64 x 256 tile, 6 = the wave-specialised 256 x 128 kernel (K16w)
-def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
+# 5 = 64 x 256 tile, 6 = the wave-specialised 256 x 128 kernel (K16w), 7 = 64 x 64 with the in-workgroup split-K (4 K groups)
+@pytest.mark.parametrize("K", [72, 392])                   # 2 steps + a tail of 8 (split-K: two idle K groups); 12 steps + a tail
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 5, 6, 7])
+def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint, K):
     g = torch.Generator().manual_seed(hint)
-    batch, M, N, K = 2, 300, 333, 72                       # M, N tails in every variant; K = 2 steps + a tail of 8
+    batch, M, N = 2, 300, 333                              # M, N tails in every variant
     a = torch.randn(M, K, generator=g) / K ** 0.5
     b = torch.randn(batch, K, N, generator=g)
     bias = torch.randn(M, generator=g)
@@ -78,7 +80,7 @@ def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint):
         err = float((got - ref).abs().max() / ref.abs().max())
         assert err < (3e-6 if act == "swish" else 2e-6), (hint, act, err)      # (swish: hardware exp2 / rcp, ~3 ulp)
     forms = [(a.to(DEV), b.to(DEV))]
-    if hint != 6:                                          # (K16w takes float32 operands only)
+    if hint < 6:                                           # (K16w and the split-K form take float32 operands only)
         forms += [(hip.GemmPacked(a.to(DEV), "a"), b.to(DEV)), (a.to(DEV), hip.GemmPacked(b.to(DEV), "b"))]
     for xa, xb in forms:
         got = run(hip, xa, xb, tile_hint=hint).cpu().double()
@@ -188,7 +190,7 @@ def test_gemm_plain_bf16_mode_equals_float64_on_rounded_operands(hip):
 # the block's skip in the epilogue (.res) -- (batch, Cout = M, pixels = N, Cin = K, skip?)
 @pytest.mark.parametrize("shape", [(2, 48, 2837, 288, True), (2, 384, 468, 2304, True), (2, 80, 1799, 480, False),
                                    (1, 224, 463, 1344, True), (2, 32, 2001, 32, True), (3, 70, 131, 104, True)])
-@pytest.mark.parametrize("hint", [0, 4])
+@pytest.mark.parametrize("hint", [0, 4, 7])
 def test_gemm_x3_gate_and_skip_epilogue(hip, shape, hint):
     batch, M, N, K, skip = shape
     g = torch.Generator().manual_seed(M + N + K)
