@@ -86,16 +86,21 @@ __device__ __forceinline__ void split3(f32x4 a, f32x4 b, u32x4& hi, u32x4& mid, 
 
 // SPLIT = 1: plain bf16 operands.  SPLIT = 3 (opt-in experiment): float32 activations and weights as
 // three bf16 terms each, six MFMAs per K step instead of one -- float32-level accuracy at 6/16 of the fp32-MFMA time.
-template <int MT, int NT, int WM, int WN, bool IN_BF16, bool OUT_BF16, int SPLIT = 1>
-__global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p) {
-    constexpr int NTH = WM * WN * 64;
+// KS > 1: in-workgroup split-K as in K2 (conv3d_igemm.hip): the KS wave groups take interleaved 32-channel chunks, each with
+// its own LDS slab, and their accumulators are summed through LDS before the epilogue -- the 3x3x3 convolutions of the 1/8
+// level (4096 voxels, K = 27 x 256): 128 output tiles for 256 CUs.
+template <int MT, int NT, int WM, int WN, bool IN_BF16, bool OUT_BF16, int SPLIT = 1, int KS = 1>
+__global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const ConvBP p) {
+    constexpr int NTH = WM * WN * 64;   // threads of one K group
     constexpr int RSB = SPLIT == 3 ? kRSB3 : kRSB;
     static_assert(SPLIT == 1 || (SPLIT == 3 && !IN_BF16 && !OUT_BF16), "the 3-way split takes and returns float32");
-    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_all[];
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tid = threadIdx.x;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = KS == 1 ? 0 : wave_all / (WM * WN);          // K group of this wave
+    const int wave = wave_all - kg * (WM * WN);
+    const int tid = threadIdx.x - kg * NTH;                      // thread index inside the K group
     const int wm = wave / WN;
     const int wn = wave - wm * WN;
     const int li = lane & 31;
@@ -143,6 +148,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
     const size_t w_img = (size_t)p.KX * p.KY * p.KZ * p.K16tot * w_step;   // u32x4 per split image of the weights
     const u32x4* const wlane = p.wpk + lane;
     const int rows = p.YIN * p.ZIN;
+    unsigned char* const slab = slab_all + (size_t)kg * rows * RSB;   // this K group's slab
+    const int n_chunks = (p.cin16 + 31) / 32;
+    const int chunk_iters = (n_chunks + KS - 1) / KS;
 
 #define OCCD_MFMA1(WS, XS)                                                                                          \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = \
@@ -163,12 +171,14 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
         const int xi = xo * p.SX - p.PX + kx * p.DX;
         if (xi < 0 || xi >= p.X) continue;   // workgroup-uniform
         const size_t plane = ((size_t)(b * p.X + xi) * p.Y) * p.Z * p.in_cs + p.in_coff;
-        for (int c0 = 0; c0 < p.cin16; c0 += 32) {
-            const int ck = min(32, p.cin16 - c0);        // 16 or 32 channels in this chunk
+        for (int ci = 0; ci < chunk_iters; ++ci) {
+            const int c0 = (ci * KS + kg) * 32;
+            const bool active = KS == 1 || c0 < p.cin16;     // uniform per K group; every group still joins the barriers
+            const int ck = active ? min(32, p.cin16 - c0) : 16;   // 16 or 32 channels in this chunk
             const int k16n = ck >> 4;
             const int sh = k16n;                         // chunks of 8 channels per row: 2 (shift 1) or 4 (shift 2)
-            const int S = p.KY * p.KZ * k16n;
-            const u32x4* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.K16tot + (c0 >> 4)) * w_step;
+            const int S = active ? p.KY * p.KZ * k16n : 0;
+            const u32x4* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.K16tot + (active ? c0 >> 4 : 0)) * w_step;
 
             u32x4 b_cur[NT][SPLIT];   // first B fragments fly while the slab is staged
 #pragma unroll
@@ -178,7 +188,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
 
             __syncthreads();   // previous slab fully consumed
             const int F = rows << sh;
-            for (int f0 = 0; f0 < F; f0 += NTH * 4) {
+            for (int f0 = 0; active && f0 < F; f0 += NTH * 4) {
                 u32x4 v[4][SPLIT];
                 int dst[4];
 #pragma unroll
@@ -264,11 +274,37 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3d_bf16_kernel(const ConvBP p
 #pragma unroll
                     for (int sp = 0; sp < SPLIT; ++sp) b_cur[nt][sp] = b_nxt[nt][sp];
             }
-            OCCD_MFMA_BLOCK();
+            if (active) { OCCD_MFMA_BLOCK(); }
         }
     }
 #undef OCCD_MFMA1
 #undef OCCD_MFMA_BLOCK
+
+    if (KS > 1) {
+        // sum the K groups' accumulators through LDS (slabs are dead after the barrier), group 0 stores
+        float* red = reinterpret_cast<float*>(slab_all);
+        __syncthreads();
+        if (kg > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((kg - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mt][nt][r] += red[((((g - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane];
+    }
 
     // ---------------- epilogue (the layout of K2's: lane -> voxel li of the M tile, registers -> couts
     // (r & 3) + 8 (r >> 2) + 4 h: four groups of 4 consecutive output channels of ONE voxel per lane)
@@ -348,15 +384,15 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
 }
 
 struct VariantB {
-    int MT, NT, WM, WN;
+    int MT, NT, WM, WN, KS;
     void (*kern[3])(const ConvBP);   // [0] fp32 in / fp32 out, [1] bf16 in / bf16 out, [2] fp32 with the 3-way split (or null)
 };
 
 #define OCCD_VARIANT_B(MT, NT, WM, WN) \
-    VariantB { MT, NT, WM, WN, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true>, nullptr } }
+    VariantB { MT, NT, WM, WN, 1, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true>, nullptr } }
 #define OCCD_VARIANT_B3(MT, NT, WM, WN) \
-    VariantB { MT, NT, WM, WN, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true>, \
-                                 conv3d_bf16_kernel<MT, NT, WM, WN, false, false, 3> } }
+    VariantB { MT, NT, WM, WN, 1, { conv3d_bf16_kernel<MT, NT, WM, WN, false, false>, conv3d_bf16_kernel<MT, NT, WM, WN, true, true>, \
+                                    conv3d_bf16_kernel<MT, NT, WM, WN, false, false, 3> } }
 
 const VariantB kVariantsB[] = {
     OCCD_VARIANT_B(4, 1, 4, 1),    // 0: M512 x N32
@@ -367,6 +403,8 @@ const VariantB kVariantsB[] = {
     OCCD_VARIANT_B(4, 2, 2, 2),    // 5: M256 x N128
     OCCD_VARIANT_B3(2, 2, 2, 2),   // 6: M128 x N128
     OCCD_VARIANT_B3(1, 2, 2, 2),   // 7: M64  x N128
+    // 8: M32 x N128 with the 3-way split and 4-way in-workgroup split-K (16 waves): small volumes with a long K
+    VariantB { 1, 1, 1, 4, 4, { nullptr, nullptr, conv3d_bf16_kernel<1, 1, 1, 4, false, false, 3, 4> } },
 };
 constexpr int kNumVariantsB = sizeof(kVariantsB) / sizeof(kVariantsB[0]);
 constexpr size_t kMaxLdsB = 160 * 1024;
@@ -398,7 +436,9 @@ bool plan_b(const occd_conv3d_args* a, const VariantB& v, int NTtot, TilingB* be
         t.ZIN = (t.TZ - 1) * a->sz + (a->kz - 1) * a->dz + 1;
         t.ytiles = (a->Yo + t.TY - 1) / t.TY;
         t.ztiles = (a->Zo + t.TZ - 1) / t.TZ;
-        t.lds = (size_t)t.YIN * t.ZIN * rsb;
+        t.lds = (size_t)t.YIN * t.ZIN * rsb * v.KS;
+        const size_t red = (size_t)(v.KS - 1) * v.WM * v.WN * v.MT * v.NT * 4096;   // split-K reduction scratch
+        if (red > t.lds) t.lds = red;
         const int nwg_n = v.NT * v.WN;
         t.ngroups = (NTtot + nwg_n - 1) / nwg_n;
         t.nwg = (long)a->Xo * t.ytiles * t.ztiles;
@@ -547,6 +587,14 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
         if (t.nwg * t.ngroups * a->batch >= 512) break;   // else keep refining to the finest fit
     }
     if (pick < 0) return OCCD_ENOMEM;
+    if (ksel == 2 && a->tile_hint == 0 && til.nwg * til.ngroups * a->batch <= 320 && cin16 >= 128 && NTtot % 4 == 0) {
+        // too few output tiles to fill the chip: multiply the waves by splitting K inside the workgroup (K2's rule)
+        TilingB t{};
+        if (plan_b(a, kVariantsB[8], NTtot, &t, rsb) && t.nwg * t.ngroups * a->batch <= 1024) {
+            pick = 8;
+            til = t;
+        }
+    }
     const VariantB& v = kVariantsB[pick];
 
     ConvBP p;
@@ -577,6 +625,6 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     occd::ProfScope prof(ksel == 2 ? "conv3d_bf16x3" : dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16", (hipStream_t)stream, flops,
                          bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
-                       dim3(v.WM * v.WN * 64), til.lds, (hipStream_t)stream, p);
+                       dim3(v.WM * v.WN * v.KS * 64), til.lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }

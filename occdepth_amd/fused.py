@@ -140,15 +140,43 @@ def _head_weight(w, layout):
     return layout == 0 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[0] <= 32 and 24 < w.shape[1] <= 32
 
 
+# Also part of the default ("head") mode since late round 4: the 3x3x3 convolutions with a long K on a SMALL volume (the
+# ASPP branches and `mega_context` of the CRP at the 1/8 level: 256 -> 256 / 512 on 32x32x4 = 4096 voxels, K = 27 x 256).
+# Too few output tiles to fill 256 CUs, so K2 runs them on its in-workgroup split-K variant at ~96 TF/s of the exact-fp32
+# instruction; K2b's split form with the same 4-way split-K (variant 8: M32 x N128, 16 waves) does the MFMA work at 6/16 of
+# that instruction's time.  OCCDEPTH_BF16X3_SMALLVOL=0 keeps them on K2.
+BF16X3_SMALLVOL = os.environ.get("OCCDEPTH_BF16X3_SMALLVOL", "1") == "1"
+SMALLVOL_MAX_VOXELS = 8192
+
+
+def _smallvol_weight(w, layout):
+    return (BF16X3_SMALLVOL and layout == 0 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[1] >= 128
+            and w.shape[1] % 16 == 0 and w.shape[0] % 128 == 0)
+
+
 def _pack_w(w, scale=None, layout=0):
-    if BF16X3 == "all" or (BF16X3 == "head" and _head_weight(w, layout)):
+    if BF16X3 == "all" or (BF16X3 == "head" and (_head_weight(w, layout) or _smallvol_weight(w, layout))):
         return _DualW(hip.pack_weights(w, scale, layout), hip.pack_weights_bf16(w, scale, layout, split3=True))
     return hip.pack_weights(w, scale, layout)
+
+
+def _smallvol_eligible(x, wpk, cout, kernel, out, **kw):
+    if not BF16X3_SMALLVOL or tuple(kernel) != (3, 3, 3) or kw.get("cin") is not None or x.C < 128 or cout % 128:
+        return False
+    if x.cs % 8 or x.coff % 8 or x.buf.dtype != torch.float32 or kw.get("act_in", ACT_NONE) not in (ACT_NONE, ACT_RELU):
+        return False
+    pos = kw.get("out_pos")
+    if pos is None:
+        st, dl, pd = kw.get("stride", (1, 1, 1)), kw.get("dilation", (1, 1, 1)), kw.get("padding", (0, 0, 0))
+        pos = tuple((n + 2 * p - d * 2 - 1) // s + 1 for n, p, d, s in zip(x.dims, pd, dl, st))
+    return x.batch * pos[0] * pos[1] * pos[2] <= SMALLVOL_MAX_VOXELS and kw.get("tile_hint", 0) == 0
 
 
 def _conv3d(x, wpk, bias, cout, kernel, out, **kw):
     if isinstance(wpk, _DualW):
         if hip.c32x3_eligible(x, cout, kernel, out, **kw):        # K2s3 (all three dilations)
+            return hip.conv3d_bf16(x, wpk.x3, bias, cout, kernel, out, split3=True, **kw)
+        if _smallvol_eligible(x, wpk, cout, kernel, out, **kw):   # K2b split form, in-workgroup split-K
             return hip.conv3d_bf16(x, wpk.x3, bias, cout, kernel, out, split3=True, **kw)
         aligned = x.cs % 8 == 0 and x.coff % 8 == 0          # K2b stages 8 channels per 16-byte LDS chunk
         dil = tuple(kw.get("dilation", (1, 1, 1)))

@@ -44,6 +44,9 @@ FWD_CASES = {
     "axis_y_s2": (1, 32, 32, (6, 10, 8), (1, 3, 1), (1, 2, 1), (0, 1, 0), (1, 1, 1)),
     "k3_s2": (1, 128, 256, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1)),
     "aspp_256": (1, 256, 256, (8, 8, 4), (3, 3, 3), (1, 1, 1), (2, 2, 2), (2, 2, 2)),
+    # the 1/8 level of config 2 at full size: 128 output tiles -> K2b's M32 x N128 variant with 4-way in-workgroup split-K
+    "aspp_256_full_d3": (1, 256, 256, (32, 32, 4), (3, 3, 3), (1, 1, 1), (3, 3, 3), (3, 3, 3)),
+    "cin_144_splitk": (2, 144, 128, (6, 10, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),   # 4.5 chunks: idle K groups, 16-channel tail
     "ragged_5_20": (2, 5, 20, (4, 6, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     "nyu_z15": (1, 24, 40, (5, 4, 15), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
     # 2-D decoder levels: (B, H, W, C) images as X = 1 volumes, kernel (1, 3, 3)
@@ -109,7 +112,7 @@ def test_conv3d_bf16_all_variants(hip, hint):
 
 
 SPLIT3_CASES = ["head_d1", "head_d2", "head_d3", "classes_34_20", "k1_64_16", "k3_s2", "aspp_256", "ragged_5_20", "nyu_z15",
-                "dec_80_80"]
+                "dec_80_80", "aspp_256_full_d3", "cin_144_splitk"]
 
 
 @pytest.mark.parametrize("name", SPLIT3_CASES)
