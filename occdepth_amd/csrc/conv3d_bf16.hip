@@ -49,6 +49,12 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     return v;
 }
+// (the expf + IEEE division form of K2's apply_act, csrc/conv3d_igemm.hip: same values)
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+    v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y));
+    v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+    return v;
+}
 
 __device__ __forceinline__ u32x4 pack_bf16x8(f32x4 a, f32x4 b) {
     bf16x8 r = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
@@ -221,6 +227,7 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
                         f32x4 lo = *(const f32x4*)((const float*)p.in + e);
                         f32x4 hi = *(const f32x4*)((const float*)p.in + e + 4);
                         if (p.act_in == OCCD_ACT_RELU) { lo = relu4(lo); hi = relu4(hi); }
+                        else if (SPLIT == 3 && p.act_in == OCCD_ACT_SIGMOID) { lo = sigmoid4(lo); hi = sigmoid4(hi); }
                         if (SPLIT == 3) split3(lo, hi, w[0], w[SPLIT == 3 ? 1 : 0], w[SPLIT == 3 ? 2 : 0]);
                         else w[0] = pack_bf16x8(lo, hi);
                     }
@@ -556,7 +563,8 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     if ((a->Xo - 1) * a->o_stride_x + a->o_off_x >= a->OX || (a->Yo - 1) * a->o_stride_y + a->o_off_y >= a->OY ||
         (a->Zo - 1) * a->o_stride_z + a->o_off_z >= a->OZ)
         return OCCD_EINVAL;
-    if (a->act_in != OCCD_ACT_NONE && a->act_in != OCCD_ACT_RELU) return OCCD_EINVAL;
+    // (input sigmoid: the CRP products sigmoid(P_logits) @ mega, CRP3D.py:80 -- float32 operands with the split only)
+    if (a->act_in != OCCD_ACT_NONE && a->act_in != OCCD_ACT_RELU && !(a->act_in == OCCD_ACT_SIGMOID && ksel == 2)) return OCCD_EINVAL;
     if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
         return OCCD_EINVAL;
 

@@ -147,10 +147,18 @@ def _head_weight(w, layout):
 # that instruction's time.  OCCDEPTH_BF16X3_SMALLVOL=0 keeps them on K2.
 BF16X3_SMALLVOL = os.environ.get("OCCDEPTH_BF16X3_SMALLVOL", "1") == "1"
 SMALLVOL_MAX_VOXELS = 8192
+# (1x1x1 convolutions and the CRP products sigmoid(P_logits) @ mega can take the same kernel -- input sigmoid applied while
+#  staging -- but do not gain: 512 -> 512 on 4096 rows 78 us against K2's 61, 256 -> 512 27 against 28, 2304 -> 256 75 against
+#  78: two MFMA steps per staged chunk.  OCCDEPTH_BF16X3_SMALLVOL_K1=1 routes them there for A/B.)
+SMALLVOL_KERNELS = ((3, 3, 3), (1, 1, 1)) if os.environ.get("OCCDEPTH_BF16X3_SMALLVOL_K1", "0") == "1" else ((3, 3, 3),)
 
 
 def _smallvol_weight(w, layout):
-    return (BF16X3_SMALLVOL and layout == 0 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[1] >= 128
+    if not BF16X3_SMALLVOL:
+        return False
+    if layout == 2:          # a dynamic (K, N) row-GEMM operand: the CRP products sigmoid(P_logits) @ mega
+        return (1, 1, 1) in SMALLVOL_KERNELS and w.dim() == 2 and w.shape[0] >= 128 and w.shape[0] % 16 == 0 and w.shape[1] % 128 == 0
+    return (layout == 0 and w.dim() == 5 and tuple(w.shape[2:]) in SMALLVOL_KERNELS and w.shape[1] >= 128
             and w.shape[1] % 16 == 0 and w.shape[0] % 128 == 0)
 
 
@@ -161,14 +169,14 @@ def _pack_w(w, scale=None, layout=0):
 
 
 def _smallvol_eligible(x, wpk, cout, kernel, out, **kw):
-    if not BF16X3_SMALLVOL or tuple(kernel) != (3, 3, 3) or kw.get("cin") is not None or x.C < 128 or cout % 128:
+    if not BF16X3_SMALLVOL or tuple(kernel) not in SMALLVOL_KERNELS or kw.get("cin") not in (None, x.C) or x.C < 128 or cout % 128:
         return False
-    if x.cs % 8 or x.coff % 8 or x.buf.dtype != torch.float32 or kw.get("act_in", ACT_NONE) not in (ACT_NONE, ACT_RELU):
+    if x.cs % 8 or x.coff % 8 or x.buf.dtype != torch.float32:
         return False
     pos = kw.get("out_pos")
     if pos is None:
         st, dl, pd = kw.get("stride", (1, 1, 1)), kw.get("dilation", (1, 1, 1)), kw.get("padding", (0, 0, 0))
-        pos = tuple((n + 2 * p - d * 2 - 1) // s + 1 for n, p, d, s in zip(x.dims, pd, dl, st))
+        pos = tuple((n + 2 * p - d * (k - 1) - 1) // s + 1 for n, p, d, s, k in zip(x.dims, pd, dl, st, kernel))
     return x.batch * pos[0] * pos[1] * pos[2] <= SMALLVOL_MAX_VOXELS and kw.get("tile_hint", 0) == 0
 
 
@@ -347,10 +355,11 @@ class ConvTransposePlan:
             return lambda: _conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
                                    out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
 
-        if PHASES_ONE_LAUNCH and len(self._phases) > 1 and not any(isinstance(ph[3], _DualW) for ph in self._phases):
-            # one K2 launch for the 8 phases (phase = low bits of blockIdx.y, heaviest tap subset first)
-            return hip.conv3d_phases(x, [(wpk, kern, off) for off, kern, _, wpk in self._phases], self._bias, self.cout, out,
-                                     res1=res1, act_out=act_out, out_pos=x.dims, o_stride=(self.up,) * 3)
+        if PHASES_ONE_LAUNCH and len(self._phases) > 1 and BF16X3 != "all":
+            # one K2 launch for the 8 phases (phase = low bits of blockIdx.y, heaviest tap subset first); exact-fp32 images
+            return hip.conv3d_phases(x, [(wpk.f32 if isinstance(wpk, _DualW) else wpk, kern, off) for off, kern, _, wpk in self._phases],
+                                     self._bias, self.cout, out, res1=res1, act_out=act_out, out_pos=x.dims,
+                                     o_stride=(self.up,) * 3)
         thunks = [phase(*ph) for ph in self._phases]
         if x.buf.is_cuda and len(thunks) > 1:
             run_parallel(thunks)                     # the phases write disjoint voxels of `out`

@@ -98,7 +98,7 @@ def conv3d_bf16(x, wpk, bias, cout, kernel, out, **kw):
     """bf16 operands, exact products, float32 accumulation == the float32 emulation on bf16-rounded inputs."""
     assert getattr(wpk, "bf16", False), "conv3d_bf16 needs pack_weights_bf16's image"
     act_in = kw.get("act_in", 0)
-    assert act_in in (0, ACT_RELU)
+    assert act_in in (0, ACT_RELU) or (act_in == ACT_SIGMOID and kw.get("split3", False))
     if kw.pop("split3", False):
         assert wpk.split3
         return conv3d(x, wpk, bias, cout, kernel, out, **kw)

@@ -167,6 +167,32 @@ def test_conv3d_sigmoid_gemm(hip):
     assert rel_err(got, ref) < 2e-5
 
 
+def test_crp_product_on_the_split_kernel(hip):
+    """sigmoid(P_logits) @ mega at the config-2 size (4096 rows, K = N = 512): `gemm_rows` routes it to K2b's 3-way split with
+    the in-workgroup split-K (input sigmoid applied while staging); float32-level against float64."""
+    torch.manual_seed(4)
+    from occdepth_amd import fused
+    a = torch.randn(1, 512, 32, 32, 4, device=DEV) * 2
+    bm = torch.randn(512, 512, device=DEV) / 512 ** 0.5
+    ref = (torch.sigmoid(a.double().reshape(512, -1).t()) @ bm.double())
+    outs = {}
+    saved = (fused.BF16X3_SMALLVOL, fused.SMALLVOL_KERNELS)
+    fused.SMALLVOL_KERNELS = ((3, 3, 3), (1, 1, 1))          # (opt-in route: OCCDEPTH_BF16X3_SMALLVOL_K1=1)
+    try:
+        for on in (True, False):
+            fused.BF16X3_SMALLVOL = on
+            out = hip.Vox.empty(1, (32, 32, 4), 512, DEV)
+            with hip.profile() as prof:
+                fused.gemm_rows(hip.Vox.from_ncdhw(a), bm, out, act_in=hip.ACT_SIGMOID)
+            assert any(k.startswith("conv3d_bf16x3" if on and fused.BF16X3 else "conv3d_igemm") for k in prof.rows), prof.rows.keys()
+            outs[on] = out.buf.reshape(-1, out.cs)[:, :512].double()
+    finally:
+        fused.BF16X3_SMALLVOL, fused.SMALLVOL_KERNELS = saved
+    for on, got in outs.items():
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (on, err)
+
+
 def _module_cases():
     from occdepth_amd.models.CRP3D import CPMegaVoxels
     from occdepth_amd.models.DDR import Bottleneck3D
