@@ -606,6 +606,8 @@ int occd_pack_weights_bf16(const float* w, const float* scale, void* wpk,
                            int32_t cout, int32_t cin, int32_t kx, int32_t ky, int32_t kz,
                            int32_t layout, void* stream);
 int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream);
+/* the bf16-pipe twin of occd_conv3d_fwd_phases (same contract; dtype as above; with dtype 2 also act_in = SIGMOID) */
+int occd_conv3d_bf16_fwd_phases(const occd_conv3d_args* a, int32_t n, int32_t dtype, void* stream);
 /* Pack a VIEW of a dense float32 weight tensor: element (co, ci, tap) of the packed operator is
  * w[co * s_co + ci * s_ci + tap_ofs[tap]] (tap_ofs: HOST array of ntaps <= 27 element offsets).  One launch instead of the
  * permute / index_select / contiguous chain autograd's data gradient needs for the transposed, flipped, tap-subset kernels

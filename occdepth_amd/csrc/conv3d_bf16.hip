@@ -17,6 +17,10 @@
 // CRP3D.py:54-97, unet2d.py:24-46 -- forward and, on dL/dy with flipped weights, the data gradient.
 #include "common.h"
 
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+
 using occd::FastDiv;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,9 +32,16 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+// what differs between the sub-pixel phases of one transposed convolution (see K2's PhaseP, csrc/conv3d_igemm.hip)
+struct PhaseBP {
+    const u32x4* wpk;
+    int KX, KY, KZ, oox, ooy, ooz, YIN, ZIN;
+    FastDiv div_zin;
+};
+constexpr int kMaxPhasesB = 8;
+
 struct ConvBP {
     const void* in;
-    const u32x4* wpk;
     const float* bias;
     const void* res1;
     const void* res2;
@@ -38,11 +49,13 @@ struct ConvBP {
     int X, Y, Z, cin8, cin16, in_cs, in_coff;
     int K16tot, NTtot;
     int out_cs, out_coff, res1_cs, res1_coff, res2_cs, res2_coff;
-    int KX, KY, KZ, SX, SY, SZ, DX, DY, DZ, PX, PY, PZ;
-    int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz, oox, ooy, ooz;
+    int SX, SY, SZ, DX, DY, DZ, PX, PY, PZ;
+    int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz;
     int act_in, act_out, cout_store;
-    int TY, TZ, YIN, ZIN, ytiles, ztiles, nwg;
-    FastDiv div_zin, div_tz, div_ztiles, div_ytiles;
+    int TY, TZ, ytiles, ztiles, nwg;
+    int nph_log2;           // blockIdx.y = (batch index << nph_log2) | phase
+    FastDiv div_tz, div_ztiles, div_ytiles;
+    PhaseBP ph[kMaxPhasesB];
 };
 
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
@@ -122,7 +135,8 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
     const uint32_t t2 = occd_fastdiv(t1, p.div_ytiles);
     const int yt = t1 - t2 * p.ytiles;
     const int xo = t2;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y >> p.nph_log2;
+    const PhaseBP& ph = p.ph[blockIdx.y & ((1u << p.nph_log2) - 1u)];
     const int nt0 = (blockIdx.z * WN + wn) * NT;
 
     int rowbase[MT];   // byte offset of this lane's A row (tap (0,0), k16 0) for each M tile
@@ -134,7 +148,7 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
         const bool in_tile = yl < (uint32_t)p.TY;
         yl = in_tile ? yl : 0u;
         zl = in_tile ? zl : 0u;
-        rowbase[mt] = (int)((yl * p.SY) * p.ZIN + zl * p.SZ) * RSB + h * 16;
+        rowbase[mt] = (int)((yl * p.SY) * ph.ZIN + zl * p.SZ) * RSB + h * 16;
     }
     int wofs[NT];      // u32x4 index of each owned N tile inside one (tap, k16) weight record row
 #pragma unroll
@@ -151,9 +165,9 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
     const int y_in0 = yt * p.TY * p.SY - p.PY;
     const int z_in0 = zt * p.TZ * p.SZ - p.PZ;
     const size_t w_step = (size_t)p.NTtot * 64;          // u32x4 per (tap, k16)
-    const size_t w_img = (size_t)p.KX * p.KY * p.KZ * p.K16tot * w_step;   // u32x4 per split image of the weights
-    const u32x4* const wlane = p.wpk + lane;
-    const int rows = p.YIN * p.ZIN;
+    const size_t w_img = (size_t)ph.KX * ph.KY * ph.KZ * p.K16tot * w_step;   // u32x4 per split image of the weights
+    const u32x4* const wlane = ph.wpk + lane;
+    const int rows = ph.YIN * ph.ZIN;
     unsigned char* const slab = slab_all + (size_t)kg * rows * RSB;   // this K group's slab
     const int n_chunks = (p.cin16 + 31) / 32;
     const int chunk_iters = (n_chunks + KS - 1) / KS;
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
     }                                                                      \
     OCCD_MFMA1(0, 0)
 
-    for (int kx = 0; kx < p.KX; ++kx) {
+    for (int kx = 0; kx < ph.KX; ++kx) {
         const int xi = xo * p.SX - p.PX + kx * p.DX;
         if (xi < 0 || xi >= p.X) continue;   // workgroup-uniform
         const size_t plane = ((size_t)(b * p.X + xi) * p.Y) * p.Z * p.in_cs + p.in_coff;
@@ -183,8 +197,8 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
             const int ck = active ? min(32, p.cin16 - c0) : 16;   // 16 or 32 channels in this chunk
             const int k16n = ck >> 4;
             const int sh = k16n;                         // chunks of 8 channels per row: 2 (shift 1) or 4 (shift 2)
-            const int S = active ? p.KY * p.KZ * k16n : 0;
-            const u32x4* wp = wlane + ((size_t)(kx * p.KY * p.KZ) * p.K16tot + (active ? c0 >> 4 : 0)) * w_step;
+            const int S = active ? ph.KY * ph.KZ * k16n : 0;
+            const u32x4* wp = wlane + ((size_t)(kx * ph.KY * ph.KZ) * p.K16tot + (active ? c0 >> 4 : 0)) * w_step;
 
             u32x4 b_cur[NT][SPLIT];   // first B fragments fly while the slab is staged
 #pragma unroll
@@ -203,8 +217,8 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
                     const int fc = min(f, F - 1);
                     const uint32_t row = (uint32_t)fc >> sh;
                     const int c8 = fc & ((1 << sh) - 1);
-                    const uint32_t yi = occd_fastdiv(row, p.div_zin);
-                    const int zi = (int)row - (int)yi * p.ZIN;
+                    const uint32_t yi = occd_fastdiv(row, ph.div_zin);
+                    const int zi = (int)row - (int)yi * ph.ZIN;
                     const int y = y_in0 + (int)yi, z = z_in0 + zi;
                     const int c = c0 + c8 * 8;
                     const bool ok = f < F && c < p.cin8 && (unsigned)y < (unsigned)p.Y && (unsigned)z < (unsigned)p.Z;
@@ -259,8 +273,8 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
                 if (kl == k16n) {
                     kl = 0;
                     wp += (size_t)(p.K16tot - k16n) * w_step;
-                    if (++kz == p.KZ) { kz = 0; ++ky; }
-                    lds_off = (ky * p.DY * p.ZIN + kz * p.DZ) * RSB;
+                    if (++kz == ph.KZ) { kz = 0; ++ky; }
+                    lds_off = (ky * p.DY * ph.ZIN + kz * p.DZ) * RSB;
                 }
                 u32x4 a_nxt[MT][SPLIT], b_nxt[NT][SPLIT];
 #pragma unroll
@@ -322,8 +336,8 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
         const uint32_t zl = m - yl * p.TZ;
         const int yo = yt * p.TY + (int)yl, zo = zt * p.TZ + (int)zl;
         const bool ok = yl < (uint32_t)p.TY && yo < p.Yo && zo < p.Zo;
-        const size_t vox = ((size_t)(b * p.OX + xo * p.osx + p.oox) * p.OY + (yo * p.osy + p.ooy)) * p.OZ +
-                           (zo * p.osz + p.ooz);
+        const size_t vox = ((size_t)(b * p.OX + xo * p.osx + ph.oox) * p.OY + (yo * p.osy + ph.ooy)) * p.OZ +
+                           (zo * p.osz + ph.ooz);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -533,7 +547,9 @@ static int pack_bf16_gather(const float* w, const float* scale, void* wpk, int32
 // the same type --, `a->wpk` at the image of occd_pack_weights_bf16, `a->bias` at fp32.  *_cs / *_coff count ELEMENTS.
 // dtype 2 = float32 tensors with the 3-way bf16 split of both operands (wpk from occd_pack_weights_bf16x3): float32-level
 // accuracy on the bf16 matrix pipe, an opt-in experiment beside the exact-fp32 kernels.
-extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream) {
+namespace {
+
+int validate_b(const occd_conv3d_args* a, int32_t dtype) {
     if (!a || !a->in || !a->wpk || !a->out || dtype < 0 || dtype > 2) return OCCD_EINVAL;
     const int ksel = dtype;                           // kernel table column
     if (dtype == 2) dtype = 0;                        // storage: float32
@@ -567,72 +583,128 @@ extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, vo
     if (a->act_in != OCCD_ACT_NONE && a->act_in != OCCD_ACT_RELU && !(a->act_in == OCCD_ACT_SIGMOID && ksel == 2)) return OCCD_EINVAL;
     if (a->act_out != OCCD_ACT_NONE && a->act_out != OCCD_ACT_RELU && a->act_out != OCCD_ACT_RELU_PRE)
         return OCCD_EINVAL;
+    return OCCD_OK;
+}
 
-    if (ksel == 2) {   // the full-resolution head launches: sliding-window form of the split (K2s3, conv3d_c32p.hip)
-        const int r = occd::try_conv3d_c32_slide_x3(a, (hipStream_t)stream);
-        if (r != 0) return r < 0 ? r : OCCD_OK;
+// n phases (n = 1: a plain launch) that differ only in wpk, kx / ky / kz and o_off_*: ONE launch
+int launch_b(const occd_conv3d_args* a, int n, int32_t dtype, hipStream_t stream) {
+    const int ksel = dtype;                           // kernel table column
+    if (dtype == 2) dtype = 0;                        // storage: float32
+    const int esz = dtype == 1 ? 2 : 4;
+    const int cin8 = (a->cin + 7) & ~7;
+    const int cin16 = (a->cin + 15) & ~15;
+    const int NTtot = (a->cout + 31) / 32;
+    // tiling for the phase with the largest slab (the largest ky / kz over the phases)
+    occd_conv3d_args big = a[0];
+    for (int i = 1; i < n; ++i) {
+        big.ky = a[i].ky > big.ky ? a[i].ky : big.ky;
+        big.kz = a[i].kz > big.kz ? a[i].kz : big.kz;
     }
+    const long copies = (long)a->batch * n;
     int order[kNumVariantsB];
-    int n = 0;
+    int no = 0;
     if (a->tile_hint > 0 && a->tile_hint <= kNumVariantsB) {
-        order[n++] = a->tile_hint - 1;
+        order[no++] = a->tile_hint - 1;
     } else if (NTtot == 1) {
-        order[n++] = 0; order[n++] = 1; order[n++] = 2;
+        order[no++] = 0; order[no++] = 1; order[no++] = 2;
     } else if (NTtot == 2) {
-        order[n++] = 3; order[n++] = 4; order[n++] = 6; order[n++] = 7;
+        order[no++] = 3; order[no++] = 4; order[no++] = 6; order[no++] = 7;
     } else {
-        order[n++] = 5; order[n++] = 6; order[n++] = 7;
+        order[no++] = 5; order[no++] = 6; order[no++] = 7;
     }
     const int rsb = ksel == 2 ? kRSB3 : kRSB;
     int pick = -1;
     TilingB til{};
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < no; ++i) {
         TilingB t{};
         if (kVariantsB[order[i]].kern[ksel] == nullptr) continue;
-        if (!plan_b(a, kVariantsB[order[i]], NTtot, &t, rsb)) continue;
+        if (!plan_b(&big, kVariantsB[order[i]], NTtot, &t, rsb)) continue;
         pick = order[i];
         til = t;
-        if (t.nwg * t.ngroups * a->batch >= 512) break;   // else keep refining to the finest fit
+        if (t.nwg * t.ngroups * copies >= 512) break;   // else keep refining to the finest fit
     }
     if (pick < 0) return OCCD_ENOMEM;
-    if (ksel == 2 && a->tile_hint == 0 && til.nwg * til.ngroups * a->batch <= 320 && cin16 >= 128 && NTtot % 4 == 0) {
+    if (ksel == 2 && a->tile_hint == 0 && til.nwg * til.ngroups * copies <= 320 && cin16 >= 128 && NTtot % 4 == 0) {
         // too few output tiles to fill the chip: multiply the waves by splitting K inside the workgroup (K2's rule)
         TilingB t{};
-        if (plan_b(a, kVariantsB[8], NTtot, &t, rsb) && t.nwg * t.ngroups * a->batch <= 1024) {
+        if (plan_b(&big, kVariantsB[8], NTtot, &t, rsb) && t.nwg * t.ngroups * copies <= 1024) {
             pick = 8;
             til = t;
         }
     }
     const VariantB& v = kVariantsB[pick];
 
-    ConvBP p;
-    p.in = a->in; p.wpk = (const u32x4*)a->wpk; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
+    ConvBP p{};
+    p.in = a->in; p.bias = a->bias; p.res1 = a->res1; p.res2 = a->res2; p.out = a->out;
     p.X = a->X; p.Y = a->Y; p.Z = a->Z; p.cin8 = cin8; p.cin16 = cin16; p.in_cs = a->in_cs; p.in_coff = a->in_coff;
     p.K16tot = cin16 / 16; p.NTtot = NTtot;
     p.out_cs = a->out_cs; p.out_coff = a->out_coff;
     p.res1_cs = a->res1_cs; p.res1_coff = a->res1_coff; p.res2_cs = a->res2_cs; p.res2_coff = a->res2_coff;
-    p.KX = a->kx; p.KY = a->ky; p.KZ = a->kz; p.SX = a->sx; p.SY = a->sy; p.SZ = a->sz;
+    p.SX = a->sx; p.SY = a->sy; p.SZ = a->sz;
     p.DX = a->dx; p.DY = a->dy; p.DZ = a->dz; p.PX = a->px; p.PY = a->py; p.PZ = a->pz;
     p.Xo = a->Xo; p.Yo = a->Yo; p.Zo = a->Zo; p.OX = a->OX; p.OY = a->OY; p.OZ = a->OZ;
     p.osx = a->o_stride_x; p.osy = a->o_stride_y; p.osz = a->o_stride_z;
-    p.oox = a->o_off_x; p.ooy = a->o_off_y; p.ooz = a->o_off_z;
     p.act_in = a->act_in; p.act_out = a->act_out; p.cout_store = a->cout_store;
-    p.TY = til.TY; p.TZ = til.TZ; p.YIN = til.YIN; p.ZIN = til.ZIN;
+    p.TY = til.TY; p.TZ = til.TZ;
     p.ytiles = til.ytiles; p.ztiles = til.ztiles; p.nwg = (int)til.nwg;
-    p.div_zin = occd::make_fastdiv(til.ZIN); p.div_tz = occd::make_fastdiv(til.TZ);
+    p.div_tz = occd::make_fastdiv(til.TZ);
     p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
+    p.nph_log2 = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
+    // heaviest tap subset first in dispatch order: the single-tap phases fill the tail
+    int ord[kMaxPhasesB];
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    std::stable_sort(ord, ord + n, [&](int l, int r) { return a[l].kx * a[l].ky * a[l].kz > a[r].kx * a[r].ky * a[r].kz; });
+    double flops = 0.0, bytes = 0.0;
+    const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
+    for (int i = 0; i < n; ++i) {
+        const occd_conv3d_args* ai = a + ord[i];
+        PhaseBP& ph = p.ph[i];
+        ph.wpk = (const u32x4*)ai->wpk;
+        ph.KX = ai->kx; ph.KY = ai->ky; ph.KZ = ai->kz;
+        ph.oox = ai->o_off_x; ph.ooy = ai->o_off_y; ph.ooz = ai->o_off_z;
+        ph.YIN = (til.TY - 1) * ai->sy + (ai->ky - 1) * ai->dy + 1;      // (the shared tile, this phase's extent)
+        ph.ZIN = (til.TZ - 1) * ai->sz + (ai->kz - 1) * ai->dz + 1;
+        ph.div_zin = occd::make_fastdiv(ph.ZIN);
+        if ((size_t)ph.YIN * ph.ZIN * rsb * v.KS > til.lds) return OCCD_EINVAL;
+        const double taps = (double)ai->kx * ai->ky * ai->kz;
+        flops += 2.0 * pos * taps * ai->cin * ai->cout;
+        bytes += (double)esz * ((i == 0 ? (double)a->batch * a->X * a->Y * a->Z * a->cin : 0.0) +
+                                pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr))) + 2.0 * taps * a->cin * a->cout;
+    }
+    if (copies > 65535) return OCCD_EINVAL;
 
     void (*kern)(const ConvBP) = v.kern[ksel];
     if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
-    const double taps = (double)a->kx * a->ky * a->kz;
-    const double pos = (double)a->batch * a->Xo * a->Yo * a->Zo;
-    const double flops = 2.0 * pos * taps * a->cin * a->cout;
-    const double bytes = (double)esz * ((double)a->batch * a->X * a->Y * a->Z * a->cin +
-                                        pos * a->cout * (1 + (a->res1 != nullptr) + (a->res2 != nullptr))) +
-                         2.0 * taps * a->cin * a->cout;
-    occd::ProfScope prof(ksel == 2 ? "conv3d_bf16x3" : dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16", (hipStream_t)stream, flops,
-                         bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)til.nwg, (unsigned)a->batch, (unsigned)til.ngroups),
-                       dim3(v.WM * v.WN * v.KS * 64), til.lds, (hipStream_t)stream, p);
+    occd::ProfScope prof(n > 1 ? "conv3d_bf16x3_phases" : ksel == 2 ? "conv3d_bf16x3" : dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16",
+                         stream, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)til.nwg, (unsigned)copies, (unsigned)til.ngroups),
+                       dim3(v.WM * v.WN * v.KS * 64), til.lds, stream, p);
     return occd::check_launch();
+}
+
+}  // namespace
+
+extern "C" int occd_conv3d_bf16_fwd(const occd_conv3d_args* a, int32_t dtype, void* stream) {
+    const int bad = validate_b(a, dtype);
+    if (bad != OCCD_OK) return bad;
+    if (dtype == 2) {   // the full-resolution head launches: sliding-window form of the split (K2s3, conv3d_c32p.hip)
+        const int r = occd::try_conv3d_c32_slide_x3(a, (hipStream_t)stream);
+        if (r != 0) return r < 0 ? r : OCCD_OK;
+    }
+    return launch_b(a, 1, dtype, (hipStream_t)stream);
+}
+
+// The n in {1, 2, 4, 8} sub-pixel phases of ONE transposed convolution on K2b as one launch (the bf16-pipe twin of
+// occd_conv3d_fwd_phases, same contract: a[0..n) differ ONLY in wpk, kx / ky / kz and o_off_*).
+extern "C" int occd_conv3d_bf16_fwd_phases(const occd_conv3d_args* a, int32_t n, int32_t dtype, void* stream) {
+    if (!a || (n != 1 && n != 2 && n != 4 && n != 8)) return OCCD_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const int bad = validate_b(a + i, dtype);
+        if (bad != OCCD_OK) return bad;
+        occd_conv3d_args t = a[i];
+        t.wpk = a[0].wpk; t.kx = a[0].kx; t.ky = a[0].ky; t.kz = a[0].kz;
+        t.o_off_x = a[0].o_off_x; t.o_off_y = a[0].o_off_y; t.o_off_z = a[0].o_off_z;
+        if (memcmp(&t, &a[0], offsetof(occd_conv3d_args, tile_hint) + sizeof(int32_t)) != 0) return OCCD_EINVAL;
+    }
+    return launch_b(a, n, dtype, (hipStream_t)stream);
 }

@@ -292,6 +292,9 @@ class DerivedConvPlan:
 
 # the 8 sub-pixel phases of a stride-2 transposed convolution as one launch (occd_conv3d_fwd_phases); 0 = eight launches
 PHASES_ONE_LAUNCH = os.environ.get("OCCDEPTH_PHASES_ONE_LAUNCH", "1") == "1"
+# ... and that one launch on K2b with the 3-way bf16 split (occd_conv3d_bf16_fwd_phases) instead of the exact-fp32 K2, while the
+# split is on at all (OCCDEPTH_BF16X3 != 0): float32-level accuracy, 6/16 of the fp32 instruction's MFMA time.  0 = K2.
+PHASES_X3 = os.environ.get("OCCDEPTH_PHASES_X3", "1") == "1"
 
 
 class ConvTransposePlan:
@@ -319,9 +322,15 @@ class ConvTransposePlan:
         return self.convt.out_channels
 
     def _prepare(self):
-        key = (_stamp(self.convt, self.bn), BF16X3)
+        key = (_stamp(self.convt, self.bn), BF16X3, PHASES_X3)
         if key == self._key:
             return
+        x3 = bool(BF16X3) and PHASES_X3 and PHASES_ONE_LAUNCH
+
+        def pack(w, scale):      # both images of a phase's tap subset when the merged launch may take the split kernel
+            if x3:
+                return _DualW(hip.pack_weights(w, scale), hip.pack_weights_bf16(w, scale, split3=True))
+            return _pack_w(w, scale)
         wt = self.convt.weight.detach().float()  # (Cin, Cout, 3, 3, 3)
         dev = wt.device
         scale, shift = _bn_affine(self.bn, self.cout, dev)
@@ -339,7 +348,7 @@ class ConvTransposePlan:
                 for py in (0, 1):
                     for pz in (0, 1):
                         sub = w[:, :, taps[px]][:, :, :, taps[py]][:, :, :, :, taps[pz]].contiguous()
-                        phases.append(((px, py, pz), tuple(sub.shape[2:]), (0, 0, 0), _pack_w(sub, scale)))
+                        phases.append(((px, py, pz), tuple(sub.shape[2:]), (0, 0, 0), pack(sub, scale)))
         self._phases = phases
         self._bias = _pad_bias(shift, self.cout)
         self._key = key
@@ -355,6 +364,11 @@ class ConvTransposePlan:
             return lambda: _conv3d(x, wpk, self._bias, self.cout, kern, out, padding=pad, res1=res1, act_out=act_out,
                                    out_pos=x.dims, o_stride=(self.up,) * 3, o_off=off)
 
+        if PHASES_ONE_LAUNCH and len(self._phases) > 1 and BF16X3 and PHASES_X3 and x.buf.dtype == torch.float32 and \
+                x.cs % 8 == 0 and x.coff % 8 == 0 and all(isinstance(ph[3], _DualW) for ph in self._phases):
+            # one K2b launch for the 8 phases, 3-way bf16 split
+            return hip.conv3d_phases(x, [(wpk.x3, kern, off) for off, kern, _, wpk in self._phases], self._bias, self.cout, out,
+                                     res1=res1, act_out=act_out, out_pos=x.dims, o_stride=(self.up,) * 3, split3=True)
         if PHASES_ONE_LAUNCH and len(self._phases) > 1 and BF16X3 != "all":
             # one K2 launch for the 8 phases (phase = low bits of blockIdx.y, heaviest tap subset first); exact-fp32 images
             return hip.conv3d_phases(x, [(wpk.f32 if isinstance(wpk, _DualW) else wpk, kern, off) for off, kern, _, wpk in self._phases],

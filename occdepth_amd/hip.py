@@ -137,6 +137,7 @@ EXPORTS = {
     "occd_strerror": (c_char_p, [c_int32]),
     "occd_conv3d_fwd": (c_int32, [POINTER(Conv3dArgs), c_void_p]),
     "occd_conv3d_fwd_phases": (c_int32, [POINTER(Conv3dArgs), c_int32, c_void_p]),
+    "occd_conv3d_bf16_fwd_phases": (c_int32, [POINTER(Conv3dArgs), c_int32, c_int32, c_void_p]),
     "occd_packed_weight_floats": (c_int64, [c_int32, c_int32, c_int32]),
     "occd_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
@@ -425,19 +426,24 @@ def conv3d(x, wpk, bias, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1)
     return out
 
 
-def conv3d_phases(x, phases, bias, cout, out, res1=None, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1)):
-    """The sub-pixel phases of one transposed convolution as ONE K2 launch (occd_conv3d_fwd_phases).
-    phases: 1 / 2 / 4 / 8 tuples (wpk, kernel, o_off) -- the exact-fp32 packed weights of the phase's tap subset, its extent
-    and where its voxels land in `out`; padding 0, stride / dilation 1, everything else shared."""
+def conv3d_phases(x, phases, bias, cout, out, res1=None, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1), split3=False):
+    """The sub-pixel phases of one transposed convolution as ONE launch: K2 (occd_conv3d_fwd_phases) or, split3, K2b with the
+    3-way bf16 split (occd_conv3d_bf16_fwd_phases).
+    phases: 1 / 2 / 4 / 8 tuples (wpk, kernel, o_off) -- the packed weights of the phase's tap subset (pack_weights, or
+    pack_weights_bf16(split3=True)), its extent and where its voxels land in `out`; padding 0, stride / dilation 1, everything
+    else shared."""
     n = len(phases)
     arr = (Conv3dArgs * n)()
     for i, (wpk, kernel, o_off) in enumerate(phases):
-        a = _conv3d_args(x, _f32(wpk, "wpk"), bias, cout, kernel, out, (1, 1, 1), (1, 1, 1), (0, 0, 0), res1, None, ACT_NONE,
-                         act_out, out_pos, o_stride, o_off, None, 0, _f32)
+        a = _conv3d_args(x, _ptr(wpk, "wpk") if split3 else _f32(wpk, "wpk"), bias, cout, kernel, out, (1, 1, 1), (1, 1, 1),
+                         (0, 0, 0), res1, None, ACT_NONE, act_out, out_pos, o_stride, o_off, None, 0, _f32)
         ctypes.memmove(ctypes.byref(arr, i * ctypes.sizeof(Conv3dArgs)), ctypes.byref(a), ctypes.sizeof(Conv3dArgs))
     if _PROFILING:
         set_tag("%d>%d k333 s222 transposed: %d phases @%dx%dx%d" % ((x.C, cout, n) + tuple(x.dims)))
-    _check(load().occd_conv3d_fwd_phases(arr, n, _stream()), "occd_conv3d_fwd_phases")
+    if split3:
+        _check(load().occd_conv3d_bf16_fwd_phases(arr, n, 2, _stream()), "occd_conv3d_bf16_fwd_phases")
+    else:
+        _check(load().occd_conv3d_fwd_phases(arr, n, _stream()), "occd_conv3d_fwd_phases")
     return out
 
 

@@ -88,7 +88,7 @@ def pack_weights_bf16(w, scale=None, layout=0, split3=False):
     return pk
 
 
-def conv3d_phases(x, phases, bias, cout, out, res1=None, act_out=0, out_pos=None, o_stride=(1, 1, 1)):
+def conv3d_phases(x, phases, bias, cout, out, res1=None, act_out=0, out_pos=None, o_stride=(1, 1, 1), split3=False):
     for wpk, kernel, o_off in phases:
         conv3d(x, wpk, bias, cout, kernel, out, res1=res1, act_out=act_out, out_pos=out_pos, o_stride=o_stride, o_off=o_off)
     return out

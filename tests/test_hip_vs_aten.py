@@ -271,16 +271,31 @@ def test_transposed_conv_phases_one_launch_equals_eight(hip, case):
         ref = F.relu(bn(convt(x)) + res)
         plan = fused.ConvTransposePlan(convt, bn)
         vx, vr = hip.Vox.from_ncdhw(x), hip.Vox.from_ncdhw(res)
-        saved = fused.PHASES_ONE_LAUNCH
+        saved = (fused.PHASES_ONE_LAUNCH, fused.PHASES_X3)
         try:
-            fused.PHASES_ONE_LAUNCH = True
-            one = plan(vx, res1=vr, act_out=hip.ACT_RELU).ncdhw()
+            fused.PHASES_ONE_LAUNCH, fused.PHASES_X3 = True, False
+            with hip.profile() as prof:
+                one = plan(vx, res1=vr, act_out=hip.ACT_RELU).ncdhw()
+            convs = [k for k in prof.rows if k.startswith("conv3d")]          # (the first call also packs weights)
+            assert len(convs) == 1 and convs[0].startswith("conv3d_igemm_phases"), convs
             fused.PHASES_ONE_LAUNCH = False
             eight = plan(vx, res1=vr, act_out=hip.ACT_RELU).ncdhw()
+            # the same merged launch on K2b with the 3-way bf16 split (occd_conv3d_bf16_fwd_phases): float32-level accuracy
+            fused.PHASES_ONE_LAUNCH, fused.PHASES_X3 = True, True
+            with hip.profile() as prof:
+                one_x3 = plan(vx, res1=vr, act_out=hip.ACT_RELU).ncdhw()
+            if fused.BF16X3 and cin % 8 == 0:
+                assert any(k.startswith("conv3d_bf16x3_phases") for k in prof.rows), list(prof.rows)
         finally:
-            fused.PHASES_ONE_LAUNCH = saved
+            fused.PHASES_ONE_LAUNCH, fused.PHASES_X3 = saved
+    ref64 = F.relu(bn.double()(F.conv_transpose3d(x.double(), convt.weight.double(), convt.bias.double(), stride=2, padding=1,
+                                                  output_padding=1)) + res.double())
+    bn.float()
     assert rel_err(one, ref) < 2e-5 and rel_err(eight, ref) < 2e-5
     assert rel_err(one, eight) < 1e-6
+    e_x3, e_k2 = rel_err(one_x3.double(), ref64), rel_err(one.double(), ref64)
+    print(case, f"vs float64: K2b split {e_x3:.2e}, K2 exact fp32 {e_k2:.2e}")
+    assert e_x3 < max(2e-6, 1.5 * e_k2)
 
 
 @pytest.mark.parametrize("cfg", ["kitti_ps2", "kitti_ps1", "nyu"])
