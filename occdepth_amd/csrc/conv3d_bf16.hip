@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 
 using occd::FastDiv;
@@ -53,7 +54,8 @@ struct ConvBP {
     int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz;
     int act_in, act_out, cout_store;
     int TY, TZ, ytiles, ztiles, nwg;
-    int nph_log2;           // blockIdx.y = (batch index << nph_log2) | phase
+    int nph_log2;           // blockIdx.y = (batch index << nph_log2) | phase, or (ph_fast) linear id = (tile << nph_log2) | phase
+    int ph_fast;
     FastDiv div_tz, div_ztiles, div_ytiles;
     PhaseBP ph[kMaxPhasesB];
 };
@@ -130,13 +132,19 @@ __global__ void __launch_bounds__(WM* WN * KS * 64) conv3d_bf16_kernel(const Con
         const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // phase of a merged transposed-convolution launch: the low bits of the (remapped) linear id when ph_fast -- the phases of
+    // one output tile run next to each other on one XCD, so their interleaved voxel rows meet in its L2 and the input tile is
+    // fetched once -- else the low bits of blockIdx.y (phase-major dispatch, heaviest tap subset first)
+    const uint32_t ph_mask = (1u << p.nph_log2) - 1u;
+    const uint32_t ph_i = p.ph_fast ? bid & ph_mask : blockIdx.y & ph_mask;
+    if (p.ph_fast) bid >>= p.nph_log2;
     const uint32_t t1 = occd_fastdiv(bid, p.div_ztiles);
     const int zt = bid - t1 * p.ztiles;
     const uint32_t t2 = occd_fastdiv(t1, p.div_ytiles);
     const int yt = t1 - t2 * p.ytiles;
     const int xo = t2;
-    const int b = blockIdx.y >> p.nph_log2;
-    const PhaseBP& ph = p.ph[blockIdx.y & ((1u << p.nph_log2) - 1u)];
+    const int b = p.ph_fast ? blockIdx.y : blockIdx.y >> p.nph_log2;
+    const PhaseBP& ph = p.ph[ph_i];
     const int nt0 = (blockIdx.z * WN + wn) * NT;
 
     int rowbase[MT];   // byte offset of this lane's A row (tap (0,0), k16 0) for each M tile
@@ -650,6 +658,11 @@ int launch_b(const occd_conv3d_args* a, int n, int32_t dtype, hipStream_t stream
     p.div_tz = occd::make_fastdiv(til.TZ);
     p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
     p.nph_log2 = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
+    // phase-major dispatch is the default (see occd_conv3d_fwd_phases: the tile-major order, OCCD_PHASE_FAST=1, measured slower)
+    static const bool phase_fast = getenv("OCCD_PHASE_FAST") != nullptr;
+    p.ph_fast = n > 1 && phase_fast ? 1 : 0;
+    if (p.ph_fast) p.nwg = (int)(til.nwg * n);
+    if (til.nwg * n >= (1L << 24)) return OCCD_EINVAL;
     // heaviest tap subset first in dispatch order: the single-tap phases fill the tail
     int ord[kMaxPhasesB];
     for (int i = 0; i < n; ++i) ord[i] = i;
@@ -677,7 +690,8 @@ int launch_b(const occd_conv3d_args* a, int n, int32_t dtype, hipStream_t stream
     if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
     occd::ProfScope prof(n > 1 ? "conv3d_bf16x3_phases" : ksel == 2 ? "conv3d_bf16x3" : dtype == 1 ? "conv3d_bf16s" : "conv3d_bf16",
                          stream, flops, bytes);
-    hipLaunchKernelGGL(kern, dim3((unsigned)til.nwg, (unsigned)copies, (unsigned)til.ngroups),
+    hipLaunchKernelGGL(kern, p.ph_fast ? dim3((unsigned)(til.nwg * n), (unsigned)a->batch, (unsigned)til.ngroups)
+                                       : dim3((unsigned)til.nwg, (unsigned)copies, (unsigned)til.ngroups),
                        dim3(v.WM * v.WN * v.KS * 64), til.lds, stream, p);
     return occd::check_launch();
 }

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 
 using occd::FastDiv;
@@ -55,7 +56,8 @@ struct ConvP {
     int Xo, Yo, Zo, OX, OY, OZ, osx, osy, osz;
     int act_in, act_out, cout_store;
     int TY, TZ, ytiles, ztiles, nwg;
-    int nph_log2;           // blockIdx.y = (batch index << nph_log2) | phase
+    int nph_log2;           // blockIdx.y = (batch index << nph_log2) | phase, or (ph_fast) linear id = (tile << nph_log2) | phase
+    int ph_fast;
     FastDiv div_tz, div_ztiles, div_ytiles;
     PhaseP ph[kMaxPhases];
 };
@@ -98,13 +100,19 @@ __global__ void __launch_bounds__(WM* WN* KS * 64) conv3d_igemm_kernel(const Con
         const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // phase of a merged transposed-convolution launch: the low bits of the (remapped) linear id when ph_fast -- the phases of
+    // one output tile run next to each other on one XCD, so their interleaved voxel rows meet in its L2 and the input tile is
+    // fetched once -- else the low bits of blockIdx.y (phase-major dispatch, heaviest tap subset first)
+    const uint32_t ph_mask = (1u << p.nph_log2) - 1u;
+    const uint32_t ph_i = p.ph_fast ? bid & ph_mask : blockIdx.y & ph_mask;
+    if (p.ph_fast) bid >>= p.nph_log2;
     const uint32_t t1 = occd_fastdiv(bid, p.div_ztiles);
     const int zt = bid - t1 * p.ztiles;
     const uint32_t t2 = occd_fastdiv(t1, p.div_ytiles);
     const int yt = t1 - t2 * p.ytiles;
     const int xo = t2;
-    const int b = blockIdx.y >> p.nph_log2;
-    const PhaseP& ph = p.ph[blockIdx.y & ((1u << p.nph_log2) - 1u)];
+    const int b = p.ph_fast ? blockIdx.y : blockIdx.y >> p.nph_log2;
+    const PhaseP& ph = p.ph[ph_i];
     const int nt0 = (blockIdx.z * WN + wn) * NT;
 
     // LDS float4 index of this lane's A row for each M tile.
@@ -535,6 +543,7 @@ extern "C" int occd_conv3d_fwd(const occd_conv3d_args* a, void* stream) {
     fill_shared(a, til, &p);
     fill_phase(a, til, &p.ph[0]);
     p.nph_log2 = 0;
+    p.ph_fast = 0;
     if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(v.kern)) != OCCD_OK) return OCCD_ELAUNCH;
     double flops = 0.0, bytes = 0.0;
     cost(a, &flops, &bytes, true);
@@ -596,10 +605,16 @@ extern "C" int occd_conv3d_fwd_phases(const occd_conv3d_args* a, int32_t n, void
         cost(ai, &flops, &bytes, i == 0);
     }
     p.nph_log2 = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
-    if ((long)a[0].batch * n > 65535) return OCCD_EINVAL;
+    // phase-major dispatch (all tiles of the heaviest phase first) is the default; the phases of a tile next to each other on
+    // one XCD (OCCD_PHASE_FAST=1) measured SLOWER: 64 -> 32 at 128x128x16 0.47 against 0.35 ms on K2, 0.36 against 0.34 on K2b
+    static const bool phase_fast = getenv("OCCD_PHASE_FAST") != nullptr;
+    p.ph_fast = phase_fast ? 1 : 0;
+    if (p.ph_fast) p.nwg = (int)(til.nwg * n);
+    if ((long)a[0].batch * n > 65535 || til.nwg * n >= (1L << 24)) return OCCD_EINVAL;
     if (til.lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(v.kern)) != OCCD_OK) return OCCD_ELAUNCH;
     occd::ProfScope prof("conv3d_igemm_phases", (hipStream_t)stream, flops, bytes);
-    hipLaunchKernelGGL(v.kern, dim3((unsigned)til.nwg, (unsigned)(a[0].batch * n), (unsigned)til.ngroups),
+    hipLaunchKernelGGL(v.kern, p.ph_fast ? dim3((unsigned)(til.nwg * n), (unsigned)a[0].batch, (unsigned)til.ngroups)
+                                         : dim3((unsigned)til.nwg, (unsigned)(a[0].batch * n), (unsigned)til.ngroups),
                        dim3(v.WM * v.WN * v.KS * 64), til.lds, (hipStream_t)stream, p);
     return occd::check_launch();
 }
