@@ -469,9 +469,11 @@ def _forward(args, world, rank, device, dist):
         # the head convolutions run on the bf16 matrix pipe (3-way split, six bf16 MFMAs per algorithmic MAC): the roofline is
         # priced against the instruction that is issued; the fp32-equivalent figures stay next to it
         x3_slide = any(k.startswith("conv3d_c32x3") for k, _ in head)
-        res["dtype"] = ("f32 storage and accumulate; head convolutions as 3x bf16 split (hi + mid + lo of both operands, six "
-                        "v_mfma_f32_32x32x16_bf16 per K step, error vs float64 <= the exact-fp32 kernel's); everything else exact "
-                        "fp32 MFMA / VALU.  OCCDEPTH_BF16X3=0 restores exact fp32 everywhere")
+        res["dtype"] = ("f32 storage and accumulate; matrix arithmetic as 3x bf16 split (hi + mid + lo of both operands, six "
+                        "v_mfma_f32_32x32x16_bf16 per K step, error vs float64 <= the exact-fp32 kernels') in the head convolutions "
+                        "(K2s3), the small-volume 3x3x3 convolutions and transposed-convolution phases of the 3-D stack (K2b) and "
+                        "the 2-D network's GEMMs (K16); exact fp32 MFMA / VALU everywhere else (K2, K10, K11, K14, depthwise, lift). "
+                        " OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 restores exact fp32 everywhere")
         res["roofline"].update({
             "kernel": ("conv3d_c32_slide_x3_kernel" if x3_slide else "conv3d_bf16_kernel<SPLIT=3>") +
                       ": 3x3x3 32->32 @256x256x32 (6 x v_mfma_f32_32x32x16_bf16 per 16-channel K step)",

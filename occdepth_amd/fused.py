@@ -101,7 +101,8 @@ def _pad_bias(bias, cout):
 #                         dilation 1 / 2 / 3, Z = 32) on K2s3, the sliding-window form of the split (csrc/conv3d_c32p.hip):
 #                         0.51 ms per launch against 0.90 ms for the exact-fp32 K2s, error against float64 no larger than
 #                         K2s' own (tests/test_bf16_conv.py::test_conv3d_slide_x3_head_kernel, profiles/r04_head_x3_ab.txt);
-#                         everything else exact fp32
+#                         also (see below) the long-K 3x3x3 convolutions of small volumes and the merged phase launches of the
+#                         transposed convolutions on K2b's split form; everything else exact fp32
 #   OCCDEPTH_BF16X3=0     exact-fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32): the bit-for-bit round-3 path
 #   OCCDEPTH_BF16X3=1     additionally every other large dilation-1 K2 launch on the generic K2b skeleton with the split
 #                         (csrc/conv3d_bf16.hip; the round-3 experiment)
