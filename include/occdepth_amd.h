@@ -138,6 +138,21 @@ typedef struct occd_flosp_args {
 
 int occd_flosp_sample_fwd(const occd_flosp_args* a, void* stream);
 
+/* Transpose of the frustum sample (what autograd computes through f2v/sampler.py:59-64's
+ * F.grid_sample in training_step): gdepth (B, n_cams, D, h, w) = d loss / d depth given gout (B, A*B*C) = d loss / d out.
+ * fwd.depth and fwd.out are not read (the sample is linear in the volume).  DETERMINISTIC: contributions are summed as
+ * 64-bit fixed point with a power-of-two scale derived from max |gout| (both reductions are order-free), unlike
+ * grid_sampler_3d_backward's float atomics.  workspace: >= 8 * (B n_cams D h w) + 8 bytes, 8-byte aligned, no
+ * initialisation needed.                                                                                          */
+typedef struct occd_flosp_bwd_args {
+    occd_flosp_args fwd;
+    const float* gout;
+    float* gdepth;
+    void* workspace;
+    int64_t workspace_bytes;
+} occd_flosp_bwd_args;
+int occd_flosp_sample_bwd(const occd_flosp_bwd_args* a, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * K1b: Stereo-SFA multi-scale lift.  Per voxel: for each 2-D scale gather the
  * projected pixel's C-vector from every view (mean over in-FOV pattern points),
@@ -654,6 +669,53 @@ int occd_ssc_loss_stats_fwd(const float* logits, const uint8_t* target, const ui
 int occd_ssc_loss_stats_bwd(const float* logits, const uint8_t* target, const uint8_t* masks,
                             const float* weights, const float* gstats, float* grad, int64_t batch, int32_t C,
                             int64_t S, int32_t F, int32_t map_occ, void* stream);
+/* Round 5: the same three passes on logits (and gradients) that are NOT (B, C, S) planes -- element (b, c, s) at
+ * b*s_b + c*s_c + s*s_v floats.  (s_c, s_v) = (S, 1) is the plane layout above; (1, cs) is the 3-D stack's own
+ * channels-last voxel rows (cs % 4 == 0, 16-byte aligned base), read with 16-byte loads: the two 168 MB layout copies
+ * of `ssc_logit` per training step (profiles/r04_train_step_bf16_aten_ops.txt) are gone.  bwd: grad has its own strides
+ * (g_b, g_c, g_v); for channels-last grad rows the channels [C, g_pad) are written as zeros (g_pad % 4 == 0,
+ * C <= g_pad <= g_v; 0 for the plane layout).                                                                       */
+int occd_ssc_loss_stats_fwd_strided(const float* logits, const uint8_t* target, const uint8_t* masks,
+                                    const float* weights, int64_t* stats, int64_t batch, int32_t C, int64_t S,
+                                    int32_t F, int32_t map_occ, int64_t s_b, int64_t s_c, int64_t s_v, void* stream);
+int occd_ssc_loss_stats_bwd_strided(const float* logits, const uint8_t* target, const uint8_t* masks,
+                                    const float* weights, const float* gstats, float* grad, int64_t batch, int32_t C,
+                                    int64_t S, int32_t F, int32_t map_occ, int64_t s_b, int64_t s_c, int64_t s_v,
+                                    int64_t g_b, int64_t g_c, int64_t g_v, int32_t g_pad, void* stream);
+int occd_ssc_confusion_strided(const float* logits, const uint8_t* labels, const uint8_t* target, int64_t* hist,
+                               int64_t batch, int32_t C, int64_t S, int64_t s_b, int64_t s_c, int64_t s_v, void* stream);
+
+/* the relation (context prior) loss, occdepth/loss/CRP_loss.py:4-24 -- BCEWithLogits with
+ * pos_weight[r] = #negatives / #positives of relation r over the batch, mean over all B*R*M*N elements -- as ONE pass:
+ *   loss = 1 / (R T) * sum_r ( pw_r * Spos_r + Sneg_r ),  T = B M N,
+ *   stats[3 r + 0] = #{y = 1},  stats[3 r + 1] = sum_{y = 1} softplus(-x)  (Q24),  stats[3 r + 2] = sum_{y = 0} softplus(x)  (Q24)
+ * (integer accumulation: deterministic).  logits: element (b, r, m, n) at b*l_b + r*l_r + m*l_m + n*l_n floats with
+ * l_m == 1 or l_n == 1 (the HIP forward produces (R, B, N, M) rows, the autograd graph (B, R, M, N)); labels: the batch's
+ * CP_mega_matrices, (B, R, N, M) contiguous, label_dtype 0 = uint8 (the dataloader's), 1 = float32.
+ * grad: d loss / d logits = y ? -coef[2r] * sigmoid(-x) : coef[2r + 1] * sigmoid(x), written with the logits' strides;
+ * coef (R, 2) device floats = g * (pw_r, 1) / (R T).                                                               */
+int occd_relation_bce_stats(const float* logits, const void* labels, int32_t label_dtype, int64_t* stats,
+                            int64_t batch, int32_t R, int64_t M, int64_t N, int64_t l_b, int64_t l_r, int64_t l_m,
+                            int64_t l_n, void* stream);
+int occd_relation_bce_grad(const float* logits, const void* labels, int32_t label_dtype, const float* coef,
+                           float* grad, int64_t batch, int32_t R, int64_t M, int64_t N, int64_t l_b, int64_t l_r,
+                           int64_t l_m, int64_t l_n, void* stream);
+
+/* the depth-distribution loss of FLoSP-Depth, occdepth/loss/depth_loss.py:14-87, one thread per
+ * prediction cell: nearest-resample the (Bn, srcH, srcW) metric depth map to cell x (h, w), smallest non-zero depth of
+ * every cell x cell block, LID bin k = trunc((d - d_off) / d_step) (d_off = float32(d_bound[0] - d_bound[2])), target =
+ * one-hot(k)[1:], BCE(prob, target) with both logs clamped at -100, summed over the D bins of every cell that has a
+ * target.  prob: (Bn, D, h, w) probabilities, image stride p_b floats (a camera slice of (B, n_cams, D, h, w)).
+ *   stats[0] = sum over measured cells (Q24 fixed point), stats[1] = #measured cells;  loss = stats[0] / max(1, stats[1]).
+ * grad (Bn, D, h, w) dense = gscale[0] * (p - t) / max((1 - p) p, 1e-12) on measured cells, 0 elsewhere (ATen's
+ * binary_cross_entropy_backward); gscale = device scalar g / max(1, #measured).                                   */
+int occd_depth_bce_stats(const float* prob, const float* gt, int64_t* stats, int64_t Bn, int32_t D, int32_t h,
+                         int32_t w, int32_t srcH, int32_t srcW, int32_t cell, int64_t p_b, float d_off, float d_step,
+                         void* stream);
+int occd_depth_bce_grad(const float* prob, const float* gt, const float* gscale, float* grad, int64_t Bn, int32_t D,
+                        int32_t h, int32_t w, int32_t srcH, int32_t srcW, int32_t cell, int64_t p_b, float d_off,
+                        float d_step, void* stream);
+
 /* hist[t * C + pred] += 1 over voxels with t != 255 -- every counter
  * occdepth/loss/sscMetrics.py:70-204 (SSCMetrics.add_batch) keeps derives from this matrix.  pred is either
  * `labels` (B, S) uint8 or the arg-max over C of `logits` (B, C, S) (first maximum wins, as np.argmax in

@@ -44,6 +44,9 @@ def _to_vox(x):
     cl = x.permute(0, 2, 3, 4, 1)
     if x.shape[1] % 8 == 0 and cl.is_contiguous():
         return Vox(cl, x.shape[1])
+    rows = _padded_rows(x)
+    if rows is not None:
+        return Vox(rows, x.shape[1])
     if x.dtype == torch.float32 and x.is_contiguous():
         return Vox.from_ncdhw(x)                       # NCDHW: one LDS-tiled transpose pass
     # channels-last with a ragged channel count (or a bf16 NCDHW tensor): one strided copy into zero-padded rows
@@ -51,6 +54,23 @@ def _to_vox(x):
             x.shape[1])
     v.buf[..., :x.shape[1]].copy_(cl)
     return v
+
+
+def _padded_rows(x):
+    """Round 5: a (B, C, X, Y, Z) float32 view of a WHOLE buffer of zero-padded channels-last rows (B, X, Y, Z, ceil8(C)) --
+    the layout `hip.ssc_loss_grad` writes the gradient of ragged-channel logits in (20 classes in rows of 24 floats, pads
+    written as zeros) -- is consumed in place; anything else (a channel slice of a wider tensor, whose "pads" hold data)
+    is not."""
+    if x.dtype != torch.float32 or x.dim() != 5:
+        return None
+    B, C, X, Y, Z = x.shape
+    st = x.stride()
+    cs = hip.round_up(C, 8)
+    if st != (X * Y * Z * cs, 1, Y * Z * cs, Z * cs, cs) or x.storage_offset() != 0:
+        return None
+    if x.untyped_storage().nbytes() != B * X * Y * Z * cs * 4:
+        return None
+    return torch.as_strided(x, (B, X, Y, Z, cs), (X * Y * Z * cs, Y * Z * cs, Z * cs, cs, 1))
 
 
 def _x3_head(x, cout, kernel, out, kw):

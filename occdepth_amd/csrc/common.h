@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/occdepth_amd.h"
 
 namespace occd {
@@ -30,6 +31,14 @@ struct TapMap {
 // hipFuncAttributeMaxDynamicSharedMemorySize (> 64 KB of LDS) belongs to the (kernel, DEVICE) pair: set once per pair,
 // whatever device the calling thread has current (prof.cpp).  Returns OCCD_OK / OCCD_ELAUNCH.
 int ensure_big_lds(const void* kernel);
+
+// A/B switches are read BY VALUE, all the same way: unset -> `dflt`; "0" / "" / "off" / "false" -> false; anything
+// else -> true.  (`OCCD_PHASE_FAST=0` used to ENABLE the switch because only presence was tested.)
+inline bool env_flag(const char* name, bool dflt) {
+    const char* e = getenv(name);
+    if (e == nullptr) return dflt;
+    return !(e[0] == '\0' || e[0] == '0' || e[0] == 'f' || e[0] == 'F' || ((e[0] == 'o' || e[0] == 'O') && (e[1] == 'f' || e[1] == 'F')));
+}
 
 inline int check_launch() {
     hipError_t e = hipGetLastError();

@@ -659,7 +659,7 @@ int launch_b(const occd_conv3d_args* a, int n, int32_t dtype, hipStream_t stream
     p.div_ztiles = occd::make_fastdiv(til.ztiles); p.div_ytiles = occd::make_fastdiv(til.ytiles);
     p.nph_log2 = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
     // phase-major dispatch is the default (see occd_conv3d_fwd_phases: the tile-major order, OCCD_PHASE_FAST=1, measured slower)
-    static const bool phase_fast = getenv("OCCD_PHASE_FAST") != nullptr;
+    static const bool phase_fast = occd::env_flag("OCCD_PHASE_FAST", false);
     p.ph_fast = n > 1 && phase_fast ? 1 : 0;
     if (p.ph_fast) p.nwg = (int)(til.nwg * n);
     if (til.nwg * n >= (1L << 24)) return OCCD_EINVAL;

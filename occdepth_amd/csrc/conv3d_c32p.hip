@@ -476,8 +476,12 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
 //   * weights: the hi and mid images (2 x 55,296 B, exactly the 110,592 B K2s keeps) stay in LDS for the kernel's
 //     lifetime; the lo image (one of the six products) does not fit beside the slab any more and is streamed from L2
 //     two steps ahead (3 x 1 KB per wave and step, the same addresses for all 8 waves of a CU and all CUs);
-//   * Z = 32 only: the z halo is not staged -- every y row of the slab carries ONE all-zero entry and the lanes whose
-//     tap leaves the column read that (33 entries per row instead of 32 + 2 D: at D = 3 the slab is 51.7 KB, not 59.6).
+//   * Z = 32: the z halo is not staged -- every y row of the slab carries ONE all-zero entry and the lanes whose
+//     tap leaves the column read that (33 entries per row instead of 32 + 2 D: at D = 3 the slab is 51.7 KB, not 59.6);
+//   * Z = 64, 96, ... (round 5, `ZH`: BASELINE configs[4] is 512 x 512 x 64): a workgroup owns a 32-column z tile and stages
+//     its z halo like K2s does -- rows of 32 + 2 D entries, the neighbouring tile's data or zeros outside the volume --
+//     38.1 KB at D = 1, 48.4 KB at D = 2; at D = 3 the 14 x 38 entries (59.6 KB) do not fit beside the two weight images
+//     (53.1 KB left), so dilation-3 launches of Z > 32 volumes stay on the exact-fp32 K2s.
 // Work per launch 115.96 GFLOP algorithmic = 695.8 GFLOP issued on the bf16 pipe.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -504,11 +508,13 @@ __device__ __forceinline__ void split3_bf16(f32x4 a, f32x4 b, u32x4& hi, u32x4& 
 
 // NRES: residual operands compiled in (0: neither, 1: res1, 2: res1 and res2) -- their prefetch registers (16 per
 // operand) are what the 5 of 7 head launches without residuals do not pay for.
-template <int D, int NRES>
+template <int D, int NRES, bool ZH = false>
 __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const SlideP sp) {
     const PersistP& p = sp.base;
-    constexpr int YIN = kTY + 2 * D, ROWS = YIN * kX3ZW;
-    constexpr int NITEM = YIN * kTZ * 2;          // staging items: (y row, z, 8-channel chunk of the 16-channel half)
+    constexpr int ZW = ZH ? kTZ + 2 * D : kX3ZW;  // entries per y row: the tile + its z halo (ZH), or the tile + the zero entry
+    constexpr int ZST = ZH ? ZW : kTZ;            // entries per row that are (re)staged with every slab
+    constexpr int YIN = kTY + 2 * D, ROWS = YIN * ZW;
+    constexpr int NITEM = YIN * ZST * 2;          // staging items: (y row, z, 8-channel chunk of the 16-channel half)
     constexpr int NLOAD = (NITEM + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u32x4* const w4 = reinterpret_cast<u32x4*>(lds_raw);                 // hi image | mid image
@@ -546,7 +552,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
             }
         }
         // the zero entry of every y row (never written again)
-        if (tid < YIN * 7) {
+        if (!ZH && tid < YIN * 7) {
             const int yi = tid / 7, s16 = tid - yi * 7;
             *reinterpret_cast<u32x4*>(slab + (yi * kX3ZW + kTZ) * kX3RowB + s16 * 16) = u32x4{0u, 0u, 0u, 0u};
         }
@@ -559,10 +565,10 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
         const int f = tid + i * 512;
         const bool live = f < NITEM;
         const int row = f >> 1, c8 = f & 1;
-        const int yi = row >> 5, z = row & 31;
-        sdst[i] = live ? (yi * kX3ZW + z) * kX3RowB + c8 * 16 : -1;
+        const int yi = ZH ? row / ZST : row >> 5, z = ZH ? row - yi * ZST : row & 31;
+        sdst[i] = live ? (yi * ZW + z) * kX3RowB + c8 * 16 : -1;
         syi[i] = yi;
-        sz[i] = z;
+        sz[i] = ZH ? z - D : z;                    // relative to the tile's first column
         sc8[i] = c8 * 8;
     }
     // A-fragment bases of this lane for kz = 0, 1, 2 (ky adds a constant): the voxel column li + (kz - 1) D, or the zero
@@ -571,8 +577,9 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
         const int z = li + (kz - 1) * D;
-        abase[kz] = (wave * kX3ZW + ((z >= 0 && z < kTZ) ? z : kTZ)) * kX3RowB + kk * 16;
+        abase[kz] = (wave * ZW + (ZH ? z + D : (z >= 0 && z < kTZ) ? z : kTZ)) * kX3RowB + kk * 16;
     }
+    int z0 = 0;                                    // first column of the segment's z tile (ZH)
     const size_t plane_stride = (size_t)p.Y * p.Z * p.in_cs;
 
     unsigned coloff[NLOAD];
@@ -637,7 +644,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
         const u32x4* const wmid = whi + mid_img;   // its own base register: the ds_read offsets of both images stay below 64 KB
         auto aptr = [&](int t, int term) {
             const int ky = t / 3, kz = t - 3 * ky;
-            return reinterpret_cast<const u32x4*>(slab + abase[kz] + ky * D * kX3ZW * kX3RowB + term * 32);
+            return reinterpret_cast<const u32x4*>(slab + abase[kz] + ky * D * ZW * kX3RowB + term * 32);
         };
         u32x4 an0 = *aptr(0, 0), an1 = *aptr(0, 1), an2 = *aptr(0, 2);
         u32x4 bhn = whi[(KXS[0] * 9 * 2) * 64], bmn = wmid[(KXS[0] * 9 * 2) * 64];
@@ -693,7 +700,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
     auto res_fetch = [&](int b, int yt, int x) {
         if (NRES == 0) return;
         const int y = min(yt * kTY + wave, p.Y - 1);
-        const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + li;
+        const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + z0 + li;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c = 8 * g + 4 * kk;
@@ -706,7 +713,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
     auto store2 = [&](int b, int yt, int x) {
         const int y = yt * kTY + wave;
         if (y < p.Y) {
-            const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + li;
+            const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + z0 + li;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = 8 * g + 4 * kk;
@@ -748,17 +755,21 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
             }
             break;
         }
-        // segments are ordered (b, range, ytile); ztiles == 1
-        const int yt = seg % p.ytiles;
-        const int rest = seg / p.ytiles;
+        // segments are ordered (b, range, ytile, ztile) with the z tile fastest (ztiles == 1 unless ZH)
+        const int tz = ZH ? seg % (p.ytiles * p.ztiles) : seg % p.ytiles;
+        const int zt = ZH ? tz % p.ztiles : 0, yt = ZH ? tz / p.ztiles : tz;
+        const int rest = ZH ? seg / (p.ytiles * p.ztiles) : seg / p.ytiles;
         const int b = rest / sp.segs_per_col;
         const int q0 = (rest - b * sp.segs_per_col) * sp.seg_len;
         const int q1 = min(q0 + sp.seg_len, p.X);
+        z0 = zt * kTZ;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int y = yt * kTY - D + syi[i];
-            colok[i] = sdst[i] >= 0 && y >= 0 && y < p.Y;
-            coloff[i] = (unsigned)((((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * p.Z + sz[i]) * p.in_cs + p.in_coff + sc8[i]);
+            const int z = z0 + sz[i];
+            colok[i] = sdst[i] >= 0 && y >= 0 && y < p.Y && (!ZH || (z >= 0 && z < p.Z));
+            coloff[i] = (unsigned)((((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * p.Z + (colok[i] ? z : 0)) * p.in_cs +
+                                   p.in_coff + sc8[i]);
         }
         int q = q0;
         while (q < q1) {
@@ -818,7 +829,7 @@ struct DevState {
     int* counter = nullptr;
     int num_cu = 0;
     bool slide_attr[4] = {};
-    bool slide_x3_attr[4][3] = {};
+    bool slide_x3_attr[4][3][2] = {};
     bool attr_done[4] = {};
 };
 DevState g_dev[kMaxDevices];
@@ -894,25 +905,25 @@ int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
     return occd::check_launch();
 }
 
-template <int D, int NRES>
+template <int D, int NRES, bool ZH>
 int launch_slide_x3(const PersistP& base, hipStream_t st, DevState* ds) {
-    constexpr int ROWS = (kTY + 2 * D) * kX3ZW;
-    const size_t lds = (size_t)2 * kX3WImg * 16 + (size_t)ROWS * kX3RowB + 16 + 128;
-    static_assert((size_t)2 * kX3WImg * 16 + (size_t)(kTY + 6) * kX3ZW * kX3RowB + 144 <= 160 * 1024, "K2s3 LDS budget at D = 3");
+    constexpr int ROWS = (kTY + 2 * D) * (ZH ? kTZ + 2 * D : kX3ZW);
+    constexpr size_t lds = (size_t)2 * kX3WImg * 16 + (size_t)ROWS * kX3RowB + 16 + 128;
+    static_assert(lds <= 160 * 1024, "K2s3 LDS budget (Z > 32: D <= 2 only)");
     {
         std::lock_guard<std::mutex> lock(ds->mu);
-        if (!ds->slide_x3_attr[D][NRES]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_x3_kernel<D, NRES>),
+        if (!ds->slide_x3_attr[D][NRES][ZH]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_x3_kernel<D, NRES, ZH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return OCCD_ELAUNCH;
-            ds->slide_x3_attr[D][NRES] = true;
+            ds->slide_x3_attr[D][NRES][ZH] = true;
         }
     }
     SlideP sp;
     const int rc = plan_slide<D>(base, ds, &sp);
     if (rc != OCCD_OK) return rc;
     const int grid = ds->num_cu < sp.total_segs ? ds->num_cu : sp.total_segs;
-    hipLaunchKernelGGL((conv3d_c32_slide_x3_kernel<D, NRES>), dim3((unsigned)grid), dim3(512), lds, st, sp);
+    hipLaunchKernelGGL((conv3d_c32_slide_x3_kernel<D, NRES, ZH>), dim3((unsigned)grid), dim3(512), lds, st, sp);
     return occd::check_launch();
 }
 
@@ -973,7 +984,7 @@ namespace occd {
 // Returns 1 when the launch was taken by the persistent kernel, 0 when the geometry does not qualify,
 // <0 on error.
 int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
-    static const bool tiled = getenv("OCCD_C32P_TILED") != nullptr;   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
+    static const bool tiled = env_flag("OCCD_C32P_TILED", false);   // A/B switch: per-tile variant (K2p) vs sliding window (K2s)
     PersistP p;
     double flops, bytes;
     if (!c32_geometry(a, &p, &flops, &bytes) || (tiled && a->Z != kTZ)) return 0;
@@ -992,13 +1003,14 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
 }
 
 // K2s3: the same launches on the bf16 matrix pipe with the 3-way split (a->wpk = the hi | mid | lo image of
-// occd_pack_weights_bf16x3, float32 tensors).  Same return convention; Z == 32 only (see the kernel header);
+// occd_pack_weights_bf16x3, float32 tensors).  Same return convention; Z == 32, or Z = 64, 96, ... at dilation 1 / 2 (the
+// z-halo form, see the kernel header; dilation 3 of such volumes returns 0 and the caller falls back to the exact-fp32 K2s);
 // OCCD_C32X3_SLIDE=0 leaves every split launch to the generic K2b skeleton (A/B).
 int try_conv3d_c32_slide_x3(const occd_conv3d_args* a, hipStream_t stream) {
-    static const bool off = getenv("OCCD_C32X3_SLIDE") != nullptr && getenv("OCCD_C32X3_SLIDE")[0] == '0';
+    static const bool off = !env_flag("OCCD_C32X3_SLIDE", true);
     PersistP p;
     double flops, bytes;
-    if (off || !c32_geometry(a, &p, &flops, &bytes) || a->Z != kTZ) return 0;
+    if (off || !c32_geometry(a, &p, &flops, &bytes) || (a->Z != kTZ && a->dx > 2)) return 0;
     if ((a->in_cs & 3) || (a->in_coff & 3)) return 0;
     const int d = a->dx;
     ProfScope prof("conv3d_c32x3", stream, flops, bytes);
@@ -1009,9 +1021,10 @@ int try_conv3d_c32_slide_x3(const occd_conv3d_args* a, hipStream_t stream) {
     }
     const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);
     int rc;
-#define OCCD_X3_LAUNCH(DD) \
-    (nres == 0 ? launch_slide_x3<DD, 0>(p, stream, ds) : nres == 1 ? launch_slide_x3<DD, 1>(p, stream, ds) : launch_slide_x3<DD, 2>(p, stream, ds))
-    rc = d == 1 ? OCCD_X3_LAUNCH(1) : d == 2 ? OCCD_X3_LAUNCH(2) : OCCD_X3_LAUNCH(3);
+#define OCCD_X3_LAUNCH(DD, ZZ) \
+    (nres == 0 ? launch_slide_x3<DD, 0, ZZ>(p, stream, ds) : nres == 1 ? launch_slide_x3<DD, 1, ZZ>(p, stream, ds) : launch_slide_x3<DD, 2, ZZ>(p, stream, ds))
+    if (a->Z == kTZ) rc = d == 1 ? OCCD_X3_LAUNCH(1, false) : d == 2 ? OCCD_X3_LAUNCH(2, false) : OCCD_X3_LAUNCH(3, false);
+    else rc = d == 1 ? OCCD_X3_LAUNCH(1, true) : OCCD_X3_LAUNCH(2, true);
 #undef OCCD_X3_LAUNCH
     return rc == OCCD_OK ? 1 : rc;
 }

@@ -607,7 +607,7 @@ extern "C" int occd_conv3d_fwd_phases(const occd_conv3d_args* a, int32_t n, void
     p.nph_log2 = n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3;
     // phase-major dispatch (all tiles of the heaviest phase first) is the default; the phases of a tile next to each other on
     // one XCD (OCCD_PHASE_FAST=1) measured SLOWER: 64 -> 32 at 128x128x16 0.47 against 0.35 ms on K2, 0.36 against 0.34 on K2b
-    static const bool phase_fast = getenv("OCCD_PHASE_FAST") != nullptr;
+    static const bool phase_fast = occd::env_flag("OCCD_PHASE_FAST", false);
     p.ph_fast = phase_fast ? 1 : 0;
     if (p.ph_fast) p.nwg = (int)(til.nwg * n);
     if ((long)a[0].batch * n > 65535 || til.nwg * n >= (1L << 24)) return OCCD_EINVAL;

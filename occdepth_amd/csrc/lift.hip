@@ -390,84 +390,173 @@ __device__ __forceinline__ float from_homog_scale(float w) {
     return fabsf(w) > 1e-8f ? 1.f / (w + 1e-8f) : 1.f;
 }
 
+// Continuous sample position (ix, iy, iz) of voxel n in camera `cam`'s (D, h, w) depth frustum: voxel centre -> camera ->
+// image -> LID bin -> ida -> normalised grid -> F.grid_sample(align_corners=False) un-normalisation.  Shared by the forward
+// sample (standalone kernel and fused lift) and by its transpose (flosp_sample_bwd_kernel), so that the two apply the very
+// same weights.
+__device__ __forceinline__ void frustum_coords(const FlospP& pp, int b, long n, int cam, float& ix, float& iy, float& iz) {
+    const occd_flosp_args& a = pp.a;
+    const long nvox = (long)a.A * a.Bdim * a.C;
+    float nx, ny, nz;
+    if (a.grids != nullptr) {
+        const float* g = a.grids + ((((size_t)cam * a.batch + b) * nvox) + n) * 3;
+        nx = g[0]; ny = g[1]; nz = g[2];
+    } else {
+        const long bc = (long)a.Bdim * a.C;
+        const int ia = (int)(n / bc);
+        const long rem = n - (long)ia * bc;
+        const int ib = (int)(rem / a.C), ic = (int)(rem - (long)ib * a.C);
+        const float gx = (float)ia + 0.5f, gy = (float)ib + 0.5f, gz = (float)ic + 0.5f;
+        const float* T = a.trans + ((size_t)b * a.n_cams + cam) * 16;
+        const float* K = a.proj + ((size_t)b * a.n_cams + cam) * 12;
+        const float* I = a.ida + ((size_t)b * a.n_cams + cam) * 16;
+        // voxel centre -> camera frame
+        float cx = gx * T[0] + gy * T[1] + gz * T[2] + T[3];
+        float cy = gx * T[4] + gy * T[5] + gz * T[6] + T[7];
+        float cz = gx * T[8] + gy * T[9] + gz * T[10] + T[11];
+        const float cw = gx * T[12] + gy * T[13] + gz * T[14] + T[15];
+        const float sc = from_homog_scale(cw);
+        cx *= sc; cy *= sc; cz *= sc;
+        // camera -> image plane, depth
+        const float u0 = K[0] * cx + K[1] * cy + K[2] * cz + K[3];
+        const float v0 = K[4] * cx + K[5] * cy + K[6] * cz + K[7];
+        const float w0 = K[8] * cx + K[9] * cy + K[10] * cz + K[11];
+        const float sp = from_homog_scale(w0);
+        const float u = u0 * sp, v = v0 * sp;
+        const float dep = w0 - K[11];
+        // LID depth bin
+        const float bin = -0.5f + 0.5f * sqrtf(1.f + 8.f * (dep - a.depth_min) / pp.bin_size);
+        // image-data-augmentation matrix
+        float fx = u * I[0] + v * I[1] + bin * I[2] + I[3];
+        float fy = u * I[4] + v * I[5] + bin * I[6] + I[7];
+        float fz = u * I[8] + v * I[9] + bin * I[10] + I[11];
+        const float fw = u * I[12] + v * I[13] + bin * I[14] + I[15];
+        const float si = from_homog_scale(fw);
+        fx *= si; fy *= si; fz *= si;
+        // normalise with the FULL image size (reference quirk) and D
+        nx = fx / (a.img_w - 1.f) * 2.f + -1.f;
+        ny = fy / (a.img_h - 1.f) * 2.f + -1.f;
+        nz = fz / ((float)a.D - 1.f) * 2.f + -1.f;
+        if (!isfinite(nx)) nx = -2.f;
+        if (!isfinite(ny)) ny = -2.f;
+        if (!isfinite(nz)) nz = -2.f;
+    }
+    // F.grid_sample 5-D, bilinear, zeros padding, align_corners=False
+    ix = ((nx + 1.f) * (float)a.w - 1.f) / 2.f;
+    iy = ((ny + 1.f) * (float)a.h - 1.f) / 2.f;
+    iz = ((nz + 1.f) * (float)a.D - 1.f) / 2.f;
+}
+
+// The 8 trilinear corners of a sample position: visit(corner element offset in the (D, h, w) volume, weight) for the
+// corners inside the volume (zeros padding).
+template <class F>
+__device__ __forceinline__ void frustum_corners(const occd_flosp_args& a, float ix, float iy, float iz, F&& visit) {
+    const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
+    const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
+    // float -> int is saturating on the device; far-away coordinates stay out of bounds
+    const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+        const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+        const float wgt = (dx ? wx1 : wx0) * (dy ? wy1 : wy0) * (dz ? wz1 : wz0);
+        if ((unsigned)x < (unsigned)a.w && (unsigned)y < (unsigned)a.h && (unsigned)z < (unsigned)a.D)
+            visit(((size_t)z * a.h + y) * a.w + x, wgt);
+    }
+}
+
 // One voxel of the frustum sample (shared by the standalone kernel and the fused lift).
 __device__ __forceinline__ float frustum_sample_one(const FlospP& pp, int b, long n) {
     const occd_flosp_args& a = pp.a;
-    const long nvox = (long)a.A * a.Bdim * a.C;
-    const long bc = (long)a.Bdim * a.C;
-    const int ia = (int)(n / bc);
-    const long rem = n - (long)ia * bc;
-    const int ib = (int)(rem / a.C), ic = (int)(rem - (long)ib * a.C);
-    const float gx = (float)ia + 0.5f, gy = (float)ib + 0.5f, gz = (float)ic + 0.5f;
-
     float feat_sum = 0.f, mask_sum = 0.f;
     for (int cam = 0; cam < a.n_cams; ++cam) {
-        float nx, ny, nz;
-        if (a.grids != nullptr) {
-            const float* g = a.grids + ((((size_t)cam * a.batch + b) * nvox) + n) * 3;
-            nx = g[0]; ny = g[1]; nz = g[2];
-        } else {
-            const float* T = a.trans + ((size_t)b * a.n_cams + cam) * 16;
-            const float* K = a.proj + ((size_t)b * a.n_cams + cam) * 12;
-            const float* I = a.ida + ((size_t)b * a.n_cams + cam) * 16;
-            // voxel centre -> camera frame
-            float cx = gx * T[0] + gy * T[1] + gz * T[2] + T[3];
-            float cy = gx * T[4] + gy * T[5] + gz * T[6] + T[7];
-            float cz = gx * T[8] + gy * T[9] + gz * T[10] + T[11];
-            const float cw = gx * T[12] + gy * T[13] + gz * T[14] + T[15];
-            const float sc = from_homog_scale(cw);
-            cx *= sc; cy *= sc; cz *= sc;
-            // camera -> image plane, depth
-            const float u0 = K[0] * cx + K[1] * cy + K[2] * cz + K[3];
-            const float v0 = K[4] * cx + K[5] * cy + K[6] * cz + K[7];
-            const float w0 = K[8] * cx + K[9] * cy + K[10] * cz + K[11];
-            const float sp = from_homog_scale(w0);
-            const float u = u0 * sp, v = v0 * sp;
-            const float dep = w0 - K[11];
-            // LID depth bin
-            const float bin = -0.5f + 0.5f * sqrtf(1.f + 8.f * (dep - a.depth_min) / pp.bin_size);
-            // image-data-augmentation matrix
-            float fx = u * I[0] + v * I[1] + bin * I[2] + I[3];
-            float fy = u * I[4] + v * I[5] + bin * I[6] + I[7];
-            float fz = u * I[8] + v * I[9] + bin * I[10] + I[11];
-            const float fw = u * I[12] + v * I[13] + bin * I[14] + I[15];
-            const float si = from_homog_scale(fw);
-            fx *= si; fy *= si; fz *= si;
-            // normalise with the FULL image size (reference quirk) and D
-            nx = fx / (a.img_w - 1.f) * 2.f + -1.f;
-            ny = fy / (a.img_h - 1.f) * 2.f + -1.f;
-            nz = fz / ((float)a.D - 1.f) * 2.f + -1.f;
-            if (!isfinite(nx)) nx = -2.f;
-            if (!isfinite(ny)) ny = -2.f;
-            if (!isfinite(nz)) nz = -2.f;
-        }
-        // F.grid_sample 5-D, bilinear, zeros padding, align_corners=False
-        const float ix = ((nx + 1.f) * (float)a.w - 1.f) / 2.f;
-        const float iy = ((ny + 1.f) * (float)a.h - 1.f) / 2.f;
-        const float iz = ((nz + 1.f) * (float)a.D - 1.f) / 2.f;
-        const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
-        const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
-        const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
-        // float -> int is saturating on the device; far-away coordinates stay out of bounds
-        const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+        float ix, iy, iz;
+        frustum_coords(pp, b, n, cam, ix, iy, iz);
         const float* vol = a.depth + ((size_t)b * a.n_cams + cam) * a.D * a.h * a.w;
         float acc = 0.f, msk = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-            const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
-            const float wgt = (dx ? wx1 : wx0) * (dy ? wy1 : wy0) * (dz ? wz1 : wz0);
-            if ((unsigned)x < (unsigned)a.w && (unsigned)y < (unsigned)a.h && (unsigned)z < (unsigned)a.D) {
-                acc += vol[((size_t)z * a.h + y) * a.w + x] * wgt;
-                msk += wgt;
-            }
-        }
+        frustum_corners(a, ix, iy, iz, [&](size_t off, float wgt) {
+            acc += vol[off] * wgt;
+            msk += wgt;
+        });
         feat_sum += acc;
         mask_sum += msk;
     }
     float r = feat_sum;
     if (a.n_cams > 1 && a.mean_mode && mask_sum > 0.f) r = feat_sum / mask_sum;
     return r;
+}
+
+// ---- transpose of the frustum sample (training: d loss / d depth volume; occdepth/models/f2v/sampler.py:59-64 under
+// autograd = grid_sampler_3d_backward's float atomics).  Here the scatter is DETERMINISTIC: contributions are accumulated
+// as 64-bit fixed point (integer addition is order-free) with a power-of-two scale derived from max |gout| -- itself an
+// order-free reduction (atomicMax on the float bits) -- so that nothing can overflow: |sum into one cell| <= B nvox max|g|.
+//   scale = 2^(61 - ceil(log2(B nvox)) - (exponent(max|g|) + 1))   (resolution ~2^-40 of max|g| at config 2: float32 has 2^-24)
+struct FlospBwdP {
+    FlospP f;                 // f.a.depth is not read (the sample is linear in the volume); f.a.out unused
+    const float* gout;        // (B, nvox) d loss / d sampled volume
+    long long* acc;           // (B, n_cams, D, h, w) fixed-point accumulators
+    unsigned* gmax_bits;      // one word: bits of max |gout|
+    float* gdepth;            // (B, n_cams, D, h, w)
+    long total_out, total_vol;
+    int log2_count;           // ceil(log2(B nvox))
+};
+
+__device__ __forceinline__ int flosp_scale_exp(unsigned max_bits, int log2_count) {
+    const int e = (int)((max_bits >> 23) & 0xff) - 127;              // max|g| < 2^(e + 1)  (denormals: e = -127, still an upper bound)
+    return 61 - log2_count - (e + 1);
+}
+
+__global__ void flosp_bwd_zero_kernel(unsigned* p) {       // (a kernel, not hipMemsetAsync: see loss.hip zero_u64_kernel)
+    if (threadIdx.x < 2) p[threadIdx.x] = 0u;
+}
+
+__global__ void __launch_bounds__(256) flosp_bwd_prepare_kernel(const FlospBwdP q) {
+    // zero the accumulators (grid-stride) and reduce max |gout| (non-negative floats order like their bit patterns)
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
+    for (long i = i0; i < q.total_vol; i += step) q.acc[i] = 0;
+    unsigned m = 0;
+    for (long i = i0; i < q.total_out; i += step) {
+        const float g = q.gout[i];
+        const unsigned bits = __float_as_uint(g) & 0x7fffffffu;
+        if (bits <= 0x7f800000u) m = max(m, bits);                    // (NaN gradients are not a maximum; they propagate below)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(q.gmax_bits, m);
+}
+
+__global__ void __launch_bounds__(256) flosp_sample_bwd_kernel(const FlospBwdP q) {
+    const occd_flosp_args& a = q.f.a;
+    const long nvox = (long)a.A * a.Bdim * a.C;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= nvox) return;
+    const float g = q.gout[(size_t)b * nvox + n];
+    if (g == 0.f) return;
+    float ix[OCCD_MAX_VIEWS], iy[OCCD_MAX_VIEWS], iz[OCCD_MAX_VIEWS];
+    float mask_sum = 0.f;
+    for (int cam = 0; cam < a.n_cams; ++cam) {
+        frustum_coords(q.f, b, n, cam, ix[cam], iy[cam], iz[cam]);
+        frustum_corners(a, ix[cam], iy[cam], iz[cam], [&](size_t, float wgt) { mask_sum += wgt; });
+    }
+    float gv = g;
+    if (a.n_cams > 1 && a.mean_mode && mask_sum > 0.f) gv = g / mask_sum;
+    const double scale = ldexp(1.0, flosp_scale_exp(*q.gmax_bits, q.log2_count));
+    for (int cam = 0; cam < a.n_cams; ++cam) {
+        long long* dst = q.acc + ((size_t)b * a.n_cams + cam) * a.D * a.h * a.w;
+        frustum_corners(a, ix[cam], iy[cam], iz[cam], [&](size_t off, float wgt) {
+            const long long v = __double2ll_rn((double)(gv * wgt) * scale);
+            if (v) atomicAdd((unsigned long long*)(dst + off), (unsigned long long)v);
+        });
+    }
+}
+
+__global__ void __launch_bounds__(256) flosp_bwd_finish_kernel(const FlospBwdP q) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.total_vol) return;
+    const double inv = ldexp(1.0, -flosp_scale_exp(*q.gmax_bits, q.log2_count));
+    q.gdepth[i] = (float)((double)q.acc[i] * inv);
 }
 
 __global__ void __launch_bounds__(256) flosp_sample_kernel(const FlospP pp) {
@@ -777,6 +866,37 @@ extern "C" int occd_flosp_sample_fwd(const occd_flosp_args* a, void* stream) {
     occd::ProfScope prof("flosp_sample", (hipStream_t)stream, 0.0, bytes);
     hipLaunchKernelGGL(flosp_sample_kernel, dim3((unsigned)((nvox + 255) / 256), (unsigned)a->batch), dim3(256), 0,
                        (hipStream_t)stream, p);
+    return occd::check_launch();
+}
+
+extern "C" int occd_flosp_sample_bwd(const occd_flosp_bwd_args* q, void* stream) {
+    if (!q || !q->gout || !q->gdepth || !q->workspace) return OCCD_EINVAL;
+    const occd_flosp_args* a = &q->fwd;
+    if (!a->grids && (!a->trans || !a->proj || !a->ida)) return OCCD_EINVAL;
+    if (a->batch <= 0 || a->n_cams <= 0 || a->n_cams > OCCD_MAX_VIEWS || a->D <= 1 || a->h <= 0 || a->w <= 0) return OCCD_EINVAL;
+    if (a->A <= 0 || a->Bdim <= 0 || a->C <= 0) return OCCD_EINVAL;
+    const long nvox = (long)a->A * a->Bdim * a->C;
+    const long vol = (long)a->batch * a->n_cams * a->D * a->h * a->w;
+    if (q->workspace_bytes < (int64_t)vol * 8 + 8 || (reinterpret_cast<uintptr_t>(q->workspace) & 7)) return OCCD_EINVAL;
+    FlospBwdP p{};
+    p.f.a = *a;
+    p.f.bin_size = (float)(2.0 * ((double)a->depth_max - (double)a->depth_min) / ((double)a->D * (1.0 + a->D)));
+    p.gout = q->gout; p.gdepth = q->gdepth;
+    p.acc = reinterpret_cast<long long*>(q->workspace);
+    p.gmax_bits = reinterpret_cast<unsigned*>(p.acc + vol);
+    p.total_out = (long)a->batch * nvox; p.total_vol = vol;
+    int lg = 0;
+    while ((1L << lg) < p.total_out) ++lg;
+    p.log2_count = lg;
+    hipStream_t st = (hipStream_t)stream;
+    occd::ProfScope prof("flosp_sample_bwd", st, 0.0, 4.0 * p.total_out + 20.0 * vol);
+    hipLaunchKernelGGL(flosp_bwd_zero_kernel, dim3(1), dim3(64), 0, st, p.gmax_bits);
+    const long most = vol > p.total_out ? vol : p.total_out;
+    long blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(flosp_bwd_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(flosp_sample_bwd_kernel, dim3((unsigned)((nvox + 255) / 256), (unsigned)a->batch), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(flosp_bwd_finish_kernel, dim3((unsigned)((vol + 255) / 256)), dim3(256), 0, st, p);
     return occd::check_launch();
 }
 

@@ -1007,7 +1007,7 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     // (the staged kernel addresses one image's z with 32-bit buffer offsets; OCCD_UPCONV_DIRECT: A/B switch)
-    const bool staged = getenv("OCCD_UPCONV_DIRECT") == nullptr && rw * 258.f + 3.f <= (float)kUpNC &&
+    const bool staged = !occd::env_flag("OCCD_UPCONV_DIRECT", false) && rw * 258.f + 3.f <= (float)kUpNC &&
                         9L * Cout * zcs * 4 < (1L << 31);
     const unsigned groups = (unsigned)((H + 3) / 4);
     const dim3 grid((unsigned)((W + 255) / 256), groups, (unsigned)(batch * Cout));

@@ -131,7 +131,7 @@ extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const
     while (tpc < 64 && (long)tpc * 2 * C <= 256 && tpc * 2 <= nblk) tpc *= 2;
     hipLaunchKernelGGL(se_reduce_kernel, dim3((unsigned)Cr, (unsigned)batch), dim3(256), (size_t)C * sizeof(float), st,
                        pool_part, w_reduce, b_reduce, r_scratch, C, Cr, nblk, (float)(1.0 / (double)S), tpc);
-    static const bool old_expand = getenv("OCCD_SE_EXPAND_OLD") != nullptr;                      // A/B switch
+    static const bool old_expand = occd::env_flag("OCCD_SE_EXPAND_OLD", false);                      // A/B switch
     if (!old_expand && (Cr & 3) == 0 && (reinterpret_cast<uintptr_t>(w_expand) & 15) == 0)
         hipLaunchKernelGGL(se_expand4_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)batch), dim3(256),
                            (size_t)Cr * sizeof(float), st, r_scratch, w_expand, b_expand, gate, C, Cr);

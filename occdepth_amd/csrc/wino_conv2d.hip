@@ -264,20 +264,27 @@ __global__ void __launch_bounds__(512, 2) wino3x3_kernel(const WinoP p) {
     // The exchange and the epilogue are instantiated once per domain half, like the K loop: with a run-time `h` the
     // accumulator registers are picked by a wave-uniform but DYNAMIC index, which hipcc lowers to s_set_gpr_idx moves
     // through a 16-register VGPR copy of each tile -- that copy was the kernel's 16 - 50 spilled VGPRs.
-    auto finish = [&](auto hc) {
-    constexpr int H = decltype(hc)::value;
-    constexpr bool h0 = H == 0;
+    // Only the register selection is specialised; the barrier between the exchange write and the exchange read is ONE
+    // instruction that every wave of the workgroup reaches on the same path (the two halves used to meet at two
+    // different s_barrier instructions, which works on gfx950's arrival-counting barrier but is not defined behaviour).
     // ---------------- pair exchange: wave half h finishes the cout registers r in [8h, 8h + 8) and needs the partner's
     // 8 xi for them.  xchg[pair][writer half][k * 8 + (r & 7)][lane]  (the staging buffers are dead: last barrier above)
-    float* xchg = lds;
-    {
+    float* const xchg = lds;
+    auto xwrite = [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+        constexpr bool h0 = H == 0;
         float* mine = xchg + ((pr * 2 + H) * 64) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8) mine[(k * 8 + r8) * 64] = h0 ? acc[k][8 + r8] : acc[k][r8];
-    }
+    };
+    if (h0) xwrite(std::integral_constant<int, 0>{});
+    else xwrite(std::integral_constant<int, 1>{});
     __syncthreads();
+    auto finish = [&](auto hc) {
+    constexpr int H = decltype(hc)::value;
+    constexpr bool h0 = H == 0;
     const float* theirs = xchg + ((pr * 2 + (1 - H)) * 64) * 64 + lane;
 
     // ---------------- epilogue: Y = A^T m A (A^T = [1 1 1 0; 0 1 -1 -1]), shift, activation, residual, NCHW store.

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 9   # 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 10   # 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -82,6 +82,11 @@ class LiftProjArgs(Structure):
     _fields_ = [("lift", LiftArgs), ("cam_E", c_void_p), ("cam_k", c_void_p), ("voxel_size", ctypes.c_double),
                 ("origin", c_float * 3),
                 ("img_w", c_int32), ("img_h", c_int32), ("frustum", FlospArgs)]
+
+
+class FlospBwdArgs(Structure):
+    _fields_ = [("fwd", FlospArgs), ("gout", c_void_p), ("gdepth", c_void_p), ("workspace", c_void_p),
+                ("workspace_bytes", c_int64)]
 
 
 class BneckArgs(Structure):
@@ -225,6 +230,20 @@ EXPORTS = {
     "occd_ssc_loss_stats_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                           c_int64, c_int32, c_int32, c_void_p]),
     "occd_ssc_confusion": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p]),
+    "occd_ssc_loss_stats_fwd_strided": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
+                                                  c_int32, c_int32, c_int64, c_int64, c_int64, c_void_p]),
+    "occd_ssc_loss_stats_bwd_strided": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                                  c_int64, c_int32, c_int32] + [c_int64] * 6 + [c_int32, c_void_p]),
+    "occd_ssc_confusion_strided": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int64,
+                                             c_int64, c_int64, c_void_p]),
+    "occd_relation_bce_stats": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32] + [c_int64] * 6 + [c_void_p]),
+    "occd_relation_bce_grad": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32] + [c_int64] * 6 +
+                               [c_void_p]),
+    "occd_depth_bce_stats": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 6 + [c_int64, c_float, c_float,
+                                                                                               c_void_p]),
+    "occd_depth_bce_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 6 +
+                            [c_int64, c_float, c_float, c_void_p]),
+    "occd_flosp_sample_bwd": (c_int32, [POINTER(FlospBwdArgs), c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
@@ -581,6 +600,11 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
         out = torch.empty((batch, M, N), device=dev, dtype=torch.float32)
     elif out.dtype != torch.float32 or out.stride(-1) != 1 or out.shape[-2:] != (M, N) or not out.is_cuda:
         raise RuntimeError("gemm_x3: bad output tensor")
+    elif not ((out.dim() == 3 and out.shape[0] == batch) or (out.dim() == 2 and squeeze)):
+        # the kernel trusts (batch, stride_c): a (1, M, N) or 2-D `out` under a batched operand would be written past its
+        # end / once per batch item on top of itself
+        raise RuntimeError("gemm_x3: out must be (batch, M, N) with batch = %d (2-D only when neither operand is batched)"
+                           % batch)
     q = GemmArgs()
     q.A = a.buf.data_ptr() if pa else a.data_ptr()       # (strided views: the strides travel as lda / ldb / ldc)
     q.B = b.buf.data_ptr() if pb else b.data_ptr()
@@ -688,7 +712,10 @@ def pw_conv_autograd_ok(conv, x):
     """The pointwise convolutions `_PwConvFn` takes: 1x1, stride 1, one group, no bias, channel counts K16 accepts."""
     if PW_TRAIN not in ("1", "bf16"):
         return False
-    return (GEMM_X3 and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
+    # float32 inputs only, except under autocast (where _PwConvFn casts): a plain half-precision input falls back to ATen
+    # instead of reaching gemm_x3 with operands it rejects (ADVICE r4)
+    dt_ok = x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16))
+    return (GEMM_X3 and x.is_cuda and x.dim() == 4 and dt_ok
             and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.dilation == (1, 1) and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
             and x.shape[2] * x.shape[3] >= 4 and x.shape[0] <= 65535)
@@ -744,7 +771,7 @@ def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), p
                    act_in=ACT_NONE, act_out=ACT_NONE, out_pos=None, o_stride=(1, 1, 1), o_off=(0, 0, 0), cin=None,
                    tile_hint=0):
     """True when `conv3d_bf16(..., split3=True)` takes the sliding-window split kernel K2s3 (the host-side mirror of
-    `c32_geometry` + the Z == 32 condition in csrc/conv3d_c32p.hip): the full-resolution head convolutions."""
+    `c32_geometry` + the Z / dilation condition of `try_conv3d_c32_slide_x3` in csrc/conv3d_c32p.hip): the full-resolution head convolutions."""
     d = tuple(dilation)
     if tuple(kernel) != (3, 3, 3) or tuple(stride) != (1, 1, 1) or d[0] != d[1] or d[0] != d[2] or not 1 <= d[0] <= 3:
         return False
@@ -757,9 +784,11 @@ def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), p
     if x.buf.dtype != torch.float32 or x.cs % 4 or x.coff % 4:
         return False
     X, Y, Z = x.dims
-    if Z != 32 or tuple(out.dims) != (X, Y, Z):
+    # Z = 32, or (round 5) any multiple of 32 at dilation 1 / 2: the z-halo form of the kernel; dilation 3 of a Z > 32
+    # volume does not fit LDS and stays on the exact-fp32 K2s
+    if Z % 32 or (Z != 32 and d[0] > 2) or tuple(out.dims) != (X, Y, Z):
         return False
-    return x.batch * X * ((Y + 7) // 8) >= 512 and x.batch * X * Y * Z * x.cs < 2 ** 32
+    return x.batch * X * ((Y + 7) // 8) * (Z // 32) >= 512 and x.batch * X * Y * Z * x.cs < 2 ** 32
 
 
 _wgrad_ws = {}
@@ -859,6 +888,21 @@ class Frustum:
         a.out = _f32(out, "out")
         _check(load().occd_flosp_sample_fwd(ctypes.byref(a), _stream()), "occd_flosp_sample_fwd")
         return out
+
+
+def flosp_sample_bwd(fr, gout):
+    """d loss / d depth (B, V, D, h, w) of `fr.sample()` given gout (B, A*B*C): the transpose of the frustum sample,
+    deterministic (occd_flosp_sample_bwd)."""
+    B, V, D, h, w = fr.depth.shape
+    gdepth = torch.empty((B, V, D, h, w), device=gout.device, dtype=torch.float32)
+    ws = torch.empty(B * V * D * h * w + 1, dtype=torch.int64, device=gout.device)
+    q = FlospBwdArgs()
+    fr.fill(q.fwd)
+    q.gout = _f32(gout, "gout")
+    q.gdepth = gdepth.data_ptr()
+    q.workspace, q.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+    _check(load().occd_flosp_sample_bwd(ctypes.byref(q), _stream()), "occd_flosp_sample_bwd")
+    return gdepth
 
 
 def flosp_sample(depth, trans, proj, ida, voxel_num, final_dim, d_min, d_max, mean_mode=True, grids=None):
@@ -1586,6 +1630,28 @@ def ssc_stats_scale(C, F, device):
     return sc
 
 
+def _logit_layout(logits):
+    """(s_b, s_c, s_v) element strides of a (B, C, ...) logits tensor the loss kernels read in place: (B, C, S) planes
+    (contiguous) or the 3-D stack's channels-last voxel rows (a permuted view of (B, ..., cs) rows, cs >= C); None when
+    the tensor is neither (the caller makes it contiguous)."""
+    B, C = logits.shape[:2]
+    S = logits[0, 0].numel()
+    if logits.is_contiguous():
+        return C * S, S, 1
+    st, sh = logits.stride(), logits.shape
+    if st[1] != 1 or logits.dim() < 3:
+        return None
+    cs = st[-1]
+    expect = cs
+    for d in range(logits.dim() - 1, 1, -1):            # spatial dims must merge into one row index
+        if sh[d] != 1 and st[d] != expect:
+            return None
+        expect *= sh[d]
+    if cs < C or cs % 4 or (B > 1 and st[0] % 4) or logits.data_ptr() % 16:
+        return None
+    return (st[0] if B > 1 else S * cs), 1, cs
+
+
 def _loss_operands(logits, target, masks, weights):
     if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() < 3:
         raise RuntimeError("ssc loss statistics need float32 GPU logits of shape (B, C, ...)")
@@ -1604,30 +1670,49 @@ def _loss_operands(logits, target, masks, weights):
 
 
 def ssc_loss_stats(logits, target, masks=None, weights=None, map_occ=False):
-    """-> int64 (3C + 3 + F*C) fixed-point sums (see include/occdepth_amd.h); one pass over the logits."""
+    """-> int64 (3C + 3 + F*C) fixed-point sums (see include/occdepth_amd.h); one pass over the logits, read in place
+    whether they are (B, C, S) planes or channels-last voxel rows (`_logit_layout`)."""
     B, C, S, F = _loss_operands(logits, target, masks, weights)
+    lay = _logit_layout(logits)
+    if lay is None:
+        logits = logits.contiguous()
+        lay = (C * S, S, 1)
     stats = torch.empty(3 * C + 3 + F * C, dtype=torch.int64, device=logits.device)
-    _check(load().occd_ssc_loss_stats_fwd(_ptr(logits, "logits"), _ptr(target, "target"), _ptr(masks, "masks"),
-                                          _ptr(weights, "weights"), stats.data_ptr(), B, C, S, F, int(bool(map_occ)),
-                                          _stream()), "occd_ssc_loss_stats_fwd")
+    _check(load().occd_ssc_loss_stats_fwd_strided(logits.data_ptr(), _ptr(target, "target"), _ptr(masks, "masks"),
+                                                  _ptr(weights, "weights"), stats.data_ptr(), B, C, S, F, int(bool(map_occ)),
+                                                  lay[0], lay[1], lay[2], _stream()), "occd_ssc_loss_stats_fwd_strided")
     return stats
 
 
 def ssc_loss_grad(logits, target, masks, weights, gstats, map_occ=False):
-    """d loss / d logits from d loss / d sums (float32, the layout of ssc_loss_stats)."""
+    """d loss / d logits from d loss / d sums (float32, the layout of ssc_loss_stats).  The gradient has the logits'
+    layout: channels-last logits get a channels-last gradient -- a (B, C, ...) view of zero-padded (B, ..., cs) rows, which
+    the convolution backward (autograd3d._to_vox) consumes without a transpose."""
     B, C, S, F = _loss_operands(logits, target, masks, weights)
     if gstats.dtype != torch.float32 or gstats.numel() != 3 * C + 3 + F * C:
         raise RuntimeError("gstats must be float32 of length 3C + 3 + F*C")
-    grad = torch.empty_like(logits)
-    _check(load().occd_ssc_loss_stats_bwd(_ptr(logits, "logits"), _ptr(target, "target"), _ptr(masks, "masks"),
-                                          _ptr(weights, "weights"), _ptr(gstats, "gstats"), grad.data_ptr(), B, C, S, F,
-                                          int(bool(map_occ)), _stream()), "occd_ssc_loss_stats_bwd")
+    lay = _logit_layout(logits)
+    if lay is None:
+        logits = logits.contiguous()
+        lay = (C * S, S, 1)
+    if lay[1] == 1:
+        cs = round_up(C, 8)
+        rows = torch.empty((B,) + tuple(logits.shape[2:]) + (cs,), dtype=torch.float32, device=logits.device)
+        grad = rows[..., :C].permute(0, logits.dim() - 1, *range(1, logits.dim() - 1))
+        glay, gpad = (S * cs, 1, cs), cs
+    else:
+        grad = torch.empty_like(logits)
+        glay, gpad = lay, 0
+    _check(load().occd_ssc_loss_stats_bwd_strided(logits.data_ptr(), _ptr(target, "target"), _ptr(masks, "masks"),
+                                                  _ptr(weights, "weights"), _ptr(gstats, "gstats"), grad.data_ptr(), B, C, S, F,
+                                                  int(bool(map_occ)), lay[0], lay[1], lay[2], glay[0], glay[1], glay[2], gpad,
+                                                  _stream()), "occd_ssc_loss_stats_bwd_strided")
     return grad
 
 
 def ssc_confusion(hist, target, logits=None, labels=None):
     """hist (C, C) int64 += confusion counts [target, prediction] over labelled voxels; the prediction is `labels`
-    (uint8) or the arg-max of `logits` (B, C, ...)."""
+    (uint8) or the arg-max of `logits` (B, C, ...; planes or channels-last rows, read in place)."""
     C = hist.shape[0]
     if hist.dtype != torch.int64 or hist.shape != (C, C) or target.dtype != torch.uint8:
         raise RuntimeError("hist must be int64 (C, C) and target uint8")
@@ -1635,13 +1720,116 @@ def ssc_confusion(hist, target, logits=None, labels=None):
         raise RuntimeError("give exactly one of logits / labels")
     B = target.shape[0]
     S = target[0].numel()
-    if logits is not None and (logits.dtype != torch.float32 or logits.shape[:2] != (B, C) or logits[0, 0].numel() != S):
-        raise RuntimeError("logits must be float32 (B, C, ...) matching target")
+    lay = (C * S, S, 1)
+    if logits is not None:
+        if logits.dtype != torch.float32 or logits.shape[:2] != (B, C) or logits[0, 0].numel() != S:
+            raise RuntimeError("logits must be float32 (B, C, ...) matching target")
+        lay = _logit_layout(logits)
+        if lay is None:
+            logits = logits.contiguous()
+            lay = (C * S, S, 1)
     if labels is not None and (labels.dtype != torch.uint8 or labels.shape != target.shape):
         raise RuntimeError("labels must be uint8 with the shape of target")
-    _check(load().occd_ssc_confusion(_ptr(logits, "logits"), _ptr(labels, "labels"), _ptr(target, "target"),
-                                     _ptr(hist, "hist"), B, C, S, _stream()), "occd_ssc_confusion")
+    _check(load().occd_ssc_confusion_strided(logits.data_ptr() if logits is not None else None, _ptr(labels, "labels"),
+                                             _ptr(target, "target"), _ptr(hist, "hist"), B, C, S, lay[0], lay[1], lay[2],
+                                             _stream()), "occd_ssc_confusion_strided")
     return hist
+
+
+# ---- relation (context prior) loss, occdepth/loss/CRP_loss.py:4-24 ------------------------------------------------
+REL_Q24 = 16777216.0
+
+
+def _relation_operands(logits, labels):
+    if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 4:
+        raise RuntimeError("relation logits must be a float32 GPU tensor (B, R, M, N)")
+    B, R, M, N = logits.shape
+    if labels.dtype not in (torch.uint8, torch.float32, torch.bool) or tuple(labels.shape) != (B, R, N, M) or \
+            not labels.is_contiguous() or not labels.is_cuda:
+        raise RuntimeError("relation labels must be a contiguous (B, R, N, M) uint8 / bool / float32 GPU tensor")
+    st = logits.stride()
+    if st[2] != 1 and st[3] != 1:
+        raise RuntimeError("relation logits need unit stride along M or N")
+    lab = labels.view(torch.uint8) if labels.dtype == torch.bool else labels
+    return B, R, M, N, st, lab, (1 if lab.dtype == torch.float32 else 0)
+
+
+# OCCDEPTH_LOSS_KERNELS=0 restores the ATen formulations of the relation / depth losses and of the frustum-sample backward (A/B)
+LOSS_KERNELS = os.environ.get("OCCDEPTH_LOSS_KERNELS", "1") == "1"
+
+
+def relation_bce_usable(logits, labels):
+    """The relation loss runs on `relation_bce_stats` / `relation_bce_grad`: GPU tensors, float logits (B, R, M, N) that are a
+    dense permutation with unit stride along M or N, labels (B, R, N, M) uint8 / bool / float32."""
+    if not (LOSS_KERNELS and torch.is_tensor(logits) and logits.is_cuda and logits.dim() == 4 and labels.is_cuda):
+        return False
+    if not (logits.dtype == torch.float32 or (logits.dtype.is_floating_point and torch.is_autocast_enabled())) or \
+            labels.dtype not in (torch.uint8, torch.bool, torch.float32):
+        return False
+    B, R, M, N = logits.shape
+    st = logits.stride()
+    dense = 1 + sum((n - 1) * s for n, s in zip(logits.shape, st)) == logits.numel()
+    return tuple(labels.shape) == (B, R, N, M) and (st[2] == 1 or st[3] == 1) and dense and B * R <= 65535 and R <= 64
+
+
+def relation_bce_stats(logits, labels):
+    """-> int64 (R, 3): #positives, sum_{y=1} softplus(-x) and sum_{y=0} softplus(x) in Q24 (occd_relation_bce_stats)."""
+    B, R, M, N, st, lab, ldt = _relation_operands(logits, labels)
+    stats = torch.empty((R, 3), dtype=torch.int64, device=logits.device)
+    _check(load().occd_relation_bce_stats(logits.data_ptr(), lab.data_ptr(), ldt, stats.data_ptr(), B, R, M, N, st[0], st[1],
+                                          st[2], st[3], _stream()), "occd_relation_bce_stats")
+    return stats
+
+
+def relation_bce_grad(logits, labels, coef):
+    """d loss / d logits with the logits' strides; coef (R, 2) float32 = g * (pos_weight_r, 1) / (R B M N)."""
+    B, R, M, N, st, lab, ldt = _relation_operands(logits, labels)
+    if coef.dtype != torch.float32 or tuple(coef.shape) != (R, 2) or not coef.is_contiguous():
+        raise RuntimeError("coef must be contiguous float32 (R, 2)")
+    dense = sorted(range(4), key=lambda d: -st[d])
+    need = 1 + sum((logits.shape[d] - 1) * st[d] for d in range(4))
+    if need != logits.numel():
+        raise RuntimeError("relation logits must be a dense (permuted) tensor")
+    grad = torch.empty_strided(tuple(logits.shape), st, dtype=torch.float32, device=logits.device)
+    del dense
+    _check(load().occd_relation_bce_grad(logits.data_ptr(), lab.data_ptr(), ldt, coef.data_ptr(), grad.data_ptr(), B, R, M, N,
+                                         st[0], st[1], st[2], st[3], _stream()), "occd_relation_bce_grad")
+    return grad
+
+
+# ---- depth-distribution loss, occdepth/loss/depth_loss.py:14-87 ---------------------------------------------------
+def depth_bce_usable(preds, labels):
+    """The depth loss runs on `depth_bce_stats` / `depth_bce_grad`: float32 GPU predictions and GPU labels."""
+    return LOSS_KERNELS and preds.is_cuda and labels.is_cuda and preds.dtype == torch.float32
+
+
+def _depth_operands(prob, gt, cell):
+    if prob.dtype != torch.float32 or not prob.is_cuda or prob.dim() != 4 or not prob[0].is_contiguous():
+        raise RuntimeError("depth probabilities must be float32 GPU (Bn, D, h, w) with dense images")
+    if gt.dtype != torch.float32 or gt.dim() != 3 or gt.shape[0] != prob.shape[0] or not gt.is_contiguous() or not gt.is_cuda:
+        raise RuntimeError("depth labels must be contiguous float32 GPU (Bn, H, W)")
+    Bn, D, h, w = prob.shape
+    return Bn, D, h, w, gt.shape[1], gt.shape[2], (prob.stride(0) if Bn > 1 else D * h * w)
+
+
+def depth_bce_stats(prob, gt, cell, d_off, d_step):
+    """-> int64 [sum of per-cell BCE over measured cells (Q24), #measured cells] (occd_depth_bce_stats)."""
+    Bn, D, h, w, sh, sw, pb = _depth_operands(prob, gt, cell)
+    stats = torch.empty(2, dtype=torch.int64, device=prob.device)
+    _check(load().occd_depth_bce_stats(prob.data_ptr(), gt.data_ptr(), stats.data_ptr(), Bn, D, h, w, sh, sw, int(cell), pb,
+                                       float(d_off), float(d_step), _stream()), "occd_depth_bce_stats")
+    return stats
+
+
+def depth_bce_grad(prob, gt, cell, d_off, d_step, gscale):
+    """dense (Bn, D, h, w) d loss / d prob; gscale: one-element float32 device tensor = g / max(1, #measured)."""
+    Bn, D, h, w, sh, sw, pb = _depth_operands(prob, gt, cell)
+    if gscale.dtype != torch.float32 or gscale.numel() != 1 or not gscale.is_cuda:
+        raise RuntimeError("gscale must be a one-element float32 GPU tensor")
+    grad = torch.empty((Bn, D, h, w), dtype=torch.float32, device=prob.device)
+    _check(load().occd_depth_bce_grad(prob.data_ptr(), gt.data_ptr(), gscale.data_ptr(), grad.data_ptr(), Bn, D, h, w, sh, sw,
+                                      int(cell), pb, float(d_off), float(d_step), _stream()), "occd_depth_bce_grad")
+    return grad
 
 
 def cascade_tail(part, occ_off, wn, nbr):

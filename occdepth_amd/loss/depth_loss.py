@@ -8,6 +8,8 @@ distribution and that one-hot, summed over bins, averaged over the cells that ha
 import torch
 import torch.nn.functional as F
 
+from .. import hip
+
 _NO_RETURN = 1e5        # stands in for "no lidar return" while taking the minimum of a cell
 
 
@@ -24,6 +26,26 @@ def depth_bin_onehot(depth, d_bound, n_bins):
     index = (depth - (lo - step)) / step
     index = torch.where((index >= 0.0) & (index < n_bins + 1), index, torch.zeros_like(index)).long()
     return F.one_hot(index, num_classes=n_bins + 1)[..., 1:].reshape(-1, n_bins).float()
+
+
+class _DepthBCE(torch.autograd.Function):
+    """The whole loss as one pass over the predictions (`hip.depth_bce_stats`: nearest resample of the label map, nearest
+    depth per cell, LID bin, BCE summed over the bins of the measured cells) and its gradient as one more
+    (`hip.depth_bce_grad`) -- csrc/loss.hip; ~25 ATen launches and a (cells, D) one-hot tensor in the reference form."""
+
+    @staticmethod
+    def forward(ctx, prob, gt, cell, d_off, d_step):
+        st = hip.depth_bce_stats(prob, gt, cell, d_off, d_step).double()
+        measured = st[1].clamp(min=1.0)
+        ctx.save_for_backward(prob, gt, measured)
+        ctx.geom = (cell, d_off, d_step)
+        return (st[0] / (hip.REL_Q24 * measured)).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, gt, measured = ctx.saved_tensors
+        gscale = (g.double() / measured).float().reshape(1)
+        return hip.depth_bce_grad(prob, gt, *ctx.geom, gscale), None, None, None, None
 
 
 class DepthClsLoss:
@@ -44,6 +66,12 @@ class DepthClsLoss:
         assert n_pred * cams_pred == n_gt * cams_gt, \
             f"N_pred: {n_pred}, n_cam_pred: {cams_pred}, N_gt: {n_gt}, n_cam_label: {cams_gt}"
         cell = self.downsample_factor
+        if hip.depth_bce_usable(depth_preds, depth_labels) and bins == self.depth_channels:
+            prob = depth_preds.reshape(-1, bins, h, w)
+            if prob[0].is_contiguous():
+                gt = depth_labels.reshape(-1, src_h, src_w).float().contiguous()
+                # (gt - (d0 - d2)) / d2 as the reference evaluates it: the python scalars in double, the tensor in float32
+                return _DepthBCE.apply(prob, gt, int(cell), float(self.d_bound[0] - self.d_bound[2]), float(self.d_bound[2]))
         # the label map is first resampled (nearest) to exactly cell x the prediction grid
         labels = F.interpolate(depth_labels.reshape(-1, 1, src_h, src_w), (h * cell, w * cell), mode="nearest")
         target = self._get_downsampled_gt_depth(labels)                                  # (cells, D)

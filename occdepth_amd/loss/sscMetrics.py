@@ -56,7 +56,7 @@ class SSCMetrics:
         """Fused variant of the step's `np.argmax(ssc_pred) -> add_batch`: logits (B, C, X, Y, Z) on the GPU."""
         self.count += 1
         hist = self._alloc(ssc_logit.device)
-        hip.ssc_confusion(hist, self._u8(y_true, hist.device), logits=ssc_logit.detach().float().contiguous())
+        hip.ssc_confusion(hist, self._u8(y_true, hist.device), logits=ssc_logit.detach().float())     # (planes or channels-last rows: read in place)
 
     # -- host-side views (synchronise) ----------------------------------------------------------------------
     def _counts(self):

@@ -19,7 +19,9 @@ class _SscStats(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, logits, target, masks, weights, map_occ):
-        logits = logits.contiguous()
+        # (B, C, S) planes and the 3-D stack's channels-last voxel rows are both read in place (round 5: the per-step
+        #  168 MB layout copies of `ssc_logit` -- here, in the backward and in the metric update -- are gone); any other
+        #  layout is made contiguous inside hip.ssc_loss_stats
         raw = hip.ssc_loss_stats(logits, target, masks, weights, map_occ)
         C = logits.shape[1]
         F = 0 if masks is None else masks.shape[1]

@@ -382,12 +382,28 @@ class OccDepth(_Base):
     def _kitti_origin(self, batch=None):
         """SemanticKITTI voxel origin (kitti_dataset.py:82: vox_origin = (0, -25.6, -2) for the 51.2 m wide scene): the grid
         is centred on the sensor in y, whatever the scene width of a reduced test config.  A batch that carries its own
-        `vox_origin` (host tensor / array / tuple; the reference's kitti collate does not) overrides it."""
+        `vox_origin` (host or device tensor / array / tuple; the reference's kitti collate does not) overrides it."""
         vo = None if batch is None else batch.get("vox_origin")
         if vo is not None:
             v = vo if torch.is_tensor(vo) else torch.as_tensor(vo[0] if isinstance(vo, (list, tuple)) and torch.is_tensor(vo[0]) else vo)
-            if not v.is_cuda:                                      # (a device tensor would cost a sync per frame: ignored)
+            if not v.is_cuda:
                 return tuple(float(x) for x in v.reshape(-1, 3)[0])
+            # A device tensor (Lightning's transfer_batch_to_device moves every batch tensor): the origin is a constant of
+            # the dataset, so it is read back ONCE per model (one host sync, outside any graph capture) and the host copy
+            # is reused for every later batch that brings a device `vox_origin` -- never silently ignored (ADVICE r4).
+            cached = getattr(self, "_vox_origin_from_device", None)
+            if cached is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("batch['vox_origin'] is a device tensor first seen during graph capture; run one eager "
+                                       "forward first or pass it as a host tensor")
+                cached = tuple(float(x) for x in v.detach().reshape(-1, 3)[0].cpu())
+                self._vox_origin_from_device = cached
+                default = (0.0, -0.1 * float(self.full_scene_size[1]), -2.0)
+                if cached != default:
+                    import warnings
+                    warnings.warn("occdepth_amd: using the batch's device vox_origin %s (read once, assumed constant over "
+                                  "the dataset) instead of the SemanticKITTI default %s" % (cached, default))
+            return cached
         return (0.0, -0.1 * float(self.full_scene_size[1]), -2.0)
 
     def project_voxels_on_gpu(self, batch, img):

@@ -141,6 +141,20 @@ def _grid_to_lidar(pc_range, grid_size):
     return m
 
 
+class _FrustumSampleFn(torch.autograd.Function):
+    """Training: out = frustum sample of the depth volume (K1a), d depth = its transpose (occd_flosp_sample_bwd).  The
+    geometry (calibration matrices / grids) carries no gradient, as in the reference (batch inputs)."""
+
+    @staticmethod
+    def forward(ctx, dvol, fr):
+        ctx.fr = fr
+        return fr.sample()
+
+    @staticmethod
+    def backward(ctx, gout):
+        return hip.flosp_sample_bwd(ctx.fr, gout.contiguous().float()), None
+
+
 class FlospDepth(nn.Module):
     def __init__(self, x_bound, y_bound, z_bound, d_bound, final_dim, downsample_factor, output_channels,
                  depth_net_conf, scene_size, project_scale, return_depth, agg_voxel_mode="mean",
@@ -205,30 +219,38 @@ class FlospDepth(nn.Module):
         else:
             depth = logits.softmax(1).reshape(bs, n_cams, self.depth_channels, h, w)
 
-        if needs_autograd(self):
+        if needs_autograd(self) and hip.LOSS_KERNELS and _fused.on_gpu(depth) and depth.dtype == torch.float32:
+            # training on the GPU (round 5): the frustum sample and its transpose are the HIP kernels (K1a and
+            # occd_flosp_sample_bwd: deterministic) instead of F.grid_sample x 2 per camera and its atomics-based backward
+            fr = self._frustum(depth.contiguous(), None if self.infer_mode else (t_v2c, intrins, ida), grids)
+            vox = _FrustumSampleFn.apply(fr.depth, fr).view(bs, 1, *self._grid_dims)
+        elif needs_autograd(self):
             vox = self._sample_autograd(depth, None if self.infer_mode else (t_v2c, intrins, ida), grids)
         else:
-            dvol = depth.float().contiguous()
-            if self.infer_mode:
-                g = torch.stack(list(grids)).float().contiguous()          # (n_cams, B, X, Y, Z, 3)
-                fr = hip.Frustum(dvol, None, None, None, self._grid_dims, self.final_dim, self.d_bound[0],
-                                 self.d_bound[1], self.agg_voxel_mode == "mean", grids=g)
-            else:
-                gkey = (tuple(self._pc_range), self._grid_dims, t_v2c.device)
-                if getattr(self, "_g2l_key", None) != gkey:     # cached on the device: no per-frame H2D copy
-                    self._g2l_dev = _grid_to_lidar(self._pc_range, self._grid_dims).to(t_v2c.device)
-                    self._g2l_key = gkey
-                g2l = self._g2l_dev
-                trans = (t_v2c @ g2l).contiguous()
-                proj = intrins[:, :, :3, :].contiguous()
-                fr = hip.Frustum(dvol, trans, proj, ida.contiguous(), self._grid_dims, self.final_dim,
-                                 self.d_bound[0], self.d_bound[1], self.agg_voxel_mode == "mean")
+            fr = self._frustum(depth.float().contiguous(), None if self.infer_mode else (t_v2c, intrins, ida), grids)
             if defer_sample:
                 return (fr, depth) if self.return_depth else fr
             vox = fr.sample().view(bs, 1, *self._grid_dims)
         if self.return_depth:
             return vox, depth
         return vox
+
+    def _frustum(self, dvol, mats, grids):
+        """The operands of the frustum sample as a `hip.Frustum` (mats = (T_velo_2_cam, intrinsics 4x4, ida), or the
+        precomputed grids in infer_mode)."""
+        if mats is None:
+            g = torch.stack(list(grids)).float().contiguous()          # (n_cams, B, X, Y, Z, 3)
+            return hip.Frustum(dvol, None, None, None, self._grid_dims, self.final_dim, self.d_bound[0],
+                               self.d_bound[1], self.agg_voxel_mode == "mean", grids=g)
+        t_v2c, intrins, ida = mats
+        gkey = (tuple(self._pc_range), self._grid_dims, t_v2c.device)
+        if getattr(self, "_g2l_key", None) != gkey:     # cached on the device: no per-frame H2D copy
+            self._g2l_dev = _grid_to_lidar(self._pc_range, self._grid_dims).to(t_v2c.device)
+            self._g2l_key = gkey
+        trans = (t_v2c @ self._g2l_dev).contiguous()
+        proj = intrins[:, :, :3, :].contiguous()
+        return hip.Frustum(dvol, trans, proj, ida.contiguous(), self._grid_dims, self.final_dim,
+                           self.d_bound[0], self.d_bound[1], self.agg_voxel_mode == "mean")
 
     # ---------------------------------------------------------------- ATen (training / autograd)
     def _device_const(self, key, dev, make):

@@ -478,6 +478,64 @@ def ssc_confusion(hist, target, logits=None, labels=None):
     return hist
 
 
+# ---- round 5: relation / depth BCE passes and the frustum-sample transpose (include/occdepth_amd.h semantics, float64) ----
+def _relation_xy(logits, labels):
+    x = logits.detach().double()                                       # (B, R, M, N)
+    y = labels.permute(0, 1, 3, 2) != 0                                # labels (B, R, N, M)
+    return x, y
+
+
+def relation_bce_stats(logits, labels):
+    x, y = _relation_xy(logits, labels)
+    sp = (F.softplus(-x) * y).sum((0, 2, 3))
+    sn = (F.softplus(x) * ~y).sum((0, 2, 3))
+    return torch.stack([y.sum((0, 2, 3)).double(), (sp * hip.REL_Q24).round(), (sn * hip.REL_Q24).round()], 1).to(torch.int64)
+
+
+def relation_bce_grad(logits, labels, coef):
+    x, y = _relation_xy(logits, labels)
+    c = coef.double()
+    g = torch.where(y, -c[:, 0].view(1, -1, 1, 1) * torch.sigmoid(-x), c[:, 1].view(1, -1, 1, 1) * torch.sigmoid(x))
+    return g.float()
+
+
+def _depth_target_bin(gt, cell, d_off, d_step, D, h, w):
+    """Reference depth_loss.py:14-52 + the nearest resample of :72-76 -> target bin per cell (-1 = no target)."""
+    lab = F.interpolate(gt.float().unsqueeze(1), (h * cell, w * cell), mode="nearest")[:, 0]
+    blocks = lab.reshape(-1, h, cell, w, cell)
+    nearest = blocks.masked_fill(blocks == 0.0, 1e5).amin(dim=(2, 4))
+    idx = (nearest - torch.tensor(d_off, dtype=torch.float32)) / torch.tensor(d_step, dtype=torch.float32)
+    k = torch.where((idx < D + 1) & (idx >= 0.0), idx, torch.zeros_like(idx)).long()
+    return k - 1                                                        # (Bn, h, w)
+
+
+def depth_bce_stats(prob, gt, cell, d_off, d_step):
+    Bn, D, h, w = prob.shape
+    kb = _depth_target_bin(gt, cell, d_off, d_step, D, h, w)
+    p = prob.detach().double()
+    t = F.one_hot((kb + 1).clamp(min=0), D + 1)[..., 1:].permute(0, 3, 1, 2).double()
+    bce = -(t * torch.log(p).clamp(min=-100.0) + (1 - t) * torch.log1p(-p).clamp(min=-100.0)).sum(1)
+    meas = kb >= 0
+    return torch.stack([((bce * meas).sum() * hip.REL_Q24).round(), meas.sum().double()]).to(torch.int64)
+
+
+def depth_bce_grad(prob, gt, cell, d_off, d_step, gscale):
+    Bn, D, h, w = prob.shape
+    kb = _depth_target_bin(gt, cell, d_off, d_step, D, h, w)
+    p = prob.detach().double()
+    t = F.one_hot((kb + 1).clamp(min=0), D + 1)[..., 1:].permute(0, 3, 1, 2).double()
+    g = (p - t) / ((1 - p) * p).clamp(min=1e-12) * gscale.double().reshape(())
+    return (g * (kb >= 0).unsqueeze(1)).float()
+
+
+def flosp_sample_bwd(fr, gout):
+    d = fr.depth.detach().double().requires_grad_(True)
+    dbl = lambda t: None if t is None else t.double()
+    out = flosp_sample(d, dbl(fr.trans), dbl(fr.proj), dbl(fr.ida), fr.voxel_num, fr.final_dim, fr.d_min, fr.d_max,
+                       fr.mean_mode, None if fr.grids is None else fr.grids.double())
+    return torch.autograd.grad(out, d, gout.double().reshape(out.shape))[0].float()
+
+
 def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift=None, slope=0.01):
     """K12 semantics: sum over the 9 taps of shift_t(bilinear_up(z_t, align_corners=True)), zero outside the grid."""
     if batch_inner:
@@ -571,7 +629,15 @@ def patched(fast2d=False):
                                           "ssc_confusion", "conv3d_wgrad", "wino_input_transform", "wino_output_transform",
                                           "wino_pack_weights", "conv2d_3x3_fused", "pw_pack_weights", "conv1x1",
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "pack_weights_gather", "conv3d_bf16",
-                                          "conv3d_wgrad_bf16", "gemm_x3", "gemm_x3_supported", "conv3d_phases")}
+                                          "conv3d_wgrad_bf16", "gemm_x3", "gemm_x3_supported", "conv3d_phases",
+                                          "relation_bce_stats", "relation_bce_grad", "relation_bce_usable", "depth_bce_stats",
+                                          "depth_bce_grad", "depth_bce_usable", "flosp_sample_bwd")}
+    hip.relation_bce_stats, hip.relation_bce_grad = relation_bce_stats, relation_bce_grad
+    hip.depth_bce_stats, hip.depth_bce_grad, hip.flosp_sample_bwd = depth_bce_stats, depth_bce_grad, flosp_sample_bwd
+    # the gates of the loss kernels without their is_cuda condition: the CPU suite drives the same autograd Functions
+    hip.relation_bce_usable = lambda lg, lb: (hip.LOSS_KERNELS and lg.dim() == 4 and lg.dtype == torch.float32 and
+                                              tuple(lb.shape) == (lg.shape[0], lg.shape[1], lg.shape[3], lg.shape[2]))
+    hip.depth_bce_usable = lambda pr, lb: hip.LOSS_KERNELS and pr.dtype == torch.float32
     hip.conv3d_phases = conv3d_phases
     hip.pack_weights_bf16, hip.conv3d_bf16, hip.conv3d_wgrad_bf16 = pack_weights_bf16, conv3d_bf16, conv3d_wgrad_bf16
     hip.pack_weights_gather = pack_weights_gather

@@ -114,6 +114,20 @@ def test_gemm_x3_rejects_bad_arguments(hip):
     assert lib.occd_gemm_f32x3(None, None) == -1
     q = hip.GemmArgs()
     assert lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+    # an `out` / `res` whose batch extent does not match the operands' (the kernel trusts batch x stride_c)
+    a = torch.randn(40, 16, device=DEV)
+    b = torch.randn(3, 16, 24, device=DEV)
+    for bad in (torch.empty(1, 40, 24, device=DEV), torch.empty(40, 24, device=DEV), torch.empty(2, 40, 24, device=DEV)):
+        with pytest.raises(RuntimeError, match="out must be"):
+            hip.gemm_x3(a, b, out=bad)
+    with pytest.raises(RuntimeError, match="res must be"):
+        hip.gemm_x3(a, b, res=torch.empty(1, 40, 24, device=DEV))
+    ok = torch.empty(3, 40, 24, device=DEV)
+    hip.gemm_x3(a, b, out=ok)
+    assert float((ok.cpu().double() - torch.matmul(a.double().cpu(), b.double().cpu())).abs().max()) < 1e-4
+    out2 = torch.empty(40, 24, device=DEV)                 # 2-D out: only when neither operand is batched
+    hip.gemm_x3(a, b[0], out=out2)
+    assert torch.equal(out2, ok[0])
 
 
 NT_SHAPES = {
