@@ -1,0 +1,84 @@
+#!/bin/bash
+# Round-5 GPU session driver (everything lands under gpurun_out/<tag>/; summaries are copied to profiles/ by hand).
+#   gpurun -- 'bash tools/gpu_run_r5.sh <tag> <section> [<section> ...]'
+# sections: newtests alltests smoke bench benchq config5 train trainpw exact frame prof proftrain pmc
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; shift
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+WHAT="$*"
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+line() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        t = json.loads([l for l in open(f).read().splitlines() if l.startswith('{"metric"')][-1])
+        ex = t.get("extras") or {}
+        print(f.split("/")[-1], "ms/step", round(t["ms_per_step"], 3), "stages", t.get("stages_ms"), "roof", round((t.get("roofline") or {}).get("frac") or 0, 4),
+              "head_ms", (t.get("roofline") or {}).get("avg_launch_ms"), "graph", t.get("train_graph"), "parity", (t.get("parity_rel_err") or {}).get("worst_of_all_outputs"),
+              "extras", {k: (v.get("ms_per_step"), v.get("error")) for k, v in ex.items()})
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+}
+if has newtests; then
+  timeout 1500 python -m pytest -q -m gpu -x tests/test_loss_kernels_gpu.py tests/test_losses_gpu.py tests/test_bf16_conv.py tests/test_gemm_x3.py tests/test_train_step.py ${EXTRA_TESTS:-} > $O/pytest_new.txt 2>&1; tail -15 $O/pytest_new.txt
+fi
+if has benchq; then
+  timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/benchq.json 2> $O/benchq.err; line $O/benchq.json
+fi
+if has config5; then
+  timeout 400 python bench.py --config 5 --steps 5 --warmup 2 > $O/config5.json 2> $O/config5.err; line $O/config5.json
+  python - <<PY
+import json
+t = json.loads([l for l in open("$O/config5.json").read().splitlines() if l.startswith('{"metric"')][-1])
+print(json.dumps(t["roofline"], indent=None)[:900]); print(t["top_conv_launches_ms"])
+PY
+fi
+if has train; then
+  timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16.json 2> $O/train_bf16.err; line $O/train_bf16.json
+  timeout 500 python bench.py --train --steps 5 --warmup 2 > $O/train_fp32.json 2> $O/train_fp32.err; line $O/train_fp32.json
+  OCCDEPTH_LOSS_KERNELS=0 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_aten_losses.json 2> $O/train_bf16_aten_losses.err; line $O/train_bf16_aten_losses.json
+fi
+if has trainpw; then
+  OCCDEPTH_TRAIN_PW_GEMM=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_pw.json 2> $O/train_bf16_pw.err; line $O/train_bf16_pw.json
+fi
+if has exact; then
+  OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_exact_fp32.json 2> $O/bench_exact_fp32.err; line $O/bench_exact_fp32.json
+fi
+if has bench; then
+  timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; line $O/bench.json
+fi
+if has frame; then
+  timeout 300 python tools/frame_table.py > $O/frame_per_launch.txt 2> $O/frame_per_launch.err; tail -2 $O/frame_per_launch.txt | cut -c1-400
+fi
+if has alltests; then
+  timeout 2400 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -5 $O/pytest_gpu.txt
+fi
+if has smoke; then
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+fi
+cd /tmp && export TMPDIR=/tmp
+if has prof; then
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-extras > $O/bench_under_rocprof.json 2> /tmp/prof_bench.err
+  f=$(ls /tmp/prof_bench/*/*kernel_trace.csv | head -1)
+  python $R/tools/summarize_trace.py $f $O/steady_state_kernel_stats.csv 5 > /dev/null; head -12 $O/steady_state_kernel_stats.csv | cut -c1-140
+fi
+if has proftrain; then
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_train -- python $R/bench.py --train --bf16 --steps 3 --warmup 2 > $O/train_bf16_under_rocprof.json 2> /tmp/prof_train.err
+  f=$(ls /tmp/prof_train/*/*kernel_trace.csv | head -1)
+  python $R/tools/summarize_trace.py $f $O/train_step_bf16_kernels.csv train > /dev/null 2>&1; head -8 $O/train_step_bf16_kernels.csv | cut -c1-140
+  cd $R && timeout 500 python tools/prof_train_aten.py > $O/train_step_bf16_aten_ops.txt 2>&1; cd /tmp
+fi
+if has pmc; then
+  for c in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" FETCH_SIZE WRITE_SIZE; do
+    n=$(echo $c | cut -d' ' -f1)
+    OCCDEPTH_GRAPH_ALL=0 OCCDEPTH_GRAPH_2D=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras > /tmp/pmcf_$n.log 2>&1
+    cp $(ls /tmp/pmcf_$n/*/*counter_collection.csv | head -1) /tmp/pmcf_$n.csv
+  done
+  python $R/tools/pmc_frame.py /tmp/pmcf_GRBM_GUI_ACTIVE.csv /tmp/pmcf_FETCH_SIZE.csv /tmp/pmcf_WRITE_SIZE.csv > $O/pmc_frame.txt 2>&1; cat $O/pmc_frame.txt | cut -c1-130
+fi
+echo "[gpu_run_r5 $TAG done: $WHAT]"
