@@ -381,6 +381,12 @@ int occd_dwconv2d_nchw(const float* x, const float* w, const float* scale, const
                        float* y, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
                        int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
                        int32_t act, void* stream);
+/* Encoder stem (round 5; geffnet conv_stem + bn1 + act1 behind occdepth/models/unet2d.py:175-190): 3x3 convolution of the
+ * 3-channel image x (B, 3, H, W) with w (cout, 3, 3, 3), stride 1 or 2, explicit top/left zero padding (TensorFlow SAME),
+ * y (B, cout, Ho, Wo) = act(conv * scale[c] + shift[c]); act: 0 none, 1 relu, 2 swish.                              */
+int occd_stem_conv3x3_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                           int32_t batch, int32_t H, int32_t W, int32_t cout, int32_t stride, int32_t pad_top,
+                           int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act, void* stream);
 /* out (B, C + Cskip, H, W): [:, :C] = bilinear resize of x (B, C, h, w) with align_corners=True,
  * [:, C:] = skip (B, Cskip, H, W)  -- F.interpolate + torch.cat of unet2d.py:38-46.          */
 int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* out, int32_t batch,
@@ -470,6 +476,15 @@ int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, 
                             float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
                             int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
                             int32_t act, void* stream);
+/* DepthNet's camera-aware squeeze-excite gate in one launch (round 5; occdepth/models/flosp_depth/flosp_depth.py:201-257:
+ * `Mlp(1, C, C)` of the scaled pixel size -> `SELayer(C)`):
+ *   gate[i][c] = sigmoid(We relu(Wr (W2 relu(w1 s_i + b1) + b2) + br) + be),   i = 0 .. images-1
+ * s_i = sps[i] (infer_mode) or factor * |(1 / K_i[0][0], 1 / K_i[1][1])| from `intrins` (row-major matrices with >= 6
+ * floats per image, `intr_stride` floats apart: element [1][1] at offset 5 -- the (B, n_cams, 4, 4) intrinsics of the
+ * batch); exactly one of sps / intrins is non-NULL.  w1 (C), w2 / wr / we (C, C) row major, biases (C).          */
+int occd_depthnet_gate(const float* sps, const float* intrins, int64_t intr_stride, float factor, const float* w1,
+                       const float* b1, const float* w2, const float* b2, const float* wr, const float* br,
+                       const float* we, const float* be, float* gate, int32_t images, int32_t C, void* stream);
 int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_reduce, const float* w_expand,
                  const float* b_expand, float* r_scratch, float* gate, int32_t batch, int32_t C, int32_t Cr,
                  int32_t nblk, int64_t S, void* stream);

@@ -868,6 +868,86 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
     return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, nullptr, stream);
 }
 
+// ---- encoder stem: 3x3 convolution of a FEW input channels (the RGB image), stride 1 / 2, TensorFlow SAME padding,
+// + BatchNorm affine + activation in one pass (geffnet conv_stem + bn1 + act1 behind occdepth/models/unet2d.py:175-190;
+// round 5: the last MIOpen convolution of the encoder -- miopenSp3AsmConv f3x2_stride2 56 us + BatchNormFwdInfer + swish).
+// K = 27: nothing for the matrix pipe; the launch is bound by its output stream (58 MB at config 2).  A workgroup is 64
+// output pixels of one row x 4 groups of 16 output channels; a lane keeps the 27 taps of its pixel in registers and walks
+// the 16 channels of its group with the (scale-folded) weights read from LDS as broadcast float4s.
+constexpr int kStemCin = 3;
+template <int STRIDE>
+__global__ void __launch_bounds__(256) stem_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ y, int H, int W, int Cout, int pad_top,
+                                                           int pad_left, int Ho, int Wo, int act) {
+    extern __shared__ float wl[];                       // [27][Cout16]: tap-major, couts contiguous (zero padded to 16)
+    const int Cout16 = (Cout + 15) & ~15;
+    for (int i = threadIdx.x; i < 27 * Cout16; i += 256) {
+        const int t = i / Cout16, co = i - t * Cout16;
+        wl[i] = co < Cout ? w[co * 27 + t] * (scale != nullptr ? scale[co] : 1.f) : 0.f;     // w (Cout, 3, 3, 3): t = ci*9 + ky*3 + kx
+    }
+    __syncthreads();
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const int grp = threadIdx.x >> 6;
+    if (ox >= Wo) return;
+    float v[27];
+    const float* xb = x + (size_t)b * kStemCin * H * W;
+#pragma unroll
+    for (int ci = 0; ci < kStemCin; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * STRIDE - pad_top + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * STRIDE - pad_left + kx;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                v[ci * 9 + ky * 3 + kx] = ok ? xb[((size_t)ci * H + iy) * W + ix] : 0.f;
+            }
+        }
+    for (int c0 = grp * 16; c0 < Cout16; c0 += 64) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4* wp = (const f32x4*)(wl + t * Cout16 + c0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += wp[q] * v[t];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = c0 + 4 * q + j;
+                if (co < Cout) {
+                    const float o = acc[q][j] + (shift != nullptr ? shift[co] : 0.f);
+                    y[(((size_t)b * Cout + co) * Ho + oy) * Wo + ox] = act_apply(o, act, 0.f);
+                }
+            }
+    }
+}
+
+extern "C" int occd_stem_conv3x3_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                      int32_t batch, int32_t H, int32_t W, int32_t cout, int32_t stride, int32_t pad_top,
+                                      int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act, void* stream) {
+    if (x == nullptr || w == nullptr || y == nullptr) return OCCD_EINVAL;
+    if (batch < 1 || batch > 65535 || H < 1 || W < 1 || cout < 1 || cout > 512 || (stride != 1 && stride != 2)) return OCCD_EINVAL;
+    if (Ho < 1 || Ho > 65535 || Wo < 1 || pad_top < 0 || pad_left < 0 || act < 0 || act > 2) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((Wo + 63) / 64), (unsigned)Ho, (unsigned)batch);
+    const size_t lds = (size_t)27 * ((cout + 15) & ~15) * sizeof(float);
+    occd::ProfScope prof("stem_conv3x3", st, 2.0 * batch * (double)Ho * Wo * 27 * cout,
+                         4.0 * batch * ((double)kStemCin * H * W + (double)cout * Ho * Wo));
+    if (stride == 2)
+        hipLaunchKernelGGL(stem_conv3x3_kernel<2>, grid, dim3(256), lds, st, x, w, scale, shift, y, H, W, cout, pad_top,
+                           pad_left, Ho, Wo, act);
+    else
+        hipLaunchKernelGGL(stem_conv3x3_kernel<1>, grid, dim3(256), lds, st, x, w, scale, shift, y, H, W, cout, pad_top,
+                           pad_left, Ho, Wo, act);
+    return occd::check_launch();
+}
+
 extern "C" int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo) { return (Ho * ((Wo + 3) / 4) + 255) / 256; }
 
 extern "C" int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,

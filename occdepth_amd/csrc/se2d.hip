@@ -118,7 +118,70 @@ __global__ void __launch_bounds__(256) se_expand4_kernel(const float* __restrict
     if (q == 0 && c < C) gate[(size_t)b * C + c] = 1.f / (1.f + expf(-(bias + s)));
 }
 
+// ---- DepthNet's camera-aware gate (occdepth/models/flosp_depth/flosp_depth.py:201-257: Mlp of the scaled pixel size ->
+// SELayer): gate[i][c] = sigmoid(We . relu(Wr . (W2 . relu(w1 s_i + b1) + b2) + br) + be), i = image (b, view),
+// s_i = 1000 * |(1 / fx_i, 1 / fy_i)| (the diagonal of the inverse pinhole intrinsics) or a given scalar (infer_mode).
+// Round 5: ONE launch instead of ~20 ATen / rocBLAS ones (reciprocal, stack, norm, 2 Linear, ReLU, 2 1x1 convolutions on 1x1
+// maps, ReLU, sigmoid: the last Cijk_* rows of the eval trace).  One workgroup per image; the three C x C mat-vecs run
+// row per wave-quarter: 16 lanes walk a row in coalesced 64-byte pieces and reduce through DPP / shuffles (fixed order).
+__device__ __forceinline__ void gate_matvec(const float* __restrict__ W, const float* __restrict__ bias, const float* in,
+                                            float* out, int C, int act) {        // out = act(W in + bias); act 1 relu, 2 sigmoid
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;                      // 16 row groups of 16 lanes
+    for (int r = grp; r < C; r += 16) {
+        const float* w = W + (size_t)r * C;
+        float a = 0.f;
+        for (int k = sub; k < C; k += 16) a += w[k] * in[k];
+        a += __shfl_xor(a, 8, 64);
+        a += __shfl_xor(a, 4, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 1, 64);
+        if (sub == 0) {
+            a += bias[r];
+            out[r] = act == 1 ? fmaxf(a, 0.f) : act == 2 ? 1.f / (1.f + expf(-a)) : a;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) depthnet_gate_kernel(const float* __restrict__ sps, const float* __restrict__ intrins,
+                                                            long intr_stride, float factor, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, const float* __restrict__ wr,
+                                                            const float* __restrict__ br, const float* __restrict__ we,
+                                                            const float* __restrict__ be, float* __restrict__ gate, int C) {
+    extern __shared__ float buf[];                       // 2 x C
+    float* v0 = buf;
+    float* v1 = buf + C;
+    const int i = blockIdx.x;
+    float s;
+    if (sps != nullptr) {
+        s = sps[i];
+    } else {
+        // DepthNet.scaled_pixel_size: diag(K^-1) = 1 / diag(K) for upper-triangular pinhole intrinsics; torch.norm of the pair
+        const float d0 = 1.f / intrins[(size_t)i * intr_stride], d1 = 1.f / intrins[(size_t)i * intr_stride + 5];
+        s = sqrtf(d0 * d0 + d1 * d1) * factor;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) v0[c] = fmaxf(w1[c] * s + b1[c], 0.f);     // fc1 (C, 1) + ReLU
+    __syncthreads();
+    gate_matvec(w2, b2, v0, v1, C, 0);                   // fc2
+    __syncthreads();
+    gate_matvec(wr, br, v1, v0, C, 1);                   // conv_reduce + ReLU
+    __syncthreads();
+    gate_matvec(we, be, v0, gate + (size_t)i * C, C, 2); // conv_expand + sigmoid
+}
+
 }  // namespace
+
+extern "C" int occd_depthnet_gate(const float* sps, const float* intrins, int64_t intr_stride, float factor, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, const float* wr, const float* br,
+                                  const float* we, const float* be, float* gate, int32_t images, int32_t C, void* stream) {
+    if ((sps == nullptr) == (intrins == nullptr) || !w1 || !b1 || !w2 || !b2 || !wr || !br || !we || !be || !gate) return OCCD_EINVAL;
+    if (images < 1 || C < 1 || C > 4096 || (intrins != nullptr && intr_stride < 6)) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    occd::ProfScope prof("depthnet_gate", st, 6.0 * images * C * C, 12.0 * C * C);
+    hipLaunchKernelGGL(depthnet_gate_kernel, dim3((unsigned)images), dim3(256), (size_t)2 * C * sizeof(float), st, sps, intrins,
+                       (long)intr_stride, factor, w1, b1, w2, b2, wr, br, we, be, gate, C);
+    return occd::check_launch();
+}
 
 extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_reduce, const float* w_expand,
                             const float* b_expand, float* r_scratch, float* gate, int32_t batch, int32_t C, int32_t Cr,

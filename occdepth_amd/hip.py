@@ -244,6 +244,8 @@ EXPORTS = {
     "occd_depth_bce_grad": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_int32] * 6 +
                             [c_int64, c_float, c_float, c_void_p]),
     "occd_flosp_sample_bwd": (c_int32, [POINTER(FlospBwdArgs), c_void_p]),
+    "occd_stem_conv3x3_nchw": (c_int32, [c_void_p] * 5 + [c_int32] * 10 + [c_void_p]),
+    "occd_depthnet_gate": (c_int32, [c_void_p, c_void_p, c_int64, c_float] + [c_void_p] * 9 + [c_int32, c_int32, c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
@@ -1298,6 +1300,57 @@ def dwconv2d_same(x, w, scale, shift, stride, act=None):
                                      _f32(shift, "shift") if shift is not None else None, _f32(y, "y"), B, C, H, W, k,
                                      stride, pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
            "occd_dwconv2d_nchw")
+    return y
+
+
+def depthnet_gate(mlp, se, images, sps=None, intrins=None, factor=1000.0):
+    """(images, C) gate of DepthNet's camera-aware SE layer in one launch (occd_depthnet_gate): `mlp` = Mlp(1, C, C), `se` =
+    SELayer(C); the scaled pixel size comes from `sps` (images,) or is derived from `intrins` (images, 4, 4) pinhole
+    matrices (float32, dense)."""
+    C = mlp.fc2.out_features
+
+    def f(t):
+        t = t.detach().float()
+        return t if t.is_contiguous() else t.contiguous()
+    gate = torch.empty((images, C), device=mlp.fc1.weight.device, dtype=torch.float32)
+    if (sps is None) == (intrins is None):
+        raise RuntimeError("depthnet_gate: give exactly one of sps / intrins")
+    if intrins is not None:
+        intr = f(intrins).reshape(images, -1)
+        if intr.shape[1] < 6:
+            raise RuntimeError("depthnet_gate: intrinsics need at least 6 floats per image")
+        sp, ip, stride = None, _f32(intr, "intrins"), intr.shape[1]
+    else:
+        sv = f(sps).reshape(-1)
+        if sv.numel() != images:
+            raise RuntimeError("depthnet_gate: one scaled pixel size per image")
+        sp, ip, stride = _f32(sv, "sps"), None, 0
+    ws = [f(mlp.fc1.weight).reshape(-1), f(mlp.fc1.bias), f(mlp.fc2.weight), f(mlp.fc2.bias),
+          f(se.conv_reduce.weight).reshape(C, C), f(se.conv_reduce.bias), f(se.conv_expand.weight).reshape(C, C),
+          f(se.conv_expand.bias)]
+    _check(load().occd_depthnet_gate(sp, ip, stride, float(factor), *[_f32(w, "w") for w in ws], gate.data_ptr(), images, C,
+                                     _stream()), "occd_depthnet_gate")
+    return gate
+
+
+def stem_conv3x3(x, w, scale, shift, stride, act=None):
+    """conv3x3 (TensorFlow SAME padding, stride 1 / 2) of a 3-channel image + per-channel affine + activation in one launch
+    (occd_stem_conv3x3_nchw): the EfficientNet stem."""
+    if x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape[1:]) != (3, 3, 3):
+        raise RuntimeError("stem_conv3x3: x must be (B, 3, H, W) and w (cout, 3, 3, 3)")
+    x = x if x.is_contiguous() else x.contiguous()
+    B, _, H, W = x.shape
+    cout = w.shape[0]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    pad_h = max((Ho - 1) * stride + 3 - H, 0)
+    pad_w = max((Wo - 1) * stride + 3 - W, 0)
+    y = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    wc = w.detach().float()
+    wc = wc if wc.is_contiguous() else wc.contiguous()
+    _check(load().occd_stem_conv3x3_nchw(_f32(x, "x"), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
+                                         _f32(shift, "shift") if shift is not None else None, y.data_ptr(), B, H, W, cout,
+                                         int(stride), pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
+           "occd_stem_conv3x3_nchw")
     return y
 
 

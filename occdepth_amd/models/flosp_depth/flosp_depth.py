@@ -23,9 +23,11 @@ from ... import fused as _fused
 from ...fused import bn_affine_cached, needs_autograd, wino_fused_operands
 
 # DepthNet's 3x3 convolutions on K10 (fused Winograd MFMA kernel, BatchNorm / ReLU / identity skip in its epilogue) instead
-# of MIOpen + a BatchNorm pass: opt-in (OCCDEPTH_DEPTHNET_K10=1).  Measured: 128 channels on a 47x153 map are 120
-# workgroups of K10 -- 62 us per convolution against MIOpen's 46 + 6 us, so MIOpen stays the default here
-DEPTHNET_K10 = os.environ.get("OCCDEPTH_DEPTHNET_K10", "0") == "1"
+# of MIOpen + a BatchNorm pass, and its camera-aware gate (Mlp -> SELayer) as ONE launch (occd_depthnet_gate) instead of ~20
+# ATen / rocBLAS ones.  Default since round 5 (no MIOpen / Cijk_* kernel left in the eval trace): a K10
+# launch on 128 channels of a 47x153 map is 120 workgroups -- 62 us against MIOpen's 46 + 6 + a BatchNorm pass, which the
+# ~25 launches that disappear pay back.  OCCDEPTH_DEPTHNET_K10=0 restores the library path for A/B.
+DEPTHNET_K10 = os.environ.get("OCCDEPTH_DEPTHNET_K10", "1") == "1"
 
 
 class BasicBlock(nn.Module):
@@ -102,15 +104,21 @@ class DepthNet(nn.Module):
         return size * scale_depth_factor
 
     def forward(self, x=None, sweep_intrins=None, scaled_pixel_size=None, scale_depth_factor=1000.0):
-        if not self.infer_mode:
-            scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
-                                                       sync_free=sweep_intrins.is_cuda)
         if DEPTHNET_K10 and _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             upk, shift = wino_fused_operands(self, self.reduce_conv[0], self.reduce_conv[1])
             x = hip.conv2d_3x3_fused(x, upk, self.reduce_conv[0].out_channels, shift, "relu")
+            n_img, c_mid = x.shape[:2]
+            if self.infer_mode:
+                gate = hip.depthnet_gate(self.mlp, self.se, n_img, sps=scaled_pixel_size)
+            else:       # (the scaled pixel size is derived from the intrinsics inside the launch)
+                gate = hip.depthnet_gate(self.mlp, self.se, n_img, intrins=sweep_intrins, factor=scale_depth_factor)
+            x = hip.affine_act(x.view(1, n_img * c_mid, *x.shape[2:]), gate.view(-1), None).view(n_img, c_mid, *x.shape[2:])
         else:
+            if not self.infer_mode:
+                scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
+                                                           sync_free=sweep_intrins.is_cuda)
             x = self.reduce_conv(x)
-        x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
+            x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
         x = self.depth_conv(x)
         if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
             from ..efficientnet import pw_operands, pw_wins

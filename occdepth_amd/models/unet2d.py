@@ -275,6 +275,11 @@ class DecoderBN(nn.Module):
         return res
 
 
+# eval fast path: the encoder stem (conv_stem + bn1 + swish) as one HIP launch instead of MIOpen + BatchNormFwdInfer + an
+# activation pass (OCCDEPTH_STEM_FUSED=0 restores them for A/B)
+STEM_FUSED = os.environ.get("OCCDEPTH_STEM_FUSED", "1") == "1"
+
+
 class Encoder(nn.Module):
     def __init__(self, backend):
         super().__init__()
@@ -287,7 +292,20 @@ class Encoder(nn.Module):
         the modules behind it -- the decoder only taps conv_head's output (features[11]) and, in the eval path, gets it
         folded into its own first convolution (DecoderBN._conv2_merged); bn2 / act2 / pool / classifier are dead code."""
         features = [x]
+        om = self.original_model
+        names = list(om._modules)
+        fused_stem = (names[:3] == ["conv_stem", "bn1", "act1"] and _fused.on_gpu(x) and not _fused.needs_autograd(self)
+                      and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and STEM_FUSED
+                      and om.conv_stem.kernel_size == (3, 3) and om.conv_stem.stride in ((1, 1), (2, 2))
+                      and om.conv_stem.bias is None and om.conv_stem.groups == 1 and om.conv_stem.dilation == (1, 1))
+        if fused_stem:
+            # eval fast path: conv_stem + bn1 + act1 (swish) in ONE launch; the decoder taps features[4, 5, 6, 8, 11] only, so
+            # the slots of the stem's own intermediates stay empty (like skip_head's)
+            features += [None, None, hip.stem_conv3x3(x, om.conv_stem.weight, *_fused.bn_affine_cached(om.bn1),
+                                                      om.conv_stem.stride[0], "swish")]
         for name, mod in self.original_model._modules.items():
+            if fused_stem and name in ("conv_stem", "bn1", "act1"):
+                continue
             if name == "blocks":
                 for stage in mod._modules.values():
                     features.append(stage(features[-1]))

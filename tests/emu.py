@@ -529,11 +529,38 @@ def depth_bce_grad(prob, gt, cell, d_off, d_step, gscale):
 
 
 def flosp_sample_bwd(fr, gout):
-    d = fr.depth.detach().double().requires_grad_(True)
-    dbl = lambda t: None if t is None else t.double()
-    out = flosp_sample(d, dbl(fr.trans), dbl(fr.proj), dbl(fr.ida), fr.voxel_num, fr.final_dim, fr.d_min, fr.d_max,
-                       fr.mean_mode, None if fr.grids is None else fr.grids.double())
-    return torch.autograd.grad(out, d, gout.double().reshape(out.shape))[0].float()
+    # float32 geometry like the kernel (and like the reference's grid); the sample is linear in the volume, so autograd
+    # through the emulated forward IS the transpose of the weights that forward applies
+    d = fr.depth.detach().float().cpu().requires_grad_(True)
+    cpu = lambda t: None if t is None else t.detach().float().cpu()
+    out = flosp_sample(d, cpu(fr.trans), cpu(fr.proj), cpu(fr.ida), fr.voxel_num, fr.final_dim, fr.d_min, fr.d_max,
+                       fr.mean_mode, cpu(fr.grids))
+    return torch.autograd.grad(out, d, gout.detach().float().cpu().reshape(out.shape))[0]
+
+
+def depthnet_gate(mlp, se, images, sps=None, intrins=None, factor=1000.0):
+    if intrins is not None:
+        k = intrins.detach().double().reshape(images, -1)
+        sps = torch.sqrt((1.0 / k[:, 0]) ** 2 + (1.0 / k[:, 5]) ** 2) * factor
+    s = sps.detach().double().reshape(images, 1)
+    C = mlp.fc2.out_features
+    d = lambda t: t.detach().double()
+    h = F.relu(s * d(mlp.fc1.weight).reshape(1, C) + d(mlp.fc1.bias))
+    m = h @ d(mlp.fc2.weight).t() + d(mlp.fc2.bias)
+    r = F.relu(m @ d(se.conv_reduce.weight).reshape(C, C).t() + d(se.conv_reduce.bias))
+    return torch.sigmoid(r @ d(se.conv_expand.weight).reshape(C, C).t() + d(se.conv_expand.bias)).float()
+
+
+def stem_conv3x3(x, w, scale, shift, stride, act=None):
+    H, W = x.shape[-2:]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + 3 - H, 0), max((Wo - 1) * stride + 3 - W, 0)
+    y = F.conv2d(F.pad(x.double(), [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]), w.detach().double(), None, stride)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    return _act2d(y, act, 0.0).float()
 
 
 def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift=None, slope=0.01):
@@ -631,7 +658,8 @@ def patched(fast2d=False):
                                           "dwconv2d_same_pool", "se_gate", "upconv_gather", "pack_weights_bf16", "pack_weights_gather", "conv3d_bf16",
                                           "conv3d_wgrad_bf16", "gemm_x3", "gemm_x3_supported", "conv3d_phases",
                                           "relation_bce_stats", "relation_bce_grad", "relation_bce_usable", "depth_bce_stats",
-                                          "depth_bce_grad", "depth_bce_usable", "flosp_sample_bwd")}
+                                          "depth_bce_grad", "depth_bce_usable", "flosp_sample_bwd", "stem_conv3x3", "depthnet_gate")}
+    hip.stem_conv3x3, hip.depthnet_gate = stem_conv3x3, depthnet_gate
     hip.relation_bce_stats, hip.relation_bce_grad = relation_bce_stats, relation_bce_grad
     hip.depth_bce_stats, hip.depth_bce_grad, hip.flosp_sample_bwd = depth_bce_stats, depth_bce_grad, flosp_sample_bwd
     # the gates of the loss kernels without their is_cuda condition: the CPU suite drives the same autograd Functions

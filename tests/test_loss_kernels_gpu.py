@@ -71,7 +71,7 @@ def test_relation_bce_kernels(hip, shape, label_dtype, layout):
         loss = compute_super_CP_multilabel_loss(lg, labels)
         loss.backward()
     assert {k.split(":")[0] for k in prof.rows} >= {"relation_bce_stats", "relation_bce_grad"}, prof.rows.keys()
-    assert float(loss) == pytest.approx(float(ref), rel=2e-6)
+    assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=2e-6)
     got = leaf.grad.cpu().double()
     if layout == "m_contiguous":
         assert float(got[..., M:].abs().max() if got.shape[-1] > M else 0.0) == 0.0
