@@ -553,10 +553,11 @@ def _forward(args, world, rank, device, dist):
                 res["roofline"]["traffic"] = json.load(f).get("bytes_per_launch")
             res["roofline"]["traffic_source"] = (f"profiles/{xname}: in-frame launches of this command, rocprofv3 --pmc FETCH_SIZE "
                                                  "(x2, gfx950) and --pmc WRITE_SIZE, separate passes")
-    try:
-        res["roofline"]["isolated_random_data"] = isolated_head(device, split_head)
-    except Exception as e:  # a report, never a reason to lose the measurement
-        res["roofline"]["isolated_random_data"] = {"error": repr(e)}
+    if os.environ.get("OCCDEPTH_BENCH_ISOLATED", "1") == "1":     # (0 under rocprofv3: tools/summarize_trace.py counts head launches)
+        try:
+            res["roofline"]["isolated_random_data"] = isolated_head(device, split_head)
+        except Exception as e:  # a report, never a reason to lose the measurement
+            res["roofline"]["isolated_random_data"] = {"error": repr(e)}
     for attr in ("graph_2d_error", "graph_all_error"):
         if getattr(model, attr, None):
             res["config"][attr] = getattr(model, attr)

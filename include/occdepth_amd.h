@@ -476,6 +476,20 @@ int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, 
                             float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
                             int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
                             int32_t act, void* stream);
+/* Squeeze-excite in TRAINING (autograd of geffnet's SqueezeExcite in training_step):
+ *   forward : sums = occd_plane_reduce(x, NULL)  ->  occd_se_gate(sums, ..., nblk = 1, S)  ->  occd_affine_act_nchw (x * gate)
+ *   backward: gg = occd_plane_reduce(gout, x)    ->  occd_se_bwd                           ->  occd_affine_act_nchw
+ *             (gx = gout * gate + gm / S)
+ * occd_plane_reduce: out[p] = sum_s a[p][s] (* b[p][s] when b != NULL) over `planes` dense planes of S floats, fixed order.
+ * occd_se_bwd: from gg (B, C), the forward's gate (B, C), sums (B, C) and r = swish(Wr m + br) (B, Cr; occd_se_gate's
+ * r_scratch), m = sums / S:  ds = gg g (1 - g);  gr = ds We;  z = Wr m + br;  dz = gr swish'(z)  and
+ *   gm (B, C) = dz Wr,  gw_reduce (Cr, C) = dz^T m,  gb_reduce (Cr) = sum_b dz,  gw_expand (C, Cr) = ds^T r,  gb_expand (C) =
+ *   sum_b ds;  dz_scratch: B * Cr floats.  batch <= 16.                                                                    */
+int occd_plane_reduce(const float* a, const float* b, float* out, int64_t planes, int64_t S, void* stream);
+int occd_se_bwd(const float* gg, const float* gate, const float* sums, const float* r, const float* w_reduce,
+                const float* b_reduce, const float* w_expand, float* dz_scratch, float* gm, float* gw_reduce,
+                float* gb_reduce, float* gw_expand, float* gb_expand, int32_t batch, int32_t C, int32_t Cr, int64_t S,
+                void* stream);
 /* DepthNet's camera-aware squeeze-excite gate in one launch (round 5; occdepth/models/flosp_depth/flosp_depth.py:201-257:
  * `Mlp(1, C, C)` of the scaled pixel size -> `SELayer(C)`):
  *   gate[i][c] = sigmoid(We relu(Wr (W2 relu(w1 s_i + b1) + b2) + br) + be),   i = 0 .. images-1

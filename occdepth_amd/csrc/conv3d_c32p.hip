@@ -481,7 +481,10 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_kernel(const SlideP s
 //   * Z = 64, 96, ... (round 5, `ZH`: BASELINE configs[4] is 512 x 512 x 64): a workgroup owns a 32-column z tile and stages
 //     its z halo like K2s does -- rows of 32 + 2 D entries, the neighbouring tile's data or zeros outside the volume --
 //     38.1 KB at D = 1, 48.4 KB at D = 2; at D = 3 the 14 x 38 entries (59.6 KB) do not fit beside the two weight images
-//     (53.1 KB left), so dilation-3 launches of Z > 32 volumes stay on the exact-fp32 K2s.
+//     (53.1 KB left) and every cheaper row format conflicts on the 16-lane groups of ds_read_b128 (a 96-byte entry needs an
+//     odd number of 16-byte slots), so the dilation-3 form works on y tiles of SIX rows (`TYV` = 6: 12 x 38 entries = 51.1 KB;
+//     waves 6 and 7 stage and synchronise but own no output row -- 3/4 of the matrix-pipe rate, still well ahead of the
+//     exact-fp32 K2s: 5.x against 7.8 ms per launch at 512 x 512 x 64).
 // Work per launch 115.96 GFLOP algorithmic = 695.8 GFLOP issued on the bf16 pipe.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -508,12 +511,13 @@ __device__ __forceinline__ void split3_bf16(f32x4 a, f32x4 b, u32x4& hi, u32x4& 
 
 // NRES: residual operands compiled in (0: neither, 1: res1, 2: res1 and res2) -- their prefetch registers (16 per
 // operand) are what the 5 of 7 head launches without residuals do not pay for.
-template <int D, int NRES, bool ZH = false>
+template <int D, int NRES, bool ZH = false, int TYV = kTY>
 __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const SlideP sp) {
+    static_assert(TYV >= 1 && TYV <= kTY, "output rows per y tile: one wave each");
     const PersistP& p = sp.base;
     constexpr int ZW = ZH ? kTZ + 2 * D : kX3ZW;  // entries per y row: the tile + its z halo (ZH), or the tile + the zero entry
     constexpr int ZST = ZH ? ZW : kTZ;            // entries per row that are (re)staged with every slab
-    constexpr int YIN = kTY + 2 * D, ROWS = YIN * ZW;
+    constexpr int YIN = TYV + 2 * D, ROWS = YIN * ZW;
     constexpr int NITEM = YIN * ZST * 2;          // staging items: (y row, z, 8-channel chunk of the 16-channel half)
     constexpr int NLOAD = (NITEM + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
         const int z = li + (kz - 1) * D;
-        abase[kz] = (wave * ZW + (ZH ? z + D : (z >= 0 && z < kTZ) ? z : kTZ)) * kX3RowB + kk * 16;
+        abase[kz] = ((wave < TYV ? wave : 0) * ZW + (ZH ? z + D : (z >= 0 && z < kTZ) ? z : kTZ)) * kX3RowB + kk * 16;
     }
     int z0 = 0;                                    // first column of the segment's z tile (ZH)
     const size_t plane_stride = (size_t)p.Y * p.Z * p.in_cs;
@@ -699,7 +703,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
     }
     auto res_fetch = [&](int b, int yt, int x) {
         if (NRES == 0) return;
-        const int y = min(yt * kTY + wave, p.Y - 1);
+        if (TYV < kTY && wave >= TYV) return;
+        const int y = min(yt * TYV + wave, p.Y - 1);
         const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + z0 + li;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -711,8 +716,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
         }
     };
     auto store2 = [&](int b, int yt, int x) {
-        const int y = yt * kTY + wave;
-        if (y < p.Y) {
+        const int y = yt * TYV + wave;
+        if (y < p.Y && (TYV == kTY || wave < TYV)) {
             const size_t vox = ((size_t)(b * p.X + x) * p.Y + y) * p.Z + z0 + li;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -734,6 +739,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
         }
     };
     auto slab_mma = [&](auto hsel, bool u0, bool u1, bool u2) {
+        if (TYV < kTY && wave >= TYV) return;                 // (a wave without an output row: stages and synchronises only)
         if (u0 && u1 && u2) mma(hsel, T_{}, T_{}, T_{});      // interior plane
         else if (u0 && u1) mma(hsel, T_{}, T_{}, F_{});       // second plane of a run
         else if (u1 && u2) mma(hsel, F_{}, T_{}, T_{});       // second to last
@@ -765,7 +771,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
         z0 = zt * kTZ;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int y = yt * kTY - D + syi[i];
+            const int y = yt * TYV - D + syi[i];
             const int z = z0 + sz[i];
             colok[i] = sdst[i] >= 0 && y >= 0 && y < p.Y && (!ZH || (z >= 0 && z < p.Z));
             coloff[i] = (unsigned)((((size_t)b * p.X * p.Y + (colok[i] ? y : 0)) * p.Z + (colok[i] ? z : 0)) * p.in_cs +
@@ -829,7 +835,7 @@ struct DevState {
     int* counter = nullptr;
     int num_cu = 0;
     bool slide_attr[4] = {};
-    bool slide_x3_attr[4][3][2] = {};
+    bool slide_x3_attr[4][3][3] = {};
     bool attr_done[4] = {};
 };
 DevState g_dev[kMaxDevices];
@@ -905,25 +911,31 @@ int launch_slide(const PersistP& base, hipStream_t st, DevState* ds) {
     return occd::check_launch();
 }
 
-template <int D, int NRES, bool ZH>
-int launch_slide_x3(const PersistP& base, hipStream_t st, DevState* ds) {
-    constexpr int ROWS = (kTY + 2 * D) * (ZH ? kTZ + 2 * D : kX3ZW);
+template <int D, int NRES, bool ZH, int TYV = kTY>
+int launch_slide_x3(const PersistP& base0, hipStream_t st, DevState* ds) {
+    PersistP base = base0;
+    if (TYV != kTY) {                                     // the work list is cut in y tiles of TYV rows
+        base.ytiles = (base.Y + TYV - 1) / TYV;
+        base.tiles_total = base.batch * base.X * base.ytiles * base.ztiles;
+    }
+    constexpr int ROWS = (TYV + 2 * D) * (ZH ? kTZ + 2 * D : kX3ZW);
     constexpr size_t lds = (size_t)2 * kX3WImg * 16 + (size_t)ROWS * kX3RowB + 16 + 128;
     static_assert(lds <= 160 * 1024, "K2s3 LDS budget (Z > 32: D <= 2 only)");
     {
         std::lock_guard<std::mutex> lock(ds->mu);
-        if (!ds->slide_x3_attr[D][NRES][ZH]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_x3_kernel<D, NRES, ZH>),
+        constexpr int VAR = ZH ? (TYV == kTY ? 1 : 2) : 0;
+        if (!ds->slide_x3_attr[D][NRES][VAR]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c32_slide_x3_kernel<D, NRES, ZH, TYV>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return OCCD_ELAUNCH;
-            ds->slide_x3_attr[D][NRES][ZH] = true;
+            ds->slide_x3_attr[D][NRES][VAR] = true;
         }
     }
     SlideP sp;
     const int rc = plan_slide<D>(base, ds, &sp);
     if (rc != OCCD_OK) return rc;
     const int grid = ds->num_cu < sp.total_segs ? ds->num_cu : sp.total_segs;
-    hipLaunchKernelGGL((conv3d_c32_slide_x3_kernel<D, NRES, ZH>), dim3((unsigned)grid), dim3(512), lds, st, sp);
+    hipLaunchKernelGGL((conv3d_c32_slide_x3_kernel<D, NRES, ZH, TYV>), dim3((unsigned)grid), dim3(512), lds, st, sp);
     return occd::check_launch();
 }
 
@@ -1003,14 +1015,14 @@ int try_conv3d_c32_persist(const occd_conv3d_args* a, hipStream_t stream) {
 }
 
 // K2s3: the same launches on the bf16 matrix pipe with the 3-way split (a->wpk = the hi | mid | lo image of
-// occd_pack_weights_bf16x3, float32 tensors).  Same return convention; Z == 32, or Z = 64, 96, ... at dilation 1 / 2 (the
-// z-halo form, see the kernel header; dilation 3 of such volumes returns 0 and the caller falls back to the exact-fp32 K2s);
+// occd_pack_weights_bf16x3, float32 tensors).  Same return convention; Z == 32, or Z = 64, 96, ... through the z-halo form
+// (see the kernel header; dilation 3 of such volumes on six-row y tiles);
 // OCCD_C32X3_SLIDE=0 leaves every split launch to the generic K2b skeleton (A/B).
 int try_conv3d_c32_slide_x3(const occd_conv3d_args* a, hipStream_t stream) {
     static const bool off = !env_flag("OCCD_C32X3_SLIDE", true);
     PersistP p;
     double flops, bytes;
-    if (off || !c32_geometry(a, &p, &flops, &bytes) || (a->Z != kTZ && a->dx > 2)) return 0;
+    if (off || !c32_geometry(a, &p, &flops, &bytes)) return 0;
     if ((a->in_cs & 3) || (a->in_coff & 3)) return 0;
     const int d = a->dx;
     ProfScope prof("conv3d_c32x3", stream, flops, bytes);
@@ -1024,7 +1036,9 @@ int try_conv3d_c32_slide_x3(const occd_conv3d_args* a, hipStream_t stream) {
 #define OCCD_X3_LAUNCH(DD, ZZ) \
     (nres == 0 ? launch_slide_x3<DD, 0, ZZ>(p, stream, ds) : nres == 1 ? launch_slide_x3<DD, 1, ZZ>(p, stream, ds) : launch_slide_x3<DD, 2, ZZ>(p, stream, ds))
     if (a->Z == kTZ) rc = d == 1 ? OCCD_X3_LAUNCH(1, false) : d == 2 ? OCCD_X3_LAUNCH(2, false) : OCCD_X3_LAUNCH(3, false);
-    else rc = d == 1 ? OCCD_X3_LAUNCH(1, true) : OCCD_X3_LAUNCH(2, true);
+    else if (d < 3) rc = d == 1 ? OCCD_X3_LAUNCH(1, true) : OCCD_X3_LAUNCH(2, true);
+    else rc = nres == 0 ? launch_slide_x3<3, 0, true, 6>(p, stream, ds) : nres == 1 ? launch_slide_x3<3, 1, true, 6>(p, stream, ds)
+                                                                                    : launch_slide_x3<3, 2, true, 6>(p, stream, ds);
 #undef OCCD_X3_LAUNCH
     return rc == OCCD_OK ? 1 : rc;
 }

@@ -900,9 +900,12 @@ __global__ void __launch_bounds__(256) stem_conv3x3_kernel(const float* __restri
             const int iy = oy * STRIDE - pad_top + ky;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
+                // unconditional load from a clamped address + select: a load guarded by a run-time condition becomes a
+                // branch with its own s_waitcnt (27 serialised HBM round trips per thread: 153 us for this launch)
                 const int ix = ox * STRIDE - pad_left + kx;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                v[ci * 9 + ky * 3 + kx] = ok ? xb[((size_t)ci * H + iy) * W + ix] : 0.f;
+                const float t = xb[((size_t)ci * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+                v[ci * 9 + ky * 3 + kx] = ok ? t : 0.f;
             }
         }
     for (int c0 = grp * 16; c0 < Cout16; c0 += 64) {

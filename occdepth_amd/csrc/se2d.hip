@@ -169,7 +169,200 @@ __global__ void __launch_bounds__(256) depthnet_gate_kernel(const float* __restr
     gate_matvec(we, be, v0, gate + (size_t)i * C, C, 2); // conv_expand + sigmoid
 }
 
+// ---- squeeze-excite in TRAINING (round 5): forward and backward of geffnet's SqueezeExcite
+//     m = mean_hw(x),  r = swish(Wr m + br),  g = sigmoid(We r + be),  out = x * g
+// as 4 + 4 launches instead of the ~22 of the autograd graph (mean, two 1x1 convolutions with bias on 1x1 maps, swish, sigmoid,
+// broadcast multiply; and backwards: 2 multiplies, ~12 `sum` launches, the convolutions' data / weight / bias gradients, the
+// mean's expand + divide, a gradient add): 55 blocks x that was 726 tiny `aten::sum` launches of the config-2 step alone.
+//   forward : plane_reduce (sum)  ->  occd_se_gate (nblk = 1)  ->  affine (x * g)
+//   backward: plane_reduce (dot: gg = sum_hw gout * x)  ->  se_bwd_reduce  ->  se_bwd_expand  ->  affine (gout * g + gm / S)
+// All reductions run in a fixed order (deterministic).
+constexpr int kSeMaxB = 16;      // images per call (batch x views)
+
+// out[p] = sum_s a[p][s] (* b[p][s]) over the S elements of plane p; TPP threads per plane (64: one wave, 256: the workgroup)
+template <int TPP, bool DOT>
+__global__ void __launch_bounds__(256) plane_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, long planes, long S) {
+    __shared__ float part[4];
+    const int sub = threadIdx.x % TPP;
+    const long p = (long)blockIdx.x * (256 / TPP) + threadIdx.x / TPP;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (p < planes) {
+        const float* pa = a + (size_t)p * S;
+        const float* pb = DOT ? b + (size_t)p * S : nullptr;
+        long i = sub;
+        for (; i + 3 * TPP < S; i += 4 * TPP) {
+            if (DOT) {
+                s0 += pa[i] * pb[i]; s1 += pa[i + TPP] * pb[i + TPP];
+                s2 += pa[i + 2 * TPP] * pb[i + 2 * TPP]; s3 += pa[i + 3 * TPP] * pb[i + 3 * TPP];
+            } else {
+                s0 += pa[i]; s1 += pa[i + TPP]; s2 += pa[i + 2 * TPP]; s3 += pa[i + 3 * TPP];
+            }
+        }
+        for (; i < S; i += TPP) s0 += DOT ? pa[i] * pb[i] : pa[i];
+    }
+    float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (TPP == 64) {
+        if (sub == 0 && p < planes) out[p] = s;
+    } else {
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0 && p < planes) out[p] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+}
+
+struct SeBwdP {
+    const float* gg;      // (B, C)  sum_hw gout * x
+    const float* gate;    // (B, C)
+    const float* sums;    // (B, C)  sum_hw x  (m = sums / S)
+    const float* r;       // (B, Cr) swish(z) from the forward
+    const float* wr;      // (Cr, C)
+    const float* br;      // (Cr)
+    const float* we;      // (C, Cr)
+    float* dz;            // (B, Cr)   out of phase 1
+    float* gbr;           // (Cr)
+    float* gm;            // (B, C)    out of phase 2: d loss / d mean
+    float* gwe;           // (C, Cr)
+    float* gwr;           // (Cr, C)
+    float* gbe;           // (C)
+    int B, C, Cr;
+    float inv_s;
+};
+
+// phase 1: 16 squeeze channels i per workgroup; thread (cl = t / 16, il = t % 16) walks c = cl, cl + 16, ...
+//   gr[b][i] = sum_c ds[b][c] We[c][i],  ds = gg g (1 - g);   z[b][i] = sum_c Wr[i][c] m[b][c] + br[i]
+//   dz[b][i] = gr swish'(z),  swish'(z) = s (1 + z (1 - s)),  s = sigmoid(z);   gbr[i] = sum_b dz[b][i]
+__global__ void __launch_bounds__(256) se_bwd_reduce_kernel(const SeBwdP q) {
+    __shared__ float red[16][16][2];                   // [cl][il][gr | z] of one image at a time
+    const int il = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
+    const bool i_ok = i < q.Cr;
+    const int ic = i_ok ? i : q.Cr - 1;
+    float gbr = 0.f;
+    for (int b = 0; b < q.B; ++b) {
+        const float* gg = q.gg + (size_t)b * q.C;
+        const float* g = q.gate + (size_t)b * q.C;
+        const float* sm = q.sums + (size_t)b * q.C;
+        float a_gr = 0.f, a_z = 0.f;
+        for (int c = cl; c < q.C; c += 16) {
+            const float gv = g[c];
+            a_gr += gg[c] * gv * (1.f - gv) * q.we[(size_t)c * q.Cr + ic];
+            a_z += q.wr[(size_t)ic * q.C + c] * (sm[c] * q.inv_s);
+        }
+        red[cl][il][0] = a_gr;
+        red[cl][il][1] = a_z;
+        __syncthreads();
+        if (cl == 0) {
+            float gr = 0.f, z = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { gr += red[k][il][0]; z += red[k][il][1]; }
+            z += q.br[ic];
+            const float sg = 1.f / (1.f + expf(-z));
+            const float dz = gr * sg * (1.f + z * (1.f - sg));
+            if (i_ok) q.dz[(size_t)b * q.Cr + i] = dz;
+            gbr += dz;
+        }
+        __syncthreads();
+    }
+    if (cl == 0 && i_ok) q.gbr[i] = gbr;
+}
+
+// phase 2: 256 channels c per workgroup
+//   gm[b][c] = sum_i dz[b][i] Wr[i][c];  gWr[i][c] = sum_b dz[b][i] m[b][c];  gbe[c] = sum_b ds[b][c];
+//   gWe[c][i] = sum_b ds[b][c] r[b][i]   (second pass, threads remapped so that a row's i are written by neighbouring lanes)
+__global__ void __launch_bounds__(256) se_bwd_expand_kernel(const SeBwdP q) {
+    extern __shared__ float sh[];                      // dz (B, Cr) | r (B, Cr) | ds (B, 256)
+    float* s_dz = sh;
+    float* s_r = sh + q.B * q.Cr;
+    float* s_ds = s_r + q.B * q.Cr;
+    for (int k = threadIdx.x; k < q.B * q.Cr; k += 256) { s_dz[k] = q.dz[k]; s_r[k] = q.r[k]; }
+    const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
+    const bool c_ok = c < q.C;
+    float m[kSeMaxB], gm[kSeMaxB];
+    float gbe = 0.f;
+#pragma unroll
+    for (int b = 0; b < kSeMaxB; ++b) {
+        m[b] = gm[b] = 0.f;
+        if (b < q.B) {
+            float ds = 0.f;
+            if (c_ok) {
+                const float gv = q.gate[(size_t)b * q.C + c];
+                ds = q.gg[(size_t)b * q.C + c] * gv * (1.f - gv);
+                m[b] = q.sums[(size_t)b * q.C + c] * q.inv_s;
+            }
+            s_ds[b * 256 + threadIdx.x] = ds;
+            gbe += ds;
+        }
+    }
+    __syncthreads();
+    if (c_ok) {
+        for (int i = 0; i < q.Cr; ++i) {
+            const float w = q.wr[(size_t)i * q.C + c];
+            float gw = 0.f;
+#pragma unroll
+            for (int b = 0; b < kSeMaxB; ++b)
+                if (b < q.B) {
+                    const float d = s_dz[b * q.Cr + i];
+                    gm[b] += d * w;
+                    gw += d * m[b];
+                }
+            q.gwr[(size_t)i * q.C + c] = gw;
+        }
+#pragma unroll
+        for (int b = 0; b < kSeMaxB; ++b)
+            if (b < q.B) q.gm[(size_t)b * q.C + c] = gm[b];
+        q.gbe[c] = gbe;
+    }
+    const int nc = min(256, q.C - c0);
+    for (int o = threadIdx.x; o < nc * q.Cr; o += 256) {
+        const int cl = o / q.Cr, i = o - cl * q.Cr;
+        float v = 0.f;
+        for (int b = 0; b < q.B; ++b) v += s_ds[b * 256 + cl] * s_r[b * q.Cr + i];
+        q.gwe[(size_t)(c0 + cl) * q.Cr + i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int occd_plane_reduce(const float* a, const float* b, float* out, int64_t planes, int64_t S, void* stream) {
+    if (a == nullptr || out == nullptr || planes < 1 || S < 1 || planes > 0x7fffffffL * 4) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    occd::ProfScope prof(b != nullptr ? "plane_dot" : "plane_sum", st, (double)planes * S * (b ? 2.0 : 1.0),
+                         4.0 * planes * S * (b ? 2.0 : 1.0));
+    // one wave per plane for small planes (the 1/16 and 1/32 encoder stages), the workgroup for large ones
+    if (S >= 4096) {
+        if (b != nullptr) hipLaunchKernelGGL((plane_reduce_kernel<256, true>), dim3((unsigned)planes), dim3(256), 0, st, a, b, out, (long)planes, (long)S);
+        else hipLaunchKernelGGL((plane_reduce_kernel<256, false>), dim3((unsigned)planes), dim3(256), 0, st, a, b, out, (long)planes, (long)S);
+    } else {
+        const unsigned grid = (unsigned)((planes + 3) / 4);
+        if (b != nullptr) hipLaunchKernelGGL((plane_reduce_kernel<64, true>), dim3(grid), dim3(256), 0, st, a, b, out, (long)planes, (long)S);
+        else hipLaunchKernelGGL((plane_reduce_kernel<64, false>), dim3(grid), dim3(256), 0, st, a, b, out, (long)planes, (long)S);
+    }
+    return occd::check_launch();
+}
+
+extern "C" int occd_se_bwd(const float* gg, const float* gate, const float* sums, const float* r, const float* w_reduce,
+                           const float* b_reduce, const float* w_expand, float* dz_scratch, float* gm, float* gw_reduce,
+                           float* gb_reduce, float* gw_expand, float* gb_expand, int32_t batch, int32_t C, int32_t Cr,
+                           int64_t S, void* stream) {
+    if (!gg || !gate || !sums || !r || !w_reduce || !b_reduce || !w_expand || !dz_scratch || !gm || !gw_reduce || !gb_reduce ||
+        !gw_expand || !gb_expand)
+        return OCCD_EINVAL;
+    if (batch < 1 || batch > kSeMaxB || C < 1 || C > 16384 || Cr < 1 || Cr > 4096 || S < 1) return OCCD_EINVAL;
+    const size_t lds = ((size_t)2 * batch * Cr + (size_t)batch * 256) * sizeof(float);
+    if (lds > 64 * 1024) return OCCD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SeBwdP q{};
+    q.gg = gg; q.gate = gate; q.sums = sums; q.r = r; q.wr = w_reduce; q.br = b_reduce; q.we = w_expand;
+    q.dz = dz_scratch; q.gbr = gb_reduce; q.gm = gm; q.gwe = gw_expand; q.gwr = gw_reduce; q.gbe = gb_expand;
+    q.B = batch; q.C = C; q.Cr = Cr; q.inv_s = (float)(1.0 / (double)S);
+    occd::ProfScope prof("se_bwd", st, 8.0 * batch * C * Cr, 16.0 * C * Cr);
+    hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3((unsigned)((Cr + 15) / 16)), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(se_bwd_expand_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), lds, st, q);
+    return occd::check_launch();
+}
 
 extern "C" int occd_depthnet_gate(const float* sps, const float* intrins, int64_t intr_stride, float factor, const float* w1,
                                   const float* b1, const float* w2, const float* b2, const float* wr, const float* br,

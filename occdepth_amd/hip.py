@@ -245,6 +245,8 @@ EXPORTS = {
                             [c_int64, c_float, c_float, c_void_p]),
     "occd_flosp_sample_bwd": (c_int32, [POINTER(FlospBwdArgs), c_void_p]),
     "occd_stem_conv3x3_nchw": (c_int32, [c_void_p] * 5 + [c_int32] * 10 + [c_void_p]),
+    "occd_plane_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "occd_se_bwd": (c_int32, [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "occd_depthnet_gate": (c_int32, [c_void_p, c_void_p, c_int64, c_float] + [c_void_p] * 9 + [c_int32, c_int32, c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
@@ -786,9 +788,8 @@ def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), p
     if x.buf.dtype != torch.float32 or x.cs % 4 or x.coff % 4:
         return False
     X, Y, Z = x.dims
-    # Z = 32, or (round 5) any multiple of 32 at dilation 1 / 2: the z-halo form of the kernel; dilation 3 of a Z > 32
-    # volume does not fit LDS and stays on the exact-fp32 K2s
-    if Z % 32 or (Z != 32 and d[0] > 2) or tuple(out.dims) != (X, Y, Z):
+    # Z = 32, or (round 5) any multiple of 32: the z-halo form of the kernel (dilation 3 of a Z > 32 volume on six-row y tiles)
+    if Z % 32 or tuple(out.dims) != (X, Y, Z):
         return False
     return x.batch * X * ((Y + 7) // 8) * (Z // 32) >= 512 and x.batch * X * Y * Z * x.cs < 2 ** 32
 
@@ -1576,6 +1577,84 @@ def se_gate(part, plane_size, batch, w_reduce, b_reduce, w_expand, b_expand):
                                _f32(we, "w_expand"), _f32(b_expand.detach().contiguous(), "b_expand"), _f32(r, "r"),
                                _f32(gate, "gate"), batch, C, Cr, part.shape[1], int(plane_size), _stream()), "occd_se_gate")
     return gate
+
+
+def plane_reduce(a, b=None):
+    """(planes,) sums over the trailing plane of `a` ((..., H, W) dense), or of a * b when b is given (occd_plane_reduce)."""
+    a = a if a.is_contiguous() else a.contiguous()
+    S = a.shape[-2] * a.shape[-1]
+    planes = a.numel() // S
+    if b is not None:
+        b = b if b.is_contiguous() else b.contiguous()
+        if b.shape != a.shape:
+            raise RuntimeError("plane_reduce: operands must have the same shape")
+    out = torch.empty(planes, device=a.device, dtype=torch.float32)
+    _check(load().occd_plane_reduce(_f32(a, "a"), _f32(b, "b") if b is not None else None, out.data_ptr(), planes, S, _stream()),
+           "occd_plane_reduce")
+    return out
+
+
+class _SqueezeExciteFn(torch.autograd.Function):
+    """Training: geffnet's SqueezeExcite -- out = x * sigmoid(We swish(Wr mean_hw(x) + br) + be) -- forward and backward on the
+    HIP passes of csrc/se2d.hip (4 + 4 launches instead of the ~22 of the autograd graph; deterministic)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w_reduce, b_reduce, w_expand, b_expand):
+        x = x if x.is_contiguous() else x.contiguous()
+        B, C, H, W = x.shape
+        Cr = w_reduce.shape[0]
+        sums = plane_reduce(x)
+        wr = w_reduce.detach().reshape(Cr, C).contiguous()
+        we = w_expand.detach().reshape(C, Cr).contiguous()
+        br, be = b_reduce.detach().contiguous(), b_expand.detach().contiguous()
+        r = torch.empty((B, Cr), device=x.device, dtype=torch.float32)
+        gate = torch.empty((B, C), device=x.device, dtype=torch.float32)
+        _check(load().occd_se_gate(sums.data_ptr(), _f32(wr, "w_reduce"), _f32(br, "b_reduce"), _f32(we, "w_expand"),
+                                   _f32(be, "b_expand"), r.data_ptr(), gate.data_ptr(), B, C, Cr, 1, H * W, _stream()),
+               "occd_se_gate")
+        out = affine_act(x.view(1, B * C, H, W), gate.view(-1), None, out=torch.empty_like(x).view(1, B * C, H, W))
+        ctx.save_for_backward(x, sums, gate, r, wr, br, we)
+        return out.view(B, C, H, W)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gout):
+        x, sums, gate, r, wr, br, we = ctx.saved_tensors
+        B, C, H, W = x.shape
+        Cr = wr.shape[0]
+        gout = gout.float()
+        gout = gout if gout.is_contiguous() else gout.contiguous()
+        gg = plane_reduce(gout, x)
+        dev = x.device
+        dz = torch.empty((B, Cr), device=dev, dtype=torch.float32)
+        gm = torch.empty((B, C), device=dev, dtype=torch.float32)
+        gwr = torch.empty((Cr, C), device=dev, dtype=torch.float32)
+        gbr = torch.empty(Cr, device=dev, dtype=torch.float32)
+        gwe = torch.empty((C, Cr), device=dev, dtype=torch.float32)
+        gbe = torch.empty(C, device=dev, dtype=torch.float32)
+        _check(load().occd_se_bwd(gg.data_ptr(), gate.data_ptr(), sums.data_ptr(), r.data_ptr(), wr.data_ptr(), br.data_ptr(),
+                                  we.data_ptr(), dz.data_ptr(), gm.data_ptr(), gwr.data_ptr(), gbr.data_ptr(), gwe.data_ptr(),
+                                  gbe.data_ptr(), B, C, Cr, H * W, _stream()), "occd_se_bwd")
+        gm.mul_(1.0 / (H * W))                                     # d loss / d x through the mean: + gm / S on every pixel
+        gx = affine_act(gout.view(1, B * C, H, W), gate.view(-1), gm.view(-1), out=torch.empty_like(x).view(1, B * C, H, W))
+        return gx.view(B, C, H, W), gwr.view(Cr, C, 1, 1), gbr, gwe.view(C, Cr, 1, 1), gbe
+
+
+SE_TRAIN_MAX_IMAGES = 16
+# OCCDEPTH_TRAIN_SE=0 restores the autograd graph of the SE blocks in training (A/B)
+SE_TRAIN = os.environ.get("OCCDEPTH_TRAIN_SE", "1") == "1"
+
+
+def squeeze_excite_autograd_ok(se, x):
+    return (SE_TRAIN and x.is_cuda and x.dim() == 4 and x.shape[0] <= SE_TRAIN_MAX_IMAGES
+            and (x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16)))
+            and se.conv_reduce.bias is not None and se.conv_expand.bias is not None
+            and 2 * x.shape[0] * se.conv_reduce.out_channels * 4 + x.shape[0] * 1024 <= 64 * 1024)
+
+
+def squeeze_excite_autograd(se, x):
+    return _SqueezeExciteFn.apply(x, se.conv_reduce.weight, se.conv_reduce.bias, se.conv_expand.weight, se.conv_expand.bias)
 
 
 def upsample_bilinear_cat(x, skip):

@@ -191,6 +191,8 @@ class SqueezeExcite(nn.Module):
         self.conv_expand = nn.Conv2d(reduced, chs, 1, bias=True)
 
     def forward(self, x):
+        if needs_autograd(self) and hip.squeeze_excite_autograd_ok(self, x):
+            return hip.squeeze_excite_autograd(self, x)        # training on the GPU: 4 + 4 HIP launches (csrc/se2d.hip)
         g = self.conv_expand(self.act1(self.conv_reduce(x.mean((2, 3), keepdim=True))))
         return x * torch.sigmoid(g)
 

@@ -140,8 +140,8 @@ def test_conv3d_bf16x3_reaches_float32_accuracy(hip, name):
         assert float(out.buf[..., cout:].abs().max()) == 0.0
 
 
-# (B, cin, cout, dims, dilation): shapes the sliding-window split kernel K2s3 takes (Z == 32, or Z = 64, 96, ... at dilation
-# 1 / 2; >= 512 (plane, y tile, z tile) units)
+# (B, cin, cout, dims, dilation): shapes the sliding-window split kernel K2s3 takes (Z a multiple of 32; >= 512 (plane, y tile,
+# z tile) units)
 SLIDE_X3_CASES = [
     (1, 32, 32, (16, 256, 32), 1),
     (1, 32, 32, (16, 256, 32), 2),
@@ -150,10 +150,13 @@ SLIDE_X3_CASES = [
     (1, 32, 2, (20, 208, 32), 1),
     (1, 27, 32, (5, 1000, 32), 3),      # X smaller than two dilation steps: runs of a single output plane
     # round 5: Z = 64 / 96 -- the z-halo form (a 32-column z tile + its neighbours' columns), dilation 1 / 2
-    (1, 32, 32, (12, 128, 64), 1),
-    (1, 32, 32, (12, 128, 64), 2),
+    (1, 32, 32, (16, 128, 64), 1),
+    (1, 32, 32, (16, 128, 64), 2),
     (2, 30, 22, (7, 100, 96), 2),       # three z tiles (the middle one has data on both sides), ragged Y / channels, batch 2
-    (1, 29, 32, (6, 72, 96), 1),
+    (1, 29, 32, (20, 72, 96), 1),
+    (1, 32, 32, (16, 128, 64), 3),      # dilation 3 at Z > 32: the six-row y-tile variant (two waves of a workgroup stage only)
+    (2, 30, 22, (7, 100, 96), 3),       # ... Y % 6 != 0, three z tiles, X = 7 (three residue classes, short runs)
+    (1, 32, 32, (4, 1030, 64), 3),      # ... Y = 1030 = 171 tiles of 6 + 4
 ]
 
 
@@ -205,27 +208,6 @@ def test_conv3d_slide_x3_head_kernel(hip, case):
     hip.conv3d_bf16(vx, w3, bpad, cout, (3, 3, 3), o1, dilation=(d,) * 3, padding=(d,) * 3, split3=True)
     hip.conv3d_bf16(vx, w3, bpad, cout, (3, 3, 3), o2, dilation=(d,) * 3, padding=(d,) * 3, split3=True)
     assert torch.equal(o1.buf, o2.buf)
-
-
-def test_conv3d_slide_x3_dilation3_of_tall_volumes_falls_back(hip):
-    """Dilation 3 at Z > 32 does not fit K2s3's LDS budget (14 x 38 slab entries beside the two weight images): the launch is
-    NOT eligible, and a split launch of that geometry lands on the generic split kernel K2b with the same float32-level result."""
-    from occdepth_amd.fused import _pad_bias
-    g = torch.Generator().manual_seed(3)
-    dims = (8, 128, 64)
-    x = torch.randn(1, 32, *dims, generator=g)
-    w = torch.randn(32, 32, 3, 3, 3, generator=g) / (32 * 27) ** 0.5
-    bias = torch.randn(32, generator=g)
-    vx = vox_of(hip, x, torch.float32)
-    out = hip.Vox.empty(1, dims, 32, DEV)
-    assert not hip.c32x3_eligible(vx, 32, (3, 3, 3), out, dilation=(3,) * 3, padding=(3,) * 3)
-    assert hip.c32x3_eligible(vx, 32, (3, 3, 3), out, dilation=(2,) * 3, padding=(2,) * 3)
-    with hip.profile() as prof:
-        hip.conv3d_bf16(vx, hip.pack_weights_bf16(w.to(DEV), split3=True), _pad_bias(bias.to(DEV), 32), 32, (3, 3, 3), out,
-                        dilation=(3,) * 3, padding=(3,) * 3, split3=True)
-    assert not any(k.startswith("conv3d_c32x3") for k in prof.rows), prof.rows.keys()
-    ref = F.conv3d(x.double(), w.double(), bias.double(), padding=3, dilation=3)
-    assert float((out.ncdhw().cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
 def test_conv3d_bf16_output_scatter_phases(hip):

@@ -202,7 +202,9 @@ def test_frustum_sample_backward_is_the_transpose_and_deterministic(hip, geo):
     scale = want.abs().max()
     assert float(scale) > 0
     err = float((got.cpu() - want).abs().max() / scale)
-    assert err < 5e-6, err
+    # the trilinear weights come from float32 sample coordinates (ulp ~1e-5 at ix ~ 150) evaluated by two different
+    # instruction sequences (the kernel's fma contraction vs ATen's): bound = a few coordinate ulps, not the sum's round-off
+    assert err < 3e-5, err
     out = fr.sample()
     lhs = float((out.double().cpu() * gout.double()).sum())
     rhs = float((depth.double() * got.double().cpu()).sum())

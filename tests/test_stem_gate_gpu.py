@@ -115,7 +115,8 @@ def test_depthnet_fused_equals_library_form(hip):
         fd.DEPTHNET_K10 = on
         try:
             with torch.no_grad(), hip.profile() as prof:
-                res[on] = (net(x=x, sweep_intrins=k), {t.split(":")[0] for t in prof.rows})
+                y = net(x=x, sweep_intrins=k)
+            res[on] = (y, {t.split(":")[0] for t in prof.rows})        # (the rows are collected when the profile closes)
         finally:
             fd.DEPTHNET_K10 = saved
     assert {"wino_conv3x3", "depthnet_gate"} <= res[True][1] and "depthnet_gate" not in res[False][1]

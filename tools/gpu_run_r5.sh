@@ -63,7 +63,7 @@ if has smoke; then
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-extras > $O/bench_under_rocprof.json 2> /tmp/prof_bench.err
+  OCCDEPTH_BENCH_ISOLATED=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-extras > $O/bench_under_rocprof.json 2> /tmp/prof_bench.err
   f=$(ls /tmp/prof_bench/*/*kernel_trace.csv | head -1)
   python $R/tools/summarize_trace.py $f $O/steady_state_kernel_stats.csv 5 > /dev/null; head -12 $O/steady_state_kernel_stats.csv | cut -c1-140
 fi
@@ -76,7 +76,7 @@ fi
 if has pmc; then
   for c in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" FETCH_SIZE WRITE_SIZE; do
     n=$(echo $c | cut -d' ' -f1)
-    OCCDEPTH_GRAPH_ALL=0 OCCDEPTH_GRAPH_2D=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras > /tmp/pmcf_$n.log 2>&1
+    OCCDEPTH_BENCH_ISOLATED=0 OCCDEPTH_GRAPH_ALL=0 OCCDEPTH_GRAPH_2D=0 timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras > /tmp/pmcf_$n.log 2>&1
     cp $(ls /tmp/pmcf_$n/*/*counter_collection.csv | head -1) /tmp/pmcf_$n.csv
   done
   python $R/tools/pmc_frame.py /tmp/pmcf_GRBM_GUI_ACTIVE.csv /tmp/pmcf_FETCH_SIZE.csv /tmp/pmcf_WRITE_SIZE.csv > $O/pmc_frame.txt 2>&1; cat $O/pmc_frame.txt | cut -c1-130
