@@ -722,6 +722,8 @@ def _train(args, world, rank, device, dist):
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dist, device)
     loss_value = float(loss.detach())
+    if None in shard._SMALL:
+        shard._SMALL[None].check()                 # a peer-memory exchange that gave up waiting fails the run, loudly
     with hip.profile() as prof:                    # kernel table: ONE eager step after the timed loop (HIP events per launch)
         step()
         torch.cuda.synchronize()
@@ -746,8 +748,9 @@ def _train(args, world, rank, device, dist):
         "config": {"workload": f"BASELINE configs[{3 if args.bf16 else 2}]: training step, SemanticKITTI stereo 370x1220, "
                                "tf_efficientnet_b7_ns, feature 64, flosp_depth + CRP + cascade head, batch 1/GPU",
                    "global_batch": world, "ranks": dist.get_world_size() if dist is not None else 1,
-                   "parallelism": f"dp{world}: SyncBatchNorm (packed all-reduce per layer) + "
-                                  f"{len(buckets.buckets) if buckets else 0} gradient buckets ({buckets.algo if buckets else 'none'})"},
+                   "parallelism": f"dp{world}: SyncBatchNorm (packed all-reduce per layer, " +
+                                  ("peer-memory kernel csrc/ipc_allreduce.hip" if None in shard._SMALL else "process group") +
+                                  f") + {len(buckets.buckets) if buckets else 0} gradient buckets ({buckets.algo if buckets else 'none'})"},
         "train_graph": graphed is not None, "train_graph_error": graph_error,
         "loss": loss_value, "max_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
         "hip_kernels_ms_per_step": {k: v["ms"] for k, v in rows},

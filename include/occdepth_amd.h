@@ -753,6 +753,25 @@ int occd_ssc_confusion(const float* logits, const uint8_t* labels, const uint8_t
                        int64_t batch, int32_t C, int64_t S, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * Small-message all-reduce over peer-mapped device memory (round 5; csrc/ipc_allreduce.hip): the latency-optimal form
+ * of SyncBatchNorm's per-layer exchange of (2C + 1) statistics -- `Trainer(sync_batchnorm=True)`,
+ * occdepth/scripts/train.py:176-206 -- one kernel per call, no library, deterministic (rows summed in rank order).
+ * Set-up (once per process group, host side): every rank creates a mailbox of occd_ipc_mailbox_bytes(world, max_bytes)
+ * bytes (fine-grained device memory, zeroed) and its 64-byte IPC handle, the handles are exchanged by any means
+ * (torch.distributed object collectives), every rank opens its peers' handles.  Call: all ranks issue the same sequence of
+ * occd_ipc_allreduce calls (dtype 0 float32 / 1 float64, count * elem <= max_bytes) on a stream; `mailboxes` is a HOST
+ * array of `world` device pointers, [rank] = the rank's own mailbox; the per-call sequence number lives in the mailbox and
+ * is advanced by the kernel, so a captured launch replays correctly.  The wait is bounded by timeout_ms (<= 0: unbounded):
+ * on expiry the kernel sets *status = 1 (device int, optional), leaves `out` untouched and returns.                  */
+int64_t occd_ipc_mailbox_bytes(int32_t world, int64_t max_bytes);
+int occd_ipc_mailbox_create(int64_t bytes, void** mailbox, void* handle64);
+int occd_ipc_mailbox_open(const void* handle64, void** peer);
+int occd_ipc_mailbox_close(void* peer);
+int occd_ipc_mailbox_free(void* mailbox);
+int occd_ipc_allreduce(const void* in, void* out, int64_t count, int32_t dtype, void* const* mailboxes, int32_t rank,
+                       int32_t world, int64_t max_bytes, int32_t timeout_ms, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * In-library kernel timing (HIP events on the launch stream) used by bench.py
  * for `roofline.achieved`.  occd_prof_enable(1) starts recording one event pair
  * per launch; occd_prof_report() synchronises the recorded events and returns,

@@ -186,7 +186,8 @@ class _BNActFn(torch.autograd.Function):
             if exchange:
                 import torch.distributed as dist
                 hip._check(lib.occd_bn_stats_combine(ctypes.byref(a), packed.data_ptr(), st), "occd_bn_stats_combine")
-                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+                from .shard import packed_all_reduce
+                packed_all_reduce(packed, group)
                 hip._check(lib.occd_bn_finish(packed.data_ptr(), C, *fin, st), "occd_bn_finish")
             else:
                 hip._check(lib.occd_bn_stats_finish(ctypes.byref(a), packed.data_ptr(), *fin, st), "occd_bn_stats_finish")
@@ -257,7 +258,8 @@ class _BNActFn(torch.autograd.Function):
             local = torch.empty(2 * C, device=dev, dtype=torch.float32)
             hip._check(lib.occd_bn_bwd_combine(partial.data_ptr(), a.nblk, C, local.data_ptr(), st), "occd_bn_bwd_combine")
             total = local.clone()
-            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            from .shard import packed_all_reduce
+            packed_all_reduce(total, group)
             hip._check(lib.occd_bn_bwd_finish(local.data_ptr(), total.data_ptr(), C, packed.data_ptr(), vec[0].data_ptr(),
                                               vec[1].data_ptr(), vec[2].data_ptr(), *kp, gw_p, gb_p, st), "occd_bn_bwd_finish")
         else:

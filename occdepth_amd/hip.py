@@ -245,6 +245,13 @@ EXPORTS = {
                             [c_int64, c_float, c_float, c_void_p]),
     "occd_flosp_sample_bwd": (c_int32, [POINTER(FlospBwdArgs), c_void_p]),
     "occd_stem_conv3x3_nchw": (c_int32, [c_void_p] * 5 + [c_int32] * 10 + [c_void_p]),
+    "occd_ipc_mailbox_bytes": (c_int64, [c_int32, c_int64]),
+    "occd_ipc_mailbox_create": (c_int32, [c_int64, POINTER(c_void_p), c_void_p]),
+    "occd_ipc_mailbox_open": (c_int32, [c_void_p, POINTER(c_void_p)]),
+    "occd_ipc_mailbox_close": (c_int32, [c_void_p]),
+    "occd_ipc_mailbox_free": (c_int32, [c_void_p]),
+    "occd_ipc_allreduce": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, POINTER(c_void_p), c_int32, c_int32, c_int64,
+                                     c_int32, c_void_p, c_void_p]),
     "occd_plane_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "occd_se_bwd": (c_int32, [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "occd_depthnet_gate": (c_int32, [c_void_p, c_void_p, c_int64, c_float] + [c_void_p] * 9 + [c_int32, c_int32, c_void_p]),

@@ -245,6 +245,121 @@ def allreduce_confusion(hist, dist=None):
     return hist
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Small-message all-reduce over peer-mapped device memory (csrc/ipc_allreduce.hip): SyncBatchNorm's per-layer packets.
+class SmallAllReduce:
+    """One-kernel, library-free, deterministic all-reduce (SUM) for vectors of up to `max_bytes` among the ranks of `group`
+    on ONE node: every rank owns a mailbox in its HBM, exported through hipIpcGetMemHandle and mapped by all peers once;
+    a call pushes the rank's vector into every mailbox, waits for all flags, sums the rows in rank order (see the kernel
+    file).  532 of these per config-2 training step replace RCCL launches of ~45 us each that sit on one dependency chain.
+    Capturable into a hipGraph.  The IPC handles travel through `dist.all_gather_object` on `group` (any backend).
+
+    `timeout_ms` bounds the in-kernel wait (a lost peer surfaces as `RuntimeError` at the next `check()` instead of a hung
+    GPU); `check()` costs a device-to-host read and is meant for tests / the end of a step, not for every call."""
+
+    MAX_WORLD = 16
+
+    def __init__(self, dist, group=None, max_bytes=64 * 1024, device=None, timeout_ms=20000):
+        import ctypes
+        from . import hip
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if self.world > self.MAX_WORLD:
+            raise RuntimeError(f"SmallAllReduce: world size {self.world} > {self.MAX_WORLD}")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_bytes = int(max_bytes)
+        self.timeout_ms = int(timeout_ms)
+        lib = hip.load()
+        self._lib = lib
+        nbytes = lib.occd_ipc_mailbox_bytes(self.world, self.max_bytes)
+        if nbytes <= 0:
+            raise RuntimeError("occd_ipc_mailbox_bytes failed")
+        with torch.cuda.device(self.device):
+            own = ctypes.c_void_p()
+            handle = (ctypes.c_ubyte * 64)()
+            hip._check(lib.occd_ipc_mailbox_create(nbytes, ctypes.byref(own), handle), "occd_ipc_mailbox_create")
+            self._own = own.value
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle), group=group)
+            ptrs = (ctypes.c_void_p * self.world)()
+            self._opened = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs[r] = self._own
+                    continue
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+                peer = ctypes.c_void_p()
+                hip._check(lib.occd_ipc_mailbox_open(buf, ctypes.byref(peer)), "occd_ipc_mailbox_open")
+                ptrs[r] = peer.value
+                self._opened.append(peer.value)
+            self._ptrs = ptrs
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        dist.barrier(group=group)                 # every mailbox is mapped everywhere before the first push
+
+    def all_reduce_(self, t):
+        """In-place SUM over the ranks of a contiguous float32 / float64 GPU tensor of <= max_bytes (asynchronous on the
+        current stream)."""
+        from . import hip
+        if not self.usable(t):
+            raise RuntimeError("SmallAllReduce: tensor must be a contiguous float32 / float64 tensor of <= max_bytes on the group's device")
+        hip._check(self._lib.occd_ipc_allreduce(t.data_ptr(), t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
+                                                self._ptrs, self.rank, self.world, self.max_bytes, self.timeout_ms,
+                                                self.status.data_ptr(), hip._stream()), "occd_ipc_allreduce")
+        return t
+
+    def usable(self, t):
+        return (t.is_cuda and t.device == self.device and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+                and 0 < t.numel() * t.element_size() <= self.max_bytes)
+
+    def check(self):
+        """Raise if any exchange since the last check gave up waiting (synchronises the stream)."""
+        if int(self.status.item()) != 0:
+            self.status.zero_()
+            raise RuntimeError("SmallAllReduce: a peer did not arrive within the time budget")
+
+    def close(self):
+        if getattr(self, "_own", None) is None:
+            return
+        torch.cuda.synchronize(self.device)
+        try:
+            self.dist.barrier(group=self.group)   # nobody is still pushing into a mailbox that is about to go away
+        except Exception:
+            pass
+        for p in self._opened:
+            self._lib.occd_ipc_mailbox_close(p)
+        self._lib.occd_ipc_mailbox_free(self._own)
+        self._own, self._opened = None, []
+
+
+_SMALL = {}            # process group (None = default) -> SmallAllReduce
+
+
+def install_small_all_reduce(dist, group=None, **kw):
+    """Route SyncBatchNorm's packed exchanges of `group` through `SmallAllReduce` (returns it).  Ranks must call this
+    collectively; `uninstall_small_all_reduce` restores the backend's all_reduce."""
+    sm = SmallAllReduce(dist, group, **kw)
+    _SMALL[group] = sm
+    return sm
+
+
+def uninstall_small_all_reduce(group=None):
+    sm = _SMALL.pop(group, None)
+    if sm is not None:
+        sm.close()
+
+
+def packed_all_reduce(t, group=None):
+    """SUM all-reduce of a SyncBatchNorm statistics packet: the peer-memory kernel when one is installed for the group and
+    takes the tensor, the process group's all_reduce otherwise."""
+    sm = _SMALL.get(group)
+    if sm is not None and sm.usable(t):
+        return sm.all_reduce_(t)
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def _group_active(group):
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
@@ -291,7 +406,7 @@ class _SyncBNFn(torch.autograd.Function):
         m64 = mean_l.double()
         packed = torch.cat([m64 * n_l, (var_l.double() + m64 * m64) * n_l, m64.new_full((1,), n_l)])
         if _group_active(group):
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+            packed_all_reduce(packed, group)
         n = packed[2 * C]
         mean64 = packed[:C] / n
         var64 = (packed[C:2 * C] / n - mean64 * mean64).clamp_min(0.0)
@@ -329,7 +444,7 @@ class _SyncBNFn(torch.autograd.Function):
             gb = sum_dy.clone() if weight is not None else None           # the gradient buckets average them like any other
         packed = torch.cat([sum_dy, sum_dy_xmu])
         if _group_active(ctx.group):
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
+            packed_all_reduce(packed, ctx.group)
         if fused:
             gx = torch.batch_norm_backward_elemt(gy, x, mean, invstd, weight, packed[:C], packed[C:],
                                                  n.to(torch.int32).reshape(1))
@@ -413,6 +528,16 @@ def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, forc
         model = convert_sync_batchnorm(model)
         if hasattr(model, "invalidate_graphs"):
             model.invalidate_graphs()     # module surgery: a captured eval graph would keep replaying the old layers
+        # SyncBatchNorm's per-layer packets over peer-mapped memory instead of the backend's all_reduce (one node, <= 16
+        # ranks, GPU tensors): 532 latency-bound exchanges per config-2 step.  OCCDEPTH_SYNCBN_IPC=0 keeps RCCL.
+        import os
+        if (os.environ.get("OCCDEPTH_SYNCBN_IPC", "1") == "1" and torch.cuda.is_available() and None not in _SMALL
+                and dist.get_world_size() <= SmallAllReduce.MAX_WORLD and next(model.parameters()).is_cuda):
+            try:
+                install_small_all_reduce(dist)
+            except Exception as e:        # (no IPC support on this box / driver: the process group's all_reduce keeps working)
+                import warnings
+                warnings.warn(f"occdepth_amd: peer-memory all-reduce unavailable ({e!r}); SyncBatchNorm uses the process group")
     buckets = GradBuckets(model.parameters(), dist, bucket_bytes, algo=algo, force=force)
     buckets._restore_force = was_forced if force else None
     return model, buckets

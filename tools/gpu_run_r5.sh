@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 GPU session driver (everything lands under gpurun_out/<tag>/; summaries are copied to profiles/ by hand).
 #   gpurun -- 'bash tools/gpu_run_r5.sh <tag> <section> [<section> ...]'
-# sections: newtests alltests smoke bench benchq config5 train trainpw exact frame prof proftrain pmc
+# sections: newtests alltests smoke bench benchq config5 train trainpw ipc exact frame prof proftrain pmc
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
@@ -45,6 +45,12 @@ if has train; then
 fi
 if has trainpw; then
   OCCDEPTH_TRAIN_PW_GEMM=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_pw.json 2> $O/train_bf16_pw.err; line $O/train_bf16_pw.json
+fi
+if has ipc; then
+  timeout 600 python -m pytest -q -m gpu -x tests/test_ipc_allreduce_gpu.py -s > $O/pytest_ipc.txt 2>&1; tail -12 $O/pytest_ipc.txt | cut -c1-400
+  OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_forced_ipc.json 2> $O/train_bf16_forced_ipc.err; line $O/train_bf16_forced_ipc.json
+  OCCDEPTH_SYNCBN_IPC=0 OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_forced_rccl.json 2> $O/train_bf16_forced_rccl.err; line $O/train_bf16_forced_rccl.json
+  grep -o '"parallelism": "[^"]*"' $O/train_bf16_forced_ipc.json $O/train_bf16_forced_rccl.json
 fi
 if has exact; then
   OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_exact_fp32.json 2> $O/bench_exact_fp32.err; line $O/bench_exact_fp32.json
