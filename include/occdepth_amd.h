@@ -632,6 +632,20 @@ int occd_bn_fwd_small(const occd_bn_args* a, double* packed, float eps, float mo
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
                       float* av, float* bv, void* stream);
 int occd_bn_bwd_small(const occd_bn_args* a, float* gw, float* gb, void* stream);
+/* Round 5: the one-launch small layer with SYNCHRONISED statistics (SyncBatchNorm over the ranks of one node): workgroup c
+ * exchanges channel c's packet with the peers' workgroups c inside the launch, through peer-mapped CHANNEL mailboxes
+ * (occd_bn_xchg_mailbox_bytes(world, cmax) bytes each, created / opened with the occd_ipc_mailbox_* calls; records of
+ * {flag, 3 doubles} per (slot, rank, channel); the protocol, the determinism and the bounded wait of occd_ipc_allreduce).
+ * mailboxes: HOST array of `world` device pointers, [rank] = own; C <= cmax.  Forward: `packed` receives the TOTALS over the
+ * ranks [sum n mean, sum (M2 + n mean^2), sum n]; backward: packed_fwd = that vector, gw / gb stay this rank's sums.
+ * Every rank must be able to schedule its workgroups while the peers' wait (one GPU per rank).                        */
+int64_t occd_bn_xchg_mailbox_bytes(int32_t world, int32_t cmax);
+int occd_bn_fwd_small_xchg(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* mean, float* invstd, float* av, float* bv, void* const* mailboxes, int32_t rank,
+                           int32_t world, int32_t cmax, int32_t timeout_ms, int32_t* status, void* stream);
+int occd_bn_bwd_small_xchg(const occd_bn_args* a, const double* packed_fwd, float* gw, float* gb, void* const* mailboxes,
+                           int32_t rank, int32_t world, int32_t cmax, int32_t timeout_ms, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * K2b / K8b: the same convolution forward (data gradient: the forward on dL/dy with flipped weights) and weight

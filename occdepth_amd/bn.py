@@ -173,8 +173,17 @@ class _BNActFn(torch.autograd.Function):
         if res is not None:
             a.res, a.res_cs = res.data_ptr(), geo.like(x, res, "res")
         a.act, a.slope, a.res_first = act, float(slope), 1 if res_first else 0
-        small = (not exchange) and bool(lib.occd_bn_small_ok(ctypes.byref(a)))
-        if small:
+        small = bool(lib.occd_bn_small_ok(ctypes.byref(a)))
+        xc = None
+        if small and exchange:
+            # synchronised small layer: still ONE launch -- the ranks' statistics are exchanged inside it through the
+            # peer-mapped channel mailboxes (shard.SmallAllReduce) when they are installed for the group
+            from .shard import channel_exchange
+            xc = channel_exchange(group, C, dev)
+            small = xc is not None
+        if small and xc is not None:
+            hip._check(lib.occd_bn_fwd_small_xchg(ctypes.byref(a), packed.data_ptr(), *fin, *xc, st), "occd_bn_fwd_small_xchg")
+        elif small:
             hip._check(lib.occd_bn_fwd_small(ctypes.byref(a), packed.data_ptr(), *fin, st), "occd_bn_fwd_small")
         else:
             a.nblk = lib.occd_bn_blocks(ctypes.byref(a))
@@ -244,7 +253,15 @@ class _BNActFn(torch.autograd.Function):
         a.cw = min(hip.round_up(C, 8), gcs) if geo.layout == 0 else 0
         if gres is not None:
             a.out2, a.out2_cs = gres.data_ptr(), (geo.like(x, gres, "gres") if geo.layout == 0 else 0)
-        small = (not exchange) and bool(lib.occd_bn_small_ok(ctypes.byref(a)))
+        small = bool(lib.occd_bn_small_ok(ctypes.byref(a)))
+        if small and exchange:
+            from .shard import channel_exchange
+            xc = channel_exchange(group, C, dev)
+            if xc is not None:
+                hip._check(lib.occd_bn_bwd_small_xchg(ctypes.byref(a), packed.data_ptr(), gw_p, gb_p, *xc, st),
+                           "occd_bn_bwd_small_xchg")
+                return
+            small = False
         if small:
             hip._check(lib.occd_bn_bwd_small(ctypes.byref(a), gw_p, gb_p, st), "occd_bn_bwd_small")
             return

@@ -577,13 +577,82 @@ __global__ void bn_bwd_combine_finish_kernel(const float* partial, int nblk, int
 // ---- small NCHW tensors (the EfficientNet stages at 1/8 ... 1/32 resolution: a few thousand pixels per plane, up to 3840
 // channels, ~220 BatchNorm calls per step): the whole layer in ONE launch, one workgroup per channel -- reduction pass,
 // per-channel finish in the workgroup, apply pass (the plane comes back from L2).  Local statistics only.
-template <int MODE>
+// XCHG (round 5, SyncBatchNorm over several ranks of one node): the per-channel statistics are exchanged INSIDE this launch
+// through peer-mapped mailboxes (the protocol of csrc/ipc_allreduce.hip, one 32-byte record {flag, 3 doubles} per (slot, rank,
+// channel)): thread 0 .. world-1 of workgroup c push the channel's packet into every rank's mailbox and wait for every rank's
+// packet of the same sequence number, the sums are taken in rank order -- so a synchronised small layer stays ONE launch per
+// direction (the separate path is statistics + combine + all-reduce + finish + apply: five).  Workgroups of one launch are
+// independent of each other; across ranks workgroup c only waits for the peers' workgroup c, which never waits for anything
+// this rank has not already pushed (pushes precede waits), so the exchange cannot deadlock as long as every rank's
+// workgroups get scheduled.  The sequence number is read from the mailbox header by every workgroup and advanced by the last
+// one to finish (stream order separates launches): captured launches replay correctly.
+struct BnXchg {
+    unsigned char* mbox[16];     // peer-mapped channel mailboxes, [rank] = own
+    int rank, world;
+    long slot_bytes, row_bytes;  // slot = world rows, row = cmax records of 32 bytes
+    long long timeout_ticks;     // wall_clock64 ticks (100 MHz); <= 0: unbounded
+    int* status;                 // device int, set to 1 when a wait gives up
+};
+constexpr int kXchgHeader = 256;  // bytes: [0] u64 sequence counter, [1] u64 finished-workgroup count, [2] u64 error
+
+// sums over the ranks of (v0, v1, v2) for channel c; returns false on timeout.  Called by ALL threads of the workgroup.
+__device__ __forceinline__ bool xchg_channel(const BnXchg& q, int c, double v0, double v1, double v2, double (&tot)[3],
+                                             double* sh) {
+    unsigned long long* hdr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank]);
+    const unsigned long long seq = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const int slot = (int)(seq & 1);
+    const int t = threadIdx.x;
+    bool ok = true;
+    if (t < q.world) {
+        unsigned char* rec = q.mbox[t] + kXchgHeader + (size_t)slot * q.slot_bytes + (size_t)q.rank * q.row_bytes + (size_t)c * 32;
+        double* d = reinterpret_cast<double*>(rec + 8);
+        d[0] = v0; d[1] = v1; d[2] = v2;
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned char* mine = q.mbox[q.rank] + kXchgHeader + (size_t)slot * q.slot_bytes + (size_t)t * q.row_bytes + (size_t)c * 32;
+        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(mine);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) { ok = false; break; }
+        }
+        __threadfence_system();
+        const double* src = reinterpret_cast<const double*>(mine + 8);
+        sh[t * 3 + 0] = ok ? __builtin_nontemporal_load(src) : 0.0;
+        sh[t * 3 + 1] = ok ? __builtin_nontemporal_load(src + 1) : 0.0;
+        sh[t * 3 + 2] = ok ? __builtin_nontemporal_load(src + 2) : 0.0;
+        if (!ok && q.status != nullptr) *q.status = 1;
+    }
+    __syncthreads();
+    tot[0] = tot[1] = tot[2] = 0.0;
+    for (int r = 0; r < q.world; ++r) {          // rank order: the same sum, bit for bit, on every rank
+        tot[0] += sh[r * 3]; tot[1] += sh[r * 3 + 1]; tot[2] += sh[r * 3 + 2];
+    }
+    return ok;
+}
+
+// the last workgroup of a launch advances the sequence counter (all workgroups read it at their start; the next launch on
+// the stream starts after this one has drained)
+__device__ __forceinline__ void xchg_finish(const BnXchg& q) {
+    if (threadIdx.x != 0) return;
+    unsigned long long* hdr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank]);
+    __threadfence();
+    if (atomicAdd(hdr + 1, 1ULL) == (unsigned long long)gridDim.x - 1) {
+        hdr[1] = 0;
+        __threadfence();
+        atomicAdd(hdr, 1ULL);
+    }
+}
+
+template <int MODE, bool XCHG = false>
 __global__ void __launch_bounds__(256) bn_small_planes_kernel(const BnP p, float eps, float momentum, const float* gamma,
                                                               const float* beta, float* running_mean, float* running_var,
                                                               long* num_batches, double* packed, float* mean_o,
-                                                              float* invstd_o, float* a_o, float* b_o, float* gw, float* gb) {
+                                                              float* invstd_o, float* a_o, float* b_o, float* gw, float* gb,
+                                                              const BnXchg xq) {
     __shared__ float red[4];
     __shared__ float coef[4];
+    __shared__ double xsh[16 * 3];
     const int tid = threadIdx.x, c = blockIdx.x;
     const float* x = (const float*)p.x;
     const float* gy = (const float*)p.gy;
@@ -626,30 +695,49 @@ __global__ void __launch_bounds__(256) bn_small_planes_kernel(const BnP p, float
     }
     const float t1 = block_sum(a1, red, tid);
     const float t2 = block_sum(a2, red, tid);
+    double xt[3] = {0.0, 0.0, 0.0};
+    if (XCHG) {
+        if (MODE == 0) {
+            // this rank's packet in Chan's form (shard.py): [n mean, M2 + n mean^2, n], centred on the rank's own mean
+            const double mu_l = (double)x0 + (double)t1 / n;
+            const double m2_l = (double)t2 - (double)t1 * (double)t1 / n;
+            xchg_channel(xq, c, n * mu_l, m2_l + n * mu_l * mu_l, n, xt, xsh);
+        } else {
+            xchg_channel(xq, c, (double)t1, (double)t2, 0.0, xt, xsh);
+        }
+    }
     if (tid == 0) {
         if (MODE == 0) {
-            const double mu = (double)x0 + (double)t1 / n;
+            double mu = (double)x0 + (double)t1 / n;
             double var = ((double)t2 - (double)t1 * (double)t1 / n) / n;
+            double n_tot = n;
+            if (XCHG) {
+                n_tot = xt[2];
+                mu = xt[0] / n_tot;
+                var = xt[1] / n_tot - mu * mu;
+            }
             if (var < 0.0) var = 0.0;
             const float isd = (float)(1.0 / sqrt(var + (double)eps));
             const float sc = (gamma != nullptr ? gamma[c] : 1.f) * isd;
             const float sh = (beta != nullptr ? beta[c] : 0.f) - (float)mu * sc;
-            packed[c] = n * mu;
-            packed[p.C + c] = n * (var + mu * mu);
+            packed[c] = XCHG ? xt[0] : n * mu;
+            packed[p.C + c] = XCHG ? xt[1] : n * (var + mu * mu);
             if (c == 0) {
-                packed[2 * p.C] = n;
+                packed[2 * p.C] = n_tot;
                 if (num_batches != nullptr) *num_batches += 1;
             }
             mean_o[c] = (float)mu; invstd_o[c] = isd; a_o[c] = sc; b_o[c] = sh;
             if (running_mean != nullptr) {
-                const double unbiased = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+                const double unbiased = var * (n_tot / (n_tot > 1.0 ? n_tot - 1.0 : 1.0));
                 running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
                 running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
             }
             coef[0] = sc; coef[1] = sh;
         } else {
-            const float nf = (float)n;
-            const float mg = t1 / nf, mgx = t2 / nf;
+            // (synchronised: the batch statistics span the ranks -- totals over n_total = packed_fwd[2C], handed over in
+            //  `packed`; the parameter gradients stay this rank's sums, the gradient buckets average them)
+            const float nf = XCHG ? (float)packed[2 * p.C] : (float)n;
+            const float mg = (XCHG ? (float)xt[0] : t1) / nf, mgx = (XCHG ? (float)xt[1] : t2) / nf;
             coef[0] = a;
             coef[1] = -is * mgx * a;
             coef[2] = (m * is * mgx - mg) * a;
@@ -704,6 +792,7 @@ __global__ void __launch_bounds__(256) bn_small_planes_kernel(const BnP p, float
             }
         }
     }
+    if (XCHG) xchg_finish(xq);
 }
 
 int fill(const occd_bn_args* a, BnP& p, bool need_partial) {
@@ -944,7 +1033,69 @@ int occd_bn_fwd_small(const occd_bn_args* a, double* packed, float eps, float mo
     occd::ProfScope prof("bn_fwd_small", (hipStream_t)stream, 0.0, 4.0 * elems * (3 + (a->res != nullptr)));
     hipLaunchKernelGGL((bn_small_planes_kernel<0>), dim3(a->C), dim3(256), 0, (hipStream_t)stream, p, eps, momentum, gamma, beta,
                        running_mean, running_var, (long*)num_batches_tracked, packed, mean, invstd, av, bv, (float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, BnXchg{});
+    return occd::check_launch();
+}
+
+/* The same launches with the statistics of `world` ranks exchanged inside the kernel (see BnXchg): mailboxes = HOST array of
+ * `world` peer-mapped channel mailboxes of occd_bn_xchg_mailbox_bytes(world, cmax) bytes (created / opened with the
+ * occd_ipc_mailbox_* calls), [rank] = own.  Forward: `packed` receives the TOTALS [sum n mean, sum (M2 + n mean^2), sum n];
+ * backward: `packed_fwd` = that vector (n_total), gw / gb stay this rank's sums.                                      */
+static int fill_xchg(BnXchg& x, void* const* mailboxes, int32_t rank, int32_t world, int32_t cmax, int32_t C, int32_t timeout_ms,
+                     int32_t* status) {
+    if (mailboxes == nullptr || world < 1 || world > 16 || rank < 0 || rank >= world || cmax < C) return OCCD_EINVAL;
+    for (int r = 0; r < world; ++r) {
+        if (mailboxes[r] == nullptr) return OCCD_EINVAL;
+        x.mbox[r] = static_cast<unsigned char*>(mailboxes[r]);
+    }
+    x.rank = rank; x.world = world;
+    x.row_bytes = (long)cmax * 32;
+    x.slot_bytes = (long)world * x.row_bytes;
+    x.timeout_ticks = timeout_ms > 0 ? (long long)timeout_ms * 100000LL : 0;
+    x.status = status;
+    return OCCD_OK;
+}
+
+int64_t occd_bn_xchg_mailbox_bytes(int32_t world, int32_t cmax) {
+    if (world < 1 || world > 16 || cmax < 1) return OCCD_EINVAL;
+    return kXchgHeader + 2 * (int64_t)world * cmax * 32;
+}
+
+int occd_bn_fwd_small_xchg(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* mean, float* invstd, float* av, float* bv, void* const* mailboxes, int32_t rank, int32_t world,
+                           int32_t cmax, int32_t timeout_ms, int32_t* status, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, false);
+    if (rc != OCCD_OK) return rc;
+    if (a->layout != 1 || !a->out || !packed || !mean || !invstd || !av || !bv ||
+        (running_mean == nullptr) != (running_var == nullptr))
+        return OCCD_EINVAL;
+    BnXchg x{};
+    if (fill_xchg(x, mailboxes, rank, world, cmax, a->C, timeout_ms, status) != OCCD_OK) return OCCD_EINVAL;
+    const double elems = (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_fwd_small_xchg", (hipStream_t)stream, 0.0, 4.0 * elems * (3 + (a->res != nullptr)));
+    hipLaunchKernelGGL((bn_small_planes_kernel<0, true>), dim3(a->C), dim3(256), 0, (hipStream_t)stream, p, eps, momentum, gamma,
+                       beta, running_mean, running_var, (long*)num_batches_tracked, packed, mean, invstd, av, bv, (float*)nullptr,
+                       (float*)nullptr, x);
+    return occd::check_launch();
+}
+
+int occd_bn_bwd_small_xchg(const occd_bn_args* a, const double* packed_fwd, float* gw, float* gb, void* const* mailboxes,
+                           int32_t rank, int32_t world, int32_t cmax, int32_t timeout_ms, int32_t* status, void* stream) {
+    BnP p{};
+    const int rc = fill(a, p, false);
+    if (rc != OCCD_OK) return rc;
+    if (a->layout != 1 || !a->out || !a->gy || !a->a || !a->b || !a->mean || !a->invstd || !packed_fwd) return OCCD_EINVAL;
+    BnXchg x{};
+    if (fill_xchg(x, mailboxes, rank, world, cmax, a->C, timeout_ms, status) != OCCD_OK) return OCCD_EINVAL;
+    const double elems = (double)a->batch * a->C * a->S;
+    occd::ProfScope prof("bn_bwd_small_xchg", (hipStream_t)stream, 0.0,
+                         4.0 * elems * (5 + 2 * (a->y != nullptr) + (a->out2 != nullptr)));
+    hipLaunchKernelGGL((bn_small_planes_kernel<1, true>), dim3(a->C), dim3(256), 0, (hipStream_t)stream, p, 0.f, 0.f,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (long*)nullptr,
+                       const_cast<double*>(packed_fwd), (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, gw,
+                       gb, x);
     return occd::check_launch();
 }
 
@@ -958,7 +1109,7 @@ int occd_bn_bwd_small(const occd_bn_args* a, float* gw, float* gb, void* stream)
                          4.0 * elems * (5 + 2 * (a->y != nullptr) + (a->out2 != nullptr)));
     hipLaunchKernelGGL((bn_small_planes_kernel<1>), dim3(a->C), dim3(256), 0, (hipStream_t)stream, p, 0.f, 0.f,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (long*)nullptr,
-                       (double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, gw, gb);
+                       (double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, gw, gb, BnXchg{});
     return occd::check_launch();
 }
 

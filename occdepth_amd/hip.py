@@ -224,6 +224,11 @@ EXPORTS = {
     "occd_bn_small_ok": (c_int32, [POINTER(BnArgs)]),
     "occd_bn_fwd_small": (c_int32, [POINTER(BnArgs), c_void_p, c_float, c_float] + [c_void_p] * 9 + [c_void_p]),
     "occd_bn_bwd_small": (c_int32, [POINTER(BnArgs), c_void_p, c_void_p, c_void_p]),
+    "occd_bn_xchg_mailbox_bytes": (c_int64, [c_int32, c_int32]),
+    "occd_bn_fwd_small_xchg": (c_int32, [POINTER(BnArgs), c_void_p, c_float, c_float] + [c_void_p] * 9 +
+                               [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "occd_bn_bwd_small_xchg": (c_int32, [POINTER(BnArgs), c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_int32,
+                                         c_int32, c_int32, c_void_p, c_void_p]),
     "occd_ssc_stats_len": (c_int64, [c_int32, c_int32]),
     "occd_ssc_loss_stats_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64,
                                           c_int32, c_int32, c_void_p]),

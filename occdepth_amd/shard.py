@@ -259,6 +259,8 @@ class SmallAllReduce:
 
     MAX_WORLD = 16
 
+    CHANNELS = 4096          # channel capacity of the second mailbox (SyncBatchNorm's in-kernel exchange, csrc/bn.hip BnXchg)
+
     def __init__(self, dist, group=None, max_bytes=64 * 1024, device=None, timeout_ms=20000):
         import ctypes
         from . import hip
@@ -273,27 +275,35 @@ class SmallAllReduce:
         lib = hip.load()
         self._lib = lib
         nbytes = lib.occd_ipc_mailbox_bytes(self.world, self.max_bytes)
-        if nbytes <= 0:
+        cbytes = lib.occd_bn_xchg_mailbox_bytes(self.world, self.CHANNELS)
+        if nbytes <= 0 or cbytes <= 0:
             raise RuntimeError("occd_ipc_mailbox_bytes failed")
-        with torch.cuda.device(self.device):
+        self._owned, self._opened = [], []
+
+        def mapped(nb):
+            """One mailbox per rank of `nb` bytes, mapped everywhere -> ctypes array of `world` pointers ([rank] = own)."""
             own = ctypes.c_void_p()
             handle = (ctypes.c_ubyte * 64)()
-            hip._check(lib.occd_ipc_mailbox_create(nbytes, ctypes.byref(own), handle), "occd_ipc_mailbox_create")
-            self._own = own.value
+            hip._check(lib.occd_ipc_mailbox_create(nb, ctypes.byref(own), handle), "occd_ipc_mailbox_create")
+            self._owned.append(own.value)
             handles = [None] * self.world
             dist.all_gather_object(handles, bytes(handle), group=group)
             ptrs = (ctypes.c_void_p * self.world)()
-            self._opened = []
             for r, h in enumerate(handles):
                 if r == self.rank:
-                    ptrs[r] = self._own
+                    ptrs[r] = own.value
                     continue
                 buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
                 peer = ctypes.c_void_p()
                 hip._check(lib.occd_ipc_mailbox_open(buf, ctypes.byref(peer)), "occd_ipc_mailbox_open")
                 ptrs[r] = peer.value
                 self._opened.append(peer.value)
-            self._ptrs = ptrs
+            return ptrs
+
+        with torch.cuda.device(self.device):
+            self._ptrs = mapped(nbytes)            # vectors (occd_ipc_allreduce)
+            self._cptrs = mapped(cbytes)           # per-channel records (occd_bn_*_small_xchg)
+            self._own = self._owned[0]
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         dist.barrier(group=group)                 # every mailbox is mapped everywhere before the first push
 
@@ -328,8 +338,15 @@ class SmallAllReduce:
             pass
         for p in self._opened:
             self._lib.occd_ipc_mailbox_close(p)
-        self._lib.occd_ipc_mailbox_free(self._own)
-        self._own, self._opened = None, []
+        for p in self._owned:
+            self._lib.occd_ipc_mailbox_free(p)
+        self._own, self._opened, self._owned = None, [], []
+
+    def channel_args(self, C, device):
+        """(mailboxes, rank, world, cmax, timeout_ms, status) for occd_bn_*_small_xchg, or None when the layer does not fit."""
+        if C > self.CHANNELS or torch.device(device) != self.device or getattr(self, "_own", None) is None:
+            return None
+        return (self._cptrs, self.rank, self.world, self.CHANNELS, self.timeout_ms, self.status.data_ptr())
 
 
 _SMALL = {}            # process group (None = default) -> SmallAllReduce
@@ -347,6 +364,13 @@ def uninstall_small_all_reduce(group=None):
     sm = _SMALL.pop(group, None)
     if sm is not None:
         sm.close()
+
+
+def channel_exchange(group, C, device):
+    """Arguments of the in-kernel per-channel exchange (one-launch synchronised small BatchNorm layers) when a peer-memory
+    exchange is installed for `group`, else None."""
+    sm = _SMALL.get(group)
+    return None if sm is None else sm.channel_args(C, device)
 
 
 def packed_all_reduce(t, group=None):

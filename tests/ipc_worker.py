@@ -66,33 +66,41 @@ def main():
     sm.check()
     res["graph_replays_exact"] = bool(ok)
 
-    # (3) SyncBatchNorm (K13 passes) forward + backward through the peer-memory exchange == through gloo's all_reduce
+    # (3) SyncBatchNorm (K13 passes) forward + backward through the peer-memory exchange == through gloo's all_reduce:
+    #     a layer that takes the separate passes + the vector exchange (48 channels), a SMALL layer whose exchange happens inside
+    #     its single launch (96 channels x 360 pixels: occd_bn_*_small_xchg), and a large one (separate passes)
     from occdepth_amd import bn as _bn
-    torch.manual_seed(5)
-    layer = shard.SyncBatchNorm(48).to(dev).train()
-    with torch.no_grad():
-        layer.weight.uniform_(0.5, 1.5)
-        layer.bias.normal_()
-    gx = torch.Generator().manual_seed(77 + rank)
-    x0 = torch.randn(2, 48, 9, 20, generator=gx).to(dev)
-    gy = torch.randn(2, 48, 9, 20, generator=gx).to(dev)
-    outs = {}
-    for mode in ("ipc", "gloo"):
-        if mode == "gloo":
-            shard._SMALL.pop(None)                   # (keep `sm` alive: re-installed below)
-        lay = shard.SyncBatchNorm(48).to(dev).train()
-        lay.load_state_dict(layer.state_dict())
-        x = x0.clone().requires_grad_(True)
-        t0 = time.perf_counter()
-        y = lay(x)
-        y.backward(gy)
-        torch.cuda.synchronize()
-        outs[mode] = (y.detach().cpu(), x.grad.cpu(), lay.weight.grad.cpu(), lay.running_mean.cpu(), lay.running_var.cpu(),
-                      time.perf_counter() - t0)
-        if mode == "gloo":
-            shard._SMALL[None] = sm
     res["syncbn_used_kernels"] = bool(_bn.ENABLED)
-    res["syncbn_max_diff"] = max(float((a.double() - b.double()).abs().max()) for a, b in zip(outs["ipc"][:5], outs["gloo"][:5]))
+    res["syncbn_max_diff"] = 0.0
+    res["syncbn_tags"] = {}
+    for ci, (C, H, W) in enumerate([(48, 9, 20), (96, 9, 20), (96, 80, 80)]):
+        torch.manual_seed(5 + ci)
+        layer = shard.SyncBatchNorm(C).to(dev).train()
+        with torch.no_grad():
+            layer.weight.uniform_(0.5, 1.5)
+            layer.bias.normal_()
+        gx = torch.Generator().manual_seed(77 + rank + 10 * ci)
+        x0 = (torch.randn(2, C, H, W, generator=gx) * (1.0 + rank) + 0.3 * rank).to(dev)
+        gy = torch.randn(2, C, H, W, generator=gx).to(dev)
+        outs = {}
+        for mode in ("ipc", "gloo"):
+            if mode == "gloo":
+                shard._SMALL.pop(None)               # (keep `sm` alive: re-installed below)
+            lay = shard.SyncBatchNorm(C).to(dev).train()
+            lay.load_state_dict(layer.state_dict())
+            x = x0.clone().requires_grad_(True)
+            with hip.profile() as prof:
+                y = torch.relu(lay(x))
+                y.backward(gy)
+                torch.cuda.synchronize()
+            outs[mode] = (y.detach().cpu(), x.grad.cpu(), lay.weight.grad.cpu(), lay.bias.grad.cpu(), lay.running_mean.cpu(),
+                          lay.running_var.cpu())
+            if mode == "gloo":
+                shard._SMALL[None] = sm
+            else:
+                res["syncbn_tags"][f"{C}x{H}x{W}"] = sorted({k.split(":")[0] for k in prof.rows if k.startswith(("bn_", "ipc_"))})
+        d = max(float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)) for a, b in zip(outs["ipc"], outs["gloo"]))
+        res["syncbn_max_diff"] = max(res["syncbn_max_diff"], d)
     sm.check()
 
     # (4) latency of one exchange (2C + 1 doubles, C = 384), stream-timed over 200 back-to-back calls
@@ -113,7 +121,7 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print("IPC_RESULT " + json.dumps(res), flush=True)
-    bad = worst != 0.0 or not ok or res["syncbn_max_diff"] > 1e-6
+    bad = worst != 0.0 or not ok or res["syncbn_max_diff"] > 2e-6
     sys.exit(1 if bad else 0)
 
 

@@ -54,7 +54,11 @@ def test_small_all_reduce_processes_sharing_one_gpu(world):
         results.append(json.loads(line[-1][len("IPC_RESULT "):]))
     for r in results:
         assert r["world"] == world and r["series_max_abs_diff"] == 0.0 and r["graph_replays_exact"]
-        assert r["syncbn_max_diff"] <= 1e-6
+        assert r["syncbn_max_diff"] <= 2e-6
+        tags = r["syncbn_tags"]
+        assert "ipc_allreduce" in tags["48x9x20"] and "ipc_allreduce" in tags["96x80x80"], tags
+        # the small layer: ONE launch per direction, the exchange inside it
+        assert tags["96x9x20"] == ["bn_bwd_small_xchg", "bn_fwd_small_xchg"], tags
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"ipc_allreduce_world{world}.json"), "w") as f:
         json.dump(results, f)
