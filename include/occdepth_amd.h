@@ -634,8 +634,9 @@ int occd_bn_fwd_small(const occd_bn_args* a, double* packed, float eps, float mo
 int occd_bn_bwd_small(const occd_bn_args* a, float* gw, float* gb, void* stream);
 /* Round 5: the one-launch small layer with SYNCHRONISED statistics (SyncBatchNorm over the ranks of one node): workgroup c
  * exchanges channel c's packet with the peers' workgroups c inside the launch, through peer-mapped CHANNEL mailboxes
- * (occd_bn_xchg_mailbox_bytes(world, cmax) bytes each, created / opened with the occd_ipc_mailbox_* calls; records of
- * {flag, 3 doubles} per (slot, rank, channel); the protocol, the determinism and the bounded wait of occd_ipc_allreduce).
+ * (occd_bn_xchg_mailbox_bytes(world, cmax) bytes each, created / opened with the occd_ipc_mailbox_* calls; one 64-byte
+ * record of six self-validating {data : 32, sequence : 32} words per (slot, rank, channel); the fence-free protocol, the
+ * determinism and the bounded wait of occd_ipc_allreduce).
  * mailboxes: HOST array of `world` device pointers, [rank] = own; C <= cmax.  Forward: `packed` receives the TOTALS over the
  * ranks [sum n mean, sum (M2 + n mean^2), sum n]; backward: packed_fwd = that vector, gw / gb stay this rank's sums.
  * Every rank must be able to schedule its workgroups while the peers' wait (one GPU per rank).                        */
@@ -775,7 +776,8 @@ int occd_ssc_confusion(const float* logits, const uint8_t* labels, const uint8_t
  * (torch.distributed object collectives), every rank opens its peers' handles.  Call: all ranks issue the same sequence of
  * occd_ipc_allreduce calls (dtype 0 float32 / 1 float64, count * elem <= max_bytes) on a stream; `mailboxes` is a HOST
  * array of `world` device pointers, [rank] = the rank's own mailbox; the per-call sequence number lives in the mailbox and
- * is advanced by the kernel, so a captured launch replays correctly.  The wait is bounded by timeout_ms (<= 0: unbounded):
+ * is advanced by the kernel, so a captured launch replays correctly.  Wire format: every 32-bit half of the payload in its
+ * own 8-byte word {data, sequence}, one system-scope atomic store / load each -- no fence anywhere.  The wait is bounded by timeout_ms (<= 0: unbounded):
  * on expiry the kernel sets *status = 1 (device int, optional), leaves `out` untouched and returns.                  */
 int64_t occd_ipc_mailbox_bytes(int32_t world, int64_t max_bytes);
 int occd_ipc_mailbox_create(int64_t bytes, void** mailbox, void* handle64);

@@ -229,8 +229,12 @@ class _BNActFn(torch.autograd.Function):
             cut = (lambda t: t[sl] if t is not None and G > 1 else t)
             _BNActFn._backward_group(cut(x), cut(gy), cut(y), cut(gx), cut(gres) if (has_res and res_first and act != 0) else None,
                                      vec[g], packed[g], k[g], want_w, act, slope, res_first, group, exchange)
-        gw = k[:, 3].sum(0).to(weight.dtype) if want_w else None           # parameter gradients: sum over the groups
-        gb = k[:, 4].sum(0).to(weight.dtype) if want_w else None
+        gw = gb = None
+        if want_w:
+            # parameter gradients: sum over the view groups -- no launch at all for one group, ONE for both vectors otherwise
+            # (these were 2 x 266 `aten::sum` launches of a config-2 step, most of them over a single row)
+            wb = k[0, 3:5] if G == 1 else k[:, 3:5].sum(0)
+            gw, gb = wb[0].to(weight.dtype), wb[1].to(weight.dtype)
         return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod

@@ -578,69 +578,82 @@ __global__ void bn_bwd_combine_finish_kernel(const float* partial, int nblk, int
 // channels, ~220 BatchNorm calls per step): the whole layer in ONE launch, one workgroup per channel -- reduction pass,
 // per-channel finish in the workgroup, apply pass (the plane comes back from L2).  Local statistics only.
 // XCHG (round 5, SyncBatchNorm over several ranks of one node): the per-channel statistics are exchanged INSIDE this launch
-// through peer-mapped mailboxes (the protocol of csrc/ipc_allreduce.hip, one 32-byte record {flag, 3 doubles} per (slot, rank,
-// channel)): thread 0 .. world-1 of workgroup c push the channel's packet into every rank's mailbox and wait for every rank's
-// packet of the same sequence number, the sums are taken in rank order -- so a synchronised small layer stays ONE launch per
-// direction (the separate path is statistics + combine + all-reduce + finish + apply: five).  Workgroups of one launch are
-// independent of each other; across ranks workgroup c only waits for the peers' workgroup c, which never waits for anything
-// this rank has not already pushed (pushes precede waits), so the exchange cannot deadlock as long as every rank's
-// workgroups get scheduled.  The sequence number is read from the mailbox header by every workgroup and advanced by the last
-// one to finish (stream order separates launches): captured launches replay correctly.
+// through peer-mapped mailboxes (the fence-free "LL" protocol of csrc/ipc_allreduce.hip: every 32-bit half of the channel's
+// three doubles travels in its own 8-byte word {data, sequence}, one 64-byte record per (slot, rank, channel)): thread 0 ..
+// world-1 of workgroup c push the channel's packet into every rank's mailbox and poll every rank's packet of the same
+// sequence number; the sums are taken in rank order -- so a synchronised small layer stays ONE launch per direction (the
+// separate path is statistics + combine + all-reduce + finish + apply: five).  Workgroups of one launch are independent of
+// each other; across ranks workgroup c only waits for the peers' workgroup c, which never waits for anything this rank has
+// not already pushed (pushes precede polls), so the exchange cannot deadlock as long as every rank's workgroups get
+// scheduled.  The sequence number is read from the mailbox header by every workgroup and advanced by the last one to finish
+// (stream order separates launches): captured launches replay correctly.  No fence anywhere: the first version bracketed the
+// exchange with two system-scope fences per workgroup (an L2 write-back + invalidate each) and the config-2 step went from
+// 128 ms (five-launch path over RCCL) to 172 ms.
 struct BnXchg {
     unsigned char* mbox[16];     // peer-mapped channel mailboxes, [rank] = own
     int rank, world;
-    long slot_bytes, row_bytes;  // slot = world rows, row = cmax records of 32 bytes
+    long slot_bytes, row_bytes;  // slot = world rows, row = cmax records of 64 bytes
     long long timeout_ticks;     // wall_clock64 ticks (100 MHz); <= 0: unbounded
-    int* status;                 // device int, set to 1 when a wait gives up
+    int* status;                 // device int, set to 1 when a poll gives up
 };
-constexpr int kXchgHeader = 256;  // bytes: [0] u64 sequence counter, [1] u64 finished-workgroup count, [2] u64 error
+constexpr int kXchgHeader = 256;  // bytes: [0] u64 sequence counter, [1] u64 finished-workgroup count
+constexpr int kXchgRec = 64;      // bytes per (slot, rank, channel) record: 6 LL words + pad
 
-// sums over the ranks of (v0, v1, v2) for channel c; returns false on timeout.  Called by ALL threads of the workgroup.
-__device__ __forceinline__ bool xchg_channel(const BnXchg& q, int c, double v0, double v1, double v2, double (&tot)[3],
+// sums over the ranks of (v0, v1, v2) for channel c.  Called by ALL threads of the workgroup.
+__device__ __forceinline__ void xchg_channel(const BnXchg& q, int c, double v0, double v1, double v2, double (&tot)[3],
                                              double* sh) {
-    unsigned long long* hdr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank]);
+    const unsigned long long* hdr = reinterpret_cast<const unsigned long long*>(q.mbox[q.rank]);
     const unsigned long long seq = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const unsigned seq32 = (unsigned)seq;
     const int slot = (int)(seq & 1);
     const int t = threadIdx.x;
-    bool ok = true;
     if (t < q.world) {
-        unsigned char* rec = q.mbox[t] + kXchgHeader + (size_t)slot * q.slot_bytes + (size_t)q.rank * q.row_bytes + (size_t)c * 32;
-        double* d = reinterpret_cast<double*>(rec + 8);
-        d[0] = v0; d[1] = v1; d[2] = v2;
-        __threadfence_system();
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned char* mine = q.mbox[q.rank] + kXchgHeader + (size_t)slot * q.slot_bytes + (size_t)t * q.row_bytes + (size_t)c * 32;
-        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(mine);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            __builtin_amdgcn_s_sleep(1);
-            if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) { ok = false; break; }
+        const size_t rec_off = kXchgHeader + (size_t)slot * q.slot_bytes + (size_t)c * kXchgRec;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(q.mbox[t] + rec_off + (size_t)q.rank * q.row_bytes);
+        const double v[3] = {v0, v1, v2};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v[j]);
+            __hip_atomic_store(dst + 2 * j, (bits & 0xffffffffULL) | ((unsigned long long)seq32 << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 2 * j + 1, (bits >> 32) | ((unsigned long long)seq32 << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        __threadfence_system();
-        const double* src = reinterpret_cast<const double*>(mine + 8);
-        sh[t * 3 + 0] = ok ? __builtin_nontemporal_load(src) : 0.0;
-        sh[t * 3 + 1] = ok ? __builtin_nontemporal_load(src + 1) : 0.0;
-        sh[t * 3 + 2] = ok ? __builtin_nontemporal_load(src + 2) : 0.0;
-        if (!ok && q.status != nullptr) *q.status = 1;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(q.mbox[q.rank] + rec_off + (size_t)t * q.row_bytes);
+        bool fail = false;
+        const long long t0 = wall_clock64();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            unsigned half[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned long long w = __hip_atomic_load(src + 2 * j + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                while ((unsigned)(w >> 32) != seq32 && !fail) {
+                    __builtin_amdgcn_s_sleep(1);
+                    w = __hip_atomic_load(src + 2 * j + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) fail = true;
+                }
+                half[h] = (unsigned)w;
+            }
+            sh[t * 3 + j] = fail ? 0.0 : __longlong_as_double((long long)(((unsigned long long)half[1] << 32) | half[0]));
+        }
+        if (fail && q.status != nullptr) *q.status = 1;
     }
     __syncthreads();
     tot[0] = tot[1] = tot[2] = 0.0;
     for (int r = 0; r < q.world; ++r) {          // rank order: the same sum, bit for bit, on every rank
         tot[0] += sh[r * 3]; tot[1] += sh[r * 3 + 1]; tot[2] += sh[r * 3 + 2];
     }
-    return ok;
 }
 
 // the last workgroup of a launch advances the sequence counter (all workgroups read it at their start; the next launch on
-// the stream starts after this one has drained)
+// the stream starts after this one has drained).  Atomics only: nothing another workgroup reads is ordered by this.
 __device__ __forceinline__ void xchg_finish(const BnXchg& q) {
     if (threadIdx.x != 0) return;
     unsigned long long* hdr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank]);
-    __threadfence();
-    if (atomicAdd(hdr + 1, 1ULL) == (unsigned long long)gridDim.x - 1) {
-        hdr[1] = 0;
-        __threadfence();
-        atomicAdd(hdr, 1ULL);
+    if (__hip_atomic_fetch_add(hdr + 1, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1) {
+        __hip_atomic_store(hdr + 1, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(hdr, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1049,7 +1062,7 @@ static int fill_xchg(BnXchg& x, void* const* mailboxes, int32_t rank, int32_t wo
         x.mbox[r] = static_cast<unsigned char*>(mailboxes[r]);
     }
     x.rank = rank; x.world = world;
-    x.row_bytes = (long)cmax * 32;
+    x.row_bytes = (long)cmax * kXchgRec;
     x.slot_bytes = (long)world * x.row_bytes;
     x.timeout_ticks = timeout_ms > 0 ? (long long)timeout_ms * 100000LL : 0;
     x.status = status;
@@ -1058,7 +1071,7 @@ static int fill_xchg(BnXchg& x, void* const* mailboxes, int32_t rank, int32_t wo
 
 int64_t occd_bn_xchg_mailbox_bytes(int32_t world, int32_t cmax) {
     if (world < 1 || world > 16 || cmax < 1) return OCCD_EINVAL;
-    return kXchgHeader + 2 * (int64_t)world * cmax * 32;
+    return kXchgHeader + 2 * (int64_t)world * cmax * kXchgRec;
 }
 
 int occd_bn_fwd_small_xchg(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,

@@ -6,25 +6,29 @@
 // launch + completion latency (~45 us inside a captured step: +16 % on one rank, 0.72 - 0.78 weak-scaling efficiency
 // budgeted for 8 GPUs).  This is the latency-optimal exchange for that regime, one kernel per call, no library in the path:
 //
-//   every rank owns a MAILBOX in its own HBM -- 2 slots x world x (flag, payload) -- allocated fine-grained (coherent across
-//   XCDs and over xGMI while a kernel runs) and exported with hipIpcGetMemHandle; every rank maps all peers' mailboxes
-//   (hipIpcOpenMemHandle) once, at set-up.  all_reduce(seq):
-//     1. push : write my vector into slot seq & 1, row `rank`, of EVERY mailbox (N - 1 remote writes over the N - 1 direct
-//               xGMI links of a fully connected node + one local), system-scope release, then store seq into the row's flag;
-//     2. wait : spin (system-scope acquire loads, bounded by a wall-clock budget) until all N flags of my slot hold seq;
-//     3. sum  : out = sum over rows in RANK ORDER (every rank adds the same numbers in the same order: bit-identical results
-//               on all ranks, run to run -- RCCL's ring / tree order is neither).
+//   every rank owns a MAILBOX in its own HBM -- 2 slots x world rows -- allocated fine-grained (coherent across XCDs and
+//   over xGMI while a kernel runs) and exported with hipIpcGetMemHandle; every rank maps all peers' mailboxes
+//   (hipIpcOpenMemHandle) once, at set-up.  The wire format is the "LL" one of the collective libraries: every 32-bit half of
+//   the payload travels in its own 8-byte word {data : 32, sequence : 32}, written with ONE system-scope atomic store and
+//   polled with system-scope atomic loads -- a word is either entirely there or not, so NO FENCE is needed anywhere
+//   (a system-scope release / acquire pair costs an L2 write-back + invalidate, several microseconds each; round 5 measured
+//   8.1 us per exchange with fences, and a one-launch SyncBatchNorm layer with two fences per workgroup was 35 % SLOWER than
+//   the five-launch path).  all_reduce(seq):
+//     1. push : write my vector, word by word, into slot seq & 1, row `rank`, of EVERY mailbox (N - 1 remote writes over the
+//               N - 1 direct xGMI links of a fully connected node + one local);
+//     2. pull : every thread polls the words of ITS elements in all N rows of my mailbox until they carry seq (bounded by a
+//               wall-clock budget) and sums them in RANK ORDER (every rank adds the same numbers in the same order:
+//               bit-identical results on all ranks, run to run -- RCCL's ring / tree order is neither).
 //   Two slots suffice: a rank can only start seq + 2 (which reuses the slot) after completing seq + 1, i.e. after every peer
 //   has pushed seq + 1, which a peer does only after finishing its reads of seq.  The sequence number lives in DEVICE memory
 //   and is advanced by the kernel itself, so a launch captured in a hipGraph replays correctly (no host-side argument
 //   changes between replays); all ranks issue the same sequence of calls, as with any collective.
-// Cost: one launch, the push of N x bytes per rank and one xGMI round trip of latency -- no proxy thread, no host
-// involvement, no second kernel.  world <= 16, count * elem <= the slot's payload capacity.
+// Cost: one launch, the push of 2 x N x bytes per rank and one xGMI round trip of latency -- no proxy thread, no host
+// involvement, no fence, no second kernel.  world <= 16, count * elem <= max_bytes.
 //
 // Hardware facts used (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): per-XCD L2s are
 // not coherent with each other or with another device's writes for ordinary (coarse-grained) allocations, so the mailbox is
-// hipDeviceMallocFinegrained memory and every flag access is a system-scope atomic; payload stores are followed by a
-// system-scope fence before the flag store, payload loads preceded by one after the flag loads.
+// hipDeviceMallocFinegrained memory and every access to it is a system-scope atomic (sc0 sc1: past the caches).
 #include <cstring>
 
 #include "common.h"
@@ -40,73 +44,64 @@ struct IpcP {
     void* out;
     int count, elem;                            // elements, bytes per element (4: float, 8: double)
     int rank, world;
-    long slot_bytes, row_bytes;                 // one slot = world rows; one row = 64-byte flag line + payload
-    long long timeout_ticks;                    // wall_clock64 ticks (100 MHz) the wait may take; <= 0: unbounded
+    long slot_bytes, row_bytes;                 // one slot = world rows; one row = 2 x max_bytes (8-byte word per 32-bit half)
+    long long timeout_ticks;                    // wall_clock64 ticks (100 MHz) a poll may take; <= 0: unbounded
     int* status;                                // device int: set to 1 on timeout (sticky), untouched otherwise
 };
 
-__device__ __forceinline__ unsigned char* ipc_row(const IpcP& q, int peer, int slot, int row) {
-    return q.mbox[peer] + kIpcHeader + (size_t)slot * q.slot_bytes + (size_t)row * q.row_bytes;
+__device__ __forceinline__ unsigned long long* ipc_row(const IpcP& q, int peer, int slot, int row) {
+    return reinterpret_cast<unsigned long long*>(q.mbox[peer] + kIpcHeader + (size_t)slot * q.slot_bytes + (size_t)row * q.row_bytes);
+}
+
+// poll one LL word until it carries `seq32`; returns its data half (0 after a timeout, `fail` set)
+__device__ __forceinline__ unsigned ipc_poll(const unsigned long long* w, unsigned seq32, long long timeout_ticks, bool& fail) {
+    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(v >> 32) == seq32) return (unsigned)v;
+    const long long t0 = wall_clock64();
+    while (true) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(v >> 32) == seq32) return (unsigned)v;
+        if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) { fail = true; return 0u; }
+    }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) ipc_allreduce_kernel(const IpcP q) {
-    __shared__ unsigned long long s_seq;
-    __shared__ int s_fail;
+    constexpr int WPE = sizeof(T) / 4;          // LL words per element
     unsigned long long* my_hdr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank]);
-    if (threadIdx.x == 0) {
-        s_seq = my_hdr[0] + 1;                  // (only this kernel, one launch at a time on the stream, touches the counter)
-        s_fail = 0;
-    }
-    __syncthreads();
-    const unsigned long long seq = s_seq;
+    // (only this kernel, one launch at a time on the stream, touches the counter: a plain uniform load)
+    const unsigned long long seq = __hip_atomic_load(my_hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const unsigned seq32 = (unsigned)seq;
     const int slot = (int)(seq & 1);
-    const T* in = static_cast<const T*>(q.in);
-    // ---- 1. push my vector into row `rank` of every mailbox
-    for (int p = 0; p < q.world; ++p) {
-        T* dst = reinterpret_cast<T*>(ipc_row(q, p, slot, q.rank) + 64);
-        for (int i = threadIdx.x; i < q.count; i += 256) dst[i] = in[i];
+    const unsigned* in32 = static_cast<const unsigned*>(q.in);
+    const int nwords = q.count * WPE;
+    // ---- 1. push my vector, one self-validating word per 32-bit half, into row `rank` of every mailbox
+    for (int w = threadIdx.x; w < nwords; w += 256) {
+        const unsigned long long word = (unsigned long long)in32[w] | ((unsigned long long)seq32 << 32);
+        for (int p = 0; p < q.world; ++p)
+            __hip_atomic_store(ipc_row(q, p, slot, q.rank) + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();                     // payload visible system-wide before any flag
-    __syncthreads();
-    if (threadIdx.x < q.world) {
-        unsigned long long* flag = reinterpret_cast<unsigned long long*>(ipc_row(q, threadIdx.x, slot, q.rank));
-        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // ---- 2. wait for every rank's flag in MY mailbox
-    if (threadIdx.x < q.world) {
-        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(ipc_row(q, q.rank, slot, threadIdx.x));
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            __builtin_amdgcn_s_sleep(2);
-            if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) {
-                s_fail = 1;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __threadfence_system();                     // acquire for the payload reads of all threads
-    // ---- 3. sum the rows in rank order
+    // ---- 2. pull: the words of my elements from all rows of MY mailbox, summed in rank order
     T* out = static_cast<T*>(q.out);
-    if (s_fail == 0) {
-        for (int i = threadIdx.x; i < q.count; i += 256) {
-            T acc = 0;
-            for (int r = 0; r < q.world; ++r) {
-                const T* src = reinterpret_cast<const T*>(ipc_row(q, q.rank, slot, r) + 64);
-                acc += __builtin_nontemporal_load(src + i);
+    bool fail = false;
+    for (int i = threadIdx.x; i < q.count; i += 256) {
+        T acc = 0;
+        for (int r = 0; r < q.world; ++r) {
+            const unsigned long long* src = ipc_row(q, q.rank, slot, r) + (size_t)i * WPE;
+            if (WPE == 1) {
+                acc += (T)__uint_as_float(ipc_poll(src, seq32, q.timeout_ticks, fail));
+            } else {
+                const unsigned lo = ipc_poll(src, seq32, q.timeout_ticks, fail);
+                const unsigned hi = ipc_poll(src + 1, seq32, q.timeout_ticks, fail);
+                acc += (T)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
             }
-            out[i] = acc;
         }
+        if (!fail) out[i] = acc;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        my_hdr[0] = seq;
-        if (s_fail != 0) {
-            my_hdr[1] = seq;                    // which exchange gave up
-            if (q.status != nullptr) *q.status = 1;
-        }
-    }
+    if (fail && q.status != nullptr) *q.status = 1;
+    __syncthreads();                            // every thread has read its words of this sequence number
+    if (threadIdx.x == 0) __hip_atomic_store(my_hdr, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void ipc_zero_kernel(unsigned long long* p, long n) {
@@ -121,7 +116,7 @@ extern "C" {
 // Bytes a mailbox needs for `world` ranks exchanging vectors of up to `max_bytes` each (64-byte aligned rows).
 int64_t occd_ipc_mailbox_bytes(int32_t world, int64_t max_bytes) {
     if (world < 1 || world > kIpcMaxWorld || max_bytes < 8) return OCCD_EINVAL;
-    const int64_t row = 64 + ((max_bytes + 63) / 64) * 64;
+    const int64_t row = 2 * (((max_bytes + 63) / 64) * 64);          // LL: an 8-byte word per 32-bit half of the payload
     return kIpcHeader + 2 * (int64_t)world * row;
 }
 
@@ -191,7 +186,7 @@ int occd_ipc_allreduce(const void* in, void* out, int64_t count, int32_t dtype, 
         q.mbox[p] = static_cast<unsigned char*>(mailboxes[p]);
     }
     q.in = in; q.out = out; q.count = (int)count; q.elem = elem; q.rank = rank; q.world = world;
-    q.row_bytes = 64 + ((max_bytes + 63) / 64) * 64;
+    q.row_bytes = 2 * (((max_bytes + 63) / 64) * 64);
     q.slot_bytes = (long)world * q.row_bytes;
     q.timeout_ticks = timeout_ms > 0 ? (long long)timeout_ms * 100000LL : 0;      // wall_clock64: 100 MHz
     q.status = status;

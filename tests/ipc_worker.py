@@ -22,6 +22,8 @@ def main():
     from occdepth_amd import hip, shard
     hip.load()
     sm = shard.install_small_all_reduce(dist, max_bytes=64 * 1024, timeout_ms=8000)
+    if world == 1:
+        shard.FORCE_COLLECTIVES = True               # a single rank still runs every exchange (against itself)
     res = {"rank": rank, "world": world}
 
     def vec(n, dtype, r, k):

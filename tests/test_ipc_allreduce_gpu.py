@@ -69,5 +69,5 @@ def test_small_all_reduce_argument_checks():
     from occdepth_amd import hip
     lib = hip.load()
     assert lib.occd_ipc_mailbox_bytes(0, 1024) < 0 and lib.occd_ipc_mailbox_bytes(17, 1024) < 0
-    assert lib.occd_ipc_mailbox_bytes(2, 1024) == 256 + 2 * 2 * (64 + 1024)
+    assert lib.occd_ipc_mailbox_bytes(2, 1024) == 256 + 2 * 2 * (2 * 1024)        # LL: 8-byte word per 32-bit half
     assert lib.occd_ipc_allreduce(None, None, 1, 0, None, 0, 1, 1024, 0, None, None) == -1
