@@ -585,30 +585,34 @@ __global__ void bn_bwd_combine_finish_kernel(const float* partial, int nblk, int
 // separate path is statistics + combine + all-reduce + finish + apply: five).  Workgroups of one launch are independent of
 // each other; across ranks workgroup c only waits for the peers' workgroup c, which never waits for anything this rank has
 // not already pushed (pushes precede polls), so the exchange cannot deadlock as long as every rank's workgroups get
-// scheduled.  The sequence number is read from the mailbox header by every workgroup and advanced by the last one to finish
-// (stream order separates launches): captured launches replay correctly.  No fence anywhere: the first version bracketed the
-// exchange with two system-scope fences per workgroup (an L2 write-back + invalidate each) and the config-2 step went from
-// 128 ms (five-launch path over RCCL) to 172 ms.
+// scheduled.  Every CHANNEL keeps its own sequence counter in the owner's mailbox (read and advanced by workgroup c alone;
+// all ranks run the same layers, so the per-channel sequences agree across ranks; stream order separates launches), so
+// captured launches replay correctly and no two workgroups ever touch the same word.  No fence and no shared atomic
+// anywhere -- measured on the forced single-rank config-2 step (105 ms without exchanges, 125 ms on the five-launch path over
+// RCCL): two system-scope fences per workgroup (an L2 write-back + invalidate each) 172 ms; a launch-wide sequence number
+// advanced by the last workgroup through one atomic counter (thousands of atomics on one address per launch) 135 ms.
 struct BnXchg {
     unsigned char* mbox[16];     // peer-mapped channel mailboxes, [rank] = own
     int rank, world;
     long slot_bytes, row_bytes;  // slot = world rows, row = cmax records of 64 bytes
+    long slots_off;              // byte offset of slot 0 = kXchgHeader + 8 cmax
     long long timeout_ticks;     // wall_clock64 ticks (100 MHz); <= 0: unbounded
     int* status;                 // device int, set to 1 when a poll gives up
 };
-constexpr int kXchgHeader = 256;  // bytes: [0] u64 sequence counter, [1] u64 finished-workgroup count
+constexpr int kXchgHeader = 256;  // bytes (reserved); then cmax u64 per-channel sequence counters; then the two slots
 constexpr int kXchgRec = 64;      // bytes per (slot, rank, channel) record: 6 LL words + pad
 
 // sums over the ranks of (v0, v1, v2) for channel c.  Called by ALL threads of the workgroup.
 __device__ __forceinline__ void xchg_channel(const BnXchg& q, int c, double v0, double v1, double v2, double (&tot)[3],
                                              double* sh) {
-    const unsigned long long* hdr = reinterpret_cast<const unsigned long long*>(q.mbox[q.rank]);
-    const unsigned long long seq = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    // channel c's own sequence counter (this workgroup is its only reader and writer; every lane reads the same word)
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank] + kXchgHeader) + c;
+    const unsigned long long seq = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const unsigned seq32 = (unsigned)seq;
     const int slot = (int)(seq & 1);
     const int t = threadIdx.x;
     if (t < q.world) {
-        const size_t rec_off = kXchgHeader + (size_t)slot * q.slot_bytes + (size_t)c * kXchgRec;
+        const size_t rec_off = (size_t)q.slots_off + (size_t)slot * q.slot_bytes + (size_t)c * kXchgRec;
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(q.mbox[t] + rec_off + (size_t)q.rank * q.row_bytes);
         const double v[3] = {v0, v1, v2};
 #pragma unroll
@@ -639,21 +643,11 @@ __device__ __forceinline__ void xchg_channel(const BnXchg& q, int c, double v0, 
         }
         if (fail && q.status != nullptr) *q.status = 1;
     }
-    __syncthreads();
+    __syncthreads();                              // (every lane has read the counter before it advances)
+    if (t == 0) __hip_atomic_store(ctr, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tot[0] = tot[1] = tot[2] = 0.0;
     for (int r = 0; r < q.world; ++r) {          // rank order: the same sum, bit for bit, on every rank
         tot[0] += sh[r * 3]; tot[1] += sh[r * 3 + 1]; tot[2] += sh[r * 3 + 2];
-    }
-}
-
-// the last workgroup of a launch advances the sequence counter (all workgroups read it at their start; the next launch on
-// the stream starts after this one has drained).  Atomics only: nothing another workgroup reads is ordered by this.
-__device__ __forceinline__ void xchg_finish(const BnXchg& q) {
-    if (threadIdx.x != 0) return;
-    unsigned long long* hdr = reinterpret_cast<unsigned long long*>(q.mbox[q.rank]);
-    if (__hip_atomic_fetch_add(hdr + 1, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1) {
-        __hip_atomic_store(hdr + 1, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(hdr, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -805,7 +799,6 @@ __global__ void __launch_bounds__(256) bn_small_planes_kernel(const BnP p, float
             }
         }
     }
-    if (XCHG) xchg_finish(xq);
 }
 
 int fill(const occd_bn_args* a, BnP& p, bool need_partial) {
@@ -1063,6 +1056,7 @@ static int fill_xchg(BnXchg& x, void* const* mailboxes, int32_t rank, int32_t wo
     }
     x.rank = rank; x.world = world;
     x.row_bytes = (long)cmax * kXchgRec;
+    x.slots_off = kXchgHeader + (long)cmax * 8;
     x.slot_bytes = (long)world * x.row_bytes;
     x.timeout_ticks = timeout_ms > 0 ? (long long)timeout_ms * 100000LL : 0;
     x.status = status;
@@ -1071,7 +1065,7 @@ static int fill_xchg(BnXchg& x, void* const* mailboxes, int32_t rank, int32_t wo
 
 int64_t occd_bn_xchg_mailbox_bytes(int32_t world, int32_t cmax) {
     if (world < 1 || world > 16 || cmax < 1) return OCCD_EINVAL;
-    return kXchgHeader + 2 * (int64_t)world * cmax * kXchgRec;
+    return kXchgHeader + (int64_t)cmax * 8 + 2 * (int64_t)world * cmax * kXchgRec;
 }
 
 int occd_bn_fwd_small_xchg(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
