@@ -624,23 +624,24 @@ __device__ __forceinline__ void xchg_channel(const BnXchg& q, int c, double v0, 
                                __HIP_MEMORY_SCOPE_SYSTEM);
         }
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(q.mbox[q.rank] + rec_off + (size_t)t * q.row_bytes);
+        // all six words in flight at once (an access past the caches is a ~2 us round trip: polled one after the other the
+        // exchange cost six of them), re-polled together until every one carries the sequence number
         bool fail = false;
         const long long t0 = wall_clock64();
+        unsigned long long w[6];
+        while (true) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            unsigned half[2];
+            for (int j = 0; j < 6; ++j) w[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            bool ready = true;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                unsigned long long w = __hip_atomic_load(src + 2 * j + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                while ((unsigned)(w >> 32) != seq32 && !fail) {
-                    __builtin_amdgcn_s_sleep(1);
-                    w = __hip_atomic_load(src + 2 * j + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) fail = true;
-                }
-                half[h] = (unsigned)w;
-            }
-            sh[t * 3 + j] = fail ? 0.0 : __longlong_as_double((long long)(((unsigned long long)half[1] << 32) | half[0]));
+            for (int j = 0; j < 6; ++j) ready = ready && (unsigned)(w[j] >> 32) == seq32;
+            if (ready) break;
+            if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) { fail = true; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            sh[t * 3 + j] = fail ? 0.0 : __longlong_as_double((long long)((w[2 * j + 1] << 32) | (w[2 * j] & 0xffffffffULL)));
         if (fail && q.status != nullptr) *q.status = 1;
     }
     __syncthreads();                              // (every lane has read the counter before it advances)

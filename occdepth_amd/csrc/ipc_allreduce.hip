@@ -53,19 +53,6 @@ __device__ __forceinline__ unsigned long long* ipc_row(const IpcP& q, int peer, 
     return reinterpret_cast<unsigned long long*>(q.mbox[peer] + kIpcHeader + (size_t)slot * q.slot_bytes + (size_t)row * q.row_bytes);
 }
 
-// poll one LL word until it carries `seq32`; returns its data half (0 after a timeout, `fail` set)
-__device__ __forceinline__ unsigned ipc_poll(const unsigned long long* w, unsigned seq32, long long timeout_ticks, bool& fail) {
-    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((unsigned)(v >> 32) == seq32) return (unsigned)v;
-    const long long t0 = wall_clock64();
-    while (true) {
-        __builtin_amdgcn_s_sleep(1);
-        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(v >> 32) == seq32) return (unsigned)v;
-        if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) { fail = true; return 0u; }
-    }
-}
-
 template <typename T>
 __global__ void __launch_bounds__(256) ipc_allreduce_kernel(const IpcP q) {
     constexpr int WPE = sizeof(T) / 4;          // LL words per element
@@ -82,22 +69,41 @@ __global__ void __launch_bounds__(256) ipc_allreduce_kernel(const IpcP q) {
         for (int p = 0; p < q.world; ++p)
             __hip_atomic_store(ipc_row(q, p, slot, q.rank) + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // ---- 2. pull: the words of my elements from all rows of MY mailbox, summed in rank order
+    // ---- 2. pull: the words of my elements from all rows of MY mailbox -- all rows in flight at once (an access past the
+    //         caches is a ~2 us round trip), re-polled together until complete -- summed in rank order
     T* out = static_cast<T*>(q.out);
     bool fail = false;
     for (int i = threadIdx.x; i < q.count; i += 256) {
-        T acc = 0;
-        for (int r = 0; r < q.world; ++r) {
-            const unsigned long long* src = ipc_row(q, q.rank, slot, r) + (size_t)i * WPE;
-            if (WPE == 1) {
-                acc += (T)__uint_as_float(ipc_poll(src, seq32, q.timeout_ticks, fail));
-            } else {
-                const unsigned lo = ipc_poll(src, seq32, q.timeout_ticks, fail);
-                const unsigned hi = ipc_poll(src + 1, seq32, q.timeout_ticks, fail);
-                acc += (T)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            }
+        unsigned long long w[kIpcMaxWorld][WPE];
+        const long long t0 = wall_clock64();
+        while (true) {
+            bool ready = true;
+#pragma unroll
+            for (int r = 0; r < kIpcMaxWorld; ++r)
+                if (r < q.world) {
+                    const unsigned long long* src = ipc_row(q, q.rank, slot, r) + (size_t)i * WPE;
+#pragma unroll
+                    for (int h = 0; h < WPE; ++h) w[r][h] = __hip_atomic_load(src + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+#pragma unroll
+            for (int r = 0; r < kIpcMaxWorld; ++r)
+                if (r < q.world) {
+#pragma unroll
+                    for (int h = 0; h < WPE; ++h) ready = ready && (unsigned)(w[r][h] >> 32) == seq32;
+                }
+            if (ready) break;
+            if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) { fail = true; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (!fail) out[i] = acc;
+        if (fail) break;
+        T acc = 0;
+#pragma unroll
+        for (int r = 0; r < kIpcMaxWorld; ++r)
+            if (r < q.world) {
+                if (WPE == 1) acc += (T)__uint_as_float((unsigned)w[r][0]);
+                else acc += (T)__longlong_as_double((long long)((w[r][WPE - 1] << 32) | (w[r][0] & 0xffffffffULL)));
+            }
+        out[i] = acc;
     }
     if (fail && q.status != nullptr) *q.status = 1;
     __syncthreads();                            // every thread has read its words of this sequence number
