@@ -715,13 +715,15 @@ class _PwConvFn(torch.autograd.Function):
         return gx, gw
 
 
-# OCCDEPTH_TRAIN_PW_GEMM: 0 (default) = the encoder's pointwise convolutions stay on ATen in training; 1 = on K16 / K16t with
-# the 3-way split (float32-accurate; measured a wash against MIOpen / rocBLAS on these small shapes: 153.1 vs 152 ms fp32,
-# 107.7 vs 106.5 ms bf16 mode, while ~12 ms of library work moves in-repo); bf16 = plain bf16 operands in the bf16-MFMA mode
-# (105.5 vs 106.7 ms) -- NOT the default: through the 55 MBConv blocks of a random-init B7 the bf16 rounding of 110 chained
-# pointwise convolutions turns the encoder's gradient directions to cosine 0.2 - 0.35 against the real reference (0.93 - 0.97
-# with the encoder in fp32; tests/test_train_step.py::test_train_step_full_config2_matches_reference_gpu).
-PW_TRAIN = os.environ.get("OCCDEPTH_TRAIN_PW_GEMM", "0")
+# OCCDEPTH_TRAIN_PW_GEMM: 1 (default since round 5) = the encoder's pointwise (expand / project) convolutions run forward, data
+# gradient and weight gradient on K16 / K16t with the 3-way split (float32-accurate) in training -- the same time as MIOpen /
+# rocBLAS on these small shapes (round 4: 153.1 vs 152 ms fp32, 107.7 vs 106.5 ms bf16 mode; round 5: 104.1 / 105.0 vs 104.6 /
+# 105.6 ms), but ~13 ms of library work (the largest non-repo share of the step) becomes in-repo and deterministic, and the full
+# training-step parity test holds unchanged; 0 = ATen (A/B); bf16 = plain bf16 operands in the bf16-MFMA mode (105.5 vs 106.7 ms)
+# -- NOT the default: through the 55 MBConv blocks of a random-init B7 the bf16 rounding of 110 chained pointwise convolutions
+# turns the encoder's gradient directions to cosine 0.2 - 0.35 against the real reference (0.93 - 0.97 with the encoder in
+# fp32; tests/test_train_step.py::test_train_step_full_config2_matches_reference_gpu).
+PW_TRAIN = os.environ.get("OCCDEPTH_TRAIN_PW_GEMM", "1")
 
 
 def pw_conv_autograd_ok(conv, x):

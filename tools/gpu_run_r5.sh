@@ -44,13 +44,19 @@ if has train; then
   OCCDEPTH_LOSS_KERNELS=0 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_aten_losses.json 2> $O/train_bf16_aten_losses.err; line $O/train_bf16_aten_losses.json
 fi
 if has trainpw; then
-  OCCDEPTH_TRAIN_PW_GEMM=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_pw.json 2> $O/train_bf16_pw.err; line $O/train_bf16_pw.json
+  OCCDEPTH_TRAIN_PW_GEMM=0 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_pw0.json 2> $O/train_bf16_pw0.err; line $O/train_bf16_pw0.json
 fi
 if has ipc; then
   timeout 600 python -m pytest -q -m gpu -x tests/test_ipc_allreduce_gpu.py -s > $O/pytest_ipc.txt 2>&1; tail -12 $O/pytest_ipc.txt | cut -c1-400
   OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_forced_ipc.json 2> $O/train_bf16_forced_ipc.err; line $O/train_bf16_forced_ipc.json
   OCCDEPTH_SYNCBN_IPC=0 OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_forced_rccl.json 2> $O/train_bf16_forced_rccl.err; line $O/train_bf16_forced_rccl.json
   grep -o '"parallelism": "[^"]*"' $O/train_bf16_forced_ipc.json $O/train_bf16_forced_rccl.json
+fi
+if has forceparts; then
+  for parts in bn buckets; do for ipc in 1 0; do
+    OCCDEPTH_FORCE_PARTS=$parts OCCDEPTH_SYNCBN_IPC=$ipc OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_forced_${parts}_ipc$ipc.json 2> $O/train_bf16_forced_${parts}_ipc$ipc.err; line $O/train_bf16_forced_${parts}_ipc$ipc.json
+  done; done
+  timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_plain.json 2> $O/train_bf16_plain.err; line $O/train_bf16_plain.json
 fi
 if has exact; then
   OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_exact_fp32.json 2> $O/bench_exact_fp32.err; line $O/bench_exact_fp32.json
@@ -77,7 +83,7 @@ if has proftrain; then
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_train -- python $R/bench.py --train --bf16 --steps 3 --warmup 2 > $O/train_bf16_under_rocprof.json 2> /tmp/prof_train.err
   f=$(ls /tmp/prof_train/*/*kernel_trace.csv | head -1)
   python $R/tools/summarize_trace.py $f $O/train_step_bf16_kernels.csv train > /dev/null 2>&1; head -8 $O/train_step_bf16_kernels.csv | cut -c1-140
-  cd $R && timeout 500 python tools/prof_train_aten.py > $O/train_step_bf16_aten_ops.txt 2>&1; cd /tmp
+  cd $R && timeout 500 python tools/prof_train_aten.py bf16 > $O/train_step_bf16_aten_ops.txt 2>&1; cd /tmp
 fi
 if has pmc; then
   for c in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" FETCH_SIZE WRITE_SIZE; do
