@@ -680,14 +680,10 @@ def _train(args, world, rank, device, dist):
         batch = synthetic.attach_projection(model, synthetic.to_device(synthetic.kitti_frame(seed=rank), device))
     synthetic.attach_training_targets(model, batch, cfg, seed=1 + rank)
     forced = os.environ.get("OCCDEPTH_FORCE_DIST") == "1"    # one GPU: SyncBatchNorm + buckets on a single-rank RCCL group
-    model, buckets = shard.prepare_for_ddp(model, dist, force=forced)
     parts = os.environ.get("OCCDEPTH_FORCE_PARTS", "all")          # forced single-rank runs: which exchanges to drive
-    if forced and parts == "bn" and buckets is not None:            # SyncBatchNorm's exchanges only (no gradient buckets)
-        buckets.release()
-        buckets = None
-        shard.FORCE_COLLECTIVES = True
-    elif forced and parts == "buckets":                             # gradient buckets only (BatchNorm keeps local statistics)
-        shard.FORCE_COLLECTIVES = False
+    # "bn": SyncBatchNorm's exchanges only (no gradient buckets); "buckets": gradient buckets only (local BatchNorm statistics)
+    model, buckets = shard.prepare_for_ddp(model, dist, force=forced, grad_buckets=not (forced and parts == "bn"),
+                                           sync_bn=not (forced and parts == "buckets"))
     opt = model.configure_optimizers()[0][0]
     # whole-step hipGraph: default on one rank without buckets; with buckets (collectives launched from autograd hooks
     # inside the capture) it is opt-in until it has run on a multi-GPU node: OCCDEPTH_TRAIN_GRAPH_DDP=1

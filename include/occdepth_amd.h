@@ -268,6 +268,9 @@ typedef struct occd_gemm_args {
     const float* scale_k;                  /* optional (ABI 9): (batch, K) floats, B[b][k][:] is multiplied by scale_k[b][k]
                                               (rounded to float32, as the reference's x * gate) while it is staged: the
                                               squeeze-excite gate in front of the project convolution; pre must not be 2   */
+    int32_t act_a;                         /* (ABI 11) 1: A[b][m][k] -> sigmoid(A[b][m][k]) while it is staged -- the relation
+                                              products torch.bmm(sigmoid(P_logits), mega) of occdepth/models/CRP3D.py:80 as ONE
+                                              batched launch over the relations; float32 A only (pre 0 / 2)                 */
 } occd_gemm_args;
 int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
 /* K16t, the "NT" form: C[b][m][n] = sum_k A[b][m][k] B[b][n][k], BOTH operands with k contiguous (lda, ldb >= K), any dword

@@ -44,6 +44,7 @@ struct GemmP {
     int M, N, K;
     long lda, ldb, ldc, sA, sB, sC;     // elements
     int act;                            // 0 none, 1 swish, 2 leaky relu (slope)
+    int act_a;                          // 1: sigmoid applied to the A elements while they are staged (CRP: sigmoid(P_logits) @ mega)
     float slope;
     int mtiles, ntiles, n_fast;         // n_fast: the N-tile index runs fastest in the block order (A tile reused), else M
     unsigned nwg;
@@ -193,7 +194,15 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
             const bool ok = FAST || k0 + a_k[i] < p.K;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             u32x4 hi, mid, lo;
-            split8(ok ? ra[u][i][0] : z, ok ? ra[u][i][1] : z, hi, mid, lo);
+            f32x4 a0 = ra[u][i][0], a1 = ra[u][i][1];
+            if (p.act_a) {                                   // (launch-uniform branch: the CRP products only)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0[j] = 1.f / (1.f + __expf(-a0[j]));
+                    a1[j] = 1.f / (1.f + __expf(-a1[j]));
+                }
+            }
+            split8(ok ? a0 : z, ok ? a1 : z, hi, mid, lo);
             *(u32x4*)(lA + a_dst[i]) = hi;
             if (TERMS == 3) {
                 *(u32x4*)(lA + a_dst[i] + 64) = mid;
@@ -900,7 +909,8 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     // the longest K (tap GEMM of the 1/16 level, K = 2560: 0.438 against 0.462 ms); K16w keeps that launch
     if ((a->res != nullptr || a->scale_k != nullptr) && (a->tile_hint == kNumVariantsG + 1 || a->pre == 2)) return OCCD_EINVAL;
     if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
-    const bool ws = a->pre == 0 && a->res == nullptr && a->scale_k == nullptr &&
+    if (a->act_a != 0 && (a->act_a != 1 || a->pre == 1 || a->pre == 3 || a->tile_hint == kNumVariantsG + 1)) return OCCD_EINVAL;
+    const bool ws = a->pre == 0 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0 &&
                     (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 2048));
     if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
@@ -917,7 +927,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a; p.sB = a->stride_b; p.sC = a->stride_c;
     if (a->pre == 1) p.sA = a->stride_a / 8;        // bf16 elements -> u32x4 records
     if (a->pre == 2) p.sB = a->stride_b / 8;
-    p.act = a->act; p.slope = a->slope;
+    p.act = a->act; p.slope = a->slope; p.act_a = a->act_a;
     p.mtiles = (a->M + TM - 1) / TM;
     p.ntiles = (a->N + TN - 1) / TN;
     // the tile of the LARGER operand is the one worth fetching once per L2: iterate over the other dimension fastest

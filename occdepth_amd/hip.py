@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 10   # 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 11   # 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -104,7 +104,8 @@ class GemmArgs(Structure):
     _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p)] + \
         [(n, c_int32) for n in ("M", "N", "K", "batch")] + \
         [(n, c_int64) for n in ("lda", "ldb", "ldc", "stride_a", "stride_b", "stride_c")] + \
-        [("act", c_int32), ("slope", c_float), ("tile_hint", c_int32), ("pre", c_int32), ("res", c_void_p), ("scale_k", c_void_p)]
+        [("act", c_int32), ("slope", c_float), ("tile_hint", c_int32), ("pre", c_int32), ("res", c_void_p), ("scale_k", c_void_p),
+         ("act_a", c_int32)]
 
 
 class WinoArgs(Structure):
@@ -593,14 +594,16 @@ def gemm_x3_supported(a, b):
     return nb_a is None or nb_b is None or nb_a == nb_b
 
 
-def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_bf16=False, res=None, k_scale=None):
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_bf16=False, res=None, k_scale=None,
+            sigmoid_a=False):
     """K16 (occd_gemm_f32x3): out[i] = act(a[i] @ (b[i] * k_scale[i][:, None]) + bias[:, None]) + res[i] in float32-level
     accuracy on the bf16 matrix pipe (k_scale: (batch, K), the squeeze-excite gate of a project convolution; res: laid out
     like out, the block's skip connection).
     a: (M, K) shared over the batch, or (batch, M, K); b: (K, N) or (batch, K, N); out: (batch, M, N) ((M, N) when neither
     operand is batched).  Tensor operands may be strided views as long as the innermost stride is 1; a static operand may be
     given as `GemmPacked(w, "a" / "b")` (split once, read straight from L2).  plain_bf16: operands rounded to ONE bf16 term
-    (the bf16 training mode: bf16 MFMA, fp32 storage and accumulate) instead of the split."""
+    (the bf16 training mode: bf16 MFMA, fp32 storage and accumulate) instead of the split.  sigmoid_a: a -> sigmoid(a) while
+    it is staged (the CRP's relation products)."""
     if not gemm_x3_supported(a, b):
         raise RuntimeError("gemm_x3: unsupported operands")
     pa, pb = isinstance(a, GemmPacked), isinstance(b, GemmPacked)
@@ -647,6 +650,10 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
         if pb or k_scale.dtype != torch.float32 or tuple(k_scale.shape) != (batch, K) or not k_scale.is_contiguous():
             raise RuntimeError("gemm_x3: k_scale must be (batch, K) contiguous floats and b a float32 tensor")
         q.scale_k = k_scale.data_ptr()
+    if sigmoid_a:
+        if pa or plain_bf16:
+            raise RuntimeError("gemm_x3: sigmoid_a takes a float32 tensor A and the split arithmetic")
+        q.act_a = 1
     if _PROFILING:
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")

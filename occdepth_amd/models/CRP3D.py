@@ -4,8 +4,8 @@ Eval-mode dataflow on the HIP kernels (N = voxels at this level, M = mega voxels
   x_agg   = ASPP(x)                                              6 x K2 (3x3x3, dilated)
   mega    = mega_context(x_agg)          (M rows x 2C)           K2, stride 2
   logit_r = context_prior_logits[r](x_agg)   (N rows x M)        K2 1x1x1  -> P_logits[:, r]
-  ctx_r   = sigmoid(logit_r) @ mega          (N rows x 2C)       K2 as GEMM: sigmoid fused on the
-                                                                 A-operand load, `mega` packed as B
+  ctx_r   = sigmoid(logit_r) @ mega          (N rows x 2C)       K16 (round 5): the R products of an image as ONE
+                                                                 batched launch, sigmoid applied while A is staged
   x       = resize([x | ctx_0 .. ctx_{R-1}])                     ctx_r written straight into its
                                                                  channel slice of the concat rows
 """
@@ -16,6 +16,10 @@ from .. import hip
 from ..autograd3d import Conv3d, ConvTranspose3d  # noqa: F401  (nn.Conv3d subclasses: HIP forward/backward in training)
 from ..fused import ACT_SIGMOID, ConvPlan, Vox, as_vox, gemm_rows, needs_autograd, pack_rows, run_parallel
 from .modules import ASPP, Process
+import os
+
+# the relation products sigmoid(P_logits) @ mega as one batched K16 launch (OCCDEPTH_CRP_K16=0: four K2 launches, A/B)
+CRP_PRODUCTS_K16 = os.environ.get("OCCDEPTH_CRP_K16", "1") == "1"
 
 
 class CPMegaVoxels(nn.Module):
@@ -77,23 +81,35 @@ class CPMegaVoxels(nn.Module):
         else:
             for th in first:
                 th()
-        packed = []                                             # the mega rows are the B operand of all R products
-        for b in range(B):
-            rows_b = mega.buf[b].reshape(M, mega.cs)[:, :C2]
-            packed.append(pack_rows(rows_b if rows_b.is_contiguous() else rows_b.contiguous()))
-
-        def product(r):
-            def run():
-                for b in range(B):
-                    gemm_rows(Vox(lgs[r].buf[b:b + 1], M), packed[b], Vox(cat[b:b + 1], C2, C + r * C2), act_in=ACT_SIGMOID)
-            return run
-
-        second = [product(r) for r in range(R)]                 # sigmoid(logits_r) @ mega: independent, disjoint outputs
-        if x.buf.is_cuda:
-            run_parallel(second)
+        if x.buf.is_cuda and CRP_PRODUCTS_K16 and hip.GEMM_X3 and M % 8 == 0 and m_cs % 4 == 0:
+            # round 5: the R relation products sigmoid(logits_r) @ mega of one image as ONE batched K16 launch (3-way bf16
+            # split, float32-level accuracy): A = the relations' logit rows (N x M each, the sigmoid applied while they are
+            # staged), B = the mega rows (M x 2C, shared over the relations), C = the relations' slices of the concat rows.
+            # Four generic K2 launches at 35 TF/s (0.25 ms per frame at config 2) before.
+            Ct = C + R * C2
+            for b in range(B):
+                a_op = torch.as_strided(logits, (R, N, M), (B * N * m_cs, m_cs, 1), b * N * m_cs)
+                b_op = mega.buf[b].reshape(M, mega.cs)[:, :C2]
+                out = torch.as_strided(cat, (R, N, C2), (C2, Ct, 1), b * N * Ct + C)
+                hip.gemm_x3(a_op, b_op, out=out, sigmoid_a=True)
         else:
-            for th in second:
-                th()
+            packed = []                                         # the mega rows are the B operand of all R products
+            for b in range(B):
+                rows_b = mega.buf[b].reshape(M, mega.cs)[:, :C2]
+                packed.append(pack_rows(rows_b if rows_b.is_contiguous() else rows_b.contiguous()))
+
+            def product(r):
+                def run():
+                    for b in range(B):
+                        gemm_rows(Vox(lgs[r].buf[b:b + 1], M), packed[b], Vox(cat[b:b + 1], C2, C + r * C2), act_in=ACT_SIGMOID)
+                return run
+
+            second = [product(r) for r in range(R)]             # sigmoid(logits_r) @ mega: independent, disjoint outputs
+            if x.buf.is_cuda:
+                run_parallel(second)
+            else:
+                for th in second:
+                    th()
         y = pl["resize"](Vox(cat, C + R * C2))
         y = self.resize[1].forward_vox(y)
         p_logits = logits.view(R, B, N, m_cs)[..., :M].permute(1, 0, 3, 2)

@@ -535,7 +535,7 @@ def convert_sync_batchnorm(module, process_group=None):
     return out
 
 
-def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, force=False, algo=None):
+def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, force=False, algo=None, grad_buckets=True):
     """What `Trainer(accelerator="ddp", sync_batchnorm=True)` does for the reference (scripts/train.py:176-206),
     without Lightning: BatchNorm -> SyncBatchNorm (statistics over the frames of all ranks; with 1 frame per GPU the
     per-rank statistics would otherwise be those of a single scene) and the gradient buckets.
@@ -562,6 +562,8 @@ def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, forc
             except Exception as e:        # (no IPC support on this box / driver: the process group's all_reduce keeps working)
                 import warnings
                 warnings.warn(f"occdepth_amd: peer-memory all-reduce unavailable ({e!r}); SyncBatchNorm uses the process group")
+    if not grad_buckets:                  # (measurement aid: SyncBatchNorm's exchanges alone; FORCE_COLLECTIVES stays as set)
+        return model, None
     buckets = GradBuckets(model.parameters(), dist, bucket_bytes, algo=algo, force=force)
     buckets._restore_force = was_forced if force else None
     return model, buckets

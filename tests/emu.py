@@ -630,12 +630,12 @@ def gemm_x3_supported(a, b):
     return a.dim() == 2 or b.dim() == 2 or a.shape[0] == b.shape[0]
 
 
-def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, res=None, k_scale=None):
+def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, res=None, k_scale=None, sigmoid_a=False):
     """occd_gemm_f32x3: float32-level GEMM (B rows scaled by k_scale, rounded to float32 like the kernel's staging) + bias[:, None]
     + activation + res (evaluated in float64 here)."""
     if k_scale is not None:
         b = b * k_scale.unsqueeze(-1)
-    y = torch.matmul(a.double(), b.double())
+    y = torch.matmul(torch.sigmoid(a.double()) if sigmoid_a else a.double(), b.double())
     if bias is not None:
         y = y + bias.double().view(-1, 1)
     y = _act2d(y, act, slope)

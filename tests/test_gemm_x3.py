@@ -108,6 +108,33 @@ def test_gemm_x3_strided_views_and_output(hip):
     assert not hip.gemm_x3_supported(abig[:, 1:1 + K], bbig[:, :K]) # rows of A not 16-byte aligned
 
 
+def test_gemm_x3_sigmoid_on_a_batched_into_strided_slices(hip):
+    """The CRP's relation products (occdepth/models/CRP3D.py:80: torch.bmm(sigmoid(P_logits_r), mega) for r = 0 .. 3) as ONE
+    batched launch: A = the relations' logit rows (sigmoid applied while staged), B shared over the batch, C = channel
+    slices of wider concat rows (stride_c = slice width, ldc = row width) -- against float64; nothing outside the slices is
+    written."""
+    g = torch.Generator().manual_seed(21)
+    R, N, M, C2, C = 4, 520, 136, 72, 40                    # (N, M, C2 not multiples of the tiles)
+    m_cs = 136
+    logits = (torch.randn(R, N, m_cs, generator=g) * 2.0).to(DEV)
+    mega = torch.randn(M, C2 + 8, generator=g).to(DEV)
+    Ct = C + R * C2
+    cat = torch.full((N, Ct), 7.0, device=DEV)
+    a_op = torch.as_strided(logits, (R, N, M), (N * m_cs, m_cs, 1), 0)
+    out = torch.as_strided(cat, (R, N, C2), (C2, Ct, 1), C)
+    with hip.profile() as prof:
+        hip.gemm_x3(a_op, mega[:, :C2], out=out, sigmoid_a=True)
+    assert any(k.startswith("gemm_f32x3") for k in prof.rows)
+    ref = torch.matmul(torch.sigmoid(logits[..., :M].double().cpu()), mega[:, :C2].double().cpu())        # (R, N, C2)
+    got = cat.cpu().double()
+    assert torch.equal(got[:, :C], torch.full((N, C), 7.0, dtype=torch.float64))
+    for r in range(R):
+        sl = got[:, C + r * C2:C + (r + 1) * C2]
+        assert float((sl - ref[r]).abs().max() / ref[r].abs().max()) < 2e-6, r
+    with pytest.raises(RuntimeError):
+        hip.gemm_x3(hip.GemmPacked(logits[0, :, :M].contiguous(), "a"), mega[:, :C2], sigmoid_a=True)
+
+
 def test_gemm_x3_rejects_bad_arguments(hip):
     import ctypes
     lib = hip.load()
