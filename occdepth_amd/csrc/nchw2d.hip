@@ -875,8 +875,10 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
 // output pixels of one row x 4 groups of 16 output channels; a lane keeps the 27 taps of its pixel in registers and walks
 // the 16 channels of its group with the (scale-folded) weights read from LDS as broadcast float4s.
 constexpr int kStemCin = 3;
+// (4 waves per SIMD requested: left alone, hipcc hoists all 108 broadcast weight reads of a lane above the multiplies --
+//  256 VGPRs + 224 AGPRs, one wave per SIMD, 156 us for the config-2 launch)
 template <int STRIDE>
-__global__ void __launch_bounds__(256) stem_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ void __launch_bounds__(256, 2) stem_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ y, int H, int W, int Cout, int pad_top,
                                                            int pad_left, int Ho, int Wo, int act) {
@@ -909,25 +911,28 @@ __global__ void __launch_bounds__(256) stem_conv3x3_kernel(const float* __restri
             }
         }
     for (int c0 = grp * 16; c0 < Cout16; c0 += 64) {
-        f32x4 acc[4];
+        // four output channels at a time (a rolled loop: the weight offset is an address, not a register index), the 27 taps
+        // unrolled in three fenced groups so that at most nine broadcast weight vectors are live beside the 27 taps
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* wq = wl + c0 + 4 * q;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; t0 < 27; t0 += 9) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const f32x4* wp = (const f32x4*)(wl + t * Cout16 + c0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] += wp[q] * v[t];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
+                for (int t = t0; t < t0 + 9; ++t) acc += *(const f32x4*)(wq + t * Cout16) * v[t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = c0 + 4 * q + j;
                 if (co < Cout) {
-                    const float o = acc[q][j] + (shift != nullptr ? shift[co] : 0.f);
+                    const float o = acc[j] + (shift != nullptr ? shift[co] : 0.f);
                     y[(((size_t)b * Cout + co) * Ho + oy) * Wo + ox] = act_apply(o, act, 0.f);
                 }
             }
+        }
     }
 }
 

@@ -124,8 +124,40 @@ __global__ void __launch_bounds__(256) se_expand4_kernel(const float* __restrict
 // Round 5: ONE launch instead of ~20 ATen / rocBLAS ones (reciprocal, stack, norm, 2 Linear, ReLU, 2 1x1 convolutions on 1x1
 // maps, ReLU, sigmoid: the last Cijk_* rows of the eval trace).  One workgroup per image; the three C x C mat-vecs run
 // row per wave-quarter: 16 lanes walk a row in coalesced 64-byte pieces and reduce through DPP / shuffles (fixed order).
+// (C <= 128, DepthNet's width: ALL of a lane's 64 weights are requested before the first is used -- the launch is two
+//  workgroups walking three dependent mat-vecs, i.e. pure latency: the rolled form below took 60 us, 8 L2 round trips per row)
+__device__ __forceinline__ void gate_matvec128(const float* __restrict__ W, const float* __restrict__ bias, const float* in,
+                                               float* out, int C, int act) {
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    float wv[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            wv[j][i] = W[(size_t)min(grp + 16 * j, C - 1) * C + min(sub + 16 * i, C - 1)];
+    float iv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) iv[i] = sub + 16 * i < C ? in[sub + 16 * i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = grp + 16 * j;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += wv[j][i] * iv[i];
+        a += __shfl_xor(a, 8, 64);
+        a += __shfl_xor(a, 4, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 1, 64);
+        if (sub == 0 && r < C) {
+            a += bias[r];
+            out[r] = act == 1 ? fmaxf(a, 0.f) : act == 2 ? 1.f / (1.f + expf(-a)) : a;
+        }
+    }
+}
+
 __device__ __forceinline__ void gate_matvec(const float* __restrict__ W, const float* __restrict__ bias, const float* in,
                                             float* out, int C, int act) {        // out = act(W in + bias); act 1 relu, 2 sigmoid
+    if (C <= 128) { gate_matvec128(W, bias, in, out, C, act); return; }
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;                      // 16 row groups of 16 lanes
     for (int r = grp; r < C; r += 16) {
         const float* w = W + (size_t)r * C;

@@ -30,6 +30,15 @@ from ...fused import bn_affine_cached, needs_autograd, wino_fused_operands
 DEPTHNET_K10 = os.environ.get("OCCDEPTH_DEPTHNET_K10", "1") == "1"
 
 
+def _conv3x3_train(conv, x):
+    """Training on the GPU: DepthNet's 3x3 / pad 1 convolutions forward and data gradient on K10 (hip.conv2d_3x3_autograd), as
+    the decoder's; anything else (CPU, half precision, OCCDEPTH_DEPTHNET_K10=0) is the module itself."""
+    if DEPTHNET_K10 and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and \
+            conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1:
+        return hip.conv2d_3x3_autograd(x, conv.weight, conv.bias)
+    return conv(x)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes):
         super().__init__()
@@ -47,7 +56,7 @@ class BasicBlock(nn.Module):
                 return hip.conv2d_3x3_fused(y, upk, self.conv2.out_channels, shift, "relu", res=x, res_first=True)
             y = hip.affine_act(self.conv1(x), *bn_affine_cached(self.bn1), "relu")
             return hip.affine_act(self.conv2(y), *bn_affine_cached(self.bn2), "relu", res=x, res_first=True)
-        out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+        out = self.bn2(_conv3x3_train(self.conv2, F.relu(self.bn1(_conv3x3_train(self.conv1, x)))))
         return F.relu(out + x)
 
 
@@ -117,7 +126,7 @@ class DepthNet(nn.Module):
             if not self.infer_mode:
                 scaled_pixel_size = self.scaled_pixel_size(sweep_intrins, scale_depth_factor,
                                                            sync_free=sweep_intrins.is_cuda)
-            x = self.reduce_conv(x)
+            x = self.reduce_conv[2](self.reduce_conv[1](_conv3x3_train(self.reduce_conv[0], x)))
             x = self.se(x, self.mlp(scaled_pixel_size.to(self.mlp.fc1.weight.dtype))[..., None, None])
         x = self.depth_conv(x)
         if _fused.on_gpu(x) and not needs_autograd(self) and x.dtype == torch.float32:
@@ -255,7 +264,8 @@ class FlospDepth(nn.Module):
         if getattr(self, "_g2l_key", None) != gkey:     # cached on the device: no per-frame H2D copy
             self._g2l_dev = _grid_to_lidar(self._pc_range, self._grid_dims).to(t_v2c.device)
             self._g2l_key = gkey
-        trans = (t_v2c @ self._g2l_dev).contiguous()
+        # (B, V, 4, 4) @ (4, 4) as a broadcast multiply + sum: the last hipBLASLt launch of the eval frame was this 4 x 4 product
+        trans = (t_v2c.unsqueeze(-1) * self._g2l_dev).sum(-2).contiguous()
         proj = intrins[:, :, :3, :].contiguous()
         return hip.Frustum(dvol, trans, proj, ida.contiguous(), self._grid_dims, self.final_dim,
                            self.d_bound[0], self.d_bound[1], self.agg_voxel_mode == "mean")
