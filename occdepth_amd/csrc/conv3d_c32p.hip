@@ -212,6 +212,7 @@ struct SlideP {
     int segs_per_col;        // position ranges per (b, ytile) column
     int seg_len;             // planes per range (the last one of a column may be shorter)
     int total_segs;
+    int res_early;           // K2s3: residual rows requested in front of the FIRST 16-channel half of their plane
 };
 
 template <int D>
@@ -804,12 +805,17 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_slide_x3_kernel(const Slide
                     commit();
                     __syncthreads();
                     issue(xi, 1);
+                    // the residual rows of out[j-2] (it completes with this plane): requested a whole half-slab before their
+                    // use (round 5, `res_early`): issued in front of the second half they sit in the in-order vmcnt queue
+                    // right before the lo-weight stream the MFMAs wait for two steps later (0.53 / 0.63 ms per launch with
+                    // one / two residual operands against 0.45 - 0.51 without)
+                    if (NRES > 0 && sp.res_early && u2) res_fetch(b, yt, xi - D);
                     slab_mma(H0{}, u0, u1, u2);
                     __syncthreads();
                     commit();
                     __syncthreads();
                     if (j < jlast) issue(xi + D, 0);
-                    if (u2) res_fetch(b, yt, xi - D);                      // out[j-2] completes with this slab
+                    if (NRES > 0 && !sp.res_early && u2) res_fetch(b, yt, xi - D);
                     slab_mma(H1{}, u0, u1, u2);
                 }
                 if (u2) {
@@ -934,6 +940,8 @@ int launch_slide_x3(const PersistP& base0, hipStream_t st, DevState* ds) {
     SlideP sp;
     const int rc = plan_slide<D>(base, ds, &sp);
     if (rc != OCCD_OK) return rc;
+    static const bool res_early = occd::env_flag("OCCD_C32X3_RES_EARLY", true);      // A/B switch (0: in front of the second half)
+    sp.res_early = res_early ? 1 : 0;
     const int grid = ds->num_cu < sp.total_segs ? ds->num_cu : sp.total_segs;
     hipLaunchKernelGGL((conv3d_c32_slide_x3_kernel<D, NRES, ZH, TYV>), dim3((unsigned)grid), dim3(512), lds, st, sp);
     return occd::check_launch();

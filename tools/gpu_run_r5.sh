@@ -58,6 +58,9 @@ if has forceparts; then
   done; done
   timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_plain.json 2> $O/train_bf16_plain.err; line $O/train_bf16_plain.json
 fi
+if has headab; then
+  for e in 1 0; do OCCD_C32X3_RES_EARLY=$e timeout 300 python tools/bench_head_x3.py > $O/head_x3_res_early$e.txt 2>&1; grep "nres=[12] K2s3\|nres=0 K2s3" $O/head_x3_res_early$e.txt | cut -c1-120; done
+fi
 if has exact; then
   OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_exact_fp32.json 2> $O/bench_exact_fp32.err; line $O/bench_exact_fp32.json
 fi
