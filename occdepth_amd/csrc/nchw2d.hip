@@ -875,6 +875,7 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
 // output pixels of one row x 4 groups of 16 output channels; a lane keeps the 27 taps of its pixel in registers and walks
 // the 16 channels of its group with the (scale-folded) weights read from LDS as broadcast float4s.
 constexpr int kStemCin = 3;
+constexpr int kStemRows = 8;
 // (4 waves per SIMD requested: left alone, hipcc hoists all 108 broadcast weight reads of a lane above the multiplies --
 //  256 VGPRs + 224 AGPRs, one wave per SIMD, 156 us for the config-2 launch)
 template <int STRIDE>
@@ -890,9 +891,12 @@ __global__ void __launch_bounds__(256, 2) stem_conv3x3_kernel(const float* __res
     }
     __syncthreads();
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oy = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.z;
     const int grp = threadIdx.x >> 6;
     if (ox >= Wo) return;
+    // kStemRows output rows per workgroup: the weight prologue (a gather + a barrier, ~2 us of latency) is paid once per eight
+    // rows, and the whole launch is one round of resident workgroups (3700 one-row workgroups took 82 us)
+    for (int oy = blockIdx.y * kStemRows; oy < min(Ho, (int)(blockIdx.y + 1) * kStemRows); ++oy) {
     float v[27];
     const float* xb = x + (size_t)b * kStemCin * H * W;
 #pragma unroll
@@ -934,6 +938,7 @@ __global__ void __launch_bounds__(256, 2) stem_conv3x3_kernel(const float* __res
             }
         }
     }
+    }
 }
 
 extern "C" int occd_stem_conv3x3_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
@@ -943,7 +948,7 @@ extern "C" int occd_stem_conv3x3_nchw(const float* x, const float* w, const floa
     if (batch < 1 || batch > 65535 || H < 1 || W < 1 || cout < 1 || cout > 512 || (stride != 1 && stride != 2)) return OCCD_EINVAL;
     if (Ho < 1 || Ho > 65535 || Wo < 1 || pad_top < 0 || pad_left < 0 || act < 0 || act > 2) return OCCD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((Wo + 63) / 64), (unsigned)Ho, (unsigned)batch);
+    const dim3 grid((unsigned)((Wo + 63) / 64), (unsigned)((Ho + kStemRows - 1) / kStemRows), (unsigned)batch);
     const size_t lds = (size_t)27 * ((cout + 15) & ~15) * sizeof(float);
     occd::ProfScope prof("stem_conv3x3", st, 2.0 * batch * (double)Ho * Wo * 27 * cout,
                          4.0 * batch * ((double)kStemCin * H * W + (double)cout * Ho * Wo));

@@ -114,3 +114,29 @@ def test_lift_proj_rejects_what_it_cannot_do():
     with pytest.raises(RuntimeError):                       # non-power-of-two (Y, Z) of the grid (X is free)
         hip.lift_proj(feats, (1, 2), cam[0], cam[1], (0.0, -25.6, -2.0), voxel, (610, 185), (64, 60, 8), (480, 8, 1),
                       Vox.empty(1, (64, 60, 8), 32, DEV))
+
+
+def test_device_vox_origin_is_honoured_not_ignored():
+    """Lightning's transfer_batch_to_device moves every batch tensor to the GPU, so a batch-supplied `vox_origin`
+    arrives as a CUDA tensor: it is read back ONCE per model (cached host copy, a warning when it differs from the
+    SemanticKITTI default), never silently replaced by the default; first seen during a graph capture it raises."""
+    import warnings
+    from test_oracle_vs_golden import build_product
+    m, cfg, sd = build_product("kitti_small")
+    default = (0.0, -0.1 * float(cfg.full_scene_size[1]), -2.0)
+    assert m._kitti_origin({}) == default and m._kitti_origin(None) == default
+    assert m._kitti_origin({"vox_origin": torch.tensor([[0.0, -3.2, -2.0]])}) == pytest.approx((0.0, -3.2, -2.0))
+    dev_origin = torch.tensor([[0.5, -3.0, -1.5]], device="cuda")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m._kitti_origin({"vox_origin": dev_origin})
+    assert got == pytest.approx((0.5, -3.0, -1.5)) and any("vox_origin" in str(x.message) for x in w)
+    assert m._kitti_origin({"vox_origin": dev_origin}) == got          # cached: no second read-back
+    m2, _, _ = build_product("kitti_small")
+    real = torch.cuda.is_current_stream_capturing
+    torch.cuda.is_current_stream_capturing = lambda: True        # (what the whole-forward capture sees; no real capture needed)
+    try:
+        with pytest.raises(RuntimeError, match="graph capture"):
+            m2._kitti_origin({"vox_origin": dev_origin})
+    finally:
+        torch.cuda.is_current_stream_capturing = real
