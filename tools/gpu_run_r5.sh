@@ -57,6 +57,26 @@ if has forceparts; then
     OCCDEPTH_FORCE_PARTS=$parts OCCDEPTH_SYNCBN_IPC=$ipc OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1 timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_forced_${parts}_ipc$ipc.json 2> $O/train_bf16_forced_${parts}_ipc$ipc.err; line $O/train_bf16_forced_${parts}_ipc$ipc.json
   done; done
   timeout 500 python bench.py --train --bf16 --steps 5 --warmup 2 > $O/train_bf16_plain.json 2> $O/train_bf16_plain.err; line $O/train_bf16_plain.json
+  python - > $O/forced_decomposition.txt <<PY
+import json
+def ms(f):
+    try:
+        return json.loads([l for l in open("$O/" + f).read().splitlines() if l.startswith('{"metric"')][-1])["ms_per_step"]
+    except Exception as e:
+        return float("nan")
+plain = ms("train_bf16_plain.json")
+print("# config-2 training step, bf16-MFMA mode, one MI355X, 5 timed steps each (bench.py --train --bf16; OCCDEPTH_FORCE_DIST=1 OCCDEPTH_TRAIN_GRAPH_DDP=1")
+print("# drives SyncBatchNorm + gradient buckets through a single-rank RCCL group; OCCDEPTH_FORCE_PARTS picks which exchanges run)")
+print("plain step (no exchanges)                                   %8.2f ms" % plain)
+for parts, what in (("bn", "SyncBatchNorm exchanges only"), ("buckets", "gradient buckets only (600 MB all-reduced onto itself)")):
+    for ipc, how in ((1, "peer-memory path (csrc/ipc_allreduce.hip, in-kernel exchange)"), (0, "process group (RCCL)")):
+        v = ms("train_bf16_forced_%s_ipc%d.json" % (parts, ipc))
+        print("%-34s %-62s %8.2f ms  %+5.1f %%" % (what[:34], how, v, 100.0 * (v / plain - 1.0)))
+for f, how in (("train_bf16_forced_ipc.json", "both, peer-memory SyncBatchNorm"), ("train_bf16_forced_rccl.json", "both, RCCL SyncBatchNorm")):
+    v = ms(f)
+    print("%-34s %-62s %8.2f ms  %+5.1f %%" % ("SyncBatchNorm + buckets", how, v, 100.0 * (v / plain - 1.0)))
+PY
+  cat $O/forced_decomposition.txt
 fi
 if has headab; then
   for e in 1 0; do OCCD_C32X3_RES_EARLY=$e timeout 300 python tools/bench_head_x3.py > $O/head_x3_res_early$e.txt 2>&1; grep "nres=[12] K2s3\|nres=0 K2s3" $O/head_x3_res_early$e.txt | cut -c1-120; done

@@ -17,7 +17,9 @@ FAMILIES = [("conv3d_c32_slide_x3_kernel", "K2s3 head conv 32->32 3x3x3 (3x bf16
             ("wino3x3_kernel", "K10 fused Winograd 3x3"), ("pw_gemm_splitk_kernel", "K11s split-K pointwise GEMM"),
             ("pw_gemm_kernel", "K11 streaming pointwise GEMM"), ("upconv_gather_kernel", "K12 upsample-shift-accumulate"),
             ("dwconv2d_kernel", "depthwise + SE pooling"), ("lift_p1_kernel", "K1b lift"), ("lift_proj_kernel", "K1b fused lift (projection + frustum)"), ("Cijk_", "library GEMM (hipBLASLt / rocBLAS)"),
-            ("cascade_tail", "cascade tail"), ("se_reduce_kernel", "SE reduce"), ("se_expand", "SE expand"), ("wino_input_kernel", "K9 input transform")]
+            ("cascade_tail", "cascade tail"), ("se_reduce_kernel", "SE reduce"), ("se_expand", "SE expand"), ("wino_input_kernel", "K9 input transform"),
+            ("stem_conv3x3_kernel", "encoder stem conv + BN + swish (round 5)"), ("depthnet_gate_kernel", "DepthNet gate (round 5)"),
+            ("miopen", "MIOpen"), ("MIOpen", "MIOpen")]
 
 
 def family(name):
