@@ -530,7 +530,7 @@ def _forward(args, world, rank, device, dist):
         # priced against the instruction that is issued; the fp32-equivalent figures stay next to it
         x3_slide = any(k.startswith("conv3d_c32x3") for k, _ in head)
         res["dtype"] = ("f32 storage and accumulate; matrix arithmetic as 3x bf16 split (hi + mid + lo of both operands, six "
-                        "v_mfma_f32_32x32x16_bf16 per K step, error vs float64 <= the exact-fp32 kernels') in the head convolutions "
+                        "v_mfma_f32_32x32x16_bf16 per K step; error vs float64 tested within 1.5x of the exact-fp32 kernels', measured 0.8-1.1x) in the head convolutions "
                         "(K2s3), the small-volume 3x3x3 convolutions and transposed-convolution phases of the 3-D stack (K2b) and "
                         "the 2-D network's GEMMs (K16); exact fp32 MFMA / VALU everywhere else (K2, K10, K11, K14, depthwise, lift). "
                         " OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 restores exact fp32 everywhere")
