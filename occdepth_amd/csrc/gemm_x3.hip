@@ -47,6 +47,7 @@ struct GemmP {
     int act_a;                          // 1: sigmoid applied to the A elements while they are staged (CRP: sigmoid(P_logits) @ mega)
     float slope;
     int mtiles, ntiles, n_fast;         // n_fast: the N-tile index runs fastest in the block order (A tile reused), else M
+    int mr_tiles;                       // K16p: 32-row tiles per row range (mtiles = the number of ranges)
     unsigned nwg;
 };
 
@@ -647,6 +648,169 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K16p -- panel-stationary form for SHORT K with pre-split weights (PRE = 1 operands; K <= 352): the expand convolutions of
+// the MBConv stages and the tap GEMM of the 1/1 decoder level (K = 32 ... 224).  The barrier-phased kernel above re-stages
+// and re-splits the same B columns once per 64 ... 256 rows of A and spends two barriers per 32 k; with K this short a
+// workgroup is mostly prologue.  Here a workgroup owns a 64-column panel of B over the WHOLE K: staged + split into LDS once
+// ([k][hi | mid | lo][64 columns] + 64 B: 448 B per k, two workgroups per CU up to K = 176, K <= 352 fits), ONE barrier, and then its 8 waves walk the row tiles of A (MT x 32 rows each,
+// fragments of the pre-split image straight from L2, one 16-k step ahead) against the resident panel -- no barrier and no
+// split arithmetic in the K loop, B fragments by ds_read_b64_tr_b16 as in K16.  The grid is (column panels) x (row ranges);
+// the host cuts M into ranges only as far as it needs workgroups for 256 CUs.
+constexpr int kPanelRow = 3 * 128 + 64;              // LDS bytes per k of the panel: [hi | mid | lo] x 64 columns + 64 B (= 64 mod 128)
+constexpr int kPanelPass = 6;                         // float4 loads in flight per thread while the panel is staged
+template <int MT>
+__global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
+    constexpr int TN = 64, SB = kPanelRow;
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int K16tot = (p.K + 15) >> 4, KP = K16tot * 16;
+
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nwg = p.nwg, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt_i = bid % p.ntiles, mr_i = bid / p.ntiles;       // column panel fastest: an XCD shares the row range's weights
+    const int bz = blockIdx.y;
+    const int n0 = nt_i * TN;
+    const int tiles_all = (p.M + 31) >> 5;
+    const int t0 = mr_i * p.mr_tiles, t1 = min(t0 + p.mr_tiles, tiles_all);   // 32-row tiles of this workgroup
+
+    // ---- the B panel: (k, 4-column chunk) items, 16 per k row; four loads in flight per thread, then split -> LDS
+    {
+        const float* const Bb = p.B + (size_t)bz * p.sB;
+        const int total = KP * 16;
+        const bool edge = n0 + TN > p.N;
+        // (all loads of a pass in flight before the first split: K <= 192 is ONE pass, one HBM round trip)
+        for (int base = 0; base < total; base += 512 * kPanelPass) {
+            f32x4 v[kPanelPass];
+#pragma unroll
+            for (int i = 0; i < kPanelPass; ++i) {
+                const int f = base + i * 512 + tid;
+                const int k = min(f >> 4, p.K - 1), c = min(n0 + (f & 15) * 4, p.N - 4);
+                v[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + c);
+            }
+#pragma unroll
+            for (int i = 0; i < kPanelPass; ++i) {
+                const int f = base + i * 512 + tid;
+                const int k = f >> 4, c4 = f & 15;
+                if (f >= total) continue;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 w = k < p.K ? v[i] : z;
+                if (edge) {                              // (workgroup-uniform: the last panel of a row only)
+                    const int sh = n0 + c4 * 4 - min(n0 + c4 * 4, p.N - 4);
+                    const f32x4 u = w;
+                    w.x = sh == 0 ? u.x : sh == 1 ? u.y : sh == 2 ? u.z : u.w;
+                    w.y = sh == 0 ? u.y : sh == 1 ? u.z : sh == 2 ? u.w : 0.f;
+                    w.z = sh == 0 ? u.z : sh == 1 ? u.w : 0.f;
+                    w.w = sh == 0 ? u.w : 0.f;
+                }
+                u32x2 hi, mid, lo;
+                split4(w, hi, mid, lo);
+                unsigned char* dst = glds + k * SB + c4 * 8;
+                *(u32x2*)dst = hi;
+                *(u32x2*)(dst + 128) = mid;
+                *(u32x2*)(dst + 256) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    int b_lane[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) b_lane[nt] = (8 * h + (i16 >> 2)) * SB + (nt * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
+    const u32x4* const Abase = reinterpret_cast<const u32x4*>(p.A) + (size_t)bz * p.sA + lane;
+    float* const Cb = p.C + (size_t)bz * p.sC;
+
+    for (int tb = t0 + wave * MT; tb < t1; tb += 8 * MT) {
+        const u32x4* pk[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) pk[j] = Abase + (size_t)min(tb + j, tiles_all - 1) * K16tot * 192;
+        f32x16 acc[MT][2];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+        u32x4 an[MT][3];
+        bf16x8 bn[2][3];
+        auto fetch = [&](int k16) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) an[j][t] = pk[j][(k16 * 3 + t) * 64];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bn[nt][t] = tr_frag(glds + t * 128 + b_lane[nt] + k16 * 16 * SB, 4 * SB);
+        };
+        fetch(0);
+#define OCCD_GP(WT, XT)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < MT; ++j) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[j][nt] =    \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j][WT]), bf[nt][XT], acc[j][nt], 0, 0, 0)
+        for (int k16 = 0; k16 < K16tot; ++k16) {
+            u32x4 af[MT][3];
+            bf16x8 bf[2][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) af[j][t] = an[j][t];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bf[nt][t] = bn[nt][t];
+            }
+            if (k16 + 1 < K16tot) fetch(k16 + 1);
+            OCCD_GP(1, 1);
+            OCCD_GP(0, 2);
+            OCCD_GP(2, 0);
+            OCCD_GP(0, 1);
+            OCCD_GP(1, 0);
+            OCCD_GP(0, 0);
+        }
+#undef OCCD_GP
+        // epilogue of this tile set: lane -> column, registers -> rows (as K16)
+        auto store_all = [&](auto has_bias, auto act_sel) {
+            constexpr bool BIAS = decltype(has_bias)::value;
+            constexpr int ACT = decltype(act_sel)::value;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                if (tb + j >= t1) continue;                              // (wave-uniform: a row tile of the next range / past M)
+                const int mb = (tb + j) * 32 + 4 * h;
+                float bv[16];
+                if (BIAS) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bv[r] = p.bias[min(mb + (r & 3) + 8 * (r >> 2), p.M - 1)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = n0 + nt * 32 + li;
+                    const bool n_ok = n < p.N;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        float v = acc[j][nt][r];
+                        if (BIAS) v += bv[r];
+                        if (ACT == 1) v = occd::swish_fast(v);
+                        else if (ACT == 2) v = v > 0.f ? v : v * p.slope;
+                        if (n_ok && m < p.M) Cb[(size_t)m * p.ldc + n] = v;
+                    }
+                }
+            }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (p.bias == nullptr && p.act == 0) store_all(F_{}, std::integral_constant<int, 0>{});
+        else if (p.bias != nullptr && p.act == 1) store_all(T_{}, std::integral_constant<int, 1>{});
+        else if (p.bias != nullptr && p.act == 2) store_all(T_{}, std::integral_constant<int, 2>{});
+        else if (p.bias != nullptr) store_all(T_{}, std::integral_constant<int, 0>{});
+        else if (p.act == 1) store_all(F_{}, std::integral_constant<int, 1>{});
+        else store_all(F_{}, std::integral_constant<int, 2>{});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K16t -- "NT" form for weight gradients: C[b][m][n] = sum_k A[b][m][k] * B[b][n][k], BOTH operands with k contiguous and
 // of ANY dword alignment and any K (rows of H*W pixels: odd lengths are the rule).  dW of a pointwise convolution is
 // gy (Cout x HW) . x^T (HW x Cin): both tensors lie k(= pixel)-contiguous in NCHW memory, so both are staged like K16's A
@@ -854,7 +1018,8 @@ extern "C" int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_
     return occd::check_launch();
 }
 
-// a->tile_hint: 0 = pick (see below), 1 .. 5 = force a tile variant, 6 = force K16w, 7 = force the 64 x 64 split-K form.
+// a->tile_hint: 0 = pick (see below), 1 .. 5 = force a tile variant, 6 = force K16w, 7 = force the 64 x 64 split-K form,
+// 8 = force K16p (pre = 1, K <= 352, no res / scale_k).
 // a->pre: 0 = A and B float32; 1 = a->A is the role-0 image of occd_gemm_x3_pack (lda ignored, stride_a = bf16 elements
 // between batch items, 0 = shared); 2 = a->B is the role-1 image (ldb ignored, stride_b likewise).
 extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
@@ -868,7 +1033,56 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (a->pre == 1 && ((reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 7))) return OCCD_EINVAL;
     if (a->pre == 2 && ((reinterpret_cast<uintptr_t>(a->B) & 15) || (a->stride_b & 7))) return OCCD_EINVAL;
     if (reinterpret_cast<uintptr_t>(a->C) & 3) return OCCD_EINVAL;
-    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 2) return OCCD_EINVAL;
+    if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 3) return OCCD_EINVAL;
+    if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
+    {
+        // K16p: pre-split A, the whole-K panel of 64 B columns fits LDS, plain epilogue.  hint 8 forces it, hint 0 picks it for
+        // matrices of >= 256 rows -- one row tile for each of the 8 waves (OCCD_GEMM_PANEL=0 keeps the barrier-phased PRE = 1
+        // kernel for A/B)
+        static const bool panel_off = !occd::env_flag("OCCD_GEMM_PANEL", true);
+        const int KP = ((a->K + 15) / 16) * 16;
+        const size_t plds = (size_t)KP * kPanelRow;
+        const bool fits = a->pre == 1 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0 && plds <= 160 * 1024;
+        if (a->tile_hint == kNumVariantsG + 3 && !fits) return OCCD_EINVAL;
+        if (fits && (a->tile_hint == kNumVariantsG + 3 || (a->tile_hint == 0 && !panel_off && a->M >= 256))) {
+            GemmP p;
+            p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.res = nullptr; p.kscale = nullptr;
+            p.M = a->M; p.N = a->N; p.K = a->K;
+            p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a / 8; p.sB = a->stride_b; p.sC = a->stride_c;
+            p.act = a->act; p.slope = a->slope; p.act_a = 0;
+            p.ntiles = (a->N + 63) / 64;
+            const int tiles = (a->M + 31) / 32;
+            // row ranges: one, unless the column panels alone leave CUs idle -- then as many as fill ~256 workgroups, each
+            // of at least 8 row tiles (one per wave)
+            const long panels = (long)p.ntiles * a->batch;
+            long ranges = panels >= 256 ? 1 : 256 / panels;
+            if (ranges > (tiles + 7) / 8) ranges = (tiles + 7) / 8;
+            if (ranges < 1) ranges = 1;
+            static const int dev_ranges = getenv("OCCD_GEMM_PANEL_RANGES") ? atoi(getenv("OCCD_GEMM_PANEL_RANGES")) : 0;   // (development A/B)
+            if (dev_ranges >= 1 && dev_ranges <= tiles) ranges = dev_ranges;
+            p.mr_tiles = (int)((tiles + ranges - 1) / ranges);
+            p.mtiles = (tiles + p.mr_tiles - 1) / p.mr_tiles;
+            // row tiles per wave: the smallest of 1 / 2 / 3 that covers a range in one round of the 8 waves, else 3
+            // row tiles per wave and round: 1.  Measured (profiles/r05_gemm_panel.txt): 2 / 3 tiles per wave halve / third the
+            // LDS fragment reads but lose on every launch of the frame (tap 1/1 460 -> 471 / 487 us, 48 -> 288 on 28365 pixels
+            // 29 -> 37 / 45 us): several short rounds per wave overlap one wave's stores with the other's MFMAs; raising the
+            // priority of one wave per SIMD to force that alternation changed nothing.  (OCCD_GEMM_PANEL_MT: development A/B)
+            int mt = 1;
+            static const int dev_mt = getenv("OCCD_GEMM_PANEL_MT") ? atoi(getenv("OCCD_GEMM_PANEL_MT")) : 0;
+            if (dev_mt >= 1 && dev_mt <= 3) mt = dev_mt;
+            p.n_fast = 1;
+            const long nwg = (long)p.mtiles * p.ntiles;
+            if (nwg >= (1L << 31)) return OCCD_EINVAL;
+            p.nwg = (unsigned)nwg;
+            void (*kern)(const GemmP) = mt == 1 ? gemm_x3_panel_kernel<1> : mt == 2 ? gemm_x3_panel_kernel<2> : gemm_x3_panel_kernel<3>;
+            if (plds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
+            const double flops = 2.0 * a->M * a->N * a->K * a->batch;
+            const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
+            occd::ProfScope prof("gemm_f32x3_panel", (hipStream_t)stream, flops, bytes);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(512), plds, (hipStream_t)stream, p);
+            return occd::check_launch();
+        }
+    }
     int pick = a->tile_hint - 1;
     if (a->tile_hint == kNumVariantsG + 1) pick = 0;
     if (a->tile_hint == kNumVariantsG + 2) {

@@ -761,25 +761,54 @@ GEMM_X3 = os.environ.get("OCCDEPTH_GEMM_X3", "1") == "1"
 GEMM_X3_PACK = os.environ.get("OCCDEPTH_GEMM_X3_PACK", "0") == "1"
 
 
+# K16p (round 5): the SHORT-K left operands (expand convolutions, the 1/1 and 1/2 tap GEMMs: K <= 352, >= 256 rows) ARE pre-split, for
+# the panel-stationary kernel that keeps a 64-column panel of B over the whole K in LDS (csrc/gemm_x3.hip).  OCCDEPTH_GEMM_X3_PANEL=0
+# -> the barrier-phased K16 on float32 operands as in round 4.
+GEMM_X3_PANEL = os.environ.get("OCCDEPTH_GEMM_X3_PANEL", "1") == "1"
+PANEL_MAX_K, PANEL_MIN_ROWS = 352, 256
+
+
+def _panel_operand(w, role):
+    return GEMM_X3_PANEL and role == "a" and w.dim() == 2 and w.shape[1] <= PANEL_MAX_K and w.shape[0] >= PANEL_MIN_ROWS
+
+
 def matmul_operand(w, role):
     """A static operand (weights) in the form hip.matmul wants it: (the float32 tensor, its GemmPacked image or None)."""
     w = w.detach().float().contiguous()
-    if GEMM_X3 and GEMM_X3_PACK and w.is_cuda:
+    if GEMM_X3 and w.is_cuda and (GEMM_X3_PACK or _panel_operand(w, role)):
         return w, GemmPacked(w, role)
     return w, None
 
 
-def matmul(a, b, bias=None, act=None, slope=0.01, res=None, k_scale=None):
+# Rows of a K16 result that start on 128-byte boundaries are WRITTEN 2.2x faster than rows of an odd pixel count (H * W floats:
+# every 128-byte store segment straddles two cache lines that another workgroup completes later; tools/store_pattern.hip:
+# 650 MB in 121 us against 262 - 290 us; profiles/r05_store_alignment.txt).  `padded_rows` hands out such a result buffer:
+# (..., rows, n) as a view of (..., rows, n rounded up to 32 floats).  OCCDEPTH_PAD_ROWS=0 -> dense results as in round 4.
+PAD_ROWS = os.environ.get("OCCDEPTH_PAD_ROWS", "1") == "1"
+
+
+def padded_rows(shape, device):
+    """An uninitialised float32 tensor of `shape` whose rows (last dimension) lie 128-byte aligned: a view of a buffer with the
+    last dimension rounded up to 32 floats (stride(-1) == 1; the leading dimensions dense over the padded rows)."""
+    n = int(shape[-1])
+    pitch = round_up(n, 32) if PAD_ROWS else n
+    return torch.empty(tuple(shape[:-1]) + (pitch,), device=device, dtype=torch.float32)[..., :n]
+
+
+def matmul(a, b, bias=None, act=None, slope=0.01, res=None, k_scale=None, out=None):
     """act(a @ (b * k_scale[..., None]) + bias[:, None]) + res for the eval path: K16 when it applies, else the library + plain
-    tensor ops.  a / b may be the (tensor, GemmPacked or None) pair of `matmul_operand`."""
+    tensor ops.  a / b may be the (tensor, GemmPacked or None) pair of `matmul_operand`; out: an optional (batch, M, N) result
+    tensor (rows may be padded: `padded_rows`)."""
     ta, pa = a if isinstance(a, tuple) else (a, None)
     tb, pb = b if isinstance(b, tuple) else (b, None)
     if GEMM_X3:
-        xa, xb = (pa if pa is not None else ta), (pb if pb is not None and k_scale is None else tb)
+        # (a panel-only image serves the plain epilogue; with a residual / a k scale the float32 operand goes to K16)
+        a_img = pa is not None and (GEMM_X3_PACK or (res is None and k_scale is None))
+        xa, xb = (pa if a_img else ta), (pb if pb is not None and k_scale is None else tb)
         if gemm_x3_supported(xa, xb):
-            return gemm_x3(xa, xb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale)
+            return gemm_x3(xa, xb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale, out=out)
         if gemm_x3_supported(ta, tb):
-            return gemm_x3(ta, tb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale)
+            return gemm_x3(ta, tb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale, out=out)
     if k_scale is not None:
         tb = tb * k_scale.unsqueeze(-1)
     y = torch.matmul(ta, tb)
@@ -789,7 +818,11 @@ def matmul(a, b, bias=None, act=None, slope=0.01, res=None, k_scale=None):
         y = y * torch.sigmoid(y)
     elif act == "leaky":
         y = torch.nn.functional.leaky_relu(y, slope)
-    return y + res if res is not None else y
+    y = y + res if res is not None else y
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def c32x3_eligible(x, cout, kernel, out, stride=(1, 1, 1), dilation=(1, 1, 1), padding=(0, 0, 0), res1=None, res2=None,
@@ -1696,14 +1729,20 @@ def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift
     """sum over the 9 taps of shift_t(bilinear_up(z_t)): z (B, 9 * cout, h, w) -> (B, cout, H, W), size = (H, W).
     With z = conv1x1(x, W9) this is conv3x3(pad 1)(bilinear_up(x, align_corners=True)) (see occd_upconv_gather_nchw).
     batch_inner: z is (9 * cout, B, h, w) -- the result of ONE GEMM over the pixels of all images."""
-    if not z.is_contiguous():
+    # dense, or planes (the rows of the tap GEMM's result) on a padded pitch (`padded_rows`): the strides travel
+    if not (z.stride(3) == 1 and z.stride(2) == z.shape[3] and z.stride(0) > 0 and z.stride(1) > 0 and z.dtype == torch.float32):
         z = z.contiguous()
     if batch_inner:
         c9, B, h, w = z.shape
-        zcs, zbs = B * h * w, h * w
+        zcs, zbs = z.stride(0), z.stride(1)
+        ok = zbs == h * w and zcs >= B * h * w
     else:
         B, c9, h, w = z.shape
-        zcs, zbs = 0, 0
+        zcs, zbs = z.stride(1), z.stride(0)
+        ok = zcs >= h * w and zbs >= c9 * zcs
+    if not ok or not z.is_cuda:
+        raise RuntimeError("upconv_gather: z must be a GPU tensor, dense or with planes on a padded pitch")
+    zp = z.data_ptr()
     if c9 != 9 * cout:
         raise RuntimeError("upconv_gather: z must have 9 * cout channels")
     H, W = int(size[0]), int(size[1])
@@ -1711,11 +1750,11 @@ def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift
     if skip is not None:
         # fused tail of the level: + conv3x3 over the (<= 4) skip channels + shift, LeakyReLU (occd_upconv_gather_skip_nchw)
         sk = skip if skip.is_contiguous() else skip.contiguous()
-        _check(load().occd_upconv_gather_skip_nchw(_f32(z, "z"), _f32(sk, "skip"), _f32(wskip, "wskip"), _f32(shift, "shift"),
+        _check(load().occd_upconv_gather_skip_nchw(zp, _f32(sk, "skip"), _f32(wskip, "wskip"), _f32(shift, "shift"),
                                                    _f32(out, "out"), B, cout, sk.shape[1], h, w, H, W, zcs, zbs, float(slope),
                                                    _stream()), "occd_upconv_gather_skip_nchw")
         return out
-    _check(load().occd_upconv_gather_nchw(_f32(z, "z"), _f32(out, "out"), B, cout, h, w, H, W, zcs, zbs, _stream()),
+    _check(load().occd_upconv_gather_nchw(zp, _f32(out, "out"), B, cout, h, w, H, W, zcs, zbs, _stream()),
            "occd_upconv_gather_nchw")
     return out
 

@@ -129,13 +129,15 @@ class UpSampleBN(nn.Module):
         B, cup, h, w = x.shape
         if B > 1 and B * h * w <= self.UPCONV_FOLD_BELOW:
             # few pixels per image: ONE GEMM over the pixels of all images (the operand copy is small here)
-            z = hip.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w)).view(9 * cout, B, h, w)
+            z = hip.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w),
+                           out=hip.padded_rows((9 * cout, B * h * w), x.device)).view(9 * cout, B, h, w)
             batch_inner = True
         else:
             batch_inner = False
             if B * h * w < self.UPCONV_LIB_BELOW:
                 xc = x if x.is_contiguous() else x.contiguous()
-                z = hip.matmul(w9, xc.view(B, cup, h * w)).view(B, 9 * cout, h, w)     # K16 (csrc/gemm_x3.hip)
+                # K16 (csrc/gemm_x3.hip) into tap planes on a 128-byte pitch (written 2x faster; K12 takes the strides)
+                z = hip.matmul(w9, xc.view(B, cup, h * w), out=hip.padded_rows((B, 9 * cout, h * w), x.device)).view(B, 9 * cout, h, w)
             else:
                 z = hip.conv1x1(x, wpk9, 9 * cout)
         rw = (w - 1) / max(skip.shape[3] - 1, 1)

@@ -87,6 +87,74 @@ def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint, K):
         assert float((got - (lin - bias.double().view(1, -1, 1))).abs().max() / lin.abs().max()) < 2e-6
 
 
+# K16p (tile_hint 8): (batch, M, N, K, A batched?) -- row counts that give 1 / 2 / 3 row tiles per wave, several row ranges (few
+# column panels), idle sub-tiles and idle waves; K tails of 8 (K % 16 = 8) and the largest K that fits LDS; N tails of every
+# residue and N < 64
+PANEL_SHAPES = [(2, 720, 1100, 160, False), (2, 960, 1848, 160, False), (2, 1344, 460, 224, False), (2, 480, 7191 // 4, 80, False),
+                (2, 288, 3000, 48, False), (1, 192, 5003, 32, False), (1, 130, 70, 352, False), (3, 257, 61, 72, True),
+                (1, 40, 6, 8, False), (2, 2304 // 4, 468, 264, False)]
+
+
+@pytest.mark.parametrize("shape", PANEL_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
+def test_gemm_x3_panel_vs_float64(hip, shape):
+    """The panel-stationary kernel (pre-split A, the whole-K panel of 64 B columns resident in LDS) against float64, plain and
+    with the bias + activation epilogues, into a strided output; hint 0 picks it for >= 256 rows (profile row name)."""
+    batch, M, N, K, a_batched = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(*((batch, M, K) if a_batched else (M, K)), generator=g) / K ** 0.5
+    bbig = torch.randn(batch, K + 2, N + 5, generator=g) * 3.0
+    b = bbig[:, 1:1 + K, 2:2 + N]                            # a view: ldb > N, dword-aligned rows
+    bias = torch.randn(M, generator=g)
+    lin = torch.matmul(a.double(), b.double())
+    pa, bd = hip.GemmPacked(a.to(DEV), "a"), bbig.to(DEV)[:, 1:1 + K, 2:2 + N]
+    err32 = float((torch.matmul(a.to(DEV), bd).cpu().double() - lin).abs().max() / lin.abs().max())
+    with hip.profile() as prof:
+        got = hip.gemm_x3(pa, bd, tile_hint=8)
+    assert list(prof.rows)[0].startswith("gemm_f32x3_panel"), prof.rows.keys()
+    assert float((got.cpu().double() - lin).abs().max() / lin.abs().max()) < max(2e-6, 1.25 * err32)
+    with hip.profile() as prof:
+        auto = hip.gemm_x3(pa, bd)
+    assert list(prof.rows)[0].startswith("gemm_f32x3_panel" if M >= 256 else "gemm_f32x3_preA"), prof.rows.keys()
+    assert float((auto.cpu().double() - lin).abs().max() / lin.abs().max()) < max(2e-6, 1.25 * err32)
+    linb = lin + bias.double().view(1, -1, 1)
+    obig = torch.full((batch, M + 1, N + 3), 7.0, device=DEV)
+    for act, ref in ((None, linb), ("swish", linb * torch.sigmoid(linb)), ("leaky", torch.where(linb > 0, linb, linb * 0.2))):
+        out = obig[:, 1:, 3:]
+        hip.gemm_x3(pa, bd, bias=bias.to(DEV), act=act, slope=0.2, tile_hint=8, out=out)
+        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < max(3e-6 if act == "swish" else 2e-6, 1.25 * err32), (act, err)
+        assert float(obig[:, 0].min()) == 7.0 and float(obig[:, :, :3].min()) == 7.0 == float(obig[:, :, :3].max())
+    # bit-identical to itself (no atomics, fixed order), and the same value whichever row range / wave owns a row
+    assert torch.equal(hip.gemm_x3(pa, bd, tile_hint=8), got)
+
+
+def test_gemm_x3_panel_limits(hip):
+    a = torch.randn(256, 360, device=DEV)                    # K = 360: 368 k x 448 B > 160 KB of LDS
+    b = torch.randn(2, 360, 100, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.gemm_x3(hip.GemmPacked(a, "a"), b, tile_hint=8)
+    with hip.profile() as prof:
+        y = hip.gemm_x3(hip.GemmPacked(a, "a"), b)           # hint 0: the barrier-phased PRE = 1 kernel
+    assert list(prof.rows)[0].startswith("gemm_f32x3_preA")
+    assert float((y - torch.matmul(a, b)).abs().max()) < 1e-3
+    a2 = torch.randn(256, 64, device=DEV)
+    b2 = torch.randn(2, 64, 100, device=DEV)
+    with pytest.raises(RuntimeError):                        # float32 A / a residual: not this kernel
+        hip.gemm_x3(a2, b2, tile_hint=8)
+    with pytest.raises(RuntimeError):
+        hip.gemm_x3(hip.GemmPacked(a2, "a"), b2, tile_hint=8, res=torch.zeros(2, 256, 100, device=DEV))
+    # hip.matmul hands the image to K16 only where the panel kernel applies
+    w = hip.matmul_operand(a2, "a")
+    assert w[1] is not None and hip.matmul_operand(a, "a")[1] is None and hip.matmul_operand(a2[:64].contiguous(), "a")[1] is None
+    res = torch.randn(2, 256, 100, device=DEV)
+    with hip.profile() as prof:
+        y0 = hip.matmul(w, b2)
+        y1 = hip.matmul(w, b2, res=res)
+    names = sorted(k.split(":")[0] for k in prof.rows)
+    assert names == ["gemm_f32x3", "gemm_f32x3_panel"], names
+    assert float((y1 - res - y0).abs().max()) < 1e-5
+
+
 def test_gemm_x3_strided_views_and_output(hip):
     """Operands as views (leading dimensions larger than the logical sizes) and a caller-provided strided output: the
     forms the decoder uses -- x[b] planes of an NCHW tensor as (K, N) with ldb = H W, weights as a slice of a wider matrix."""

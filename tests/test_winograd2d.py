@@ -204,6 +204,17 @@ def test_upconv_gather_kernel_gpu(case, hip_lib):
     # the source coordinates are float32 products (as in ATen's float32 kernel): at column 600 one ulp of the coordinate
     # is 3e-5 of a pixel, which is the error of the interpolation weight against this float64 reference
     assert got.shape == ref.shape and err < (1e-5 if W < 200 else 6e-5), (case, err)
+    # the tap planes on a 128-byte pitch (hip.padded_rows: how the decoder hands them over) and batch-inner: the strides travel,
+    # the result is bit-identical and the padding is never read (NaN there)
+    zp = hip.padded_rows((B, 9 * cout, h * w), "cuda")
+    assert zp.stride(1) % 32 == 0 and zp.stride(2) == 1 and zp.stride(1) >= h * w
+    torch.as_strided(zp, (B, 9 * cout, zp.stride(1)), (zp.stride(0), zp.stride(1), 1)).fill_(float("nan"))
+    zp.copy_(z.cuda().view(B, 9 * cout, h * w))
+    assert torch.equal(hip.upconv_gather(zp.view(B, 9 * cout, h, w), cout, (H, W)).cpu(), got)
+    zi = hip.padded_rows((9 * cout, B * h * w), "cuda")
+    torch.as_strided(zi, (9 * cout, zi.stride(0)), (zi.stride(0), 1)).fill_(float("nan"))
+    zi.copy_(z.cuda().permute(1, 0, 2, 3).reshape(9 * cout, B * h * w))
+    assert torch.equal(hip.upconv_gather(zi.view(9 * cout, B, h, w), cout, (H, W), batch_inner=True).cpu(), got)
 
 
 @pytest.mark.gpu

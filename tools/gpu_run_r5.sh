@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 GPU session driver (everything lands under gpurun_out/<tag>/; summaries are copied to profiles/ by hand).
 #   gpurun -- 'bash tools/gpu_run_r5.sh <tag> <section> [<section> ...]'
-# sections: newtests alltests smoke bench benchq config5 train trainpw ipc exact frame prof proftrain pmc
+# sections: panel newtests alltests smoke bench benchq config5 train trainpw ipc exact frame prof proftrain pmc
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
@@ -26,6 +26,11 @@ PY
 }
 if has newtests; then
   timeout 1500 python -m pytest -q -m gpu -x tests/test_loss_kernels_gpu.py tests/test_losses_gpu.py tests/test_bf16_conv.py tests/test_gemm_x3.py tests/test_train_step.py ${EXTRA_TESTS:-} > $O/pytest_new.txt 2>&1; tail -15 $O/pytest_new.txt
+fi
+if has panel; then
+  timeout 900 python -m pytest -q -m gpu -x tests/test_gemm_x3.py > $O/pytest_gemm.txt 2>&1; tail -8 $O/pytest_gemm.txt
+  timeout 300 python tools/bench_gemm_panel.py > $O/gemm_panel.txt 2>&1; cat $O/gemm_panel.txt
+  OCCDEPTH_GEMM_X3_PANEL=0 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/benchq_panel0.json 2> $O/benchq_panel0.err; line $O/benchq_panel0.json
 fi
 if has benchq; then
   timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/benchq.json 2> $O/benchq.err; line $O/benchq.json
