@@ -473,12 +473,14 @@ int occd_dwconv2d_bwd_weight_nchw(const float* x, const float* gy, float* dw, fl
  * (B*C, occd_dwconv2d_pool_blocks(Ho, Wo)) holds each workgroup's share of sum_{y,x} y[b][c] (fixed summation order).
  * occd_se_gate turns the partials into the gate  sigmoid(W_e swish(W_r mean + b_r) + b_e)  (B, C) of geffnet's
  * SqueezeExcite (conv_reduce (Cr, C), conv_expand (C, Cr)); r_scratch: B * Cr floats.  The gate is consumed by
- * occd_pw_conv_fwd's `gate` operand: x * gate never exists in memory.                                            */
+ * occd_pw_conv_fwd's `gate` operand: x * gate never exists in memory.
+ * x_plane_stride (ABI 12): floats between consecutive (b, c) input planes, 0 = H * W (dense); > H * W when x is the result of
+ * an expand GEMM whose rows were put on a 128-byte pitch (rows of an odd pixel count are written 2.2x slower).            */
 int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo);
 int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                             float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
                             int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
-                            int32_t act, void* stream);
+                            int32_t act, int64_t x_plane_stride, void* stream);
 /* Squeeze-excite in TRAINING (autograd of geffnet's SqueezeExcite in training_step):
  *   forward : sums = occd_plane_reduce(x, NULL)  ->  occd_se_gate(sums, ..., nblk = 1, S)  ->  occd_affine_act_nchw (x * gate)
  *   backward: gg = occd_plane_reduce(gout, x)    ->  occd_se_bwd                           ->  occd_affine_act_nchw

@@ -648,19 +648,22 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K16p -- panel-stationary form for SHORT K with pre-split weights (PRE = 1 operands; K <= 352): the expand convolutions of
+// K16p -- panel-stationary form for SHORT K with pre-split weights (PRE = 1 operands; K <= 848): the expand convolutions of
 // the MBConv stages and the tap GEMM of the 1/1 decoder level (K = 32 ... 224).  The barrier-phased kernel above re-stages
 // and re-splits the same B columns once per 64 ... 256 rows of A and spends two barriers per 32 k; with K this short a
-// workgroup is mostly prologue.  Here a workgroup owns a 64-column panel of B over the WHOLE K: staged + split into LDS once
-// ([k][hi | mid | lo][64 columns] + 64 B: 448 B per k, two workgroups per CU up to K = 176, K <= 352 fits), ONE barrier, and then its 8 waves walk the row tiles of A (MT x 32 rows each,
+// workgroup is mostly prologue.  Here a workgroup owns a 64- (or 32-) column panel of B over the WHOLE K: staged + split into
+// LDS once ([k][hi | mid | lo][64 columns] + 64 B: 448 B per k, two workgroups per CU up to K = 176, K <= 352 fits), ONE barrier, and then its 8 waves walk the row tiles of A (MT x 32 rows each,
 // fragments of the pre-split image straight from L2, one 16-k step ahead) against the resident panel -- no barrier and no
 // split arithmetic in the K loop, B fragments by ds_read_b64_tr_b16 as in K16.  The grid is (column panels) x (row ranges);
 // the host cuts M into ranges only as far as it needs workgroups for 256 CUs.
-constexpr int kPanelRow = 3 * 128 + 64;              // LDS bytes per k of the panel: [hi | mid | lo] x 64 columns + 64 B (= 64 mod 128)
+// LDS bytes per k of a panel of NT x 32 columns: [hi | mid | lo] x (64 NT) B, + 64 B for NT = 2: 192 / 448, both = 64 mod 128
+// (conflict-free transposing reads).  NT = 1 (32 columns): twice the panels for the few-pixel stages (468 / 1848 pixels), K up
+// to 848, at twice the weight-fragment traffic per MFMA -- which a launch that small does not notice.
+constexpr int panel_row_bytes(int nt) { return 3 * 64 * nt + (nt == 1 ? 0 : 64); }
 constexpr int kPanelPass = 6;                         // float4 loads in flight per thread while the panel is staged
-template <int MT>
+template <int MT, int NT, int PD>
 __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
-    constexpr int TN = 64, SB = kPanelRow;
+    constexpr int TN = 32 * NT, SB = panel_row_bytes(NT), TB = 64 * NT, C4 = TN / 4;   // TB: bytes of one term's columns in a row
     extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -679,10 +682,31 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
     const int tiles_all = (p.M + 31) >> 5;
     const int t0 = mr_i * p.mr_tiles, t1 = min(t0 + p.mr_tiles, tiles_all);   // 32-row tiles of this workgroup
 
-    // ---- the B panel: (k, 4-column chunk) items, 16 per k row; four loads in flight per thread, then split -> LDS
+    // weight fragments of this wave's row tile, PD 16-k steps ahead of the MFMAs (a step is 6 MT NT MFMAs = 0.1 ... 0.2 us of
+    // matrix time against ~1 us of L2 latency; one workgroup per CU on the few-pixel launches, so nothing else hides it); the
+    // first PD steps are requested before the panel is staged
+    const u32x4* const Abase = reinterpret_cast<const u32x4*>(p.A) + (size_t)bz * p.sA + lane;
+    const u32x4* pk[MT];
+    u32x4 an[PD][MT][3];
+    auto fetch_a = [&](int d, int k16) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) an[d][j][t] = pk[j][(k16 * 3 + t) * 64];
+    };
+    auto first_a = [&](int tb) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) pk[j] = Abase + (size_t)min(tb + j, tiles_all - 1) * K16tot * 192;
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d < K16tot) fetch_a(d, d);
+    };
+    if (t0 + wave * MT < t1) first_a(t0 + wave * MT);
+
+    // ---- the B panel: (k, 4-column chunk) items, C4 per k row; kPanelPass loads in flight per thread, then split -> LDS
     {
         const float* const Bb = p.B + (size_t)bz * p.sB;
-        const int total = KP * 16;
+        const int total = KP * C4;
         const bool edge = n0 + TN > p.N;
         // (all loads of a pass in flight before the first split: K <= 192 is ONE pass, one HBM round trip)
         for (int base = 0; base < total; base += 512 * kPanelPass) {
@@ -690,13 +714,13 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
 #pragma unroll
             for (int i = 0; i < kPanelPass; ++i) {
                 const int f = base + i * 512 + tid;
-                const int k = min(f >> 4, p.K - 1), c = min(n0 + (f & 15) * 4, p.N - 4);
+                const int k = min(f / C4, p.K - 1), c = min(n0 + (f % C4) * 4, p.N - 4);
                 v[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + c);
             }
 #pragma unroll
             for (int i = 0; i < kPanelPass; ++i) {
                 const int f = base + i * 512 + tid;
-                const int k = f >> 4, c4 = f & 15;
+                const int k = f / C4, c4 = f % C4;
                 if (f >= total) continue;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 f32x4 w = k < p.K ? v[i] : z;
@@ -712,64 +736,64 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
                 split4(w, hi, mid, lo);
                 unsigned char* dst = glds + k * SB + c4 * 8;
                 *(u32x2*)dst = hi;
-                *(u32x2*)(dst + 128) = mid;
-                *(u32x2*)(dst + 256) = lo;
+                *(u32x2*)(dst + TB) = mid;
+                *(u32x2*)(dst + 2 * TB) = lo;
             }
         }
     }
     __syncthreads();
-    int b_lane[2];
+    int b_lane[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) b_lane[nt] = (8 * h + (i16 >> 2)) * SB + (nt * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
-    const u32x4* const Abase = reinterpret_cast<const u32x4*>(p.A) + (size_t)bz * p.sA + lane;
+    for (int nt = 0; nt < NT; ++nt) b_lane[nt] = (8 * h + (i16 >> 2)) * SB + (nt * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
     float* const Cb = p.C + (size_t)bz * p.sC;
 
     for (int tb = t0 + wave * MT; tb < t1; tb += 8 * MT) {
-        const u32x4* pk[MT];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) pk[j] = Abase + (size_t)min(tb + j, tiles_all - 1) * K16tot * 192;
-        f32x16 acc[MT][2];
+        f32x16 acc[MT][NT];
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
-        u32x4 an[MT][3];
-        bf16x8 bn[2][3];
-        auto fetch = [&](int k16) {
+        bf16x8 bn[NT][3];
+        auto fetch_b = [&](int k16) {
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) an[j][t] = pk[j][(k16 * 3 + t) * 64];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) bn[nt][t] = tr_frag(glds + t * 128 + b_lane[nt] + k16 * 16 * SB, 4 * SB);
+                for (int t = 0; t < 3; ++t) bn[nt][t] = tr_frag(glds + t * TB + b_lane[nt] + k16 * 16 * SB, 4 * SB);
         };
-        fetch(0);
+        fetch_b(0);
 #define OCCD_GP(WT, XT)                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < MT; ++j) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[j][nt] =    \
+    _Pragma("unroll") for (int j = 0; j < MT; ++j) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[j][nt] =    \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j][WT]), bf[nt][XT], acc[j][nt], 0, 0, 0)
-        for (int k16 = 0; k16 < K16tot; ++k16) {
-            u32x4 af[MT][3];
-            bf16x8 bf[2][3];
+        for (int k0 = 0; k0 < K16tot; k0 += PD) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int d = 0; d < PD; ++d) {               // (unrolled: the fragment set of a step is a compile-time index)
+                const int k16 = k0 + d;
+                if (k16 >= K16tot) break;                // (uniform)
+                u32x4 af[MT][3];
+                bf16x8 bf[NT][3];
 #pragma unroll
-                for (int j = 0; j < MT; ++j) af[j][t] = an[j][t];
+                for (int t = 0; t < 3; ++t) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) bf[nt][t] = bn[nt][t];
+                    for (int j = 0; j < MT; ++j) af[j][t] = an[d][j][t];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bf[nt][t] = bn[nt][t];
+                }
+                if (k16 + PD < K16tot) fetch_a(d, k16 + PD);
+                if (k16 + 1 < K16tot) fetch_b(k16 + 1);
+                OCCD_GP(1, 1);
+                OCCD_GP(0, 2);
+                OCCD_GP(2, 0);
+                OCCD_GP(0, 1);
+                OCCD_GP(1, 0);
+                OCCD_GP(0, 0);
             }
-            if (k16 + 1 < K16tot) fetch(k16 + 1);
-            OCCD_GP(1, 1);
-            OCCD_GP(0, 2);
-            OCCD_GP(2, 0);
-            OCCD_GP(0, 1);
-            OCCD_GP(1, 0);
-            OCCD_GP(0, 0);
         }
 #undef OCCD_GP
+        // the next row tile's first fragments go out BEFORE this tile's stores (loads return in order among loads; queued behind
+        // the stores they would wait for them to drain)
+        if (tb + 8 * MT < t1) first_a(tb + 8 * MT);
         // epilogue of this tile set: lane -> column, registers -> rows (as K16)
         auto store_all = [&](auto has_bias, auto act_sel) {
             constexpr bool BIAS = decltype(has_bias)::value;
@@ -784,7 +808,7 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
                     for (int r = 0; r < 16; ++r) bv[r] = p.bias[min(mb + (r & 3) + 8 * (r >> 2), p.M - 1)];
                 }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     const int n = n0 + nt * 32 + li;
                     const bool n_ok = n < p.N;
 #pragma unroll
@@ -1019,7 +1043,7 @@ extern "C" int occd_gemm_x3_pack(const float* w, void* out, int32_t rows, int32_
 }
 
 // a->tile_hint: 0 = pick (see below), 1 .. 5 = force a tile variant, 6 = force K16w, 7 = force the 64 x 64 split-K form,
-// 8 = force K16p (pre = 1, K <= 352, no res / scale_k).
+// 8 = force K16p (pre = 1, K <= 848, no res / scale_k).
 // a->pre: 0 = A and B float32; 1 = a->A is the role-0 image of occd_gemm_x3_pack (lda ignored, stride_a = bf16 elements
 // between batch items, 0 = shared); 2 = a->B is the role-1 image (ldb ignored, stride_b likewise).
 extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
@@ -1036,45 +1060,51 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 3) return OCCD_EINVAL;
     if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
     {
-        // K16p: pre-split A, the whole-K panel of 64 B columns fits LDS, plain epilogue.  hint 8 forces it, hint 0 picks it for
-        // matrices of >= 256 rows -- one row tile for each of the 8 waves (OCCD_GEMM_PANEL=0 keeps the barrier-phased PRE = 1
-        // kernel for A/B)
+        // K16p: pre-split A, the whole-K panel of 32 / 64 B columns fits LDS, plain epilogue.  hint 8 forces it, hint 0 picks it
+        // for matrices of >= 256 rows -- one row tile for each of the 8 waves (OCCD_GEMM_PANEL=0 keeps the barrier-phased
+        // PRE = 1 kernel for A/B)
         static const bool panel_off = !occd::env_flag("OCCD_GEMM_PANEL", true);
         const int KP = ((a->K + 15) / 16) * 16;
-        const size_t plds = (size_t)KP * kPanelRow;
-        const bool fits = a->pre == 1 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0 && plds <= 160 * 1024;
-        if (a->tile_hint == kNumVariantsG + 3 && !fits) return OCCD_EINVAL;
-        if (fits && (a->tile_hint == kNumVariantsG + 3 || (a->tile_hint == 0 && !panel_off && a->M >= 256))) {
+        const bool plain = a->pre == 1 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0;
+        const bool fits1 = plain && (size_t)KP * panel_row_bytes(1) <= 160 * 1024;      // K <= 848
+        const bool fits2 = plain && (size_t)KP * panel_row_bytes(2) <= 160 * 1024;      // K <= 352
+        if (a->tile_hint == kNumVariantsG + 3 && !fits1) return OCCD_EINVAL;
+        if (fits1 && (a->tile_hint == kNumVariantsG + 3 || (a->tile_hint == 0 && !panel_off && a->M >= 256))) {
             GemmP p;
             p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.res = nullptr; p.kscale = nullptr;
             p.M = a->M; p.N = a->N; p.K = a->K;
             p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a / 8; p.sB = a->stride_b; p.sC = a->stride_c;
-            p.act = a->act; p.slope = a->slope; p.act_a = 0;
-            p.ntiles = (a->N + 63) / 64;
-            const int tiles = (a->M + 31) / 32;
-            // row ranges: one, unless the column panels alone leave CUs idle -- then as many as fill ~256 workgroups, each
-            // of at least 8 row tiles (one per wave)
+            p.act = a->act; p.slope = a->slope; p.act_a = 0; p.n_fast = 1;
+            const int tiles = (a->M + 31) / 32, r8 = (tiles + 7) / 8;
+            // panel width: 64 columns while two workgroups fit a CU's LDS with them (K <= 176), else 32 (measured, kernel trace,
+            // profiles/r05_gemm_panel.txt: tap 1/2 (K = 320) 332 against 362 us, 224 -> 1344 on 1848 pixels 22 against 27 us; the
+            // 64-column form ahead by 3 ... 10 % on K = 48 ... 160): a second resident workgroup stages its panel under the
+            // first one's MFMAs, which is worth more than half the weight-fragment traffic
+            int nt = (fits2 && (size_t)KP * panel_row_bytes(2) <= 80 * 1024) ? 2 : 1;
+            static const int dev_nt = getenv("OCCD_GEMM_PANEL_NT") ? atoi(getenv("OCCD_GEMM_PANEL_NT")) : 0;     // (development A/B)
+            if ((dev_nt == 1 || dev_nt == 2) && (dev_nt == 1 || fits2)) nt = dev_nt;
+            p.ntiles = (a->N + 32 * nt - 1) / (32 * nt);
             const long panels = (long)p.ntiles * a->batch;
-            long ranges = panels >= 256 ? 1 : 256 / panels;
-            if (ranges > (tiles + 7) / 8) ranges = (tiles + 7) / 8;
+            // row ranges: ranges of 8 row tiles (one per wave) while that gives at most ~4 workgroups per CU; a large launch
+            // walks all its row tiles in every workgroup (the panel is staged once), cut only as far as 256 CUs need it
+            long ranges = panels * r8 <= 1024 ? r8 : panels >= 256 ? 1 : 256 / panels;
+            if (ranges > r8) ranges = r8;
             if (ranges < 1) ranges = 1;
-            static const int dev_ranges = getenv("OCCD_GEMM_PANEL_RANGES") ? atoi(getenv("OCCD_GEMM_PANEL_RANGES")) : 0;   // (development A/B)
+            static const int dev_ranges = getenv("OCCD_GEMM_PANEL_RANGES") ? atoi(getenv("OCCD_GEMM_PANEL_RANGES")) : 0;
             if (dev_ranges >= 1 && dev_ranges <= tiles) ranges = dev_ranges;
             p.mr_tiles = (int)((tiles + ranges - 1) / ranges);
             p.mtiles = (tiles + p.mr_tiles - 1) / p.mr_tiles;
-            // row tiles per wave: the smallest of 1 / 2 / 3 that covers a range in one round of the 8 waves, else 3
-            // row tiles per wave and round: 1.  Measured (profiles/r05_gemm_panel.txt): 2 / 3 tiles per wave halve / third the
-            // LDS fragment reads but lose on every launch of the frame (tap 1/1 460 -> 471 / 487 us, 48 -> 288 on 28365 pixels
-            // 29 -> 37 / 45 us): several short rounds per wave overlap one wave's stores with the other's MFMAs; raising the
-            // priority of one wave per SIMD to force that alternation changed nothing.  (OCCD_GEMM_PANEL_MT: development A/B)
-            int mt = 1;
-            static const int dev_mt = getenv("OCCD_GEMM_PANEL_MT") ? atoi(getenv("OCCD_GEMM_PANEL_MT")) : 0;
-            if (dev_mt >= 1 && dev_mt <= 3) mt = dev_mt;
-            p.n_fast = 1;
+            // row tiles per wave and round (MT): 1.  Measured (profiles/r05_gemm_panel.txt): 2 / 3 tiles per wave halve / third
+            // the LDS fragment reads but lose on every launch of the frame (tap 1/1 460 -> 471 / 487 us, 48 -> 288 on 28365
+            // pixels 29 -> 37 / 45 us): several short rounds per wave overlap one wave's stores with the other's MFMAs; raising
+            // the priority of one wave per SIMD to force that alternation changed nothing.  Weight fragments one 16-k step ahead
+            // (PD = 1): 4 / 8 steps ahead are SLOWER on every launch (tap 1/1 386 -> 445, 384 -> 2304 on 468 pixels 21.7 -> 24.0 ->
+            // 28.1 us) -- as in K16, memory latency is not what these launches wait for.
             const long nwg = (long)p.mtiles * p.ntiles;
             if (nwg >= (1L << 31)) return OCCD_EINVAL;
             p.nwg = (unsigned)nwg;
-            void (*kern)(const GemmP) = mt == 1 ? gemm_x3_panel_kernel<1> : mt == 2 ? gemm_x3_panel_kernel<2> : gemm_x3_panel_kernel<3>;
+            void (*kern)(const GemmP) = nt == 1 ? gemm_x3_panel_kernel<1, 1, 1> : gemm_x3_panel_kernel<1, 2, 1>;
+            const size_t plds = (size_t)KP * panel_row_bytes(nt);
             if (plds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
             const double flops = 2.0 * a->M * a->N * a->K * a->batch;
             const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);

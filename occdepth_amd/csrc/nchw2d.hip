@@ -63,7 +63,8 @@ template <int K, int STRIDE>
 __global__ void __launch_bounds__(256) dwconv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
-                                                              int pad_t, int pad_l, int act, float* __restrict__ pool_part) {
+                                                              int pad_t, int pad_l, int act, float* __restrict__ pool_part,
+                                                              long xps) {
     constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K;
     __shared__ float wsum[4];
     const int plane = blockIdx.y;
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(256) dwconv2d_direct_kernel(const float* __res
     if (!live && pool_part == nullptr) return;
     const int item = live ? item_raw : 0;                  // (dead lanes of the last block still join the reduction)
     const int oy = item / wq, ox0 = (item - oy * wq) * NX;
-    const float* xp = x + (size_t)plane * H * W;
+    const float* xp = x + (size_t)plane * xps;            // xps: floats between input planes (>= H * W: rows of a padded GEMM result)
     float wr[K * K];
 #pragma unroll
     for (int i = 0; i < K * K; ++i) wr[i] = w[(size_t)c * K * K + i];
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
                                                        int pad_t, int pad_l, int act, float* __restrict__ pool_part,
-                                                       int wp, occd::FastDiv wpd) {
+                                                       int wp, occd::FastDiv wpd, long xps) {
     constexpr int NX = 4, SPAN = (NX - 1) * STRIDE + K, SPAN4 = (SPAN + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [rows][wp]
     __shared__ float wsum[4];
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) dwconv2d_kernel(const float* __restrict__
     const int oy_last = min(item0 + 255, nitems - 1) / wq;
     const int iy_first = oy_first * STRIDE - pad_t;
     const int nrows = (oy_last - oy_first) * STRIDE + K;
-    const float* xp = x + (size_t)plane * H * W;
+    const float* xp = x + (size_t)plane * xps;            // xps: floats between input planes (>= H * W: rows of a padded GEMM result)
     // ---- stage: unconditional clamped loads, padding as a bit mask on the loaded value
     const int total = nrows * wp;
     for (int e = threadIdx.x; e < total; e += 256) {
@@ -822,9 +823,12 @@ extern "C" int occd_affine_act_nchw(const float* x, const float* res, float* y, 
 
 static int dwconv_launch(const float* x, const float* w, const float* scale, const float* shift, float* y,
                          int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride, int32_t pad_top,
-                         int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act, float* pool_part, void* stream) {
+                         int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act, float* pool_part, int64_t x_plane_stride,
+                         void* stream) {
     if (!x || !w || !y || batch <= 0 || C <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || stride <= 0)
         return OCCD_EINVAL;
+    if (x_plane_stride != 0 && x_plane_stride < (int64_t)H * W) return OCCD_EINVAL;
+    const long xps = x_plane_stride != 0 ? (long)x_plane_stride : (long)H * W;
     if ((k != 3 && k != 5) || act < 0 || act > 2 || (long)batch * C > 65535) return OCCD_EINVAL;
     if (stride != 1 && stride != 2) return OCCD_EINVAL;
     const int items = Ho * ((Wo + 3) / 4);
@@ -842,7 +846,7 @@ static int dwconv_launch(const float* x, const float* w, const float* scale, con
     if (lds <= 48 * 1024) {
 #define OCCD_DW(KK, SS)                                                                                             \
     hipLaunchKernelGGL((dwconv2d_kernel<KK, SS>), grid, dim3(256), lds, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
-                       pad_top, pad_left, act, pool_part, wp, occd::make_fastdiv((uint32_t)wp))
+                       pad_top, pad_left, act, pool_part, wp, occd::make_fastdiv((uint32_t)wp), xps)
         if (k == 3 && stride == 1) OCCD_DW(3, 1);
         else if (k == 3) OCCD_DW(3, 2);
         else if (stride == 1) OCCD_DW(5, 1);
@@ -852,7 +856,7 @@ static int dwconv_launch(const float* x, const float* w, const float* scale, con
     }
 #define OCCD_DW(KK, SS)                                                                                                 \
     hipLaunchKernelGGL((dwconv2d_direct_kernel<KK, SS>), grid, dim3(256), 0, st, x, w, scale, shift, y, C, H, W, Ho, Wo, \
-                       pad_top, pad_left, act, pool_part)
+                       pad_top, pad_left, act, pool_part, xps)
     if (k == 3 && stride == 1) OCCD_DW(3, 1);
     else if (k == 3) OCCD_DW(3, 2);
     else if (stride == 1) OCCD_DW(5, 1);
@@ -865,7 +869,7 @@ extern "C" int occd_dwconv2d_nchw(const float* x, const float* w, const float* s
                                   int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k, int32_t stride,
                                   int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo, int32_t act,
                                   void* stream) {
-    return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, nullptr, stream);
+    return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, nullptr, 0, stream);
 }
 
 // ---- encoder stem: 3x3 convolution of a FEW input channels (the RGB image), stride 1 / 2, TensorFlow SAME padding,
@@ -966,9 +970,10 @@ extern "C" int32_t occd_dwconv2d_pool_blocks(int32_t Ho, int32_t Wo) { return (H
 extern "C" int occd_dwconv2d_pool_nchw(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                        float* pool_part, int32_t batch, int32_t C, int32_t H, int32_t W, int32_t k,
                                        int32_t stride, int32_t pad_top, int32_t pad_left, int32_t Ho, int32_t Wo,
-                                       int32_t act, void* stream) {
+                                       int32_t act, int64_t x_plane_stride, void* stream) {
     if (pool_part == nullptr) return OCCD_EINVAL;
-    return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, pool_part, stream);
+    return dwconv_launch(x, w, scale, shift, y, batch, C, H, W, k, stride, pad_top, pad_left, Ho, Wo, act, pool_part,
+                         x_plane_stride, stream);
 }
 
 // ---- channels-last twins (bf16-mode training: the decoder levels live as (B, H, W, C) pixel rows) ------------------

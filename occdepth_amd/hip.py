@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 11   # 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 12   # 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -184,7 +184,7 @@ EXPORTS = {
     "occd_dwconv2d_bwd_weight_workspace_floats": (c_int64, [c_int32] * 5),
     "occd_dwconv2d_bwd_weight_nchw": (c_int32, [c_void_p] * 4 + [c_int32] * 10 + [c_void_p]),
     "occd_dwconv2d_pool_blocks": (c_int32, [c_int32, c_int32]),
-    "occd_dwconv2d_pool_nchw": (c_int32, [c_void_p] * 6 + [c_int32] * 11 + [c_void_p]),
+    "occd_dwconv2d_pool_nchw": (c_int32, [c_void_p] * 6 + [c_int32] * 11 + [c_int64, c_void_p]),
     "occd_se_gate": (c_int32, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "occd_pw_packed_floats": (c_int64, [c_int32, c_int32]),
     "occd_pw_pack_weights": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
@@ -761,11 +761,11 @@ GEMM_X3 = os.environ.get("OCCDEPTH_GEMM_X3", "1") == "1"
 GEMM_X3_PACK = os.environ.get("OCCDEPTH_GEMM_X3_PACK", "0") == "1"
 
 
-# K16p (round 5): the SHORT-K left operands (expand convolutions, the 1/1 and 1/2 tap GEMMs: K <= 352, >= 256 rows) ARE pre-split, for
+# K16p (round 5): the SHORT-K left operands (expand convolutions, the 1/1 and 1/2 tap GEMMs: K <= 848, >= 256 rows) ARE pre-split, for
 # the panel-stationary kernel that keeps a 64-column panel of B over the whole K in LDS (csrc/gemm_x3.hip).  OCCDEPTH_GEMM_X3_PANEL=0
 # -> the barrier-phased K16 on float32 operands as in round 4.
 GEMM_X3_PANEL = os.environ.get("OCCDEPTH_GEMM_X3_PANEL", "1") == "1"
-PANEL_MAX_K, PANEL_MIN_ROWS = 352, 256
+PANEL_MAX_K, PANEL_MIN_ROWS = 848, 256
 
 
 def _panel_operand(w, role):
@@ -1600,10 +1600,13 @@ def softmax_nchw(x):
 
 
 def dwconv2d_same_pool(x, w, scale, shift, stride, act=None):
-    """dwconv2d_same that also returns the squeeze-excite pooling partials (B*C, nblk) and the plane size Ho*Wo."""
-    if not x.is_contiguous():
-        x = x.contiguous()
+    """dwconv2d_same that also returns the squeeze-excite pooling partials (B*C, nblk) and the plane size Ho*Wo.
+    x: dense, or (B, C, H, W) planes on a padded pitch (the view of an expand GEMM's `padded_rows` result)."""
     B, C, H, W = x.shape
+    xps = x.stride(1)
+    if not (x.stride(3) == 1 and x.stride(2) == W and xps >= H * W and (B == 1 or x.stride(0) == C * xps)):
+        x = x.contiguous()
+        xps = H * W
     k = w.shape[-1]
     Ho, Wo = -(-H // stride), -(-W // stride)
     pad_h = max((Ho - 1) * stride + k - H, 0)
@@ -1612,10 +1615,12 @@ def dwconv2d_same_pool(x, w, scale, shift, stride, act=None):
     nblk = load().occd_dwconv2d_pool_blocks(Ho, Wo)
     part = torch.empty((B * C, nblk), device=x.device, dtype=torch.float32)
     wc = w if w.is_contiguous() else w.contiguous()
-    _check(load().occd_dwconv2d_pool_nchw(_f32(x, "x"), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise RuntimeError("dwconv2d_same_pool: x must be a float32 GPU tensor")
+    _check(load().occd_dwconv2d_pool_nchw(x.data_ptr(), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
                                           _f32(shift, "shift") if shift is not None else None, _f32(y, "y"),
                                           _f32(part, "pool_part"), B, C, H, W, k, stride, pad_h // 2, pad_w // 2, Ho, Wo,
-                                          ACT2D[act], _stream()), "occd_dwconv2d_pool_nchw")
+                                          ACT2D[act], xps, _stream()), "occd_dwconv2d_pool_nchw")
     return y, part, Ho * Wo
 
 

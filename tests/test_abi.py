@@ -154,7 +154,8 @@ def test_round2_2d_entry_points_validate_arguments(hip_lib):
     a.tile_hint, a.out_nhwc_cs = 0, 4
     assert hip_lib.occd_pw_conv_fwd(ctypes.byref(a), None) == -1                       # NHWC row shorter than Cout
     assert hip_lib.occd_dwconv2d_pool_blocks(185, 610) == (185 * 153 + 255) // 256
-    assert hip_lib.occd_dwconv2d_pool_nchw(ptr, ptr, None, None, ptr, None, 1, 1, 4, 4, 3, 1, 1, 1, 4, 4, 0, None) == -1
+    assert hip_lib.occd_dwconv2d_pool_nchw(ptr, ptr, None, None, ptr, None, 1, 1, 4, 4, 3, 1, 1, 1, 4, 4, 0, 0, None) == -1
+    assert hip_lib.occd_dwconv2d_pool_nchw(ptr, ptr, None, None, ptr, ptr, 1, 1, 4, 4, 3, 1, 1, 1, 4, 4, 0, 15, None) == -1   # plane stride < H * W
     assert hip_lib.occd_se_gate(None, None, None, None, None, None, None, 1, 8, 2, 1, 16, None) == -1
     assert hip_lib.occd_lift_bwd(None, None) == -1
     q = hip.LiftBwdArgs()

@@ -87,12 +87,14 @@ def test_gemm_x3_every_tile_variant_and_epilogue(hip, hint, K):
         assert float((got - (lin - bias.double().view(1, -1, 1))).abs().max() / lin.abs().max()) < 2e-6
 
 
-# K16p (tile_hint 8): (batch, M, N, K, A batched?) -- row counts that give 1 / 2 / 3 row tiles per wave, several row ranges (few
+# K16p (tile_hint 8): (batch, M, N, K, A batched?) -- row counts that give one and several rounds per wave, several row ranges (few
 # column panels), idle sub-tiles and idle waves; K tails of 8 (K % 16 = 8) and the largest K that fits LDS; N tails of every
 # residue and N < 64
 PANEL_SHAPES = [(2, 720, 1100, 160, False), (2, 960, 1848, 160, False), (2, 1344, 460, 224, False), (2, 480, 7191 // 4, 80, False),
                 (2, 288, 3000, 48, False), (1, 192, 5003, 32, False), (1, 130, 70, 352, False), (3, 257, 61, 72, True),
-                (1, 40, 6, 8, False), (2, 2304 // 4, 468, 264, False)]
+                (1, 40, 6, 8, False), (2, 2304 // 4, 468, 264, False),
+                # 32-column panels: K beyond the 64-column form (<= 848), and the few-pixel launches hint 0 gives them to
+                (2, 576, 468, 384, False), (2, 960, 468, 640, False), (1, 256, 203, 848, False), (2, 512, 1848, 224, False)]
 
 
 @pytest.mark.parametrize("shape", PANEL_SHAPES, ids=lambda s: "x".join(map(str, s[:4])))
@@ -129,8 +131,8 @@ def test_gemm_x3_panel_vs_float64(hip, shape):
 
 
 def test_gemm_x3_panel_limits(hip):
-    a = torch.randn(256, 360, device=DEV)                    # K = 360: 368 k x 448 B > 160 KB of LDS
-    b = torch.randn(2, 360, 100, device=DEV)
+    a = torch.randn(256, 856, device=DEV)                    # K = 856: 864 k x 192 B > 160 KB of LDS
+    b = torch.randn(2, 856, 100, device=DEV)
     with pytest.raises(RuntimeError):
         hip.gemm_x3(hip.GemmPacked(a, "a"), b, tile_hint=8)
     with hip.profile() as prof:

@@ -108,6 +108,13 @@ def test_dwconv_pool_and_se_gate_gpu(shape, hip_lib):
     assert torch.allclose(part.double().sum(1).cpu(), part_ref.double().sum(1), rtol=1e-5, atol=1e-4)
     y3, part3, _ = hip.dwconv2d_same_pool(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), stride, "swish")
     assert torch.equal(part, part3)                             # fixed summation order: bit-reproducible
+    # input planes on a 128-byte pitch (the view of an expand GEMM's hip.padded_rows result; NaN in the padding): the plane
+    # stride travels to the kernel, no copy, bit-identical output and partials
+    xp = hip.padded_rows((B, C, H * W), "cuda")
+    torch.as_strided(xp, (B, C, xp.stride(1)), (xp.stride(0), xp.stride(1), 1)).fill_(float("nan"))
+    xp.copy_(x.cuda().view(B, C, H * W))
+    y4, part4, _ = hip.dwconv2d_same_pool(xp.view(B, C, H, W), w.cuda(), sc.cuda(), sh.cuda(), stride, "swish")
+    assert torch.equal(y4, y) and torch.equal(part4, part)
     Cr = max(1, C // 4)
     wr, br = torch.randn(Cr, C, 1, 1, generator=g) * 0.3, torch.randn(Cr, generator=g) * 0.1
     we, be = torch.randn(C, Cr, 1, 1, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1

@@ -13,6 +13,9 @@ from bench_kernels import time_many
 SHAPES = [
     ("tap 1/1    160>9x80  @185x610", 2, 720, 112850, 160, False),
     ("tap 1/2    320>9x160 @93x305", 2, 1440, 28365, 320, False),
+    ("expand 1/32 384>2304 @12x39", 2, 2304, 468, 384, True),
+    ("expand 1/32 640>3840 @12x39", 2, 3840, 468, 640, True),
+    ("head 1/32   640>2560 @14x41", 2, 2560, 574, 640, True),
     ("expand 1/16 224>1344 @24x77", 2, 1344, 1848, 224, True),
     ("expand 1/16 160>960  @24x77", 2, 960, 1848, 160, True),
     ("expand 1/8  80>480   @47x153", 2, 480, 7191, 80, True),
