@@ -247,7 +247,11 @@ int occd_rows_gemm_pack(const float* w, float* wpk, int32_t K, int32_t N, int32_
  * A: M x K with k contiguous (lda >= K, K % 8 == 0, 16-byte aligned rows); B: K x N with n contiguous (ldb >= N, N >= 4, any
  * dword alignment); C: M x N (ldc >= N).  stride_a == 0 shares A over the batch (weights).  bias: M floats or NULL.
  * act: OCCD_GEMM_ACT_NONE / _SWISH / _LEAKY (slope).  tile_hint: 0 = choose, 1 .. 5 = force a tile variant, 6 = the
- * wave-specialised 256 x 128 kernel (tests / A-B).                                                                           */
+ * wave-specialised 256 x 128 kernel, 7 = the 64 x 64 tile with the in-workgroup split-K, 8 = the panel-stationary kernel K16p
+ * (pre = 1, K <= 848, no res / scale_k / act_a: a workgroup keeps 64 or 32 B columns over the whole K split in LDS and walks
+ * the row tiles of the pre-split A image against them; hint 0 picks it for M >= 256) (tests / A-B).
+ * Rows of C that start on 128-byte boundaries (ldc % 32 == 0, aligned base) are written 2.2x faster than rows 8 bytes off a
+ * cache line (profiles/r05_store_alignment.txt): give intermediate results a padded ldc where the consumer takes a stride. */
 #define OCCD_GEMM_ACT_NONE 0
 #define OCCD_GEMM_ACT_SWISH 1
 #define OCCD_GEMM_ACT_LEAKY 2
