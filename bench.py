@@ -439,6 +439,9 @@ def _forward(args, world, rank, device, dist):
     from occdepth_amd import fused as _fused
     graph_flags["bf16x3_split"] = _fused.BF16X3 or "off"    # "head" (default), "all" (experiment), "off" (exact-fp32 MFMA convolutions)
     graph_flags["gemm_x3"] = bool(hip.GEMM_X3)              # False: the 2-D network's GEMMs on the library's fp32 kernels
+    # late round 5: short-K GEMMs on the panel-stationary kernel over pre-split weights; tap planes / expand results on a 128-byte pitch
+    graph_flags["gemm_x3_panel"] = bool(hip.GEMM_X3 and hip.GEMM_X3_PANEL)
+    graph_flags["padded_rows"] = bool(hip.PAD_ROWS)
     graph_flags["lift_input"] = ("batch WITHOUT projected_pix_* / fov_mask_* (the kernel projects; INTEGRATION.md section 2: the "
                                  "one-line dataset edit) -- a batch from the reference's unmodified collate_fn carries the tables and "
                                  "takes the table lift (+ an 8.9 MB H2D copy, ~0.05 ms per frame; same parity)")
@@ -536,7 +539,7 @@ def _forward(args, world, rank, device, dist):
         res["dtype"] = ("f32 storage and accumulate; matrix arithmetic as 3x bf16 split (hi + mid + lo of both operands, six "
                         "v_mfma_f32_32x32x16_bf16 per K step; error vs float64 tested within 1.5x of the exact-fp32 kernels', measured 0.8-1.1x) in the head convolutions "
                         "(K2s3), the small-volume 3x3x3 convolutions and transposed-convolution phases of the 3-D stack (K2b) and "
-                        "the 2-D network's GEMMs (K16); exact fp32 MFMA / VALU everywhere else (K2, K10, K11, K14, depthwise, lift). "
+                        "the 2-D network's GEMMs (K16 / K16p); exact fp32 MFMA / VALU everywhere else (K2, K10, K11, K14, depthwise, lift). "
                         " OCCDEPTH_BF16X3=0 OCCDEPTH_GEMM_X3=0 restores exact fp32 everywhere")
         res["roofline"].update({
             "kernel": ("conv3d_c32_slide_x3_kernel" if x3_slide else "conv3d_bf16_kernel<SPLIT=3>") +
