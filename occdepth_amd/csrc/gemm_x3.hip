@@ -1069,7 +1069,11 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
         const bool fits1 = plain && (size_t)KP * panel_row_bytes(1) <= 160 * 1024;      // K <= 848
         const bool fits2 = plain && (size_t)KP * panel_row_bytes(2) <= 160 * 1024;      // K <= 352
         if (a->tile_hint == kNumVariantsG + 3 && !fits1) return OCCD_EINVAL;
-        if (fits1 && (a->tile_hint == kNumVariantsG + 3 || (a->tile_hint == 0 && !panel_off && a->M >= 256))) {
+        // (hint 0, K > 352 -- the 32-column form only: just the few-pixel launches of the 1/16 and 1/32 stages, where it leads by
+        //  ~15 %; the 1/4-level tap GEMM, 2880 x 7191 x 640, measured 0.45 ms on it against K16's 0.35)
+        const long small_launch = (long)((a->N + 63) / 64) * a->batch * (((a->M + 31) / 32 + 7) / 8);
+        const bool auto_ok = a->tile_hint == 0 && !panel_off && a->M >= 256 && (fits2 || small_launch <= 512);
+        if (fits1 && (a->tile_hint == kNumVariantsG + 3 || auto_ok)) {
             GemmP p;
             p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.res = nullptr; p.kscale = nullptr;
             p.M = a->M; p.N = a->N; p.K = a->K;

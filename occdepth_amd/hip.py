@@ -772,6 +772,14 @@ def _panel_operand(w, role):
     return GEMM_X3_PANEL and role == "a" and w.dim() == 2 and w.shape[1] <= PANEL_MAX_K and w.shape[0] >= PANEL_MIN_ROWS
 
 
+def _panel_launch(pa, b):
+    """The host-side mirror of occd_gemm_f32x3's hint-0 rule for K16p: K <= 352, or (K <= 848) a few-pixel launch."""
+    if pa.K <= 352:
+        return True
+    n, batch = b.shape[-1], (b.shape[0] if b.dim() == 3 else 1)
+    return -(-n // 64) * batch * -(-(-(-pa.rows // 32)) // 8) <= 512
+
+
 def matmul_operand(w, role):
     """A static operand (weights) in the form hip.matmul wants it: (the float32 tensor, its GemmPacked image or None)."""
     w = w.detach().float().contiguous()
@@ -803,7 +811,7 @@ def matmul(a, b, bias=None, act=None, slope=0.01, res=None, k_scale=None, out=No
     tb, pb = b if isinstance(b, tuple) else (b, None)
     if GEMM_X3:
         # (a panel-only image serves the plain epilogue; with a residual / a k scale the float32 operand goes to K16)
-        a_img = pa is not None and (GEMM_X3_PACK or (res is None and k_scale is None))
+        a_img = pa is not None and (GEMM_X3_PACK or (res is None and k_scale is None and _panel_launch(pa, tb)))
         xa, xb = (pa if a_img else ta), (pb if pb is not None and k_scale is None else tb)
         if gemm_x3_supported(xa, xb):
             return gemm_x3(xa, xb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale, out=out)
