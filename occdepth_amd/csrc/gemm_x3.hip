@@ -660,6 +660,19 @@ __global__ void __launch_bounds__(512, 2) gemm_x3_ws_kernel(const GemmP p) {
 // (conflict-free transposing reads).  NT = 1 (32 columns): twice the panels for the few-pixel stages (468 / 1848 pixels), K up
 // to 848, at twice the weight-fragment traffic per MFMA -- which a launch that small does not notice.
 constexpr int panel_row_bytes(int nt) { return 3 * 64 * nt + (nt == 1 ? 0 : 64); }
+// Development probe (tools/panel_timeline.cpp builds this file with -DOCCD_PANEL_TIMELINE; never in libocc_hip.so): the shader
+// clock of every wave of ONE workgroup at the phase boundaries of the kernel below.
+#ifdef OCCD_PANEL_TIMELINE
+__device__ unsigned long long g_panel_tl[8 * 64];
+__device__ int g_panel_probe_wg = 0;
+#define OCCD_TL(idx)                                                                                                   \
+    do {                                                                                                               \
+        if ((int)blockIdx.x == g_panel_probe_wg && blockIdx.y == 0 && lane == 0 && (idx) < 64)                         \
+            g_panel_tl[wave * 64 + (idx)] = __builtin_amdgcn_s_memtime();                                              \
+    } while (0)
+#else
+#define OCCD_TL(idx) do { } while (0)
+#endif
 constexpr int kPanelPass = 6;                         // float4 loads in flight per thread while the panel is staged
 template <int MT, int NT, int PD>
 __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
@@ -701,7 +714,9 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
         for (int d = 0; d < PD; ++d)
             if (d < K16tot) fetch_a(d, d);
     };
+    OCCD_TL(0);                                            // kernel entry
     if (t0 + wave * MT < t1) first_a(t0 + wave * MT);
+    OCCD_TL(1);                                            // first weight fragments requested
 
     // ---- the B panel: (k, 4-column chunk) items, C4 per k row; kPanelPass loads in flight per thread, then split -> LDS
     {
@@ -717,6 +732,7 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
                 const int k = min(f / C4, p.K - 1), c = min(n0 + (f % C4) * 4, p.N - 4);
                 v[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + c);
             }
+            OCCD_TL(2);                                    // panel loads of this pass requested
 #pragma unroll
             for (int i = 0; i < kPanelPass; ++i) {
                 const int f = base + i * 512 + tid;
@@ -741,7 +757,9 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
             }
         }
     }
+    OCCD_TL(3);                                            // panel split and written (this wave's share)
     __syncthreads();
+    OCCD_TL(4);                                            // panel complete
     int b_lane[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b_lane[nt] = (8 * h + (i16 >> 2)) * SB + (nt * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
@@ -780,6 +798,7 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bf[nt][t] = bn[nt][t];
                 }
+                if (tb == t0 + wave * MT) OCCD_TL(8 + k16);  // 16-k step k16 of the first row tile: operands in registers
                 if (k16 + PD < K16tot) fetch_a(d, k16 + PD);
                 if (k16 + 1 < K16tot) fetch_b(k16 + 1);
                 OCCD_GP(1, 1);
@@ -794,6 +813,7 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
         // the next row tile's first fragments go out BEFORE this tile's stores (loads return in order among loads; queued behind
         // the stores they would wait for them to drain)
         if (tb + 8 * MT < t1) first_a(tb + 8 * MT);
+        if (tb == t0 + wave * MT) OCCD_TL(5);              // K loop of the first row tile issued
         // epilogue of this tile set: lane -> column, registers -> rows (as K16)
         auto store_all = [&](auto has_bias, auto act_sel) {
             constexpr bool BIAS = decltype(has_bias)::value;
@@ -831,7 +851,9 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
         else if (p.bias != nullptr) store_all(T_{}, std::integral_constant<int, 0>{});
         else if (p.act == 1) store_all(F_{}, std::integral_constant<int, 1>{});
         else store_all(F_{}, std::integral_constant<int, 2>{});
+        if (tb == t0 + wave * MT) OCCD_TL(6);              // stores of the first row tile issued
     }
+    OCCD_TL(7);                                            // last instruction of the wave
 }
 
 // ------------------------------------------------------------------------------------------------
