@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
         for (int j = 0; j < MT; ++j) pk[j] = Abase + (size_t)min(tb + j, tiles_all - 1) * K16tot * 192;
 #pragma unroll
         for (int d = 0; d < PD; ++d)
-            if (d < K16tot) fetch_a(d, d);
+            fetch_a(d, min(d, K16tot - 1));
     };
     OCCD_TL(0);                                            // kernel entry
     if (t0 + wave * MT < t1) first_a(t0 + wave * MT);
@@ -784,31 +784,40 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
 #define OCCD_GP(WT, XT)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < MT; ++j) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[j][nt] =    \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j][WT]), bf[nt][XT], acc[j][nt], 0, 0, 0)
-        for (int k0 = 0; k0 < K16tot; k0 += PD) {
+        // One 16-k step on fragment set d (a compile-time index).  Requests are UNCONDITIONAL and come from clamped addresses (the
+        // last steps re-read the last fragments): behind a branch the compiler cannot count the loads in flight and waits for
+        // vmcnt(0) at the join -- every step then pays a full L2 round trip however deep the prefetch (tools/panel_timeline.cpp:
+        // ~700 cycles per step of 192 MFMA cycles; the ISA of the branchy form had `s_waitcnt vmcnt(0)` in front of every step).
+        auto step = [&](int k16, int d, bool more_a) {        // (always inlined into unrolled loops: d, more_a are constants there)
+            u32x4 af[MT][3];
+            bf16x8 bf[NT][3];
 #pragma unroll
-            for (int d = 0; d < PD; ++d) {               // (unrolled: the fragment set of a step is a compile-time index)
-                const int k16 = k0 + d;
-                if (k16 >= K16tot) break;                // (uniform)
-                u32x4 af[MT][3];
-                bf16x8 bf[NT][3];
+            for (int t = 0; t < 3; ++t) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int j = 0; j < MT; ++j) af[j][t] = an[d][j][t];
 #pragma unroll
-                    for (int j = 0; j < MT; ++j) af[j][t] = an[d][j][t];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bf[nt][t] = bn[nt][t];
-                }
-                if (tb == t0 + wave * MT) OCCD_TL(8 + k16);  // 16-k step k16 of the first row tile: operands in registers
-                if (k16 + PD < K16tot) fetch_a(d, k16 + PD);
-                if (k16 + 1 < K16tot) fetch_b(k16 + 1);
-                OCCD_GP(1, 1);
-                OCCD_GP(0, 2);
-                OCCD_GP(2, 0);
-                OCCD_GP(0, 1);
-                OCCD_GP(1, 0);
-                OCCD_GP(0, 0);
+                for (int nt = 0; nt < NT; ++nt) bf[nt][t] = bn[nt][t];
             }
+            if (tb == t0 + wave * MT) OCCD_TL(8 + k16);      // step k16 of the first row tile: operands in registers
+            if (more_a) fetch_a(d, min(k16 + PD, K16tot - 1));
+            fetch_b(min(k16 + 1, K16tot - 1));
+            OCCD_GP(1, 1);
+            OCCD_GP(0, 2);
+            OCCD_GP(2, 0);
+            OCCD_GP(0, 1);
+            OCCD_GP(1, 0);
+            OCCD_GP(0, 0);
+        };
+        // main loop: whole groups of PD steps, NO branch inside the body (exact vmcnt counts); then the < PD remaining steps,
+        // whose fragments are already on their way
+        int k0 = 0;
+        for (; k0 + PD <= K16tot; k0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) step(k0 + d, d, true);
         }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)
+            if (k0 + d < K16tot) step(k0 + d, d, false);
 #undef OCCD_GP
         // the next row tile's first fragments go out BEFORE this tile's stores (loads return in order among loads; queued behind
         // the stores they would wait for them to drain)
@@ -1123,13 +1132,17 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
             // row tiles per wave and round (MT): 1.  Measured (profiles/r05_gemm_panel.txt): 2 / 3 tiles per wave halve / third
             // the LDS fragment reads but lose on every launch of the frame (tap 1/1 460 -> 471 / 487 us, 48 -> 288 on 28365
             // pixels 29 -> 37 / 45 us): several short rounds per wave overlap one wave's stores with the other's MFMAs; raising
-            // the priority of one wave per SIMD to force that alternation changed nothing.  Weight fragments one 16-k step ahead
-            // (PD = 1): 4 / 8 steps ahead are SLOWER on every launch (tap 1/1 386 -> 445, 384 -> 2304 on 468 pixels 21.7 -> 24.0 ->
-            // 28.1 us) -- as in K16, memory latency is not what these launches wait for.
+            // the priority of one wave per SIMD to force that alternation changed nothing.
             const long nwg = (long)p.mtiles * p.ntiles;
             if (nwg >= (1L << 31)) return OCCD_EINVAL;
             p.nwg = (unsigned)nwg;
-            void (*kern)(const GemmP) = nt == 1 ? gemm_x3_panel_kernel<1, 1, 1> : gemm_x3_panel_kernel<1, 2, 1>;
+            // weight fragments ONE step ahead; two on the 32-column form with a long K (K >= 512: 42.8 -> 40.0 us, 40.2 -> 37.8).
+            // Measured with the branch-free loop below, i.e. with the loads really in flight (ISA: vmcnt(10) ... vmcnt(1)):
+            // deeper is slower on every other launch (tap 1/1 369 -> 384 / 382 / 412 us at 2 / 4 / 6 steps, 48 -> 288 27 -> 31 -> 41)
+            // -- tools/panel_timeline.cpp shows a 16-k step at ~700 cycles (32 columns) / ~950 (64) whatever the depth: the two
+            // waves of a SIMD keep the matrix pipe 55 - 70 % busy INSIDE the loop; the launch-level 22 - 35 % is prologue (kernel
+            // arguments + panel staging: 7k cycles of a 29k-cycle workgroup at 384 -> 2304 on 468 pixels), epilogue and dispatch.
+            void (*kern)(const GemmP) = nt == 2 ? gemm_x3_panel_kernel<1, 2, 1> : a->K >= 512 ? gemm_x3_panel_kernel<1, 1, 2> : gemm_x3_panel_kernel<1, 1, 1>;
             const size_t plds = (size_t)KP * panel_row_bytes(nt);
             if (plds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
             const double flops = 2.0 * a->M * a->N * a->K * a->batch;
