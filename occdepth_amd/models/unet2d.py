@@ -123,6 +123,12 @@ class UpSampleBN(nn.Module):
             self.__dict__["_upconv_cache"] = hit
         return hit[1:]
 
+    @staticmethod
+    def _tap_planes(shape, device):
+        # K16 writes into rows on a 128-byte pitch; the library GEMM of the exact-fp32 mode (OCCDEPTH_GEMM_X3=0) allocates its own
+        # dense result (a padded `out` would cost it a copy of the tap planes: 0.4 ms per frame)
+        return hip.padded_rows(shape, device) if hip.GEMM_X3 else None
+
     def _first_conv_upconv(self, x, skip, conv, bn, act):
         wpk9, w9, upk_skip, shift, wskip = self._upconv_operands(conv, bn, x.shape[1])
         cout = conv.out_channels
@@ -130,14 +136,14 @@ class UpSampleBN(nn.Module):
         if B > 1 and B * h * w <= self.UPCONV_FOLD_BELOW:
             # few pixels per image: ONE GEMM over the pixels of all images (the operand copy is small here)
             z = hip.matmul(w9, x.permute(1, 0, 2, 3).reshape(cup, B * h * w),
-                           out=hip.padded_rows((9 * cout, B * h * w), x.device)).view(9 * cout, B, h, w)
+                           out=self._tap_planes((9 * cout, B * h * w), x.device)).view(9 * cout, B, h, w)
             batch_inner = True
         else:
             batch_inner = False
             if B * h * w < self.UPCONV_LIB_BELOW:
                 xc = x if x.is_contiguous() else x.contiguous()
                 # K16 (csrc/gemm_x3.hip) into tap planes on a 128-byte pitch (written 2x faster; K12 takes the strides)
-                z = hip.matmul(w9, xc.view(B, cup, h * w), out=hip.padded_rows((B, 9 * cout, h * w), x.device)).view(B, 9 * cout, h, w)
+                z = hip.matmul(w9, xc.view(B, cup, h * w), out=self._tap_planes((B, 9 * cout, h * w), x.device)).view(B, 9 * cout, h, w)
             else:
                 z = hip.conv1x1(x, wpk9, 9 * cout)
         rw = (w - 1) / max(skip.shape[3] - 1, 1)
