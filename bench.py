@@ -441,7 +441,7 @@ def _forward(args, world, rank, device, dist):
     graph_flags["gemm_x3"] = bool(hip.GEMM_X3)              # False: the 2-D network's GEMMs on the library's fp32 kernels
     # late round 5: short-K GEMMs on the panel-stationary kernel over pre-split weights; tap planes / expand results on a 128-byte pitch
     graph_flags["gemm_x3_panel"] = bool(hip.GEMM_X3 and hip.GEMM_X3_PANEL)
-    graph_flags["padded_rows"] = bool(hip.PAD_ROWS)
+    graph_flags["padded_rows"] = bool(hip.PAD_ROWS and hip.GEMM_X3)     # (only K16 / K16p results are put on the padded pitch)
     graph_flags["lift_input"] = ("batch WITHOUT projected_pix_* / fov_mask_* (the kernel projects; INTEGRATION.md section 2: the "
                                  "one-line dataset edit) -- a batch from the reference's unmodified collate_fn carries the tables and "
                                  "takes the table lift (+ an 8.9 MB H2D copy, ~0.05 ms per frame; same parity)")
