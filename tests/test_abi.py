@@ -161,3 +161,29 @@ def test_round2_2d_entry_points_validate_arguments(hip_lib):
     q = hip.LiftBwdArgs()
     assert hip_lib.occd_lift_bwd(ctypes.byref(q), None) == -1
     assert hip_lib.occd_softmax_nchw(None, None, 1, 4, 8, None) == -1
+
+
+def test_gemm_entry_point_validates_kernel_hints(hip_lib):
+    """occd_gemm_f32x3: host-side checks around the kernel hints (no launch for invalid arguments) -- hint 8 (K16p, the
+    panel-stationary kernel) needs the pre-split A image, a plain epilogue and a K whose 32-column panel fits LDS."""
+    from occdepth_amd import hip
+    buf = (ctypes.c_float * 64)()
+    ptr = (ctypes.addressof(buf) + 63) & ~63            # 64-byte aligned dummy address (never dereferenced: every call is rejected)
+    q = hip.GemmArgs()
+    q.A = q.B = q.C = ptr
+    q.M, q.N, q.K, q.batch = 256, 64, 64, 1
+    q.lda, q.ldb, q.ldc = 64, 64, 64
+    for hint in (-1, 9):
+        q.tile_hint = hint
+        assert hip_lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+    q.tile_hint = 8                                      # float32 A: not the panel kernel's operand
+    q.pre = 0
+    assert hip_lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+    q.pre, q.K, q.lda = 1, 856, 856                      # 864 k x 192 B > 160 KB of LDS
+    assert hip_lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+    q.K, q.lda, q.res = 64, 64, ptr                      # a residual operand: K16's epilogue, not K16p's
+    assert hip_lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+    q.res, q.act_a = None, 1                             # sigmoid on A needs the float32 operand
+    assert hip_lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1
+    q.act_a, q.K = 0, 60                                 # K % 8
+    assert hip_lib.occd_gemm_f32x3(ctypes.byref(q), None) == -1

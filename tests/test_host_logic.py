@@ -170,3 +170,31 @@ def test_synthetic_inputs_match_survey_statistics():
     assert b["projected_pix_2"][0].shape == (2, 262144, 1, 2) and b["projected_pix_2"][0].dtype == torch.int64
     assert torch.allclose(fov, torch.tensor([0.68, 0.68]), atol=0.01)
     assert b["cam_k"][0].dtype == torch.float64 and b["T_velo_2_cam"][0].dtype == torch.float32
+
+
+def test_padded_rows_and_the_panel_launch_rule(monkeypatch):
+    """hip.padded_rows: results whose rows start on 128-byte boundaries (a view of a buffer with the last dimension rounded up
+    to 32 floats; dense under OCCDEPTH_PAD_ROWS=0), and the host-side mirror of occd_gemm_f32x3's rule for the panel-stationary
+    kernel: K <= 352 always, K <= 848 only on the few-pixel launches."""
+    import torch
+    from occdepth_amd import hip
+    monkeypatch.setattr(hip, "PAD_ROWS", True)
+    z = hip.padded_rows((2, 18, 35), "cpu")
+    assert z.shape == (2, 18, 35) and z.stride() == (18 * 64, 64, 1) and not z.is_contiguous()
+    assert z.view(2, 18, 5, 7).stride() == (18 * 64, 64, 7, 1)            # planes of (h, w) on the padded pitch: a view
+    full = hip.padded_rows((3, 64), "cpu")
+    assert full.is_contiguous() and full.stride() == (64, 1)               # already a multiple of 32: nothing to pad
+    monkeypatch.setattr(hip, "PAD_ROWS", False)
+    assert hip.padded_rows((2, 18, 35), "cpu").is_contiguous()
+
+    class Img:                                                              # what _panel_launch reads of a GemmPacked
+        def __init__(self, rows, K):
+            self.rows, self.K = rows, K
+    b = lambda batch, K, N: torch.empty(batch, K, N, device="meta")
+    assert hip._panel_launch(Img(720, 160), b(2, 160, 112850))             # tap GEMM 1/1
+    assert hip._panel_launch(Img(1440, 320), b(2, 320, 28365))             # tap GEMM 1/2
+    assert hip._panel_launch(Img(2304, 384), b(2, 384, 468))               # expand convolution of the 1/32 stage
+    assert hip._panel_launch(Img(3840, 640), b(2, 640, 468))
+    assert not hip._panel_launch(Img(2880, 640), b(2, 640, 7191))          # tap GEMM 1/4: K16 is faster
+    w = torch.empty(2880, 640)
+    assert hip.matmul_operand(w, "a")[1] is None                            # (CPU tensors are never pre-split)
