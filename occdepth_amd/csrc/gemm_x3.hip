@@ -271,13 +271,17 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
         for (int nt = 0; nt < NT; ++nt) pk[nt] = base + (size_t)min(n0 / 32 + wn * NT + nt, last) * K16tot * 192;
     }
     constexpr int NPK = PRE == 1 ? MT : PRE == 2 ? NT : 1;
-    u32x4 pn[NPK][3];
-    auto fetch_pk = [&](int k16) {
+    // two fragment sets: the 16-k sub-step `ks` of a step uses set ks and then requests the same sub-step of the NEXT 32-k step
+    // into it -- a full step (two barriers, 48 MFMAs per wave on the 256 x 128 tile) ahead.  (Round 4 requested ONE sub-step ahead
+    // into a single set; its ISA waits for the fragments a few instructions after requesting them: vmcnt(0) in front of every
+    // sub-step's MFMAs -- an L2 round trip per 16 k, which is why the pre-split form never beat splitting on the fly.)
+    u32x4 pn[2][NPK][3];
+    auto fetch_pk = [&](int slot, int k16) {
         const int kc = min(k16, K16tot - 1);      // (a step past K multiplies the other operand's zeros)
 #pragma unroll
         for (int i = 0; i < NPK; ++i)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) pn[i][t] = pk[i][(kc * 3 + t) * 64];
+            for (int t = 0; t < 3; ++t) pn[slot][i][t] = pk[i][(kc * 3 + t) * 64];
     };
 
     const int ksteps = (p.K + 31) >> 5;
@@ -286,7 +290,10 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
 #pragma unroll
     for (int u = 0; u < PF; ++u)
         if (u * KS + kg < ksteps) issue(u, (u * KS + kg) * 32, fast_c);
-    if (PRE != 0) fetch_pk(0);
+    if (PRE != 0) {
+        fetch_pk(0, 0);
+        fetch_pk(1, 1);
+    }
     for (int s0 = 0; s0 < ksteps; s0 += PF * KS) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {                  // (unrolled: the register set of a step is a compile-time index)
@@ -296,7 +303,10 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
         __syncthreads();                // previous tile consumed
         if (active) commit(u, s * 32, fast_c);
         __syncthreads();
-        if (s + PF * KS < ksteps) issue(u, (s + PF * KS) * 32, fast_c);
+        // (pre-split forms: the request is unconditional, from a clamped step -- behind a branch the compiler cannot count the
+        //  fragment loads in flight across it and waits for all of them)
+        if (PRE != 0 && KS == 1) issue(u, min(s + PF * KS, ksteps - 1) * 32, fast_c);
+        else if (s + PF * KS < ksteps) issue(u, (s + PF * KS) * 32, fast_c);
         if (!active) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -306,7 +316,7 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) af[mt][t] = pn[mt][t];
+                    for (int t = 0; t < 3; ++t) af[mt][t] = pn[ks][mt][t];
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -317,14 +327,14 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) bf[nt][t] = __builtin_bit_cast(bf16x8, pn[nt][t]);
+                    for (int t = 0; t < 3; ++t) bf[nt][t] = __builtin_bit_cast(bf16x8, pn[ks][nt][t]);
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int t = 0; t < TERMS; ++t) bf[nt][t] = tr_frag(lB + t * BTERM + b_lane[nt] + ks * 16 * SB, 4 * SB);
             }
-            if (PRE != 0) fetch_pk(s * 2 + ks + 1);
+            if (PRE != 0) fetch_pk(ks, s * 2 + ks + 2);
             if (TERMS == 3) {
                 OCCD_GX3(1, 1);
                 OCCD_GX3(0, TERMS == 3 ? 2 : 0);

@@ -769,15 +769,26 @@ PANEL_MAX_K, PANEL_MIN_ROWS = 848, 256
 
 
 def _panel_operand(w, role):
-    return GEMM_X3_PANEL and role == "a" and w.dim() == 2 and w.shape[1] <= PANEL_MAX_K and w.shape[0] >= PANEL_MIN_ROWS
+    # (any K: beyond K16p's reach the image feeds K16's pre-split form on the large launches, `_presplit_launch`)
+    return GEMM_X3_PANEL and role == "a" and w.dim() == 2 and w.shape[0] >= PANEL_MIN_ROWS
 
 
 def _panel_launch(pa, b):
     """The host-side mirror of occd_gemm_f32x3's hint-0 rule for K16p: K <= 352, or (K <= 848) a few-pixel launch."""
     if pa.K <= 352:
         return True
+    if pa.K > PANEL_MAX_K:
+        return False
     n, batch = b.shape[-1], (b.shape[0] if b.dim() == 3 else 1)
     return -(-n // 64) * batch * -(-(-(-pa.rows // 32)) // 8) <= 512
+
+
+def _presplit_launch(pa, b):
+    """K16 on the pre-split weight image (PRE = 1, fragments requested a full 32-k step ahead since late round 5): the long-K
+    GEMMs that fill the chip with 256 x 128 tiles -- the tap GEMMs of the 1/4, 1/8 and 1/16 levels: 425 -> 368, 397 -> 355, 438 ->
+    422 us against float32 operands (profiles/r05_gemm_panel.txt); small launches and the Winograd-domain products do not gain."""
+    n, batch = b.shape[-1], (b.shape[0] if b.dim() == 3 else 1)
+    return pa.K >= 512 and -(-pa.rows // 256) * -(-n // 128) * batch >= 320
 
 
 def matmul_operand(w, role):
@@ -811,7 +822,8 @@ def matmul(a, b, bias=None, act=None, slope=0.01, res=None, k_scale=None, out=No
     tb, pb = b if isinstance(b, tuple) else (b, None)
     if GEMM_X3:
         # (a panel-only image serves the plain epilogue; with a residual / a k scale the float32 operand goes to K16)
-        a_img = pa is not None and (GEMM_X3_PACK or (res is None and k_scale is None and _panel_launch(pa, tb)))
+        a_img = pa is not None and (GEMM_X3_PACK or (res is None and k_scale is None and
+                                                     (_panel_launch(pa, tb) or _presplit_launch(pa, tb))))
         xa, xb = (pa if a_img else ta), (pb if pb is not None and k_scale is None else tb)
         if gemm_x3_supported(xa, xb):
             return gemm_x3(xa, xb, bias=bias, act=act, slope=slope, res=res, k_scale=k_scale, out=out)

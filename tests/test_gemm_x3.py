@@ -147,7 +147,13 @@ def test_gemm_x3_panel_limits(hip):
         hip.gemm_x3(hip.GemmPacked(a2, "a"), b2, tile_hint=8, res=torch.zeros(2, 256, 100, device=DEV))
     # hip.matmul hands the image to K16 only where the panel kernel applies
     w = hip.matmul_operand(a2, "a")
-    assert w[1] is not None and hip.matmul_operand(a, "a")[1] is None and hip.matmul_operand(a2[:64].contiguous(), "a")[1] is None
+    assert w[1] is not None and hip.matmul_operand(a2[:64].contiguous(), "a")[1] is None        # (fewer than 256 rows: never)
+    wbig = hip.matmul_operand(a, "a")                        # K = 856: beyond K16p; the image exists for K16's pre-split form ...
+    assert wbig[1] is not None
+    with hip.profile() as prof:
+        yb = hip.matmul(wbig, b)                             # ... which only the chip-filling launches take: this one stays float32
+    assert [k.split(":")[0] for k in prof.rows] == ["gemm_f32x3"]
+    assert float((yb - torch.matmul(a, b)).abs().max()) < 1e-3
     res = torch.randn(2, 256, 100, device=DEV)
     with hip.profile() as prof:
         y0 = hip.matmul(w, b2)
@@ -155,6 +161,25 @@ def test_gemm_x3_panel_limits(hip):
     names = sorted(k.split(":")[0] for k in prof.rows)
     assert names == ["gemm_f32x3", "gemm_f32x3_panel"], names
     assert float((y1 - res - y0).abs().max()) < 1e-5
+
+
+def test_matmul_takes_the_presplit_form_on_large_long_k_launches(hip):
+    """hip.matmul on a static left operand: K16's PRE = 1 form (weight fragments a full 32-k step ahead) where 256 x 128 tiles
+    fill the chip and K >= 512 -- the tap GEMMs of the 1/4 ... 1/16 decoder levels (here: 1/8 with the pixel count cut) --
+    against float64."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K, batch = 5760, 1848, 1280, 2
+    a = (torch.randn(M, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(batch, K, N, generator=g).to(DEV)
+    w = hip.matmul_operand(a, "a")
+    assert w[1] is not None and hip._presplit_launch(w[1], b) and not hip._panel_launch(w[1], b)
+    with hip.profile() as prof:
+        y = hip.matmul(w, b)
+    assert [k.split(":")[0] for k in prof.rows] == ["gemm_f32x3_preA"], prof.rows.keys()
+    rows = torch.arange(0, M, 37, device=DEV)                # (a float64 reference of every 37th row)
+    ref = torch.matmul(a[rows].double(), b.double())
+    assert float((y[:, rows].double() - ref).abs().max() / ref.abs().max()) < 2.5e-6
+    assert torch.equal(hip.matmul(w, b), y)
 
 
 def test_gemm_x3_strided_views_and_output(hip):

@@ -195,6 +195,9 @@ def test_padded_rows_and_the_panel_launch_rule(monkeypatch):
     assert hip._panel_launch(Img(1440, 320), b(2, 320, 28365))             # tap GEMM 1/2
     assert hip._panel_launch(Img(2304, 384), b(2, 384, 468))               # expand convolution of the 1/32 stage
     assert hip._panel_launch(Img(3840, 640), b(2, 640, 468))
-    assert not hip._panel_launch(Img(2880, 640), b(2, 640, 7191))          # tap GEMM 1/4: K16 is faster
+    assert not hip._panel_launch(Img(2880, 640), b(2, 640, 7191))          # tap GEMM 1/4: K16 is faster ...
+    assert hip._presplit_launch(Img(2880, 640), b(2, 640, 7191))           # ... on its pre-split form (chip-filling, K >= 512)
+    assert hip._presplit_launch(Img(11520, 2560), b(2, 2560, 574)) and not hip._panel_launch(Img(11520, 2560), b(2, 2560, 574))
+    assert not hip._presplit_launch(Img(2304, 384), b(2, 384, 468)) and not hip._presplit_launch(Img(2560, 640), b(2, 640, 574))
     w = torch.empty(2880, 640)
     assert hip.matmul_operand(w, "a")[1] is None                            # (CPU tensors are never pre-split)
