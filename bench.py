@@ -300,6 +300,10 @@ def run_extras():
                 leg.update({"loss": t["loss"], "train_graph": t["train_graph"], "train_graph_error": t["train_graph_error"],
                             "max_mem_GiB": t["max_mem_GiB"], "parallelism": t["config"]["parallelism"],
                             "top_kernel_families_ms": dict(list(t["hip_kernel_families_ms_per_step"].items())[:6])})
+                # the same step WITHOUT the hipGraph: what `trainer.fit` of the unmodified scripts/train.py runs (eager
+                # training_step + backward + optimizer.step); OCCDEPTH_FAST_TRAIN=1 reaches the replayed one from there
+                out[name + "_eager"] = {"ms_per_step": t.get("eager_ms_per_step"), "steps": t["steps"], "dtype": t["dtype"],
+                                        "what": "training_step + backward + AdamW launched eagerly (no hipGraph), same process"}
             out[name] = leg
         except Exception as e:  # a report, never a reason to lose the measurement
             out[name] = {"error": repr(e)}
@@ -531,6 +535,7 @@ def _forward(args, world, rank, device, dist):
                  "kernel": "lift_proj_kernel (projection + frustum sample + gather in one launch)" if lift_fused
                            else "lift_p1_kernel (tables from the batch) + flosp_sample_kernel"},
     }
+    res["roofline_2d"] = roofline_2d(prof.rows, prof_steps)
     split_head = any(k.startswith(("conv3d_c32x3", "conv3d_bf16x3")) for k, _ in head)
     if split_head:
         # the head convolutions run on the bf16 matrix pipe (3-way split, six bf16 MFMAs per algorithmic MAC): the roofline is
@@ -589,6 +594,57 @@ def _forward(args, world, rank, device, dist):
     else:
         res["cpu_baseline"] = None
     return res
+
+
+def roofline_2d(rows, frames):
+    """What limits the frame besides the head convolution: the 2-D network's kernel families from the SAME
+    HIP-event pass as `roofline` -- launches and ms per frame, algorithmic rate (the flops / bytes every launch reports to the
+    in-library profiler: 2 M N K for the GEMMs, the Winograd-domain MFMA work 2 * 16 * tiles * Cin * Cout for K10, bytes read +
+    written for the memory-bound kernels) and its fraction of the pipe the family runs on.  Recomputable from
+    profiles/r06_frame_per_launch.txt (same rows, same units)."""
+    fams = {
+        "K10_wino3x3": (("wino_conv3x3",), "mfma_f32", None),
+        "K16_gemm_x3_large": (("gemm_f32x3:", "gemm_f32x3_preA"), "mfma_bf16x3", 20e9),      # launches of >= 20 GFLOP
+        "K16_gemm_x3_small": (("gemm_f32x3:", "gemm_f32x3_preA"), "mfma_bf16x3", -20e9),     # the rest of the same kernels
+        "K16p_gemm_x3_panel": (("gemm_f32x3_panel",), "mfma_bf16x3", None),
+        "K11_pw_conv": (("pw_conv",), "mfma_f32", None),
+        "K21_mbconv_project_splitk": (("gemm_f32x3_splitk",), "mfma_bf16x3", None),
+        "depthwise": (("dwconv2d_nchw", "mbconv_dw"), "hbm", None),
+        "K12_upconv_gather": (("upconv_gather",), "hbm", None),
+        "squeeze_excite": (("se_gate", "se_fused"), "hbm", None),
+    }
+    out = {}
+    for name, (prefixes, pipe, cut) in fams.items():
+        sel = []
+        for k, v in rows.items():
+            if not k.startswith(prefixes):
+                continue
+            per_launch = v["flops"] / max(v["launches"], 1)
+            if cut is not None and ((cut > 0 and per_launch < cut) or (cut < 0 and per_launch >= -cut)):
+                continue
+            sel.append(v)
+        if not sel:
+            continue
+        ms = sum(v["ms"] for v in sel) / frames
+        n = sum(v["launches"] for v in sel) / frames
+        fl = sum(v["flops"] for v in sel) / frames
+        by = sum(v["bytes"] for v in sel) / frames
+        e = {"launches_per_frame": round(n, 1), "ms_per_frame": round(ms, 4)}
+        if pipe == "hbm":
+            gbps = by / (ms * 1e-3) / 1e9 if ms else 0.0
+            e.update({"bound": "hbm", "algorithmic_GBps": round(gbps, 1), "peak": 8000.0, "frac": round(gbps / 8000.0, 4)})
+        else:
+            tf = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+            if pipe == "mfma_bf16x3":
+                e.update({"bound": "mfma", "algorithmic_tflops": round(tf, 1), "issued_tflops": round(6 * tf, 1),
+                          "peak": BF16_MFMA_PEAK_TFLOPS, "frac": round(6 * tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                          "pipe": "bf16 (six v_mfma_f32_32x32x16_bf16 per algorithmic 16-k MAC step)"})
+            else:
+                e.update({"bound": "mfma", "algorithmic_tflops": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
+                          "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "pipe": "fp32 (v_mfma_f32_32x32x2_f32)"})
+        out[name] = e
+    out["launches_per_frame_all_kinds"] = round(sum(v["launches"] for v in rows.values()) / frames, 1)
+    return out
 
 
 CONFIG5_GFLOP = 9268.2                 # SURVEY 8(d): 8718.5 conv + 549.8 CRP bmm
@@ -734,6 +790,17 @@ def _train(args, world, rank, device, dist):
     loss_value = float(loss.detach())
     if None in shard._SMALL:
         shard._SMALL[None].check()                 # a peer-memory exchange that gave up waiting fails the run, loudly
+    # the step a user of the UNMODIFIED scripts gets (Lightning's automatic optimisation: zero_grad, training_step, backward,
+    # optimizer.step, all eager -- ~4 500 launches, host-bound), timed the same way right after the replayed one
+    eager_ms = None
+    if graphed is not None:
+        step()
+        shard.fence(dist)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        shard.fence(dist)
+        eager_ms = 1e3 * shard.max_over_ranks(time.perf_counter() - t0, dist, device) / args.steps
     with hip.profile() as prof:                    # kernel table: ONE eager step after the timed loop (HIP events per launch)
         step()
         torch.cuda.synchronize()
@@ -762,6 +829,7 @@ def _train(args, world, rank, device, dist):
                                   ("peer-memory kernel csrc/ipc_allreduce.hip" if None in shard._SMALL else "process group") +
                                   f") + {len(buckets.buckets) if buckets else 0} gradient buckets ({buckets.algo if buckets else 'none'})"},
         "train_graph": graphed is not None, "train_graph_error": graph_error,
+        "eager_ms_per_step": eager_ms if graphed is not None else 1e3 * elapsed / args.steps,
         "loss": loss_value, "max_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
         "hip_kernels_ms_per_step": {k: v["ms"] for k, v in rows},
         "hip_kernel_families_ms_per_step": families,

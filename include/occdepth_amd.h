@@ -277,6 +277,18 @@ typedef struct occd_gemm_args {
                                               batched launch over the relations; float32 A only (pre 0 / 2)                 */
 } occd_gemm_args;
 int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
+/* K21 (round 6), the skinny long-K GEMMs -- the MBConv project convolutions of the 1/16 and 1/32 EfficientNet stages,
+ * `bn3(conv_pwl(x * se_gate)) + skip` (geffnet InvertedResidual behind occdepth/models/unet2d.py:188-196): K16p's
+ * panel-stationary loop with K cut into `nz` chunks over the grid's z dimension, float32 partial tiles in `workspace`, and a
+ * second launch that sums the chunks in index order (deterministic) and applies bias / activation / res.  Same operand
+ * meaning as occd_gemm_f32x3 with pre = 1 (A = the role-0 image of occd_gemm_x3_pack; lda ignored), B float32 n-contiguous,
+ * scale_k / res / bias / act optional; tile_hint and act_a must be 0.  occd_gemm_f32x3_splitk_plan proposes
+ * (k16_per_z, nz, row_ranges) and the workspace size in floats (128-byte aligned buffer).  OCCD_EINVAL when a chunk would
+ * not fit LDS (k16_per_z * 16 * 192 B <= 160 KB), the chunks do not tile K exactly, or the workspace is too small.        */
+int occd_gemm_f32x3_splitk_plan(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t* k16_per_z, int32_t* nz,
+                                int32_t* row_ranges, int64_t* workspace_floats);
+int occd_gemm_f32x3_splitk(const occd_gemm_args* a, int32_t k16_per_z, int32_t nz, int32_t row_ranges, float* workspace,
+                           int64_t workspace_floats, void* stream);
 /* K16t, the "NT" form: C[b][m][n] = sum_k A[b][m][k] B[b][n][k], BOTH operands with k contiguous (lda, ldb >= K), any dword
  * alignment, any K: autograd's weight gradient of a pointwise convolution, dW = gy (Cout x HW) . x^T, on NCHW tensors as they
  * lie (training step, the geffnet MBConv 1x1 convolutions).  The reduction dimension is split over `act` (>= 1) workgroup
@@ -648,7 +660,8 @@ int occd_bn_bwd_small(const occd_bn_args* a, float* gw, float* gb, void* stream)
  * determinism and the bounded wait of occd_ipc_allreduce).
  * mailboxes: HOST array of `world` device pointers, [rank] = own; C <= cmax.  Forward: `packed` receives the TOTALS over the
  * ranks [sum n mean, sum (M2 + n mean^2), sum n]; backward: packed_fwd = that vector, gw / gb stay this rank's sums.
- * Every rank must be able to schedule its workgroups while the peers' wait (one GPU per rank).                        */
+ * Every rank must be able to schedule its workgroups while the peers' wait (one GPU per rank).  A peer's packet that does
+ * not arrive within timeout_ms makes that channel's totals NaN (and sets *status), as in occd_ipc_allreduce.           */
 int64_t occd_bn_xchg_mailbox_bytes(int32_t world, int32_t cmax);
 int occd_bn_fwd_small_xchg(const occd_bn_args* a, double* packed, float eps, float momentum, const float* gamma,
                            const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -787,7 +800,8 @@ int occd_ssc_confusion(const float* logits, const uint8_t* labels, const uint8_t
  * array of `world` device pointers, [rank] = the rank's own mailbox; the per-call sequence number lives in the mailbox and
  * is advanced by the kernel, so a captured launch replays correctly.  Wire format: every 32-bit half of the payload in its
  * own 8-byte word {data, sequence}, one system-scope atomic store / load each -- no fence anywhere.  The wait is bounded by timeout_ms (<= 0: unbounded):
- * on expiry the kernel sets *status = 1 (device int, optional), leaves `out` untouched and returns.                  */
+ * on expiry the kernel sets *status = 1 (device int, optional) and writes NaN into the elements of `out` whose wait gave up
+ * (never a partial sum: a lost peer poisons the step's loss instead of silently skewing it).                          */
 int64_t occd_ipc_mailbox_bytes(int32_t world, int64_t max_bytes);
 int occd_ipc_mailbox_create(int64_t bytes, void** mailbox, void* handle64);
 int occd_ipc_mailbox_open(const void* handle64, void** peer);

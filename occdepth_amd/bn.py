@@ -2,14 +2,15 @@
 
     y = bn_act(bn_module, x, act="relu" | "leaky" | "swish" | None, slope=0.01, res=None, res_first=False)
 
-is `act(bn(x) [+ res]) [+ res]` of a `torch.nn.BatchNorm{2,3}d` (or `shard.SyncBatchNorm`) in TRAINING mode -- the pattern of
+is `act(bn(x) [+ res]) [+ res]` of a `torch.nn.BatchNorm{2,3}d` (or `shard.SyncBatchNorm` / `torch.nn.SyncBatchNorm`) in TRAINING mode -- the pattern of
 every normalisation site of the reference's step (occdepth/models/DDR.py:111-139 `relu(bn(conv(x)))`, `relu(bn5(.) + skip)`;
 modules.py:40-46 `y += bn2(conv2(relu(bn1(conv1(x)))))`; unet2d.py:24-46 conv-BN-LeakyReLU; the EfficientNet blocks'
 BN-swish) -- as two passes over the activation per direction plus per-channel kernels, instead of the backend's
 batch_norm and separate activation / add kernels.  The module keeps its parameters, buffers and state_dict; running
 statistics and `num_batches_tracked` are updated on the device as nn.BatchNorm does.
 
-Statistics that span ranks (`shard.SyncBatchNorm`, the reference's `sync_batchnorm=True`, scripts/train.py:179): the same
+Statistics that span ranks (`shard.SyncBatchNorm`, and `torch.nn.SyncBatchNorm` as Lightning's converter produces it for the
+reference's `sync_batchnorm=True`, scripts/train.py:179 -- its `process_group`, None = the world): the same
 kernels with ONE all-reduce of the packed (2C + 1)-element float64 vector in the forward and one of 2C floats in the
 backward (see csrc/bn.hip); the parameter gradients stay per-rank sums, the gradient buckets average them.
 
@@ -127,7 +128,7 @@ class _BNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, running_mean, running_var, nbt, eps, momentum, act, slope, res_first, group,
-                sync, ngroups):
+                sync, ngroups, proto=None):
         geo = _Geom(x)
         C = geo.C
         dev = x.device
@@ -136,6 +137,9 @@ class _BNActFn(torch.autograd.Function):
             raise RuntimeError("bn_act: the batch does not divide into the view groups")
         n = x.shape[0] // G
         exchange = bool(sync and _group_active(group))
+        # synchronised layers follow the protocol the ranks AGREED on for this module (`proto`, see bn_act): the one-launch
+        # in-kernel exchange or the packed all-reduce -- never a choice made from this rank's tensor shape alone
+        one_launch = bool(proto["one_launch"]) if (exchange and proto is not None) else None
         packed = torch.empty(G, 2 * C + 1, device=dev, dtype=torch.float64)
         vec = torch.empty(G, 4, C, device=dev, dtype=torch.float32)       # per group: mean, invstd, a, b
         w = weight.detach().float() if weight is not None else None
@@ -147,16 +151,16 @@ class _BNActFn(torch.autograd.Function):
             small = _BNActFn._forward_group(x[sl] if G > 1 else x, y[sl] if G > 1 else y,
                                             (res[sl] if G > 1 else res) if res is not None else None, w, b, running_mean,
                                             running_var, nbt, eps, momentum, act, slope, res_first, group, exchange, vec[g],
-                                            packed[g]) and small
+                                            packed[g], one_launch) and small
         # the pre-activation's sign comes from y when a residual entered before the activation (x a + b alone is not it)
         need_y = act != 0 and res is not None and res_first
         ctx.save_for_backward(x, vec, packed, weight, y if need_y else None)
-        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, exchange, G)
+        ctx.cfg = (act, float(slope), bool(res_first), res is not None, group, exchange, G, one_launch)
         return y
 
     @staticmethod
     def _forward_group(x, y, res, w, b, running_mean, running_var, nbt, eps, momentum, act, slope, res_first, group, exchange,
-                       vec, packed):
+                       vec, packed, one_launch=None):
         lib = hip.load()
         st = hip._stream()
         geo = _Geom(x)
@@ -175,12 +179,16 @@ class _BNActFn(torch.autograd.Function):
         a.act, a.slope, a.res_first = act, float(slope), 1 if res_first else 0
         small = bool(lib.occd_bn_small_ok(ctypes.byref(a)))
         xc = None
+        if exchange:
+            small = _BNActFn._agreed_small(small, one_launch, x)
         if small and exchange:
             # synchronised small layer: still ONE launch -- the ranks' statistics are exchanged inside it through the
             # peer-mapped channel mailboxes (shard.SmallAllReduce) when they are installed for the group
             from .shard import channel_exchange
             xc = channel_exchange(group, C, dev)
-            small = xc is not None
+            if xc is None:
+                raise RuntimeError("bn_act: the ranks agreed on the in-kernel exchange for this layer but no peer-memory "
+                                   "exchange is installed for its process group any more")
         if small and xc is not None:
             hip._check(lib.occd_bn_fwd_small_xchg(ctypes.byref(a), packed.data_ptr(), *fin, *xc, st), "occd_bn_fwd_small_xchg")
         elif small:
@@ -205,9 +213,22 @@ class _BNActFn(torch.autograd.Function):
         return small
 
     @staticmethod
+    def _agreed_small(local_ok, one_launch, x):
+        """The protocol of a synchronised layer is the group's, not this rank's: the one-launch exchange only when the
+        ranks agreed on it (every rank's tensor fitted at the layer's first call); then a rank whose tensor has since
+        outgrown the one-launch kernel cannot follow and must say so -- its peers are waiting in the channel mailboxes."""
+        if not one_launch:
+            return False                                 # packed all-reduce: always possible, whatever the local shape
+        if not local_ok:
+            raise RuntimeError(f"bn_act: this SyncBatchNorm layer was first called with tensors every rank could handle "
+                               f"in one launch, now this rank's input {tuple(x.shape)} does not fit; ranks must keep "
+                               "comparable shapes per layer, or set OCCDEPTH_SYNCBN_ONE_LAUNCH=0")
+        return True
+
+    @staticmethod
     def backward(ctx, gy):
         x, vec, packed, weight, y = ctx.saved_tensors
-        act, slope, res_first, has_res, group, exchange, G = ctx.cfg
+        act, slope, res_first, has_res, group, exchange, G, one_launch = ctx.cfg
         geo = _Geom(x)
         C = geo.C
         dev = x.device
@@ -228,17 +249,17 @@ class _BNActFn(torch.autograd.Function):
             sl = slice(g * n, (g + 1) * n)
             cut = (lambda t: t[sl] if t is not None and G > 1 else t)
             _BNActFn._backward_group(cut(x), cut(gy), cut(y), cut(gx), cut(gres) if (has_res and res_first and act != 0) else None,
-                                     vec[g], packed[g], k[g], want_w, act, slope, res_first, group, exchange)
+                                     vec[g], packed[g], k[g], want_w, act, slope, res_first, group, exchange, one_launch)
         gw = gb = None
         if want_w:
             # parameter gradients: sum over the view groups -- no launch at all for one group, ONE for both vectors otherwise
             # (these were 2 x 266 `aten::sum` launches of a config-2 step, most of them over a single row)
             wb = k[0, 3:5] if G == 1 else k[:, 3:5].sum(0)
             gw, gb = wb[0].to(weight.dtype), wb[1].to(weight.dtype)
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None, None, None, None, None
 
     @staticmethod
-    def _backward_group(x, gy, y, gx, gres, vec, packed, k, want_w, act, slope, res_first, group, exchange):
+    def _backward_group(x, gy, y, gx, gres, vec, packed, k, want_w, act, slope, res_first, group, exchange, one_launch=None):
         lib = hip.load()
         st = hip._stream()
         geo = _Geom(x)
@@ -258,14 +279,17 @@ class _BNActFn(torch.autograd.Function):
         if gres is not None:
             a.out2, a.out2_cs = gres.data_ptr(), (geo.like(x, gres, "gres") if geo.layout == 0 else 0)
         small = bool(lib.occd_bn_small_ok(ctypes.byref(a)))
+        if exchange:
+            small = _BNActFn._agreed_small(small, one_launch, x)
         if small and exchange:
             from .shard import channel_exchange
             xc = channel_exchange(group, C, dev)
-            if xc is not None:
-                hip._check(lib.occd_bn_bwd_small_xchg(ctypes.byref(a), packed.data_ptr(), gw_p, gb_p, *xc, st),
-                           "occd_bn_bwd_small_xchg")
-                return
-            small = False
+            if xc is None:
+                raise RuntimeError("bn_act: the forward of this layer used the in-kernel exchange, the backward finds no "
+                                   "peer-memory exchange installed for its process group")
+            hip._check(lib.occd_bn_bwd_small_xchg(ctypes.byref(a), packed.data_ptr(), gw_p, gb_p, *xc, st),
+                       "occd_bn_bwd_small_xchg")
+            return
         if small:
             hip._check(lib.occd_bn_bwd_small(ctypes.byref(a), gw_p, gb_p, st), "occd_bn_bwd_small")
             return
@@ -305,6 +329,16 @@ def _torch_reference(bn, x, act, slope, res, res_first):
         y = y + res
     return y
 
+
+# One-launch synchronised small layers (the in-kernel channel exchange); "0" keeps every synchronised layer on the packed
+# all-reduce (five launches), whatever the tensor sizes.
+ONE_LAUNCH_SYNC = __import__("os").environ.get("OCCDEPTH_SYNCBN_ONE_LAUNCH", "1") == "1"
+# ... and only for layers of at most this many channels.  The one-launch kernel is one workgroup per channel and every
+# workgroup waits for its peers' packets: each rank must be able to keep its workgroups resident while the peers' run, which
+# one GPU per rank guarantees (a GPU holds 2048 such workgroups and dispatches them in channel order).  SEVERAL ranks sharing
+# ONE GPU (the two-process tests) share those 2048 slots: a 2304-channel launch of one rank can occupy all of them and starve
+# the peer it waits for -- such set-ups cap the layer width here (tests: 512).
+ONE_LAUNCH_SYNC_MAX_C = int(__import__("os").environ.get("OCCDEPTH_SYNCBN_ONE_LAUNCH_MAX_C", "4096"))
 
 ENABLED = True      # A/B switch (bench / tests): False sends every site through the backend's batch_norm again
 
@@ -354,7 +388,44 @@ def bn_act(bn, x, act=None, slope=0.01, res=None, res_first=False):
                                                res[g * n:(g + 1) * n] if res is not None else None, res_first)
                               for g in range(G)], 0)
         return _torch_reference(bn, x, code, slope, res, res_first)
-    from . import shard
-    sync = isinstance(bn, shard.SyncBatchNorm)
+    sync, group, proto = _sync_protocol(bn, x)
     return _BNActFn.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                          bn.momentum, code, slope, res_first, getattr(bn, "process_group", None), sync, G)
+                          bn.momentum, code, slope, res_first, group, sync, G, proto)
+
+
+def is_sync(bn):
+    """Statistics over the ranks of a process group?  Both converters produce such modules: `shard.convert_sync_batchnorm`
+    (prepare_for_ddp) and `torch.nn.SyncBatchNorm.convert_sync_batchnorm` -- what Lightning's `Trainer(sync_batchnorm=True)`
+    applies to the model in the reference's unmodified scripts/train.py:175-206."""
+    from . import shard
+    return isinstance(bn, (shard.SyncBatchNorm, torch.nn.SyncBatchNorm))
+
+
+def _sync_protocol(bn, x):
+    """(sync, process group, protocol record) of a fused training-mode call.  For a synchronised module on an active group:
+    makes sure the peer-memory exchange of the group exists (lazily, collectively, once -- a model converted by torch's /
+    Lightning's converter never went through prepare_for_ddp) and fixes the layer's exchange protocol ONCE, at its first
+    call, from what ALL ranks report (`occd_bn_small_ok` of the local tensor, MIN over the group): the record lives on the
+    module (`_occd_sync_proto`, not part of the state_dict) and every later call on every rank follows it."""
+    if not is_sync(bn):
+        return False, None, None
+    group = getattr(bn, "process_group", None)
+    if not _group_active(group):
+        return True, group, None
+    from . import shard
+    sm = shard.ensure_small_all_reduce(group, x.device)
+    proto = bn.__dict__.get("_occd_sync_proto")
+    if proto is None or proto["installed"] != (sm is not None):
+        one = False
+        if (sm is not None and ONE_LAUNCH_SYNC and x.shape[1] <= ONE_LAUNCH_SYNC_MAX_C
+                and sm.channel_args(x.shape[1], x.device) is not None):
+            n = x.shape[0] // (GROUPS if bn.training else 1)
+            probe = _Geom(x[:n] if n != x.shape[0] else x)
+            a = probe.args()
+            a.x = x.data_ptr()
+            one = bool(hip.load().occd_bn_small_ok(ctypes.byref(a)))
+        if sm is not None and ONE_LAUNCH_SYNC:
+            one = shard.agree_flag(one, group, x.device)
+        proto = {"one_launch": one, "installed": sm is not None}
+        bn.__dict__["_occd_sync_proto"] = proto
+    return True, group, proto

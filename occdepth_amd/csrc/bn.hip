@@ -602,7 +602,8 @@ struct BnXchg {
 constexpr int kXchgHeader = 256;  // bytes (reserved); then cmax u64 per-channel sequence counters; then the two slots
 constexpr int kXchgRec = 64;      // bytes per (slot, rank, channel) record: 6 LL words + pad
 
-// sums over the ranks of (v0, v1, v2) for channel c.  Called by ALL threads of the workgroup.
+// sums over the ranks of (v0, v1, v2) for channel c.  Called by ALL threads of the workgroup.  A peer whose packet does not
+// arrive within the budget makes the sums NaN (the layer's output and gradients are then NaN: loud, not a wrong normalisation).
 __device__ __forceinline__ void xchg_channel(const BnXchg& q, int c, double v0, double v1, double v2, double (&tot)[3],
                                              double* sh) {
     // channel c's own sequence counter (this workgroup is its only reader and writer; every lane reads the same word)
@@ -641,7 +642,7 @@ __device__ __forceinline__ void xchg_channel(const BnXchg& q, int c, double v0, 
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            sh[t * 3 + j] = fail ? 0.0 : __longlong_as_double((long long)((w[2 * j + 1] << 32) | (w[2 * j] & 0xffffffffULL)));
+            sh[t * 3 + j] = fail ? (double)__builtin_nanf("") : __longlong_as_double((long long)((w[2 * j + 1] << 32) | (w[2 * j] & 0xffffffffULL)));
         if (fail && q.status != nullptr) *q.status = 1;
     }
     __syncthreads();                              // (every lane has read the counter before it advances)

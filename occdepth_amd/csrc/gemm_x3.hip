@@ -876,6 +876,204 @@ __global__ void __launch_bounds__(512) gemm_x3_panel_kernel(const GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K21 -- K16p cut along K over SEVERAL workgroups (round 6): the project convolutions of the 1/16 and 1/32 encoder stages,
+// `bn(conv1x1(y * gate)) + skip` with K = 960 ... 3840 input channels, 160 ... 640 output channels and 2 x 468 / 2 x 1848
+// pixels (geffnet MBConv behind occdepth/models/unet2d.py:188-196).  A 64 x 64 tiling gives 90 ... 230 output tiles for 256 CUs, each
+// walking the whole K behind two barriers per 32 k (K16: 56 us; the in-workgroup split-K form: 39 ... 56 us; K11s, exact fp32:
+// 35 us) for 1.7 ... 4.6 GFLOP -- 47 ... 57 TF/s.  Here the grid is (32-column panels of B) x (row ranges) x (batch) x (K chunks
+// of <= 416 k): every workgroup stages + splits ITS K chunk of its panel once (the gate multiplies the rows while they are
+// staged, rounded to float32 first like the reference's x * gate), ONE barrier, then its 8 waves walk the row tiles against the
+// resident chunk with pre-split weight fragments straight from L2 -- K16p's loop, no barrier, no split arithmetic -- and store
+// the float32 PARTIAL tile into a workspace [b][z][M][ld]; `splitk_reduce_kernel` sums the z partials in index order
+// (deterministic), adds the BatchNorm shift, the activation and the skip.  Two launches, both with hundreds of workgroups.
+struct GemmSKP {
+    GemmP g;
+    int k16_per_z;                      // 16-k steps per K chunk (the last chunk may be shorter, never empty)
+    float* ws;                          // partial sums
+    long ld_ws, z_stride, b_stride;     // floats: row pitch (multiple of 32), between K chunks, between batch items
+};
+
+template <int NT, int PD>
+__global__ void __launch_bounds__(512) gemm_x3_panel_splitk_kernel(const GemmSKP q) {
+    const GemmP& p = q.g;
+    constexpr int TN = 32 * NT, SB = panel_row_bytes(NT), TB = 64 * NT, C4 = TN / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char glds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int K16tot = (p.K + 15) >> 4;
+    const int kz = blockIdx.z;
+    const int ks0 = kz * q.k16_per_z;                           // first 16-k step of this chunk
+    const int nst = min(q.k16_per_z, K16tot - ks0);             // its steps (>= 1 by construction of the grid)
+    const int kbase = ks0 * 16;
+
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nwg = p.nwg, qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int nt_i = bid % p.ntiles, mr_i = bid / p.ntiles;
+    const int bz = blockIdx.y;
+    const int n0 = nt_i * TN;
+    const int tiles_all = (p.M + 31) >> 5;
+    const int t0 = mr_i * p.mr_tiles, t1 = min(t0 + p.mr_tiles, tiles_all);
+
+    const u32x4* const Abase = reinterpret_cast<const u32x4*>(p.A) + (size_t)bz * p.sA + (size_t)ks0 * 192 + lane;
+    const u32x4* pk;
+    u32x4 an[PD][3];
+    auto fetch_a = [&](int d, int k16) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) an[d][t] = pk[(k16 * 3 + t) * 64];
+    };
+    auto first_a = [&](int tb) {
+        pk = Abase + (size_t)min(tb, tiles_all - 1) * K16tot * 192;
+#pragma unroll
+        for (int d = 0; d < PD; ++d) fetch_a(d, min(d, nst - 1));
+    };
+    if (t0 + wave < t1) first_a(t0 + wave);
+
+    // ---- this chunk of the B panel: (k, 4-column chunk) items; all loads of a pass in flight before the first split
+    {
+        const float* const Bb = p.B + (size_t)bz * p.sB;
+        const float* const ksc = p.kscale != nullptr ? p.kscale + (size_t)bz * p.K : nullptr;
+        const int total = nst * 16 * C4;
+        const bool edge = n0 + TN > p.N;
+        for (int base = 0; base < total; base += 512 * kPanelPass) {
+            f32x4 v[kPanelPass];
+            float sc[kPanelPass];
+#pragma unroll
+            for (int i = 0; i < kPanelPass; ++i) {
+                const int f = base + i * 512 + tid;
+                const int k = min(kbase + f / C4, p.K - 1), c = min(n0 + (f % C4) * 4, p.N - 4);
+                v[i] = *(const f32x4u*)(Bb + (size_t)k * p.ldb + c);
+                sc[i] = ksc != nullptr ? ksc[k] : 1.f;
+            }
+#pragma unroll
+            for (int i = 0; i < kPanelPass; ++i) {
+                const int f = base + i * 512 + tid;
+                const int k = f / C4, c4 = f % C4;
+                if (f >= total) continue;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 w = kbase + k < p.K ? v[i] : z;
+                if (ksc != nullptr) w *= sc[i];                 // (one rounding to float32: the reference's x * gate)
+                if (edge) {
+                    const int sh = n0 + c4 * 4 - min(n0 + c4 * 4, p.N - 4);
+                    const f32x4 u = w;
+                    w.x = sh == 0 ? u.x : sh == 1 ? u.y : sh == 2 ? u.z : u.w;
+                    w.y = sh == 0 ? u.y : sh == 1 ? u.z : sh == 2 ? u.w : 0.f;
+                    w.z = sh == 0 ? u.z : sh == 1 ? u.w : 0.f;
+                    w.w = sh == 0 ? u.w : 0.f;
+                }
+                u32x2 hi, mid, lo;
+                split4(w, hi, mid, lo);
+                unsigned char* dst = glds + k * SB + c4 * 8;
+                *(u32x2*)dst = hi;
+                *(u32x2*)(dst + TB) = mid;
+                *(u32x2*)(dst + 2 * TB) = lo;
+            }
+        }
+    }
+    __syncthreads();
+    int b_lane[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b_lane[nt] = (8 * h + (i16 >> 2)) * SB + (nt * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
+    float* const Cb = q.ws + (size_t)bz * q.b_stride + (size_t)kz * q.z_stride;
+
+    for (int tb = t0 + wave; tb < t1; tb += 8) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        bf16x8 bn[NT][3];
+        auto fetch_b = [&](int k16) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bn[nt][t] = tr_frag(glds + t * TB + b_lane[nt] + k16 * 16 * SB, 4 * SB);
+        };
+        fetch_b(0);
+#define OCCD_GP(WT, XT)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt] =                                                      \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[WT]), bf[nt][XT], acc[nt], 0, 0, 0)
+        // (requests unconditional from clamped steps, branch-free groups of PD steps: see K16p)
+        auto step = [&](int k16, int d, bool more_a) {
+            u32x4 af[3];
+            bf16x8 bf[NT][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                af[t] = an[d][t];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt][t] = bn[nt][t];
+            }
+            if (more_a) fetch_a(d, min(k16 + PD, nst - 1));
+            fetch_b(min(k16 + 1, nst - 1));
+            OCCD_GP(1, 1);
+            OCCD_GP(0, 2);
+            OCCD_GP(2, 0);
+            OCCD_GP(0, 1);
+            OCCD_GP(1, 0);
+            OCCD_GP(0, 0);
+        };
+        int k0 = 0;
+        for (; k0 + PD <= nst; k0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) step(k0 + d, d, true);
+        }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)
+            if (k0 + d < nst) step(k0 + d, d, false);
+#undef OCCD_GP
+        if (tb + 8 < t1) first_a(tb + 8);
+        // partial tile: lane -> column, registers -> rows; the workspace rows are 128-byte aligned (ld_ws % 32 == 0)
+        const int mb = tb * 32 + 4 * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + nt * 32 + li;
+            const bool n_ok = n < q.ld_ws;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (n_ok && m < p.M) Cb[(size_t)m * q.ld_ws + n] = acc[nt][r];
+            }
+        }
+    }
+}
+
+// out[b][m][n] = act(sum_z ws[b][z][m][n] + bias[m]) + res[b][m][n]; z in index order.  One thread = 4 consecutive n.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            int M, int N, int nz, long ld_ws, long z_stride, long b_stride,
+                                                            long ldc, long sC, int act, float slope, int vec_ok) {
+    const int n4 = (N + 3) >> 2;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (long)M * n4) return;
+    const int m = (int)(item / n4), n = (int)(item - (long)m * n4) * 4;
+    const int b = blockIdx.y;
+    const float* src = ws + (size_t)b * b_stride + (size_t)m * ld_ws + n;
+    f32x4 s = *(const f32x4*)src;                               // (the pad columns of the workspace rows exist: ld_ws >= N rounded to 32)
+    for (int z = 1; z < nz; ++z) s += *(const f32x4*)(src + (size_t)z * z_stride);
+    if (bias != nullptr) s += bias[m];
+    float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (act == 1) v[j] = occd::swish_fast(v[j]);
+        else if (act == 2) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+    }
+    const size_t o = (size_t)b * sC + (size_t)m * ldc + n;
+    if (vec_ok && n + 3 < N) {
+        f32x4 r = {v[0], v[1], v[2], v[3]};
+        if (res != nullptr) r += *(const f32x4*)(res + o);
+        *(f32x4*)(out + o) = r;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < N) out[o + j] = v[j] + (res != nullptr ? res[o + j] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K16t -- "NT" form for weight gradients: C[b][m][n] = sum_k A[b][m][k] * B[b][n][k], BOTH operands with k contiguous and
 // of ANY dword alignment and any K (rows of H*W pixels: odd lengths are the rule).  dW of a pointwise convolution is
 // gy (Cout x HW) . x^T (HW x Cin): both tensors lie k(= pixel)-contiguous in NCHW memory, so both are staged like K16's A
@@ -1244,6 +1442,79 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     occd::ProfScope prof(ws ? "gemm_f32x3_ws" : a->pre == 0 ? "gemm_f32x3" : a->pre == 1 ? "gemm_f32x3_preA" : a->pre == 2 ? "gemm_f32x3_preB" : "gemm_bf16", (hipStream_t)stream, flops, bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch), dim3(ws ? 512 : v.WM * v.WN * 64 * (ksplit ? kKS : 1)), lds,
                        (hipStream_t)stream, p);
+    return occd::check_launch();
+}
+
+// K21 (see gemm_x3_panel_splitk_kernel): a->pre must be 1 (A = the role-0 image of occd_gemm_x3_pack), B float32 with n
+// contiguous, optional bias / act / res / scale_k as occd_gemm_f32x3.  `nz` K chunks of `k16_per_z` 16-k steps each
+// (occd_gemm_f32x3_splitk_plan proposes them; k16_per_z * 192 B <= 160 KB of LDS, two workgroups per CU up to 26 steps),
+// `row_ranges` >= 1 row ranges per panel, workspace: >= batch * nz * M * round_up(N, 32) floats.
+extern "C" int occd_gemm_f32x3_splitk_plan(int32_t M, int32_t N, int32_t K, int32_t batch, int32_t* k16_per_z, int32_t* nz,
+                                           int32_t* row_ranges, int64_t* workspace_floats) {
+    if (M <= 0 || N < 4 || K <= 0 || (K & 7) || batch <= 0 || !k16_per_z || !nz || !row_ranges || !workspace_floats) return OCCD_EINVAL;
+    const int K16tot = (K + 15) / 16, tiles = (M + 31) / 32;
+    const long panels = (long)((N + 31) / 32) * batch;
+    // chunks: enough workgroups for ~2 per CU, at least 8 steps (128 k) and at most 26 (416 k: 78 KB of LDS, two workgroups
+    // per CU) per chunk; rows: all row tiles in one workgroup (the chunk is staged once) unless the grid is still short
+    int z = (int)((512 + panels - 1) / panels);
+    if (z > K16tot / 8) z = K16tot / 8;
+    if (z < (K16tot + 25) / 26) z = (K16tot + 25) / 26;
+    if (z < 1) z = 1;
+    int per = (K16tot + z - 1) / z;
+    z = (K16tot + per - 1) / per;
+    int rr = 1;
+    while (panels * z * rr < 256 && rr * 8 < tiles) ++rr;
+    *k16_per_z = per; *nz = z; *row_ranges = rr;
+    *workspace_floats = (int64_t)batch * z * M * (((int64_t)N + 31) / 32 * 32);
+    return OCCD_OK;
+}
+
+extern "C" int occd_gemm_f32x3_splitk(const occd_gemm_args* a, int32_t k16_per_z, int32_t nz, int32_t row_ranges,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || !workspace) return OCCD_EINVAL;
+    if (a->M <= 0 || a->N < 4 || a->K <= 0 || (a->K & 7) || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
+    if (a->pre != 1 || a->act_a != 0 || a->act < 0 || a->act > 2 || a->ldc < a->N || a->ldb < a->N) return OCCD_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 7) || (reinterpret_cast<uintptr_t>(a->B) & 3) ||
+        (reinterpret_cast<uintptr_t>(a->C) & 3) || (reinterpret_cast<uintptr_t>(workspace) & 127))
+        return OCCD_EINVAL;
+    if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
+    const int K16tot = (a->K + 15) / 16, tiles = (a->M + 31) / 32;
+    if (k16_per_z < 1 || nz < 1 || nz > 65535 || row_ranges < 1 || row_ranges > tiles) return OCCD_EINVAL;
+    if ((long)(nz - 1) * k16_per_z >= K16tot || (long)nz * k16_per_z < K16tot) return OCCD_EINVAL;      // every chunk non-empty, all of K covered
+    const size_t lds = (size_t)k16_per_z * 16 * panel_row_bytes(1);
+    if (lds > 160 * 1024) return OCCD_EINVAL;
+    const long ld_ws = ((long)a->N + 31) / 32 * 32;
+    if (workspace_floats < (int64_t)a->batch * nz * a->M * ld_ws) return OCCD_EINVAL;
+    GemmSKP q;
+    GemmP& p = q.g;
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = nullptr; p.res = nullptr; p.kscale = a->scale_k;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.sA = a->stride_a / 8; p.sB = a->stride_b; p.sC = a->stride_c;
+    p.act = 0; p.slope = 0.f; p.act_a = 0; p.n_fast = 1;
+    p.ntiles = (a->N + 31) / 32;
+    p.mr_tiles = (tiles + row_ranges - 1) / row_ranges;
+    p.mtiles = (tiles + p.mr_tiles - 1) / p.mr_tiles;
+    const long nwg = (long)p.mtiles * p.ntiles;
+    if (nwg >= (1L << 31)) return OCCD_EINVAL;
+    p.nwg = (unsigned)nwg;
+    q.k16_per_z = k16_per_z;
+    q.ws = workspace;
+    q.ld_ws = ld_ws;
+    q.z_stride = (long)a->M * ld_ws;
+    q.b_stride = (long)nz * q.z_stride;
+    void (*kern)(const GemmSKP) = k16_per_z >= 16 ? gemm_x3_panel_splitk_kernel<1, 2> : gemm_x3_panel_splitk_kernel<1, 1>;
+    if (lds > 64 * 1024 && occd::ensure_big_lds(reinterpret_cast<const void*>(kern)) != OCCD_OK) return OCCD_ELAUNCH;
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * a->M * a->N * a->K * a->batch;
+    const double bytes = 4.0 * ((double)a->M * a->K * (a->stride_a != 0 ? a->batch : 1) + ((double)a->K + a->M) * a->N * a->batch);
+    occd::ProfScope prof("gemm_f32x3_splitk", st, flops, bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)a->batch, (unsigned)nz), dim3(512), lds, st, q);
+    const int vec_ok = ((a->ldc & 3) == 0 && (a->stride_c & 3) == 0 && (reinterpret_cast<uintptr_t>(a->C) & 15) == 0 &&
+                        (a->res == nullptr || (reinterpret_cast<uintptr_t>(a->res) & 15) == 0)) ? 1 : 0;
+    const long items = (long)a->M * ((a->N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256), (unsigned)a->batch), dim3(256), 0, st,
+                       (const float*)workspace, a->C, a->bias, a->res, a->M, a->N, nz, ld_ws, q.z_stride, q.b_stride,
+                       (long)a->ldc, (long)a->stride_c, a->act, a->slope, vec_ok);
     return occd::check_launch();
 }
 

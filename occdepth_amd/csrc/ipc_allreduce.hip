@@ -74,6 +74,10 @@ __global__ void __launch_bounds__(256) ipc_allreduce_kernel(const IpcP q) {
     T* out = static_cast<T*>(q.out);
     bool fail = false;
     for (int i = threadIdx.x; i < q.count; i += 256) {
+        if (fail) {                             // a peer is gone: every remaining element of this thread is poisoned too
+            out[i] = (T)__builtin_nanf("");
+            continue;
+        }
         unsigned long long w[kIpcMaxWorld][WPE];
         const long long t0 = wall_clock64();
         while (true) {
@@ -95,7 +99,12 @@ __global__ void __launch_bounds__(256) ipc_allreduce_kernel(const IpcP q) {
             if (q.timeout_ticks > 0 && wall_clock64() - t0 > q.timeout_ticks) { fail = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (fail) break;
+        if (fail) {
+            // gave up: the result must not look like a sum.  NaN poisons everything computed from it (the step's loss), the
+            // sticky status word makes shard.SmallAllReduce.check() / poll() raise.
+            out[i] = (T)__builtin_nanf("");
+            continue;
+        }
         T acc = 0;
 #pragma unroll
         for (int r = 0; r < kIpcMaxWorld; ++r)
@@ -179,7 +188,7 @@ int occd_ipc_mailbox_free(void* mailbox) {
 // out[i] = sum over ranks of in[i] (rank order), count elements of dtype (0: float32, 1: float64); in / out device pointers of
 // this rank (may alias); mailboxes: `world` peer-mapped mailbox pointers (HOST array, [rank] = this rank's own) of
 // occd_ipc_mailbox_bytes(world, max_bytes) bytes each; status: optional device int set to 1 when the wait gives up after
-// timeout_ms (<= 0: wait forever).  Asynchronous on `stream`; capturable (the sequence number lives in the mailbox).
+// timeout_ms (<= 0: wait forever) -- the elements whose wait gave up are then NaN in `out`, never a partial sum.  Asynchronous on `stream`; capturable (the sequence number lives in the mailbox).
 int occd_ipc_allreduce(const void* in, void* out, int64_t count, int32_t dtype, void* const* mailboxes, int32_t rank,
                        int32_t world, int64_t max_bytes, int32_t timeout_ms, int32_t* status, void* stream) {
     if (in == nullptr || out == nullptr || mailboxes == nullptr || count < 1 || (dtype != 0 && dtype != 1)) return OCCD_EINVAL;

@@ -19,6 +19,7 @@ struct Rec {
 std::mutex g_mu;
 bool g_on = false;
 std::string g_tag;
+std::string g_tag_kind;      // the kernel kind the current tag was consumed by first: a tag describes ONE kind of launch
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 
@@ -41,7 +42,15 @@ ProfScope::ProfScope(const char* kind, hipStream_t s, double flops, double bytes
     Rec r;
     r.e0 = get_event();
     r.e1 = get_event();
-    r.tag = g_tag.empty() ? std::string(kind) : std::string(kind) + ":" + g_tag;
+    // A tag is the geometry string of the operator that set it.  Kernels launched later by operators that set no tag
+    // used to inherit it ("dwconv2d_nchw:32>22 k333 ... @256x256x32": a depthwise launch labelled with the head
+    // convolution's geometry); now the tag belongs to the first kind that uses it, other kinds are reported bare.
+    bool tagged = !g_tag.empty();
+    if (tagged) {
+        if (g_tag_kind.empty()) g_tag_kind = kind;
+        else if (g_tag_kind != kind) tagged = false;
+    }
+    r.tag = tagged ? std::string(kind) + ":" + g_tag : std::string(kind);
     r.flops = flops;
     r.bytes = bytes;
     (void)hipEventRecord(r.e0, s);
@@ -78,6 +87,7 @@ extern "C" int occd_prof_enable(int32_t on) {
 extern "C" int occd_prof_set_tag(const char* tag) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_tag = tag ? tag : "";
+    g_tag_kind.clear();
     return OCCD_OK;
 }
 

@@ -262,6 +262,9 @@ EXPORTS = {
     "occd_se_bwd": (c_int32, [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_int64, c_void_p]),
     "occd_depthnet_gate": (c_int32, [c_void_p, c_void_p, c_int64, c_float] + [c_void_p] * 9 + [c_int32, c_int32, c_void_p]),
     "occd_prof_enable": (c_int32, [c_int32]),
+    "occd_gemm_f32x3_splitk_plan": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
+                                              POINTER(c_int32), POINTER(c_int64)]),
+    "occd_gemm_f32x3_splitk": (c_int32, [POINTER(GemmArgs), c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
 }
@@ -658,6 +661,66 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
     return out[0] if squeeze and out.dim() == 3 else out
+
+
+def gemm_x3_splitk_plan(M, N, K, batch):
+    """(k16_per_z, nz, row_ranges, workspace_floats) the library proposes for K21 on this problem."""
+    per, nz, rr, ws = c_int32(), c_int32(), c_int32(), c_int64()
+    _check(load().occd_gemm_f32x3_splitk_plan(M, N, K, batch, ctypes.byref(per), ctypes.byref(nz), ctypes.byref(rr),
+                                              ctypes.byref(ws)), "occd_gemm_f32x3_splitk_plan")
+    return per.value, nz.value, rr.value, ws.value
+
+
+_SPLITK_WS = {}        # device -> workspace tensor (grown on demand; stream-ordered reuse: the reduce launch follows its GEMM)
+
+
+def gemm_x3_splitk(a, b, bias=None, act=None, slope=0.01, out=None, res=None, k_scale=None, plan=None):
+    """K21 (occd_gemm_f32x3_splitk): out[i] = act(a @ (b[i] * k_scale[i][:, None]) + bias[:, None]) + res[i] for SKINNY long-K
+    problems (the MBConv project convolutions of the 1/16 and 1/32 stages): K cut over the grid, float32 partial tiles in a
+    workspace, deterministic second launch.  a: GemmPacked role "a" (shared over the batch); b: (batch, K, N) / (K, N)
+    float32, innermost stride 1; plan: (k16_per_z, nz, row_ranges) or None for the library's proposal."""
+    if not isinstance(a, GemmPacked) or a.role != "a" or a.batch is not None:
+        raise RuntimeError("gemm_x3_splitk: a must be a shared GemmPacked left operand")
+    if b.dtype != torch.float32 or not b.is_cuda or b.dim() not in (2, 3) or b.stride(-1) != 1:
+        raise RuntimeError("gemm_x3_splitk: b must be a float32 GPU tensor with innermost stride 1")
+    batch = b.shape[0] if b.dim() == 3 else 1
+    M, K, N = a.rows, a.K, b.shape[-1]
+    if b.shape[-2] != K:
+        raise RuntimeError("gemm_x3_splitk: inner dimensions differ")
+    squeeze = b.dim() == 2
+    if out is None:
+        out = torch.empty((batch, M, N), device=b.device, dtype=torch.float32)
+    elif out.dtype != torch.float32 or out.stride(-1) != 1 or tuple(out.shape) != (batch, M, N) or not out.is_cuda:
+        raise RuntimeError("gemm_x3_splitk: out must be a (batch, M, N) float32 GPU tensor")
+    per, nz, rr, _ = gemm_x3_splitk_plan(M, N, K, batch) if plan is None else (tuple(plan) + (0,))
+    need = batch * nz * M * round_up(N, 32)
+    ws = _SPLITK_WS.get(b.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 22), device=b.device, dtype=torch.float32)
+        _SPLITK_WS[b.device] = ws
+    q = GemmArgs()
+    q.A, q.B, q.C = a.buf.data_ptr(), b.data_ptr(), out.data_ptr()
+    if bias is not None:
+        if bias.numel() != M or not bias.is_contiguous():
+            raise RuntimeError("gemm_x3_splitk: bias must be M contiguous floats")
+        q.bias = _f32(bias, "bias")
+    q.M, q.N, q.K, q.batch = M, N, K, batch
+    q.lda, q.ldb, q.ldc = K, b.stride(-2), out.stride(-2)
+    q.stride_a, q.stride_b, q.stride_c = 0, (b.stride(0) if b.dim() == 3 else 0), out.stride(0)
+    q.act, q.slope, q.tile_hint, q.pre = GEMM_ACT[act], slope, 0, 1
+    if res is not None:
+        if res.dtype != torch.float32 or res.shape != out.shape or res.stride() != out.stride():
+            raise RuntimeError("gemm_x3_splitk: res must be laid out like out")
+        q.res = res.data_ptr()
+    if k_scale is not None:
+        if k_scale.dtype != torch.float32 or tuple(k_scale.shape) != (batch, K) or not k_scale.is_contiguous():
+            raise RuntimeError("gemm_x3_splitk: k_scale must be (batch, K) contiguous floats")
+        q.scale_k = k_scale.data_ptr()
+    if _PROFILING:
+        set_tag("%dx%dx%d b%d z%d" % (M, N, K, batch, nz))
+    _check(load().occd_gemm_f32x3_splitk(ctypes.byref(q), per, nz, rr, ws.data_ptr(), ws.numel(), _stream()),
+           "occd_gemm_f32x3_splitk")
+    return out[0] if squeeze else out
 
 
 def gemm_x3_nt(a, b, tile_hint=0, splits=None, reduce=True, plain_bf16=False):
@@ -1130,6 +1193,8 @@ def lift_proj(feats, scale_divs, cam_E, cam_k, origin, voxel_size, img_wh, n_dim
     q.img_w, q.img_h = int(img_wh[0]), int(img_wh[1])
     if frustum is not None:
         frustum.fill(q.frustum)
+    if _PROFILING:
+        set_tag("%d scales x %d views x %d ch > %d voxels" % (q.lift.n_scales, q.lift.n_views, q.lift.C, q.lift.N))
     _check(load().occd_lift_proj_fwd(ctypes.byref(q), _stream()), "occd_lift_proj_fwd")
     return out
 
@@ -1186,6 +1251,8 @@ def nhwc_to_nchw(vox):
 def softmax_channels(src, dst, n, dst_pad=0):
     """softmax over src's n logical channels -> dst's n logical channels (+ dst_pad zeros) on the same grid."""
     rows = src.batch * src.dims[0] * src.dims[1] * src.dims[2]
+    if _PROFILING:
+        set_tag("%d @%d rows" % (n, rows))
     _check(load().occd_softmax_channels(_f32(src.buf, "src"), _f32(dst.buf, "dst"), rows, src.cs, src.coff, dst.cs,
                                         dst.coff, n, dst_pad, _stream()), "occd_softmax_channels")
     return dst
@@ -1204,6 +1271,8 @@ def affine_act(x, scale, shift, act=None, slope=0.01, res=None, res_first=False,
     out = x if out is None else out
     if res is not None and not res.is_contiguous():
         res = res.contiguous()
+    if _PROFILING:
+        set_tag("%d @%dx%d" % (C, B, S))
     _check(load().occd_affine_act_nchw(_f32(x, "x"), _f32(res, "res") if res is not None else None, _f32(out, "out"),
                                        _f32(scale, "scale") if scale is not None else None,
                                        _f32(shift, "shift") if shift is not None else None, B, C, S, ACT2D[act],
@@ -1228,6 +1297,8 @@ def wino_input_transform(x, ty0=0, ths=None):
     T = B * ths * ((W + 1) // 2)
     V = torch.empty((16, T, C), device=x.device, dtype=torch.float32)
     xc = x if x.is_contiguous() else x.contiguous()
+    if _PROFILING:
+        set_tag("%d @%dx%dx%d" % (C, B, H, W))
     _check(load().occd_wino_input_transform_nchw(_f32(xc, "x"), V.data_ptr(), B, C, H, W, ty0, ths, _stream()),
            "occd_wino_input_transform_nchw")
     return V
@@ -1241,6 +1312,8 @@ def wino_output_transform(M, shape, scale=None, shift=None, act=None, slope=0.01
     y = torch.empty(shape, device=M.device, dtype=torch.float32) if out is None else out
     if res is not None and not res.is_contiguous():
         res = res.contiguous()
+    if _PROFILING:
+        set_tag("%d @%dx%dx%d" % (C, B, H, W))
     _check(load().occd_wino_output_transform_nchw(_f32(M, "M"), _f32(scale, "scale") if scale is not None else None,
                                                   _f32(shift, "shift") if shift is not None else None,
                                                   _f32(res, "res") if res is not None else None, _f32(y, "y"), B, C, H, W,
@@ -1371,6 +1444,8 @@ def dwconv2d_same(x, w, scale, shift, stride, act=None):
     pad_w = max((Wo - 1) * stride + k - W, 0)
     y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32)
     wc = w if w.is_contiguous() else w.contiguous()
+    if _PROFILING:
+        set_tag("%d k%d s%d @%dx%dx%d" % (C, k, stride, B, H, W))
     _check(load().occd_dwconv2d_nchw(_f32(x, "x"), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
                                      _f32(shift, "shift") if shift is not None else None, _f32(y, "y"), B, C, H, W, k,
                                      stride, pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
@@ -1403,6 +1478,8 @@ def depthnet_gate(mlp, se, images, sps=None, intrins=None, factor=1000.0):
     ws = [f(mlp.fc1.weight).reshape(-1), f(mlp.fc1.bias), f(mlp.fc2.weight), f(mlp.fc2.bias),
           f(se.conv_reduce.weight).reshape(C, C), f(se.conv_reduce.bias), f(se.conv_expand.weight).reshape(C, C),
           f(se.conv_expand.bias)]
+    if _PROFILING:
+        set_tag("%d @%d" % (C, images))
     _check(load().occd_depthnet_gate(sp, ip, stride, float(factor), *[_f32(w, "w") for w in ws], gate.data_ptr(), images, C,
                                      _stream()), "occd_depthnet_gate")
     return gate
@@ -1422,6 +1499,8 @@ def stem_conv3x3(x, w, scale, shift, stride, act=None):
     y = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
     wc = w.detach().float()
     wc = wc if wc.is_contiguous() else wc.contiguous()
+    if _PROFILING:
+        set_tag("3>%d s%d @%dx%dx%d" % (cout, int(stride), B, H, W))
     _check(load().occd_stem_conv3x3_nchw(_f32(x, "x"), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
                                          _f32(shift, "shift") if shift is not None else None, y.data_ptr(), B, H, W, cout,
                                          int(stride), pad_h // 2, pad_w // 2, Ho, Wo, ACT2D[act], _stream()),
@@ -1615,6 +1694,8 @@ def softmax_nchw(x):
         x = x.contiguous()
     B, C = x.shape[0], x.shape[1]
     y = torch.empty_like(x)
+    if _PROFILING:
+        set_tag("%d @%dx%d" % (C, B, x.numel() // (B * C)))
     _check(load().occd_softmax_nchw(_f32(x, "x"), _f32(y, "y"), B, C, x.numel() // (B * C), _stream()), "occd_softmax_nchw")
     return y
 
@@ -1637,6 +1718,8 @@ def dwconv2d_same_pool(x, w, scale, shift, stride, act=None):
     wc = w if w.is_contiguous() else w.contiguous()
     if x.dtype != torch.float32 or not x.is_cuda:
         raise RuntimeError("dwconv2d_same_pool: x must be a float32 GPU tensor")
+    if _PROFILING:
+        set_tag("%d k%d s%d @%dx%dx%d" % (C, k, stride, B, H, W))
     _check(load().occd_dwconv2d_pool_nchw(x.data_ptr(), _f32(wc, "w"), _f32(scale, "scale") if scale is not None else None,
                                           _f32(shift, "shift") if shift is not None else None, _f32(y, "y"),
                                           _f32(part, "pool_part"), B, C, H, W, k, stride, pad_h // 2, pad_w // 2, Ho, Wo,
@@ -1652,6 +1735,8 @@ def se_gate(part, plane_size, batch, w_reduce, b_reduce, w_expand, b_expand):
     we = w_expand.detach().reshape(C, Cr).contiguous()
     r = torch.empty((batch, Cr), device=part.device, dtype=torch.float32)
     gate = torch.empty((batch, C), device=part.device, dtype=torch.float32)
+    if _PROFILING:
+        set_tag("%d>%d>%d @%dx%d" % (C, Cr, C, batch, int(plane_size)))
     _check(load().occd_se_gate(_f32(part, "pool_part"), _f32(wr, "w_reduce"), _f32(b_reduce.detach().contiguous(), "b_reduce"),
                                _f32(we, "w_expand"), _f32(b_expand.detach().contiguous(), "b_expand"), _f32(r, "r"),
                                _f32(gate, "gate"), batch, C, Cr, part.shape[1], int(plane_size), _stream()), "occd_se_gate")
@@ -1772,6 +1857,8 @@ def upconv_gather(z, cout, size, batch_inner=False, skip=None, wskip=None, shift
         raise RuntimeError("upconv_gather: z must have 9 * cout channels")
     H, W = int(size[0]), int(size[1])
     out = torch.empty((B, cout, H, W), device=z.device, dtype=torch.float32)
+    if _PROFILING:
+        set_tag("%d taps9 @%dx%dx%d>%dx%d" % (cout, B, h, w, H, W))
     if skip is not None:
         # fused tail of the level: + conv3x3 over the (<= 4) skip channels + shift, LeakyReLU (occd_upconv_gather_skip_nchw)
         sk = skip if skip.is_contiguous() else skip.contiguous()
@@ -2054,6 +2141,8 @@ def cascade_tail(part, occ_off, wn, nbr):
     out = Vox.empty(part.batch, part.dims, nbr, part.buf.device, cs=round_up(nbr, 4))
     X, Y, Z = part.dims
     wc = wn.detach().float().contiguous()
+    if _PROFILING:
+        set_tag("%d @%dx%dx%d" % (nbr, X, Y, Z))
     _check(load().occd_cascade_tail_fwd(_f32(part.buf, "part"), _f32(wc, "wn"), _f32(out.buf, "out"), part.batch, X, Y,
                                         Z, part.cs, occ_off, out.cs, nbr, _stream()), "occd_cascade_tail_fwd")
     return out

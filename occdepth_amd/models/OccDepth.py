@@ -75,6 +75,16 @@ class OccDepth(_Base):
         self.clone_graph_outputs = env("OCCDEPTH_CLONE_OUTPUTS", "1") == "1"
         self._graphs = {}
         self.batch_views_train = os.environ.get("OCCDEPTH_TRAIN_BATCH_VIEWS", "1") == "1"
+        # training fast path, OFF by default (the default `training_step` returns the loss and the Trainer runs backward and
+        # the optimizer, as in the reference).  `enable_fast_train()` -- or OCCDEPTH_FAST_TRAIN=1 in the environment of an
+        # unmodified scripts/train.py run -- switches the module to manual optimisation: `training_step` then replays the
+        # WHOLE step (forward, losses, backward, gradient exchange, AdamW) from one hipGraph (train_graph.GraphedTrainStep,
+        # the step bench.py --train times).  OCCDEPTH_FAST_TRAIN_BF16=1: the bf16-MFMA convolution mode of configs[3].
+        self._fast_train = None
+        self._opt = self._sched = None
+        self.fast_train = False
+        if env("OCCDEPTH_FAST_TRAIN", "0") == "1":
+            self.enable_fast_train(bf16=env("OCCDEPTH_FAST_TRAIN_BF16", "0") == "1")
         self.fused_lift = True    # training on the GPU: HIP lift + one-launch backward (lift_autograd.py) where it applies
         if infer_mode:
             self.context_prior = False
@@ -167,9 +177,19 @@ class OccDepth(_Base):
         self._drop_graphs()
         return self
 
+    def enable_fast_train(self, bf16=False, autocast=False):
+        """Manual optimisation + the whole training step as ONE replayed hipGraph (see `_fast_training_step`).  Call before
+        `trainer.fit` (Lightning reads `automatic_optimization` when the loop starts)."""
+        self.fast_train = True
+        self.fast_train_bf16, self.fast_train_autocast = bool(bf16), bool(autocast)
+        self.automatic_optimization = False
+        self._fast_train = None
+        return self
+
     def invalidate_graphs(self):
-        """Forget every captured hipGraph (they are re-captured on the next forward)."""
+        """Forget every captured hipGraph (they are re-captured on the next forward / training step)."""
         self._drop_graphs()
+        self._fast_train = None
 
     def train(self, mode=True):
         self._drop_graphs()
@@ -620,8 +640,123 @@ class OccDepth(_Base):
         return hit[1]
 
     def training_step(self, batch, batch_idx):
+        if self.fast_train and not self.__dict__.get("_in_fast_step", False):
+            return self._fast_training_step(batch, batch_idx)
         self.cur_batch += 1
         return self.step(batch, "train", self.train_metrics)
+
+    # ---- OCCDEPTH_FAST_TRAIN: the benched training step behind the Trainer's `training_step`
+    @staticmethod
+    def _batch_signature(batch):
+        sig = []
+        for k in sorted(batch):
+            v = batch[k]
+            if torch.is_tensor(v):
+                sig.append((k, tuple(v.shape), v.dtype))
+            elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+                sig.append((k, tuple((tuple(t.shape), t.dtype) for t in v)))
+            else:
+                sig.append((k, repr(v) if isinstance(v, (int, float, str, bool, type(None))) else type(v).__name__))
+        return tuple(sig)
+
+    def _fast_optimizer(self):
+        """The raw torch optimizer of this module: the one `configure_optimizers` built (Lightning calls it before the first
+        step), else what the Trainer reports through `self.optimizers()`."""
+        if self._opt is not None:
+            return self._opt
+        opts = self.optimizers()
+        opt = opts[0] if isinstance(opts, (list, tuple)) else opts
+        return getattr(opt, "optimizer", opt)
+
+    def _fast_training_step(self, batch, batch_idx):
+        """`training_step` under manual optimisation (`automatic_optimization = False`: Lightning 1.4.9 then calls neither
+        backward nor optimizer.step, models/OccDepth.py:535-541 + scripts/train.py:208 otherwise drive them eagerly).
+        First call: the batch becomes the STATIC batch of a `GraphedTrainStep` (device copies), the step is captured (its
+        warm-up steps run on a snapshot: capturing trains nothing) and replayed; later calls copy the new batch into the
+        static tensors and replay.  Several ranks: the module is wrapped in DDP by the Trainer, whose reducer only acts on a
+        backward that follows the forward -- here the backward is INSIDE the step, so the gradient average is taken by
+        `shard.GradBuckets` (captured with the step) and DDP's hooks stay idle.  What the replay cannot do is done here:
+        `self.log` of the step's loss terms (device scalars the graph writes), the host counters (GraphedTrainStep.__call__).
+        Falls back to the eager manual step with a warning when the capture fails, on the CPU, or for a batch whose
+        keys / shapes differ from the captured one (that batch alone runs eagerly)."""
+        import warnings
+        from .. import autograd3d, shard, train_graph
+        on_gpu = next(self.parameters()).is_cuda
+        opt = self._fast_optimizer()
+        st = self._fast_train
+        if st is None:
+            st = self._fast_train = {"graph": None, "sig": None, "buckets": None, "warned": False, "logged": None}
+            if on_gpu:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    st["buckets"] = shard.GradBuckets(self.parameters(), dist)
+                dev = next(self.parameters()).device
+                static = {k: ([t.to(dev).clone() if torch.is_tensor(t) else t for t in v] if isinstance(v, (list, tuple))
+                              else (v.to(dev).clone() if torch.is_tensor(v) else v)) for k, v in batch.items()}
+                if self.fast_train_bf16:
+                    autograd3d.set_bf16_mfma(True)
+                gs = train_graph.GraphedTrainStep(self, opt, static, bf16=self.fast_train_autocast, buckets=st["buckets"],
+                                                  warmup=2, batch_idx=batch_idx)
+                self.__dict__["_in_fast_step"] = True
+                try:
+                    ok = gs.capture()
+                finally:
+                    self.__dict__["_in_fast_step"] = False
+                st["graph"], st["sig"] = gs, self._batch_signature(static)
+                st["logged"] = dict(self.logged) if ok else None     # the device scalars the captured step writes
+                if not ok:
+                    warnings.warn(f"occdepth_amd: the training step could not be captured ({gs.error}); running it eagerly")
+            else:
+                warnings.warn("occdepth_amd: OCCDEPTH_FAST_TRAIN needs the model on the GPU; running the eager manual step")
+        gs = st["graph"]
+        self.__dict__["_in_fast_step"] = True
+        try:
+            if gs is not None and self._batch_signature(batch) == st["sig"]:
+                gs.load_batch(batch)
+                loss = gs()                                  # replay (or the eager step on the static batch after a failed capture)
+                if gs.graph is not None:
+                    self.logged = dict(st["logged"])
+            else:
+                if gs is not None and not st["warned"]:
+                    st["warned"] = True
+                    warnings.warn("occdepth_amd: a training batch differs in keys / shapes from the captured one; such "
+                                  "batches run the eager step")
+                loss = self._manual_eager_step(batch, batch_idx, opt, st["buckets"])
+        finally:
+            self.__dict__["_in_fast_step"] = False
+        for k, v in self.logged.items():                    # the replay does not run Python: log what the graph wrote
+            self.log(k, v, on_epoch=True, sync_dist=True)
+        return loss.detach()
+
+    def _manual_eager_step(self, batch, batch_idx, opt, buckets=None):
+        """One manual-optimisation step without a graph: zero_grad, training_step, backward, [gradient average], optimizer."""
+        if buckets is not None:
+            buckets.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(self.fast_train_autocast and next(self.parameters()).is_cuda)):
+            loss = self.training_step(batch, batch_idx)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        opt.step()
+        return loss
+
+    def on_train_epoch_start(self, *args, **kwargs):
+        """Manual optimisation: Lightning 1.4 leaves the LR schedule to the module.  MultiStepLR counts epochs: bring it to
+        the current epoch (idempotent -- a Trainer that did step it finds nothing to do)."""
+        if not self.fast_train or self._sched is None:
+            return
+        epoch = int(getattr(self, "current_epoch", 0) or 0)
+        while self._sched.last_epoch < epoch:
+            self._sched.step()
+
+    def on_train_batch_end(self, *args, **kwargs):
+        """Once per step (Lightning calls it after backward + optimizer step): a peer-memory SyncBatchNorm exchange that
+        gave up waiting for a rank raises here instead of training on -- its results are already NaN (shard.SmallAllReduce).
+        No host synchronisation: the device flag is copied asynchronously and examined one step later."""
+        from .. import shard
+        shard.poll_exchanges()
 
     def validation_step(self, batch, batch_idx):
         self.step(batch, "val", self.val_metrics)
@@ -681,4 +816,9 @@ class OccDepth(_Base):
                 opt = None
         if opt is None:
             opt = torch.optim.AdamW(params, lr=self.lr, weight_decay=self.weight_decay)
-        return [opt], [MultiStepLR(opt, milestones=milestones, gamma=gamma)]
+        self._opt = opt
+        if self.fast_train and params and params[0].is_cuda:
+            from .. import train_graph
+            train_graph.make_capturable(opt)            # device-side step counter and learning rate, before the first step
+        self._sched = MultiStepLR(opt, milestones=milestones, gamma=gamma)
+        return [opt], [self._sched]

@@ -111,10 +111,41 @@ PW_PROJECT_K16_MIN_PIXELS = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_PIXE
 PW_PROJECT_K16_MIN_COUT = int(os.environ.get("OCCDEPTH_PW_PROJECT_K16_MIN_COUT", "48"))
 
 
+# Round 6: the project convolutions of the FEW-pixel stages (1/16, 1/32: K = 960 ... 3840 on 2 x 1848 / 2 x 468 pixels) on K21
+# (hip.gemm_x3_splitk: K cut over the grid, pre-split weights, deterministic second launch) -- they ran at 37 ... 57 TF/s on
+# K16's in-workgroup split-K form / K11s (90 ... 230 output tiles for 256 CUs).  OCCDEPTH_PW_PROJECT_SPLITK=0 restores them.
+PW_PROJECT_SPLITK = os.environ.get("OCCDEPTH_PW_PROJECT_SPLITK", "1") == "1"
+PW_PROJECT_SPLITK_MIN_K = int(os.environ.get("OCCDEPTH_PW_PROJECT_SPLITK_MIN_K", "768"))
+PW_PROJECT_SPLITK_MAX_PIXELS = int(os.environ.get("OCCDEPTH_PW_PROJECT_SPLITK_MAX_PIXELS", "8000"))
+
+
+def splitk_operands(owner, conv, bn):
+    """(GemmPacked image of W * BatchNorm scale, shift) for K21, cached on `owner` until a source tensor changes."""
+    key = _stamp(conv, bn)
+    cache = owner.__dict__.setdefault("_splitk_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        scale, shift = bn_affine_cached(bn)
+        w = (conv.weight.detach().float().flatten(1) * scale.view(-1, 1)).contiguous()
+        if conv.bias is not None:
+            shift = conv.bias.detach().float() * scale + shift
+        hit = (key, hip.GemmPacked(w, "a"), shift.contiguous())
+        cache[id(conv)] = hit
+    return hit[1], hit[2]
+
+
 def project_conv(owner, conv, bn, y, gate, res):
-    """bn(conv1x1(y * gate)) (+ res): one launch, K16 (hip.matmul) where it applies, else K11 / K11s."""
+    """bn(conv1x1(y * gate)) (+ res): K21 on the few-pixel long-K stages (two launches), else one launch of K16 (hip.matmul)
+    where it applies, else K11 / K11s."""
     B, C, H, W = y.shape
     cout = conv.out_channels
+    if (PW_PROJECT_SPLITK and hip.GEMM_X3 and C % 8 == 0 and C >= PW_PROJECT_SPLITK_MIN_K and H * W >= 4
+            and B * H * W <= PW_PROJECT_SPLITK_MAX_PIXELS and y.is_contiguous() and gate.is_contiguous()
+            and tuple(gate.shape) == (B, C) and (res is None or res.is_contiguous())):
+        pa, shift = splitk_operands(owner, conv, bn)
+        out = hip.gemm_x3_splitk(pa, y.view(B, C, H * W), bias=shift, k_scale=gate,
+                                 res=res.view(B, cout, H * W) if res is not None else None)
+        return out.view(B, cout, H, W)
     if (PW_PROJECT_K16 and hip.GEMM_X3 and C % 8 == 0 and B * H * W >= PW_PROJECT_K16_MIN_PIXELS and y.is_contiguous()
             and cout >= PW_PROJECT_K16_MIN_COUT and gate.is_contiguous() and tuple(gate.shape) == (B, C) and (res is None or res.is_contiguous())):
         w, shift = gemm_operands(owner, conv, bn)

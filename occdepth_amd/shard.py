@@ -204,6 +204,7 @@ class GradBuckets:
                 b["flat"].div_(self.world)
         if self.check_used and self.active:
             self._check_used_sets()
+        poll_exchanges()                         # a peer-memory SyncBatchNorm exchange that gave up raises here (no host sync)
         for p in unused:
             p.grad = None
         self.reset()
@@ -254,62 +255,132 @@ class SmallAllReduce:
     file).  532 of these per config-2 training step replace RCCL launches of ~45 us each that sit on one dependency chain.
     Capturable into a hipGraph.  The IPC handles travel through `dist.all_gather_object` on `group` (any backend).
 
-    `timeout_ms` bounds the in-kernel wait (a lost peer surfaces as `RuntimeError` at the next `check()` instead of a hung
-    GPU); `check()` costs a device-to-host read and is meant for tests / the end of a step, not for every call."""
+    Failure behaviour (what a collective library gives, kept):
+      * set-up is AGREED: the ranks first exchange (hostname, ok) and then the outcome of create / open, so either every
+        rank of the group ends up with the exchange installed or every rank raises the same RuntimeError (and has freed
+        what it created / closed what it opened) -- never some ranks inside IPC and others on the process group;
+      * the in-kernel wait is bounded by `timeout_ms` (default: OCCDEPTH_IPC_TIMEOUT_MS, else 30 minutes -- the process
+        group's default collective timeout; <= 0 waits forever).  A wait that gives up POISONS its result: the reduced
+        vector / the layer's statistics become NaN, so the loss is NaN from that step on instead of a silently wrong
+        normalisation, and the sticky device flag makes `check()` / `poll()` raise.  `poll()` is free of host
+        synchronisation (an asynchronous copy of the flag, examined at the NEXT call) and is what the training path calls
+        once per step (GradBuckets.finish, the model's on_train_batch_end hook); `check()` synchronises (tests, bench)."""
 
     MAX_WORLD = 16
 
     CHANNELS = 4096          # channel capacity of the second mailbox (SyncBatchNorm's in-kernel exchange, csrc/bn.hip BnXchg)
 
-    def __init__(self, dist, group=None, max_bytes=64 * 1024, device=None, timeout_ms=20000):
+    _inject_failure = None   # tests: ("create" | "open", rank) makes that stage fail on that rank only
+
+    def __init__(self, dist, group=None, max_bytes=64 * 1024, device=None, timeout_ms=None):
         import ctypes
+        import os
+        import socket
         from . import hip
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.max_bytes = int(max_bytes)
+        if timeout_ms is None:
+            timeout_ms = int(os.environ.get("OCCDEPTH_IPC_TIMEOUT_MS", str(30 * 60 * 1000)))
+        self.timeout_ms = max(0, min(int(timeout_ms), 0x7fffffff))
+        self._owned, self._opened, self._own = [], [], None
+        self._pending = None
+
+        def agree(ok, what):
+            """Every rank learns every rank's outcome of a set-up stage; all raise together when any failed."""
+            flags = [None] * self.world
+            dist.all_gather_object(flags, (bool(ok), str(what)), group=group)
+            bad = [(r, w) for r, (o, w) in enumerate(flags) if not o]
+            if bad:
+                self._release()
+                raise RuntimeError("SmallAllReduce: set-up failed on rank(s) " + ", ".join(f"{r} ({w})" for r, w in bad))
+
+        # stage 0: one node, a supported world size, a GPU and a loadable library -- decided from what ALL ranks report
+        lib, err = None, ""
+        try:
+            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            if self.device.type != "cuda" or not torch.cuda.is_available():
+                raise RuntimeError("no GPU on this rank")
+            lib = hip.load()
+        except Exception as e:                      # (the product path fails loudly elsewhere; here the group must agree first)
+            err = repr(e)
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, (socket.gethostname(), lib is not None, err), group=group)
         if self.world > self.MAX_WORLD:
             raise RuntimeError(f"SmallAllReduce: world size {self.world} > {self.MAX_WORLD}")
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.max_bytes = int(max_bytes)
-        self.timeout_ms = int(timeout_ms)
-        lib = hip.load()
+        if len({h for h, _, _ in hosts}) != 1:
+            raise RuntimeError("SmallAllReduce: the group spans several hosts (" + ", ".join(sorted({h for h, _, _ in hosts}))
+                               + "): peer-mapped device memory needs one node")
+        if not all(ok for _, ok, _ in hosts):
+            raise RuntimeError("SmallAllReduce: not every rank can take part: "
+                               + "; ".join(f"rank {r}: {e}" for r, (_, ok, e) in enumerate(hosts) if not ok))
         self._lib = lib
         nbytes = lib.occd_ipc_mailbox_bytes(self.world, self.max_bytes)
         cbytes = lib.occd_bn_xchg_mailbox_bytes(self.world, self.CHANNELS)
-        if nbytes <= 0 or cbytes <= 0:
+        if nbytes <= 0 or cbytes <= 0:              # (same arguments on every rank: same outcome on every rank)
             raise RuntimeError("occd_ipc_mailbox_bytes failed")
-        self._owned, self._opened = [], []
 
-        def mapped(nb):
-            """One mailbox per rank of `nb` bytes, mapped everywhere -> ctypes array of `world` pointers ([rank] = own)."""
-            own = ctypes.c_void_p()
-            handle = (ctypes.c_ubyte * 64)()
-            hip._check(lib.occd_ipc_mailbox_create(nb, ctypes.byref(own), handle), "occd_ipc_mailbox_create")
-            self._owned.append(own.value)
-            handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(handle), group=group)
-            ptrs = (ctypes.c_void_p * self.world)()
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    ptrs[r] = own.value
-                    continue
-                buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
-                peer = ctypes.c_void_p()
-                hip._check(lib.occd_ipc_mailbox_open(buf, ctypes.byref(peer)), "occd_ipc_mailbox_open")
-                ptrs[r] = peer.value
-                self._opened.append(peer.value)
-            return ptrs
-
+        # stage 1: create both mailboxes locally, exchange the handles together with the outcome
+        owns, handles, err = [], [], ""
         with torch.cuda.device(self.device):
-            self._ptrs = mapped(nbytes)            # vectors (occd_ipc_allreduce)
-            self._cptrs = mapped(cbytes)           # per-channel records (occd_bn_*_small_xchg)
-            self._own = self._owned[0]
+            try:
+                if self._inject_failure == ("create", self.rank):
+                    raise RuntimeError("injected failure (test)")
+                for nb in (nbytes, cbytes):
+                    own = ctypes.c_void_p()
+                    handle = (ctypes.c_ubyte * 64)()
+                    hip._check(lib.occd_ipc_mailbox_create(nb, ctypes.byref(own), handle), "occd_ipc_mailbox_create")
+                    self._owned.append(own.value)
+                    owns.append(own.value)
+                    handles.append(bytes(handle))
+            except Exception as e:
+                err = repr(e)
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, (err == "", err, handles), group=group)
+            bad = [(r, e) for r, (ok, e, _) in enumerate(gathered) if not ok]
+            if bad:
+                self._release()
+                raise RuntimeError("SmallAllReduce: mailbox allocation failed on rank(s) " + ", ".join(f"{r} ({e})" for r, e in bad))
+            # stage 2: map every peer's two mailboxes; agree on the outcome before anybody pushes
+            ptr_sets, err = [], ""
+            try:
+                if self._inject_failure == ("open", self.rank):
+                    raise RuntimeError("injected failure (test)")
+                for k in range(2):
+                    ptrs = (ctypes.c_void_p * self.world)()
+                    for r in range(self.world):
+                        if r == self.rank:
+                            ptrs[r] = owns[k]
+                            continue
+                        buf = (ctypes.c_ubyte * 64).from_buffer_copy(gathered[r][2][k])
+                        peer = ctypes.c_void_p()
+                        hip._check(lib.occd_ipc_mailbox_open(buf, ctypes.byref(peer)), "occd_ipc_mailbox_open")
+                        ptrs[r] = peer.value
+                        self._opened.append(peer.value)
+                    ptr_sets.append(ptrs)
+            except Exception as e:
+                err = repr(e)
+            agree(err == "", err or "ok")
+            self._ptrs, self._cptrs = ptr_sets       # vectors (occd_ipc_allreduce); per-channel records (occd_bn_*_small_xchg)
+            self._own = owns[0]
             self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._host_status = torch.zeros(1, dtype=torch.int32).pin_memory()
         dist.barrier(group=group)                 # every mailbox is mapped everywhere before the first push
+
+    def _release(self):
+        """Close what was opened, free what was created (set-up failure and close())."""
+        lib = getattr(self, "_lib", None)
+        if lib is not None:
+            for p in self._opened:
+                lib.occd_ipc_mailbox_close(p)
+            for p in self._owned:
+                lib.occd_ipc_mailbox_free(p)
+        self._own, self._opened, self._owned = None, [], []
 
     def all_reduce_(self, t):
         """In-place SUM over the ranks of a contiguous float32 / float64 GPU tensor of <= max_bytes (asynchronous on the
-        current stream)."""
+        current stream).  A wait that gives up leaves NaN in `t` (and sets the status flag)."""
         from . import hip
         if not self.usable(t):
             raise RuntimeError("SmallAllReduce: tensor must be a contiguous float32 / float64 tensor of <= max_bytes on the group's device")
@@ -319,14 +390,34 @@ class SmallAllReduce:
         return t
 
     def usable(self, t):
-        return (t.is_cuda and t.device == self.device and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
-                and 0 < t.numel() * t.element_size() <= self.max_bytes)
+        return (getattr(self, "_own", None) is not None and t.is_cuda and t.device == self.device and t.is_contiguous()
+                and t.dtype in (torch.float32, torch.float64) and 0 < t.numel() * t.element_size() <= self.max_bytes)
+
+    _GAVE_UP = ("SmallAllReduce: a peer did not arrive within the time budget; the affected results were set to NaN "
+                "(OCCDEPTH_IPC_TIMEOUT_MS raises the budget, OCCDEPTH_SYNCBN_IPC=0 keeps the process group's all_reduce)")
 
     def check(self):
         """Raise if any exchange since the last check gave up waiting (synchronises the stream)."""
         if int(self.status.item()) != 0:
             self.status.zero_()
-            raise RuntimeError("SmallAllReduce: a peer did not arrive within the time budget")
+            raise RuntimeError(self._GAVE_UP)
+
+    def poll(self):
+        """The per-step form of check(): no host synchronisation.  Looks at the flag copy queued by the PREVIOUS poll (if
+        that copy has completed) and queues a new one, so a give-up surfaces one step late at the latest -- and the step it
+        happened in already carries NaN.  Not callable during stream capture (skipped there)."""
+        if getattr(self, "_own", None) is None or torch.cuda.is_current_stream_capturing():
+            return
+        if self._pending is not None and self._pending.query():
+            self._pending = None
+            if int(self._host_status[0]) != 0:
+                self.status.zero_()
+                self._host_status.zero_()
+                raise RuntimeError(self._GAVE_UP)
+        if self._pending is None:
+            self._host_status.copy_(self.status, non_blocking=True)
+            self._pending = torch.cuda.Event()
+            self._pending.record()
 
     def close(self):
         if getattr(self, "_own", None) is None:
@@ -336,11 +427,7 @@ class SmallAllReduce:
             self.dist.barrier(group=self.group)   # nobody is still pushing into a mailbox that is about to go away
         except Exception:
             pass
-        for p in self._opened:
-            self._lib.occd_ipc_mailbox_close(p)
-        for p in self._owned:
-            self._lib.occd_ipc_mailbox_free(p)
-        self._own, self._opened, self._owned = None, [], []
+        self._release()
 
     def channel_args(self, C, device):
         """(mailboxes, rank, world, cmax, timeout_ms, status) for occd_bn_*_small_xchg, or None when the layer does not fit."""
@@ -350,20 +437,54 @@ class SmallAllReduce:
 
 
 _SMALL = {}            # process group (None = default) -> SmallAllReduce
+_SMALL_TRIED = set()   # groups for which the lazy set-up ran (installed or not): it is attempted once
 
 
 def install_small_all_reduce(dist, group=None, **kw):
     """Route SyncBatchNorm's packed exchanges of `group` through `SmallAllReduce` (returns it).  Ranks must call this
-    collectively; `uninstall_small_all_reduce` restores the backend's all_reduce."""
+    collectively; either every rank returns with the exchange installed or every rank raises (see the class).
+    `uninstall_small_all_reduce` restores the backend's all_reduce."""
+    _SMALL_TRIED.add(group)
     sm = SmallAllReduce(dist, group, **kw)
     _SMALL[group] = sm
     return sm
 
 
 def uninstall_small_all_reduce(group=None):
+    _SMALL_TRIED.discard(group)
     sm = _SMALL.pop(group, None)
     if sm is not None:
         sm.close()
+
+
+def ensure_small_all_reduce(group=None, device=None):
+    """Lazy, collective, once per group: what `prepare_for_ddp` does eagerly, for models that reach synchronised statistics
+    through somebody else's conversion -- `torch.nn.SyncBatchNorm.convert_sync_batchnorm`, i.e. Lightning's
+    `Trainer(sync_batchnorm=True)` of the reference's scripts/train.py:175-206.  Called from the first synchronised
+    `bn_act` of a step, which every rank reaches at the same layer.  OCCDEPTH_SYNCBN_IPC=0, a CPU model, a group of one rank
+    (unless forced) or more than 16 ranks keep the process group's all_reduce; so does a set-up that fails (on every rank
+    alike, with a warning)."""
+    import os
+    if group in _SMALL or group in _SMALL_TRIED:
+        return _SMALL.get(group)
+    import torch.distributed as dist
+    if (os.environ.get("OCCDEPTH_SYNCBN_IPC", "1") != "1" or not torch.cuda.is_available() or not dist.is_initialized()
+            or dist.get_world_size(group) > SmallAllReduce.MAX_WORLD
+            or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES)):
+        return None
+    _SMALL_TRIED.add(group)         # attempted once per group, whatever the outcome
+    try:
+        return install_small_all_reduce(dist, group, device=device)
+    except Exception as e:          # agreed across the ranks: everybody lands here together
+        import warnings
+        warnings.warn(f"occdepth_amd: peer-memory all-reduce unavailable ({e!r}); SyncBatchNorm uses the process group")
+        return None
+
+
+def poll_exchanges():
+    """Once per training step: raise if a peer-memory exchange gave up (no host synchronisation, see SmallAllReduce.poll)."""
+    for sm in list(_SMALL.values()):
+        sm.poll()
 
 
 def channel_exchange(group, C, device):
@@ -382,6 +503,17 @@ def packed_all_reduce(t, group=None):
     import torch.distributed as dist
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def agree_flag(flag, group=None, device=None):
+    """True iff `flag` is true on EVERY rank of `group` (one tiny MIN all-reduce through the process group).  Used once per
+    synchronised BatchNorm layer to pick a protocol all ranks then follow, whatever their local tensor shapes."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
 
 
 def _group_active(group):
@@ -554,14 +686,8 @@ def prepare_for_ddp(model, dist=None, bucket_bytes=128 << 20, sync_bn=True, forc
             model.invalidate_graphs()     # module surgery: a captured eval graph would keep replaying the old layers
         # SyncBatchNorm's per-layer packets over peer-mapped memory instead of the backend's all_reduce (one node, <= 16
         # ranks, GPU tensors): 532 latency-bound exchanges per config-2 step.  OCCDEPTH_SYNCBN_IPC=0 keeps RCCL.
-        import os
-        if (os.environ.get("OCCDEPTH_SYNCBN_IPC", "1") == "1" and torch.cuda.is_available() and None not in _SMALL
-                and dist.get_world_size() <= SmallAllReduce.MAX_WORLD and next(model.parameters()).is_cuda):
-            try:
-                install_small_all_reduce(dist)
-            except Exception as e:        # (no IPC support on this box / driver: the process group's all_reduce keeps working)
-                import warnings
-                warnings.warn(f"occdepth_amd: peer-memory all-reduce unavailable ({e!r}); SyncBatchNorm uses the process group")
+        if next(model.parameters()).is_cuda:
+            ensure_small_all_reduce(None, next(model.parameters()).device)
     if not grad_buckets:                  # (measurement aid: SyncBatchNorm's exchanges alone; FORCE_COLLECTIVES stays as set)
         return model, None
     buckets = GradBuckets(model.parameters(), dist, bucket_bytes, algo=algo, force=force)

@@ -266,3 +266,50 @@ def test_conv3d_wgrad_bf16_vs_float64(hip, name, dtype):
     # deterministic: fixed reduction order
     dw2 = hip.conv3d_wgrad_bf16(vox_of(hip, x, dtype), vox_of(hip, gy, dtype), cin, cout, k, s, d, p)
     assert torch.equal(dw, dw2)
+
+
+def test_non_finite_inputs_split_poisons_exact_propagates(hip):
+    """VERDICT r5 item 8, pinned rather than "fixed" -- and why a fix of the staging alone cannot exist.  The reference (ATen
+    conv3d, models/modules.py:158-175) turns ONE +Inf activation into sign(w) * Inf at the outputs it reaches.  Under the
+    3-way split x = hi + mid + lo the activation stages as hi = Inf, mid = lo = Inf - Inf = NaN; zeroing mid / lo when hi is
+    not finite (two VALU per staged element) still leaves the products Inf * w_mid and Inf * w_lo: NaN wherever a weight is
+    exactly representable in bf16 (w_mid = 0), and +Inf - Inf = NaN wherever w_mid's sign differs from w_hi's -- so the
+    split cannot return Inf without testing every PRODUCT.  The contract, both halves tested here on the head kernel (K2s3)
+    and on the exact-fp32 kernel it replaces (K2s, OCCDEPTH_BF16X3=0):
+      * split mode: every output the non-finite input reaches is NON-FINITE (NaN or Inf: never a plausible finite number),
+        every other output is unaffected bit for bit -- the poison is loud and local;
+      * exact mode: the reference's own Inf / NaN pattern, element for element."""
+    from occdepth_amd.fused import _pad_bias
+    B, cin, cout, dims, d = 1, 32, 32, (16, 256, 32), 1
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
+    w[:, :, 1, 1, 1] = w[:, :, 1, 1, 1].bfloat16().float()          # centre tap exactly representable in bf16: w_mid = w_lo = 0
+    bias = torch.randn(cout, generator=g)
+    x_inf = x.clone()
+    x_inf[0, 5, 8, 100, 16] = float("inf")
+    x_inf[0, 9, 3, 30, 7] = float("-inf")
+    x_inf[0, 2, 12, 200, 20] = float("nan")
+    ref = F.conv3d(x_inf, w, bias, padding=d, dilation=d)
+    reached = ~torch.isfinite(ref)
+    assert 3 * 27 * cout >= int(reached.sum()) > 2 * 20 * cout
+    w3, w32, bpad = hip.pack_weights_bf16(w.to(DEV), split3=True), hip.pack_weights(w.to(DEV)), _pad_bias(bias.to(DEV), cout)
+    outs = {}
+    for name, xin in (("clean", x), ("poisoned", x_inf)):
+        vx = vox_of(hip, xin, torch.float32)
+        o3, o32 = hip.Vox.empty(B, dims, cout, DEV), hip.Vox.empty(B, dims, cout, DEV)
+        with hip.profile() as prof:
+            hip.conv3d_bf16(vx, w3, bpad, cout, (3, 3, 3), o3, dilation=(d,) * 3, padding=(d,) * 3, split3=True)
+        assert any(k.startswith("conv3d_c32x3") for k in prof.rows)
+        hip.conv3d(vx, w32, bpad, cout, (3, 3, 3), o32, dilation=(d,) * 3, padding=(d,) * 3)
+        outs[name] = (o3.ncdhw().cpu(), o32.ncdhw().cpu())
+    split, exact = outs["poisoned"]
+    # split: non-finite exactly where the reference is non-finite; untouched elsewhere
+    assert torch.equal(~torch.isfinite(split), reached)
+    assert torch.equal(split[~reached], outs["clean"][0][~reached])
+    # exact fp32: the reference's pattern, value for value (Inf stays Inf of the right sign, NaN stays NaN)
+    assert torch.equal(torch.isnan(exact), torch.isnan(ref))
+    assert torch.equal(torch.isposinf(exact), torch.isposinf(ref)) and torch.equal(torch.isneginf(exact), torch.isneginf(ref))
+    assert torch.equal(exact[~reached], outs["clean"][1][~reached])
+    n_inf_ref, n_inf_split = int(torch.isinf(ref).sum()), int(torch.isinf(split).sum())
+    print(f"non-finite outputs: reference {int(reached.sum())} ({n_inf_ref} Inf), split mode Inf kept at {n_inf_split} of them")

@@ -346,3 +346,73 @@ def test_gemm_x3_gate_and_skip_epilogue(hip, shape, hint):
     assert got.shape == ref.shape and err < 2e-6, (shape, err)
     with pytest.raises(RuntimeError):                      # the wave-specialised kernel has no gate / skip path
         hip.gemm_x3(w.to(DEV), y.to(DEV), k_scale=gate.to(DEV), tile_hint=6)
+
+
+# K21 (occd_gemm_f32x3_splitk, round 6): the skinny long-K project convolutions of the 1/16 and 1/32 stages with K cut over the
+# grid -- (batch, Cout = M, pixels = N, Cin = K, skip?, plan or None = the library's)
+SPLITK_CASES = [
+    (2, 384, 468, 2304, True, None),            # 1/32 stage, the 13-fold launch
+    (2, 640, 468, 3840, True, None),
+    (2, 224, 1848, 1344, True, None),           # 1/16 stages
+    (2, 160, 1848, 960, True, None),
+    (2, 640, 468, 2304, False, None),           # first block of the last stage (no skip)
+    (1, 200, 131, 1000, True, (7, 9, 2)),       # M, N, K tails (K = 62.5 steps of 16: the last chunk is short and partial), 2 row ranges
+    (3, 40, 37, 256, False, (16, 1, 1)),        # one chunk: plain panel walk + the reduce launch; N % 4 = 1
+    (2, 96, 70, 512, True, (2, 16, 3)),         # many 2-step chunks, N % 4 = 2, three row ranges for three row tiles
+    (1, 384, 468, 2304, True, (26, 6, 1)),      # the largest chunk two workgroups per CU allow (416 k)
+    (1, 64, 100, 2304, False, (53, 3, 1)),      # > 64 KB of LDS per workgroup (the big-LDS attribute path)
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_gemm_x3_splitk_gate_skip_vs_float64(hip, case):
+    batch, M, N, K, skip, plan = case
+    g = torch.Generator().manual_seed(M + N + K)
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    y = torch.randn(batch, K, N, generator=g) * 2.0
+    gate = torch.sigmoid(torch.randn(batch, K, generator=g))
+    shift = torch.randn(M, generator=g)
+    res = torch.randn(batch, M, N, generator=g) if skip else None
+    gated = (y * gate.unsqueeze(-1))                      # float32 rounding of the product, as the reference's x * gate
+    ref = torch.matmul(w.double(), gated.double()) + shift.double().view(-1, 1)
+    if skip:
+        ref = ref + res.double()
+    pa = hip.GemmPacked(w.to(DEV), "a")
+    yd, gd, sd, rd = y.to(DEV), gate.to(DEV), shift.to(DEV), (res.to(DEV) if skip else None)
+    hip._SPLITK_WS.clear()
+    with hip.profile() as prof:
+        got = hip.gemm_x3_splitk(pa, yd, bias=sd, k_scale=gd, res=rd, plan=plan)
+    assert any(k.startswith("gemm_f32x3_splitk") for k in prof.rows), list(prof.rows)
+    # the workspace's pad columns / stale contents must not matter: poison it and run again -- bit-identical
+    hip._SPLITK_WS[yd.device].fill_(float("nan"))
+    again = hip.gemm_x3_splitk(pa, yd, bias=sd, k_scale=gd, res=rd, plan=plan)
+    assert torch.equal(got, again)
+    err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    lib = torch.matmul(w.to(DEV), gated.to(DEV)) + sd.view(-1, 1) + (rd if skip else 0)
+    err_lib = float((lib.cpu().double() - ref).abs().max() / ref.abs().max())
+    used = plan or hip.gemm_x3_splitk_plan(M, N, K, batch)[:3]
+    print(f"gemm_x3_splitk {case[:5]} plan {used}: {err:.2e} (library fp32 {err_lib:.2e})")
+    assert got.shape == ref.shape and err < 2e-6, (case, err)
+    # without gate / skip / bias, with an activation: the plain product
+    plain = hip.gemm_x3_splitk(pa, yd, act="swish", plan=plan).cpu().double()
+    r2 = torch.matmul(w.double(), y.double())
+    r2 = r2 * torch.sigmoid(r2)
+    assert float((plain - r2).abs().max() / r2.abs().max()) < 3e-6
+
+
+def test_gemm_x3_splitk_plan_and_argument_checks(hip):
+    for M, N, K, batch in ((384, 468, 2304, 2), (640, 468, 3840, 2), (224, 1848, 1344, 2), (160, 1848, 960, 2), (40, 37, 256, 3)):
+        per, nz, rr, ws = hip.gemm_x3_splitk_plan(M, N, K, batch)
+        k16 = (K + 15) // 16
+        assert 1 <= per <= 26 or nz == 1, (per, nz)
+        assert (nz - 1) * per < k16 <= nz * per and rr >= 1 and ws == batch * nz * M * ((N + 31) // 32 * 32)
+    w = torch.randn(64, 256, device=DEV)
+    pa = hip.GemmPacked(w, "a")
+    b = torch.randn(2, 256, 40, device=DEV)
+    for bad in ((8, 3, 1), (4, 3, 1), (16, 1, 3), (900, 1, 1)):      # chunks past K / not covering K / more ranges than row tiles / LDS
+        with pytest.raises(RuntimeError):
+            hip.gemm_x3_splitk(pa, b, plan=bad)
+    with pytest.raises(RuntimeError):
+        hip.gemm_x3_splitk(w, b)                                   # float32 left operand: K16's business
+    with pytest.raises(RuntimeError):
+        hip.gemm_x3_splitk(pa, b, k_scale=torch.ones(2, 255, device=DEV))

@@ -26,11 +26,32 @@ class FakeTrainer:
         self.logged = {}
         model.log = lambda key, value, **kw: self.logged.__setitem__(key, float(value))
 
-    def fit(self, train_batches, val_batches):
+    def fit(self, train_batches, val_batches, sync_batchnorm=False, optimize=False):
+        """`sync_batchnorm`: what Trainer(sync_batchnorm=True) does before the loop (pytorch-lightning 1.4.9
+        DDPPlugin.configure_sync_batchnorm -> torch.nn.SyncBatchNorm.convert_sync_batchnorm; reference scripts/train.py:179).
+        `optimize`: run the optimisation part of the loop too -- automatic optimisation: zero_grad / backward / optimizer.step
+        around training_step; manual optimisation (`automatic_optimization = False`): training_step alone."""
+        if sync_batchnorm:
+            self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
         opt = self.model.configure_optimizers()
+        self.losses = []
         for i, b in enumerate(train_batches):
-            loss = self.model.training_step(b, i)
-            assert torch.is_tensor(loss) and loss.requires_grad
+            if hasattr(self.model, "on_train_epoch_start") and i == 0:
+                self.model.on_train_epoch_start()
+            if not optimize:
+                loss = self.model.training_step(b, i)
+                assert torch.is_tensor(loss) and loss.requires_grad
+            elif getattr(self.model, "automatic_optimization", True):
+                opt[0][0].zero_grad()
+                loss = self.model.training_step(b, i)
+                loss.backward()
+                opt[0][0].step()
+            else:
+                loss = self.model.training_step(b, i)
+                assert not loss.requires_grad
+            self.losses.append(float(loss.detach()))
+            if hasattr(self.model, "on_train_batch_end"):
+                self.model.on_train_batch_end(None, b, i, 0)
         for i, b in enumerate(val_batches):
             with torch.no_grad():
                 self.model.validation_step(b, i)
@@ -198,3 +219,139 @@ def test_eval_script_flow_reaches_the_fast_path_gpu(monkeypatch, capsys):
         # (logits ~1e6, frames outside its BatchNorm calibration) amplifies that round-off; config 2 pins the parity at 1e-3
         assert d_plain < 3e-2, (i, d_plain)
     assert float((kept[0] - kept[2]).abs().max()) > 0              # (the frames really differ)
+
+
+def test_fast_train_switch_is_manual_optimisation_and_falls_back_on_the_cpu(monkeypatch):
+    """OCCDEPTH_FAST_TRAIN=1 / enable_fast_train(): `automatic_optimization` is False (Lightning then leaves backward and the
+    optimizer to `training_step`), and without a GPU the step runs eagerly -- warned, but it still optimises and logs;
+    the LR schedule (MultiStepLR by epoch) is brought up to the current epoch by the module, idempotently."""
+    monkeypatch.delenv("OCCDEPTH_FAST_TRAIN", raising=False)
+    cfg_name = "nyu_small"
+    m, cfg, _ = build_product(cfg_name)
+    assert not m.fast_train and getattr(m, "automatic_optimization", True)
+    monkeypatch.setenv("OCCDEPTH_FAST_TRAIN", "1")
+    m, cfg, _ = build_product(cfg_name)
+    assert m.fast_train and m.automatic_optimization is False and not m.fast_train_bf16
+    m.eval()
+    b = _batch(cfg_name, m, cfg)
+    w0 = next(iter(m.net_3d_decoder.parameters())).detach().clone()
+    tr = FakeTrainer(m)
+    with emu.patched(), pytest.warns(UserWarning, match="needs the model on the GPU"):
+        opts, scheds = tr.fit([b, b], [], optimize=True)
+    assert m.cur_batch == 2 and len(tr.losses) == 2 and "train/loss" in tr.logged
+    assert not torch.equal(w0, next(iter(m.net_3d_decoder.parameters())).detach())      # the optimizer stepped
+    sched = scheds[0]
+    assert sched.last_epoch == 0
+    m.current_epoch = 3
+    m.on_train_epoch_start()
+    assert sched.last_epoch == 3
+    m.on_train_epoch_start()
+    assert sched.last_epoch == 3                                                          # nothing left to do
+    assert m.invalidate_graphs() is None and m._fast_train is None
+
+
+def _gpu_frames(cfg_name, n):
+    from test_train_step import _small_train_setup
+    m, batch = _small_train_setup(cfg_name, "cuda")
+    g = torch.Generator().manual_seed(11)
+    frames = [dict(batch, img=batch["img"] + 0.05 * i * torch.randn(batch["img"].shape, generator=g).to("cuda")) for i in range(n)]
+    return m, frames
+
+
+@pytest.mark.gpu
+def test_fast_train_env_reaches_the_graphed_step_through_training_step_gpu(monkeypatch):
+    """OCCDEPTH_FAST_TRAIN=1 in the environment of an unmodified scripts/train.py makes `training_step` the
+    benched step -- manual optimisation, the whole step replayed from one hipGraph -- and trains like the plain module
+    driven by the Trainer's automatic optimisation (zero_grad, training_step, backward, optimizer.step; reference
+    scripts/train.py:208 + models/OccDepth.py:535-541).  Bounds: tests/test_train_step.py::test_whole_step_hipgraph_matches_eager_gpu."""
+    import copy
+    from occdepth_amd import train_graph
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    monkeypatch.delenv("OCCDEPTH_FAST_TRAIN", raising=False)
+    m0, frames = _gpu_frames("kitti_small", 4)
+    assert not m0.fast_train and getattr(m0, "automatic_optimization", True)
+    plain = copy.deepcopy(m0).train()
+    monkeypatch.setenv("OCCDEPTH_FAST_TRAIN", "1")
+    fast, _, _ = build_product("kitti_small")
+    assert fast.fast_train and fast.automatic_optimization is False
+    fast.load_state_dict(m0.state_dict())
+    fast = fast.to("cuda").train()
+    runs = {}
+    for name, m in (("plain", plain), ("fast", fast)):
+        m.cur_batch = 0
+        tr = FakeTrainer(m)
+        state0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        if name == "fast":                                      # the capture happens inside the first training_step
+            before = {k: v.clone() for k, v in state0.items()}
+        tr.fit(frames[:3], [], optimize=True)
+        m.eval()
+        runs[name] = (tr.losses, next(iter(m.net_3d_decoder.parameters())).detach().float().cpu().clone(), dict(tr.logged),
+                      m.cur_batch, float(m.train_metrics.count))
+    st = fast._fast_train
+    assert st is not None and st["graph"] is not None and st["graph"].graph is not None, getattr(st["graph"], "error", None)
+    (lp, pp, logp, cbp, cntp), (lf, pf, logf, cbf, cntf) = runs["plain"], runs["fast"]
+    print("plain", lp, "fast", lf)
+    assert cbp == cbf == 3 and abs(cntp - cntf) < 1e-6          # host counters advance per replay, not per capture warm-up
+    assert abs(lp[0] - lf[0]) <= 1e-5 * abs(lp[0]), (lp, lf)    # capturing trained nothing: same first step
+    assert all(abs(a - b) <= 1.5e-2 * abs(a) for a, b in zip(lp, lf)), (lp, lf)
+    assert float((pp - pf).abs().max() / pp.abs().max()) < 5e-3
+    # the loss terms reach the Trainer's logger from the replayed step too
+    keys = [k for k in logp if k.startswith("train/loss")]
+    assert keys and set(keys) <= set(logf)
+    for k in keys:
+        assert abs(logp[k] - logf[k]) <= 3e-2 * abs(logp[k]) + 1e-4, (k, logp[k], logf[k])
+    # a batch with other keys than the captured one runs the eager step (with a warning), the graph stays valid
+    fast.train()
+    odd = {k: v for k, v in frames[3].items() if k != "frustums_masks" and k != "frustums_class_dists"}
+    fp = fast.fp_loss
+    fast.fp_loss = False
+    with pytest.warns(UserWarning, match="differs in keys"):
+        l_odd = fast.training_step(odd, 3)
+    fast.fp_loss = fp
+    assert torch.isfinite(l_odd) and fast.cur_batch == 4
+    l_again = fast.training_step(frames[3], 4)
+    assert torch.isfinite(l_again) and fast.cur_batch == 5 and "train/loss" in fast.logged
+
+
+@pytest.mark.gpu
+def test_fit_after_lightnings_sync_batchnorm_conversion_gpu():
+    """Trainer(sync_batchnorm=True) converts every BatchNorm to torch.nn.SyncBatchNorm before fit (scripts/train.py:179,195).
+    One process (a group of one rank has nothing to exchange): the converted model still trains on the fused K13 kernels and
+    gives the unconverted model's step; with the group's collectives forced, the same modules exchange their statistics
+    (against themselves) through the peer-memory kernels.  The two-rank run is tests/test_syncbn_lightning_gpu.py."""
+    import copy
+    import torch.distributed as dist
+    from occdepth_amd import bn as obn
+    from occdepth_amd import hip, shard
+    from test_ipc_allreduce_gpu import _free_port
+    m0, frames = _gpu_frames("kitti_small", 1)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+        created = True
+    try:
+        outs = {}
+        for name in ("plain", "converted", "converted_forced"):
+            m = copy.deepcopy(m0).train()
+            tr = FakeTrainer(m)
+            shard.FORCE_COLLECTIVES = name == "converted_forced"
+            with hip.profile() as prof:
+                tr.fit(frames, [], sync_batchnorm=name != "plain", optimize=True)
+                torch.cuda.synchronize()
+            m = tr.model
+            n_sync = sum(isinstance(x, torch.nn.SyncBatchNorm) for x in m.modules())
+            assert (n_sync > 100) == (name != "plain")
+            tags = {k.split(":")[0] for k in prof.rows if k.startswith(("bn_", "ipc_"))}
+            outs[name] = (tr.losses[0], m.state_dict()["net_3d_decoder.ssc_head.bn1.0.running_var"].clone(), tags)
+        assert "bn_stats" in outs["converted"][2] or "bn_fwd_small" in outs["converted"][2], outs["converted"][2]
+        assert not any(t.endswith("_xchg") or t == "ipc_allreduce" for t in outs["converted"][2])
+        assert "bn_fwd_small_xchg" in outs["converted_forced"][2] and "ipc_allreduce" in outs["converted_forced"][2]
+        for name in ("converted", "converted_forced"):
+            assert abs(outs[name][0] - outs["plain"][0]) <= 2e-5 * abs(outs["plain"][0]), (name, outs[name][0], outs["plain"][0])
+            assert torch.allclose(outs[name][1], outs["plain"][1], rtol=1e-5, atol=1e-7)
+    finally:
+        shard.FORCE_COLLECTIVES = False
+        shard.uninstall_small_all_reduce()
+        if created:
+            dist.destroy_process_group()
