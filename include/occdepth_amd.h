@@ -523,6 +523,11 @@ int occd_depthnet_gate(const float* sps, const float* intrins, int64_t intr_stri
 int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_reduce, const float* w_expand,
                  const float* b_expand, float* r_scratch, float* gate, int32_t batch, int32_t C, int32_t Cr,
                  int32_t nblk, int64_t S, void* stream);
+/* Round 6: occd_se_gate is ONE launch (reduce + expand with an in-kernel hand-off through self-validating agent-scope words:
+ * csrc/se2d.hip se_fused_kernel) where C <= 4096, Cr % 4 == 0, Cr <= 192, batch * Cr <= 4096 -- bit-identical to the two
+ * launches it replaces; r_scratch is then unused.  This switch (default on; OCCD_SE_FUSED=0 in the environment) selects the
+ * two-launch form again for A/B runs and tests; returns the previous setting.                                            */
+int32_t occd_se_gate_set_fused(int32_t on);
 
 /* K11: pointwise (1x1) convolution on NCHW maps as a GEMM on the fp32 matrix pipe with the
  * EfficientNet / decoder epilogue fused -- replaces conv1x1 + BatchNorm2d (eval) + Swish (+ squeeze-excite gate on the

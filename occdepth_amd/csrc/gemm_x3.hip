@@ -1454,16 +1454,21 @@ extern "C" int occd_gemm_f32x3_splitk_plan(int32_t M, int32_t N, int32_t K, int3
     if (M <= 0 || N < 4 || K <= 0 || (K & 7) || batch <= 0 || !k16_per_z || !nz || !row_ranges || !workspace_floats) return OCCD_EINVAL;
     const int K16tot = (K + 15) / 16, tiles = (M + 31) / 32;
     const long panels = (long)((N + 31) / 32) * batch;
-    // chunks: enough workgroups for ~2 per CU, at least 8 steps (128 k) and at most 26 (416 k: 78 KB of LDS, two workgroups
-    // per CU) per chunk; rows: all row tiles in one workgroup (the chunk is staged once) unless the grid is still short
-    int z = (int)((512 + panels - 1) / panels);
-    if (z > K16tot / 8) z = K16tot / 8;
-    if (z < (K16tot + 25) / 26) z = (K16tot + 25) / 26;
+    // Measured on the five project-convolution shapes of config 2 (tools/bench_splitk.py, profiles/r06_gemm_splitk.txt): the best
+    // plans all have ~240 workgroups -- ONE per CU -- with chunks as long as that allows (fewer chunks = less workspace traffic
+    // for the second launch: 2304 -> 384 on 2 x 468 pixels 21.6 us with 4 chunks x 2 row ranges, 23.3 with 8 x 1, 30.9 with 18 x
+    // 1); a chunk may use the whole LDS (<= 52 steps = 160 KB).  Row ranges: all row tiles in one workgroup (the chunk is
+    // staged once) unless the matrix has 12 ... 16 row tiles -- then two ranges of 6 ... 8 tiles (one per wave) and half the chunks.
+    // (never more workgroups than CUs: 9 chunks x 30 panels = 270 workgroups measured 60 us where 8 x 30 = 240 take 41 -- the
+    //  chunks are long enough to hold a CU's LDS alone, so 14 stragglers are a second round)
+    int z = (int)(256 / panels);
     if (z < 1) z = 1;
+    int rr = 1;
+    if (tiles >= 12 && tiles <= 16 && z >= 8) { z /= 2; rr = 2; }
+    if (z > K16tot / 4) z = K16tot / 4 > 0 ? K16tot / 4 : 1;     // (at least 4 steps per chunk)
+    if (z < (K16tot + 51) / 52) z = (K16tot + 51) / 52;
     int per = (K16tot + z - 1) / z;
     z = (K16tot + per - 1) / per;
-    int rr = 1;
-    while (panels * z * rr < 256 && rr * 8 < tiles) ++rr;
     *k16_per_z = per; *nz = z; *row_ranges = rr;
     *workspace_floats = (int64_t)batch * z * M * (((int64_t)N + 31) / 32 * 32);
     return OCCD_OK;

@@ -8,7 +8,9 @@
 // Reference: geffnet SqueezeExcite behind occdepth/models/unet2d.py:175-190.
 #include "common.h"
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -116,6 +118,126 @@ __global__ void __launch_bounds__(256) se_expand4_kernel(const float* __restrict
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if (q == 0 && c < C) gate[(size_t)b * C + c] = 1.f / (1.f + expf(-(bias + s)));
+}
+
+// ---- Round 6: reduce + expand as ONE launch (110 launches of 5-6 us per frame were the squeeze-excite
+// gates).  The two phases above are latency chains of two memory round trips each, separated by a kernel boundary; fused,
+// the grid is max(Cr, C / 64) workgroups per image: workgroup w computes reduce output w (phase 1, exactly se_reduce_kernel's
+// arithmetic and summation order) and PUBLISHES it as one self-validating 8-byte word {value : 32, sequence : 32} with an
+// agent-scope atomic store; the first C / 64 workgroups then poll the Cr words of their image with agent-scope atomic loads
+// (past the non-coherent L1 / per-XCD L2: MI355X_MICROARCH.md, "8-B agent atomics both sides" is a valid hand-off without
+// any fence), and run se_expand4_kernel's arithmetic -- whose weight loads were issued BEFORE the poll, so the hand-off hides
+// behind them.  Bit-identical to the two-launch form.  The sequence number lives in device memory (a slot of a per-device
+// ring, zeroed once): every workgroup reads it at entry, the LAST workgroup to finish (a second counter) advances it, so a
+// launch captured in a hipGraph replays correctly and stale words of earlier launches never match.  No workgroup waits for a
+// workgroup that waits: publishers never poll before publishing, and <= 2 * 160 workgroups are always co-resident.
+constexpr int kSeWords = 4096;                             // batch * Cr words per slot
+struct SeSlot {
+    unsigned int seq, done;
+    unsigned long long pad;
+    unsigned long long words[kSeWords];
+};
+
+__global__ void __launch_bounds__(256) se_fused_kernel(const float* __restrict__ part, const float* __restrict__ wr,
+                                                       const float* __restrict__ br, const float* __restrict__ we,
+                                                       const float* __restrict__ be, float* __restrict__ gate,
+                                                       SeSlot* __restrict__ slot, int C, int Cr, int nblk, float inv_s,
+                                                       int tpc, int nexp) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];            // mean[C] | rs[Cr]
+    float* const mean = sm;
+    float* const rs = sm + ((C + 3) & ~3);
+    __shared__ float wsum[4];
+    const int b = blockIdx.y, w = blockIdx.x, t = threadIdx.x;
+    const unsigned seq = __hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    unsigned long long* const words = slot->words + (size_t)b * Cr;
+    // expand operands of this workgroup's 64 channels (requested first: they are not needed before the hand-off)
+    const bool expands = w < nexp;
+    const int q = t & 3, c_e = w * 64 + (t >> 2);
+    const int cc = min(c_e, C - 1), nch = Cr >> 2;
+    const f32x4* w4 = (const f32x4*)(we + (size_t)cc * Cr);
+    f32x4 ev[kEPre];
+    float ebias = 0.f;
+    if (expands) {
+#pragma unroll
+        for (int u = 0; u < kEPre; ++u) ev[u] = w4[min(q + 4 * u, nch - 1)];
+        ebias = be[cc];
+    }
+    // ---- phase 1: reduce output i = w (se_reduce_kernel, same order of every sum)
+    if (w < Cr) {
+        const int i = w;
+        const float* wrow = wr + (size_t)i * C;
+        float wv[kWPre];
+#pragma unroll
+        for (int u = 0; u < kWPre; ++u) wv[u] = wrow[min(t + u * 256, C - 1)];
+        const float* pb = part + (size_t)b * C * nblk;
+        const int cl = t / tpc, jp = t - cl * tpc, cpp = 256 / tpc;
+        for (int c0 = 0; c0 < C; c0 += cpp) {
+            const int c = c0 + cl;
+            const float* pc = pb + (size_t)min(c, C - 1) * nblk;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int j = jp;
+            for (; j + 3 * tpc < nblk; j += 4 * tpc) {
+                s0 += pc[j]; s1 += pc[j + tpc]; s2 += pc[j + 2 * tpc]; s3 += pc[j + 3 * tpc];
+            }
+            for (; j < nblk; j += tpc) s0 += pc[j];
+            float sum = (s0 + s1) + (s2 + s3);
+            for (int off = tpc >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+            if (jp == 0 && c < C) mean[c] = sum * inv_s;
+        }
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < kWPre; u += 4) {
+            const int c = t + u * 256;
+            if (c < C) a0 += wv[u] * mean[c];
+            if (c + 256 < C) a1 += wv[u + 1] * mean[c + 256];
+            if (c + 512 < C) a2 += wv[u + 2] * mean[c + 512];
+            if (c + 768 < C) a3 += wv[u + 3] * mean[c + 768];
+        }
+        float sum = (a0 + a1) + (a2 + a3);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if ((t & 63) == 0) wsum[t >> 6] = sum;
+        __syncthreads();
+        if (t == 0) {
+            const float v = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]) + br[i];
+            const float r = v / (1.f + expf(-v));
+            __hip_atomic_store(words + i, (unsigned long long)__float_as_uint(r) | ((unsigned long long)seq << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- phase 2: the gates of this workgroup's 64 channels (se_expand4_kernel) once all Cr words of the image carry seq
+    if (expands) {
+        for (int i = t; i < Cr; i += 256) {
+            unsigned long long word;
+            while (true) {
+                word = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(word >> 32) == seq) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            rs[i] = __uint_as_float((unsigned)word);
+        }
+        __syncthreads();
+        const f32x4* r4 = (const f32x4*)rs;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < kEPre; ++u)
+            if (q + 4 * u < nch) acc += ev[u] * r4[q + 4 * u];
+        for (int k = q + 4 * kEPre; k < nch; k += 4) acc += w4[k] * r4[k];
+        float s = (acc.x + acc.y) + (acc.z + acc.w);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (q == 0 && c_e < C) gate[(size_t)b * C + c_e] = 1.f / (1.f + expf(-(ebias + s)));
+    }
+    // ---- the last workgroup of the launch to get here advances the sequence number (everybody has read it by then)
+    __syncthreads();
+    if (t == 0) {
+        const unsigned total = gridDim.x * gridDim.y;
+        if (__hip_atomic_fetch_add(&slot->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+            __hip_atomic_store(&slot->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---- DepthNet's camera-aware gate (occdepth/models/flosp_depth/flosp_depth.py:201-257: Mlp of the scaled pixel size ->
@@ -408,6 +530,40 @@ extern "C" int occd_depthnet_gate(const float* sps, const float* intrins, int64_
     return occd::check_launch();
 }
 
+// Per-device ring of hand-off slots for se_fused_kernel (zeroed once; launches of one stream are ordered, launches captured
+// on different streams get different slots).  Allocated at the first call on a device -- the eval graph's warm-up forwards run
+// before any capture, like K2s' work-list counters (csrc/conv3d_c32p.hip).
+namespace {
+constexpr int kSeSlots = 128;
+constexpr int kSeMaxDevices = 64;
+struct SeDev {
+    std::mutex mu;
+    SeSlot* slots = nullptr;
+};
+SeDev g_se_dev[kSeMaxDevices];
+std::atomic<unsigned> g_se_next{0};
+std::atomic<int> g_se_fused{occd::env_flag("OCCD_SE_FUSED", true) ? 1 : 0};
+SeSlot* se_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSeMaxDevices) return nullptr;
+    SeDev& d = g_se_dev[dev];
+    std::lock_guard<std::mutex> lock(d.mu);
+    if (d.slots == nullptr) {
+        SeSlot* p = nullptr;
+        if (hipMalloc(&p, sizeof(SeSlot) * kSeSlots) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, sizeof(SeSlot) * kSeSlots) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        d.slots = p;
+    }
+    return d.slots + (g_se_next.fetch_add(1) % kSeSlots);
+}
+}  // namespace
+
+extern "C" int32_t occd_se_gate_set_fused(int32_t on) { return g_se_fused.exchange(on != 0 ? 1 : 0); }
+
 extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_reduce, const float* w_expand,
                             const float* b_expand, float* r_scratch, float* gate, int32_t batch, int32_t C, int32_t Cr,
                             int32_t nblk, int64_t S, void* stream) {
@@ -417,6 +573,18 @@ extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const
     occd::ProfScope prof("se_gate", st, 4.0 * batch * C * Cr, 8.0 * C * Cr + 4.0 * batch * C * nblk);
     int tpc = 1;                                           // threads per channel in the pooling phase
     while (tpc < 64 && (long)tpc * 2 * C <= 256 && tpc * 2 <= nblk) tpc *= 2;
+    // one launch (se_fused_kernel) where its preloads cover the rows: C <= 4096, Cr % 4 == 0 and <= 192, batch * Cr words fit a
+    // slot; OCCD_SE_FUSED=0 / occd_se_gate_set_fused(0) keep the two launches (A/B, and the reference of the bit-identity test)
+    if (g_se_fused.load() != 0 && C <= 256 * kWPre && (Cr & 3) == 0 && Cr <= 16 * kEPre && (long)batch * Cr <= kSeWords &&
+        (reinterpret_cast<uintptr_t>(w_expand) & 15) == 0) {
+        SeSlot* slot = se_slot();
+        if (slot == nullptr) return OCCD_ELAUNCH;
+        const int nexp = (C + 63) / 64;
+        const size_t lds = ((size_t)((C + 3) & ~3) + Cr) * sizeof(float);
+        hipLaunchKernelGGL(se_fused_kernel, dim3((unsigned)(nexp > Cr ? nexp : Cr), (unsigned)batch), dim3(256), lds, st, pool_part,
+                           w_reduce, b_reduce, w_expand, b_expand, gate, slot, C, Cr, nblk, (float)(1.0 / (double)S), tpc, nexp);
+        return occd::check_launch();
+    }
     hipLaunchKernelGGL(se_reduce_kernel, dim3((unsigned)Cr, (unsigned)batch), dim3(256), (size_t)C * sizeof(float), st,
                        pool_part, w_reduce, b_reduce, r_scratch, C, Cr, nblk, (float)(1.0 / (double)S), tpc);
     static const bool old_expand = occd::env_flag("OCCD_SE_EXPAND_OLD", false);                      // A/B switch

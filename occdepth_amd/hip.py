@@ -265,6 +265,7 @@ EXPORTS = {
     "occd_gemm_f32x3_splitk_plan": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
                                               POINTER(c_int32), POINTER(c_int64)]),
     "occd_gemm_f32x3_splitk": (c_int32, [POINTER(GemmArgs), c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
+    "occd_se_gate_set_fused": (c_int32, [c_int32]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
 }

@@ -139,7 +139,7 @@ def project_conv(owner, conv, bn, y, gate, res):
     where it applies, else K11 / K11s."""
     B, C, H, W = y.shape
     cout = conv.out_channels
-    if (PW_PROJECT_SPLITK and hip.GEMM_X3 and C % 8 == 0 and C >= PW_PROJECT_SPLITK_MIN_K and H * W >= 4
+    if (PW_PROJECT_SPLITK and hip.GEMM_X3 and y.is_cuda and C % 8 == 0 and C >= PW_PROJECT_SPLITK_MIN_K and H * W >= 4
             and B * H * W <= PW_PROJECT_SPLITK_MAX_PIXELS and y.is_contiguous() and gate.is_contiguous()
             and tuple(gate.shape) == (B, C) and (res is None or res.is_contiguous())):
         pa, shift = splitk_operands(owner, conv, bn)

@@ -123,3 +123,60 @@ def test_depthnet_fused_equals_library_form(hip):
     a, b = res[True][0], res[False][0]
     assert a.shape == b.shape == (2, 104, 47, 153)
     assert float((a - b).abs().max()) <= 3e-4 * float(b.abs().max())
+
+
+# (C, Cr, batch, pool partials per plane, plane size): the B7 stages (2304 / 96 at 1/32 ... 32 / 8 at 1/2) and ragged ones
+SE_CASES = [(2304, 96, 2, 1, 468), (3840, 160, 2, 1, 468), (1344, 56, 2, 2, 1848), (960, 40, 2, 2, 1848), (480, 20, 2, 8, 7191),
+            (288, 12, 2, 28, 28365), (192, 8, 2, 111, 112850), (32, 8, 2, 111, 112850), (70, 4, 3, 5, 100), (4096, 192, 1, 3, 77)]
+
+
+@pytest.mark.parametrize("case", SE_CASES)
+def test_se_gate_one_launch_equals_two_launches_and_float64(hip, case):
+    """Round 6: the squeeze-excite gate as ONE launch (se_fused_kernel: reduce outputs published as self-validating words,
+    polled by the expand workgroups) -- bit-identical to the reduce + expand launches it replaces, right against float64
+    (geffnet SqueezeExcite: mean -> conv_reduce -> swish -> conv_expand -> sigmoid), and replayable from a hipGraph (the
+    sequence number lives on the device).  Repeated 40 times back to back: every launch must see ITS OWN reduce results."""
+    C, Cr, batch, nblk, S = case
+    g = torch.Generator().manual_seed(C + Cr)
+    wr, br = torch.randn(Cr, C, generator=g) / C ** 0.5, torch.randn(Cr, generator=g)
+    we, be = torch.randn(C, Cr, generator=g) / Cr ** 0.5, torch.randn(C, generator=g)
+    wr, br, we, be = (t.to(DEV) for t in (wr, br, we, be))
+    lib = hip.load()
+
+    def gates(fused, parts):
+        old = lib.occd_se_gate_set_fused(1 if fused else 0)
+        try:
+            with hip.profile() as prof:
+                out = [hip.se_gate(p, S, batch, wr, br, we, be) for p in parts]
+                torch.cuda.synchronize()
+        finally:
+            lib.occd_se_gate_set_fused(old)
+        return out, sum(v["launches"] for k, v in prof.rows.items() if k.startswith("se_gate"))
+
+    parts = [(torch.randn(batch * C, nblk, generator=g) * (S / nblk) ** 0.5 + 0.1 * i).to(DEV) for i in range(40)]
+    fused, n1 = gates(True, parts)
+    plain, n2 = gates(False, parts)
+    assert n1 == n2 == 40                                              # (one profiler scope per call in both forms)
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert torch.equal(a, b), (case, i, float((a - b).abs().max()))
+    mean = parts[7].double().cpu().view(batch, C, nblk).sum(-1) / S
+    r = mean @ wr.double().cpu().t() + br.double().cpu()
+    r = r * torch.sigmoid(r)
+    ref = torch.sigmoid(r @ we.double().cpu().t() + be.double().cpu())
+    assert float((fused[7].cpu().double() - ref).abs().max()) < 2e-6
+    # captured: replays with new partials in the same static buffer
+    static = parts[0].clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        hip.se_gate(static, S, batch, wr, br, we, be)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = hip.se_gate(static, S, batch, wr, br, we, be)
+    for i in (3, 11, 12):
+        static.copy_(parts[i])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain[i]), (case, "replay", i)
