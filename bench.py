@@ -462,6 +462,16 @@ def _forward(args, world, rank, device, dist):
         for _ in range(prof_steps):
             step()
         torch.cuda.synchronize()
+    # (3) the same eager frames with the 2-D network launched kernel by kernel too (graph_2d off): its families for roofline_2d
+    saved_2d = model.graph_2d
+    model.graph_2d = False
+    step()
+    torch.cuda.synchronize()
+    with hip.profile() as prof2d:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    model.graph_2d = saved_2d
     stages = {}
 
     def timed(name, fn):
@@ -535,7 +545,7 @@ def _forward(args, world, rank, device, dist):
                  "kernel": "lift_proj_kernel (projection + frustum sample + gather in one launch)" if lift_fused
                            else "lift_p1_kernel (tables from the batch) + flosp_sample_kernel"},
     }
-    res["roofline_2d"] = roofline_2d(prof.rows, prof_steps)
+    res["roofline_2d"] = roofline_2d(prof2d.rows, 3)
     split_head = any(k.startswith(("conv3d_c32x3", "conv3d_bf16x3")) for k, _ in head)
     if split_head:
         # the head convolutions run on the bf16 matrix pipe (3-way split, six bf16 MFMAs per algorithmic MAC): the roofline is

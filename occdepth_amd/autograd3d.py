@@ -70,6 +70,13 @@ def _padded_rows(x):
         return None
     if x.untyped_storage().nbytes() != B * X * Y * Z * cs * 4:
         return None
+    # the strides / offset / storage-size test alone also admits `wide[:, :C]` at offset 0 of a channels-last tensor
+    # with cs logical channels (the first chunk torch.cat's backward narrows out of a 24-channel gradient): its "pad" lanes hold
+    # the neighbour's DATA.  A view is taken in place only when its base IS the padded row buffer -- (B, X, Y, Z, cs) dense,
+    # what hip.ssc_loss_grad allocates and fills, pads included -- not a wider (B, cs, X, Y, Z) tensor.
+    base = x._base
+    if base is not None and not (base.dim() == 5 and tuple(base.shape) == (B, X, Y, Z, cs) and base.is_contiguous()):
+        return None
     return torch.as_strided(x, (B, X, Y, Z, cs), (X * Y * Z * cs, Y * Z * cs, Z * cs, cs, 1))
 
 

@@ -26,12 +26,29 @@ def _hipcc():
     return exe
 
 
+def source_digest():
+    """sha256 over the names and CONTENTS of every source and header the library is built from (+ the compiler flags)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(f"arch={ARCH};flags=-O3 -std=c++17 -fPIC".encode())
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".srchash"
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """The shipped libocc_hip.so is trusted only when the digest recorded beside it equals the digest of the sources in the
+    tree (the old mtime test compiled nothing whenever the .so travelled next to fresher-looking sources, so a
+    driver-side build() proved little).  The stamp travels with the .so (both git-ignored, neither gpurun-ignored)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
 
 
 def build(force=False, verbose=True):
@@ -56,6 +73,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_digest() + "\n")
     return LIB
 
 

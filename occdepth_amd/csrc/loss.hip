@@ -399,6 +399,7 @@ struct DepthP {
     int Bn, D, h, w, srcH, srcW, cell;
     long p_b;
     float d_off, d_step;       // bin index = (depth - d_off) / d_step, d_off = float32(d_bound[0] - d_bound[2]) rounded by the host
+    float inv_step;            // float32(1 / d_step): the divisor as ATen's scalar true-divide applies it
     float sc_h, sc_w;          // ATen's nearest-neighbour source index: min(floor(dst * scale), src - 1), scale = src / dst
 };
 
@@ -413,7 +414,10 @@ __device__ __forceinline__ int depth_cell_bin(const DepthP& q, int bn, int y, in
             if (d != 0.f) best = fminf(best, d);
         }
     }
-    const float idx = (best - q.d_off) / q.d_step;
+    // ATen's true-divide by a Python scalar multiplies by the float reciprocal (a / b -> a * (1 / b) in the CUDA / HIP binary-op
+    // kernel): with a step that is not a power of two, (best - off) / step and (best - off) * (1 / step) can land on either side
+    // of a bin edge.  The reference's `(gt - (d_bound[0] - d_bound[2])) / d_bound[2]` runs on the GPU: follow it.
+    const float idx = (best - q.d_off) * q.inv_step;
     // (idx < D + 1) & (idx >= 0) else 0; .long() truncates; one-hot column 0 is dropped -> target bin = k - 1, k >= 1
     const int k = (idx < (float)(q.D + 1) && idx >= 0.f) ? (int)idx : 0;
     return k - 1;                                                // -1: no target
@@ -476,6 +480,7 @@ int depth_setup(DepthP* q, const float* prob, const float* gt, int64_t Bn, int32
     if (!(d_step > 0.f) || p_b < (int64_t)D * h * w || Bn * (int64_t)h * w > 0x7fffffffL) return OCCD_EINVAL;
     q->prob = prob; q->gt = gt; q->Bn = (int)Bn; q->D = D; q->h = h; q->w = w; q->srcH = srcH; q->srcW = srcW;
     q->cell = cell; q->p_b = p_b; q->d_off = d_off; q->d_step = d_step;
+    q->inv_step = 1.0f / d_step;
     // at::native::compute_scales_value<float>: (float) input_size / output_size
     q->sc_h = (float)srcH / (float)(h * cell);
     q->sc_w = (float)srcW / (float)(w * cell);

@@ -64,7 +64,7 @@ class GradBuckets:
       only has all-reduce.
     """
 
-    def __init__(self, params, dist, bucket_bytes=128 << 20, algo=None, force=False, check_used=None):
+    def __init__(self, params, dist, bucket_bytes=128 << 20, algo=None, force=False, check_used=None, comm_dtype=None):
         import os
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
@@ -77,6 +77,19 @@ class GradBuckets:
         # over the ~600 MB of gradients follows it; gloo has no AVG: SUM, then one division per bucket
         self.avg_in_collective = self.active and dist.get_backend() == "nccl"
         self.check_used = (os.environ.get("OCCDEPTH_DDP_CHECK", "0") == "1") if check_used is None else bool(check_used)
+        # wire format of the exchange: None = the gradients' own dtype (float32); torch.bfloat16 (OCCDEPTH_GRAD_COMM=bf16) halves
+        # the bytes on xGMI -- a bucket is cast into a bf16 staging buffer when it launches, reduced there, and cast back in
+        # finish() (two extra passes over the bucket on HBM, ~0.3 ms per 600 MB, against 300 MB less per link); the gradients
+        # autograd and the optimizer see stay float32
+        if comm_dtype is None and os.environ.get("OCCDEPTH_GRAD_COMM", "") in ("bf16", "bfloat16"):
+            comm_dtype = torch.bfloat16
+        self.comm_dtype = comm_dtype
+        # Which parameters receive a gradient is learned from the first synchronised backward (`_expected`): a parameter of a
+        # never-executed branch (the reference needs find_unused_parameters=True) would otherwise keep its bucket -- and, because
+        # buckets launch in order, EVERY bucket -- pending until finish(), i.e. no collective would overlap the backward at all
+        # (round 5 measured exactly that: +13.5 % for the forced single-rank exchange).  From the second step on a bucket counts
+        # down over the parameters that did receive one; see `_on_grad` for what happens when the set changes.
+        self._expected = None
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []                       # each: dict(flat, items=[(param, offset, numel)], pending, handles)
         cur, cur_bytes = [], 0
@@ -106,7 +119,8 @@ class GradBuckets:
         for p in plist:
             items.append((p, off, p.numel()))
             off += p.numel()
-        self.buckets.append({"flat": flat, "items": items, "pending": len(items), "handles": [], "seen": set(), "touched": set()})
+        self.buckets.append({"flat": flat, "items": items, "pending": len(items), "handles": [], "seen": set(), "touched": set(),
+                             "comm": None, "launched": False})
 
     def attach(self):
         """Point every p.grad at its slice of the flat buffers (keeps the contents of existing gradients)."""
@@ -133,9 +147,15 @@ class GradBuckets:
 
     def reset(self):
         for b in self.buckets:
-            b["pending"], b["handles"] = len(b["items"]), []
+            n = len(b["items"]) if self._expected is None else sum(1 for p, _, _ in b["items"] if p in self._expected)
+            b["pending"], b["handles"], b["launched"] = n, [], False
             b["seen"], b["touched"] = set(), set()
         self._next = 0
+
+    def relearn(self):
+        """Forget which parameters receive gradients (call after changing what the forward executes)."""
+        self._expected = None
+        self.reset()
 
     def no_sync(self):
         """Context manager for the non-final micro-steps of gradient accumulation (no countdown, no collective)."""
@@ -150,10 +170,23 @@ class GradBuckets:
                 self._sync = old
         return ctx()
 
+    def _launch_ready(self):
+        # collectives must be issued in the same order on every rank: bucket i only after buckets 0 .. i-1
+        # (a parameter the learned set does not expect holds zeros in its view: zero_grad() / the previous exchange of zeros)
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
     def _launch(self, b):
+        b["launched"] = True
         if not self.active:
             return
         d, flat = self.dist, b["flat"]
+        if self.comm_dtype is not None and flat.dtype != self.comm_dtype:
+            if b["comm"] is None:
+                b["comm"] = torch.empty_like(flat, dtype=self.comm_dtype)
+            b["comm"].copy_(flat)
+            flat = b["comm"]
         op = d.ReduceOp.AVG if self.avg_in_collective else d.ReduceOp.SUM
         if self.algo == "rs_ag":
             n = flat.numel() // self.world
@@ -179,11 +212,16 @@ class GradBuckets:
             raise RuntimeError("GradBuckets: a second gradient arrived for a parameter inside one synchronised "
                                "backward; wrap the non-final micro-steps of gradient accumulation in no_sync()")
         b["seen"].add(p)
+        if self._expected is not None and p not in self._expected:
+            # the executed graph grew: a parameter that never had a gradient now has one.  If its bucket's collective is
+            # already on its way the gradient would be lost on the wire -- refuse; otherwise it simply rides along.
+            if b["launched"]:
+                raise RuntimeError("GradBuckets: a parameter outside the learned set received a gradient after its bucket was "
+                                   "exchanged (the forward now executes other branches); call buckets.relearn() when the "
+                                   "executed graph changes")
+            return
         b["pending"] -= 1
-        # collectives must be issued in the same order on every rank: bucket i only after buckets 0 .. i-1
-        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
-            self._launch(self.buckets[self._next])
-            self._next += 1
+        self._launch_ready()
 
     def finish(self):
         """Call after the (last) backward(): completes all buckets; every p.grad then holds the rank average.
@@ -191,17 +229,28 @@ class GradBuckets:
         (what DDP with `find_unused_parameters=True` leaves for the reference's never-executed branches, so AdamW
         skips them exactly as it does there -- every rank runs the same graph, so local == global here)."""
         unused = []
+        for b in self.buckets[:self._next]:      # launched from the hooks: their untouched views hold the zeros of zero_grad()
+            for p, off, n in b["items"]:
+                if p not in b["touched"]:
+                    unused.append(p)
         for b in self.buckets[self._next:]:      # bucket order == launch order on every rank
             for p, off, n in b["items"]:
                 if p not in b["touched"]:
                     b["flat"][off:off + n].zero_()
                     unused.append(p)
             self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             for h in b["handles"]:
                 h.wait()
+            if self.active and b["comm"] is not None and b["launched"]:
+                b["flat"].copy_(b["comm"])       # back to the gradients' dtype (the views the optimizer reads)
             if self.active and self.world > 1 and not self.avg_in_collective:
                 b["flat"].div_(self.world)
+        if self._expected is None and self._sync:
+            self._expected = set()
+            for b in self.buckets:
+                self._expected |= b["touched"]
         if self.check_used and self.active:
             self._check_used_sets()
         poll_exchanges()                         # a peer-memory SyncBatchNorm exchange that gave up raises here (no host sync)
