@@ -41,7 +41,7 @@ extern "C" {
 #define OCCD_ACT_SIGMOID 2
 #define OCCD_ACT_RELU_PRE 3 /* act_out only: relu(conv + bias) + res1 + res2 */
 
-/* ABI version; bumped whenever a struct below changes. */
+/* ABI version; bumped whenever a struct below changes (13: occd_gemm_args.bias_n / stride_bias_n, occd_gemm_f32x3_splitk). */
 int occd_abi_version(void);
 const char* occd_strerror(int code);
 
@@ -275,6 +275,11 @@ typedef struct occd_gemm_args {
     int32_t act_a;                         /* (ABI 11) 1: A[b][m][k] -> sigmoid(A[b][m][k]) while it is staged -- the relation
                                               products torch.bmm(sigmoid(P_logits), mega) of occdepth/models/CRP3D.py:80 as ONE
                                               batched launch over the relations; float32 A only (pre 0 / 2)                 */
+    const float* bias_n;                   /* (ABI 13) optional: + bias_n[b][n] (one value per COLUMN) ahead of the activation --
+                                              products whose ROWS are voxels and whose columns are output channels, e.g. the
+                                              relation-logit 1x1x1 convolutions of occdepth/models/CRP3D.py:54-62 as one batched
+                                              launch over the relations; occd_gemm_f32x3 only, not with tile_hint 6 / 8          */
+    int64_t stride_bias_n;                 /* floats between the batch items of bias_n (0: shared)                              */
 } occd_gemm_args;
 int occd_gemm_f32x3(const occd_gemm_args* a, void* stream);
 /* K21 (round 6), the skinny long-K GEMMs -- the MBConv project convolutions of the 1/16 and 1/32 EfficientNet stages,
@@ -523,10 +528,11 @@ int occd_depthnet_gate(const float* sps, const float* intrins, int64_t intr_stri
 int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_reduce, const float* w_expand,
                  const float* b_expand, float* r_scratch, float* gate, int32_t batch, int32_t C, int32_t Cr,
                  int32_t nblk, int64_t S, void* stream);
-/* Round 6: occd_se_gate is ONE launch (reduce + expand with an in-kernel hand-off through self-validating agent-scope words:
- * csrc/se2d.hip se_fused_kernel) where C <= 4096, Cr % 4 == 0, Cr <= 192, batch * Cr <= 4096 -- bit-identical to the two
- * launches it replaces; r_scratch is then unused.  This switch (default on; OCCD_SE_FUSED=0 in the environment) selects the
- * two-launch form again for A/B runs and tests; returns the previous setting.                                            */
+/* Round 6: an opt-in ONE-launch form of occd_se_gate (reduce + expand with an in-kernel hand-off through self-validating
+ * agent-scope words: csrc/se2d.hip se_fused_kernel) for C <= 4096, Cr % 4 == 0, Cr <= 192, batch * Cr <= 4096 -- bit-identical
+ * to the two launches (r_scratch receives the squeezed activations in both forms: occd_se_bwd reads them).  Measured equal in
+ * the frame and slower per launch (14.5 against 11.8 us), so the default stays two launches; this switch (or OCCD_SE_FUSED=1
+ * in the environment) selects the one-launch kernel; returns the previous setting.                                       */
 int32_t occd_se_gate_set_fused(int32_t on);
 
 /* K11: pointwise (1x1) convolution on NCHW maps as a GEMM on the fp32 matrix pipe with the

@@ -41,6 +41,8 @@ struct GemmP {
     const float* bias;
     const float* res;                   // optional: + res[b][m][n] (laid out like C) after bias / activation
     const float* kscale;                // optional: B[b][k][n] * kscale[b][k] (the squeeze-excite gate of a project convolution)
+    const float* bias_n = nullptr;      // optional: + bias_n[b][n] ahead of the activation (K16's barrier-phased kernels only)
+    long s_bias_n = 0;                  // floats between the batch items of bias_n (0 = shared)
     int M, N, K;
     long lda, ldb, ldc, sA, sB, sC;     // elements
     int act;                            // 0 none, 1 swish, 2 leaky relu (slope)
@@ -377,6 +379,19 @@ __global__ void __launch_bounds__(WM* WN * 64 * KS) gemm_x3_kernel(const GemmP p
                         acc[mt][nt][r] += red[((((g - 1) * WM * WN + wave) * MT + mt) * NT + nt) * 1024 + r * 64 + lane];
     }
 
+    // bias along N (ABI 13: one value per COLUMN -- a lane is a column, so one load per tile column; rows-times-weights
+    // products whose rows are voxels / pixels: the CRP's relation-logit convolutions), added ahead of the activation
+    if (p.bias_n != nullptr) {                                  // (uniform branch)
+        const float* bnp = p.bias_n + (size_t)bz * p.s_bias_n;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float bnv = bnp[min(n0 + (wn * NT + nt) * 32 + li, p.N - 1)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bnv;
+        }
+    }
     // epilogue: lane -> column n, registers -> rows (r & 3) + 8 (r >> 2) + 4 h.  Bias / activation are uniform over the
     // launch: one straight-line store sequence per combination
     float* const Cb = p.C + (size_t)bz * p.sC;
@@ -1298,13 +1313,16 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (reinterpret_cast<uintptr_t>(a->C) & 3) return OCCD_EINVAL;
     if (a->act < 0 || a->act > 2 || a->tile_hint < 0 || a->tile_hint > kNumVariantsG + 3) return OCCD_EINVAL;
     if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
+    if (a->bias_n != nullptr && ((reinterpret_cast<uintptr_t>(a->bias_n) & 3) || a->stride_bias_n < 0 ||
+                                 a->tile_hint == kNumVariantsG + 1 || a->tile_hint == kNumVariantsG + 3))
+        return OCCD_EINVAL;                              // (the wave-specialised and the panel kernels have no column bias)
     {
         // K16p: pre-split A, the whole-K panel of 32 / 64 B columns fits LDS, plain epilogue.  hint 8 forces it, hint 0 picks it
         // for matrices of >= 256 rows -- one row tile for each of the 8 waves (OCCD_GEMM_PANEL=0 keeps the barrier-phased
         // PRE = 1 kernel for A/B)
         static const bool panel_off = !occd::env_flag("OCCD_GEMM_PANEL", true);
         const int KP = ((a->K + 15) / 16) * 16;
-        const bool plain = a->pre == 1 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0;
+        const bool plain = a->pre == 1 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0 && a->bias_n == nullptr;
         const bool fits1 = plain && (size_t)KP * panel_row_bytes(1) <= 160 * 1024;      // K <= 848
         const bool fits2 = plain && (size_t)KP * panel_row_bytes(2) <= 160 * 1024;      // K <= 352
         if (a->tile_hint == kNumVariantsG + 3 && !fits1) return OCCD_EINVAL;
@@ -1401,7 +1419,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if ((a->res != nullptr || a->scale_k != nullptr) && (a->tile_hint == kNumVariantsG + 1 || a->pre == 2)) return OCCD_EINVAL;
     if (a->res != nullptr && (reinterpret_cast<uintptr_t>(a->res) & 3)) return OCCD_EINVAL;
     if (a->act_a != 0 && (a->act_a != 1 || a->pre == 1 || a->pre == 3 || a->tile_hint == kNumVariantsG + 1)) return OCCD_EINVAL;
-    const bool ws = a->pre == 0 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0 &&
+    const bool ws = a->pre == 0 && a->res == nullptr && a->scale_k == nullptr && a->act_a == 0 && a->bias_n == nullptr &&
                     (a->tile_hint == kNumVariantsG + 1 || (a->tile_hint == 0 && pick == 0 && !ws_off && a->K >= 2048));
     if (a->tile_hint == kNumVariantsG + 1 && a->pre != 0) return OCCD_EINVAL;
     const VariantG& v = kVariantsG[pick];
@@ -1419,6 +1437,7 @@ extern "C" int occd_gemm_f32x3(const occd_gemm_args* a, void* stream) {
     if (a->pre == 1) p.sA = a->stride_a / 8;        // bf16 elements -> u32x4 records
     if (a->pre == 2) p.sB = a->stride_b / 8;
     p.act = a->act; p.slope = a->slope; p.act_a = a->act_a;
+    p.bias_n = a->bias_n; p.s_bias_n = a->stride_bias_n;
     p.mtiles = (a->M + TM - 1) / TM;
     p.ntiles = (a->N + TN - 1) / TN;
     // the tile of the LARGER operand is the one worth fetching once per L2: iterate over the other dimension fastest
@@ -1478,7 +1497,7 @@ extern "C" int occd_gemm_f32x3_splitk(const occd_gemm_args* a, int32_t k16_per_z
                                       float* workspace, int64_t workspace_floats, void* stream) {
     if (!a || !a->A || !a->B || !a->C || !workspace) return OCCD_EINVAL;
     if (a->M <= 0 || a->N < 4 || a->K <= 0 || (a->K & 7) || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
-    if (a->pre != 1 || a->act_a != 0 || a->act < 0 || a->act > 2 || a->ldc < a->N || a->ldb < a->N) return OCCD_EINVAL;
+    if (a->pre != 1 || a->act_a != 0 || a->act < 0 || a->act > 2 || a->ldc < a->N || a->ldb < a->N || a->bias_n != nullptr) return OCCD_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->A) & 15) || (a->stride_a & 7) || (reinterpret_cast<uintptr_t>(a->B) & 3) ||
         (reinterpret_cast<uintptr_t>(a->C) & 3) || (reinterpret_cast<uintptr_t>(workspace) & 127))
         return OCCD_EINVAL;
@@ -1544,7 +1563,7 @@ extern "C" int occd_gemm_f32x3_nt(const occd_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return OCCD_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0 || a->batch > 65535) return OCCD_EINVAL;
     if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N || (a->pre != 0 && a->pre != 3) || a->bias != nullptr || a->res != nullptr ||
-        a->scale_k != nullptr)
+        a->scale_k != nullptr || a->bias_n != nullptr)
         return OCCD_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->A) & 3) || (reinterpret_cast<uintptr_t>(a->B) & 3) || (reinterpret_cast<uintptr_t>(a->C) & 3))
         return OCCD_EINVAL;

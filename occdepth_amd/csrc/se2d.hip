@@ -141,8 +141,8 @@ struct SeSlot {
 __global__ void __launch_bounds__(256) se_fused_kernel(const float* __restrict__ part, const float* __restrict__ wr,
                                                        const float* __restrict__ br, const float* __restrict__ we,
                                                        const float* __restrict__ be, float* __restrict__ gate,
-                                                       SeSlot* __restrict__ slot, int C, int Cr, int nblk, float inv_s,
-                                                       int tpc, int nexp) {
+                                                       float* __restrict__ r_out, SeSlot* __restrict__ slot, int C, int Cr,
+                                                       int nblk, float inv_s, int tpc, int nexp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];            // mean[C] | rs[Cr]
     float* const mean = sm;
     float* const rs = sm + ((C + 3) & ~3);
@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256) se_fused_kernel(const float* __restrict__
         if (t == 0) {
             const float v = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]) + br[i];
             const float r = v / (1.f + expf(-v));
+            r_out[(size_t)b * Cr + i] = r;              // the squeezed activations: the training backward reads them (occd_se_bwd)
             __hip_atomic_store(words + i, (unsigned long long)__float_as_uint(r) | ((unsigned long long)seq << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -542,7 +543,11 @@ struct SeDev {
 };
 SeDev g_se_dev[kSeMaxDevices];
 std::atomic<unsigned> g_se_next{0};
-std::atomic<int> g_se_fused{occd::env_flag("OCCD_SE_FUSED", true) ? 1 : 0};
+// Measured and NOT adopted (round 6, same box): the config-2 frame 18.017 ms with the one-launch form, 18.021 ms with two launches;
+// per launch under HIP events 14.5 us fused against 11.8 us for the pair at 2304 -> 96 -> 2304 (the expand workgroups wait for the
+// SLOWEST of the 96 reduce workgroups plus one agent-scope poll hop: what a kernel boundary costs inside a hipGraph is no more).
+// Default: two launches; OCCD_SE_FUSED=1 / occd_se_gate_set_fused(1) select the one-launch kernel (kept: tested, bit-identical).
+std::atomic<int> g_se_fused{occd::env_flag("OCCD_SE_FUSED", false) ? 1 : 0};
 SeSlot* se_slot() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSeMaxDevices) return nullptr;
@@ -574,7 +579,7 @@ extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const
     int tpc = 1;                                           // threads per channel in the pooling phase
     while (tpc < 64 && (long)tpc * 2 * C <= 256 && tpc * 2 <= nblk) tpc *= 2;
     // one launch (se_fused_kernel) where its preloads cover the rows: C <= 4096, Cr % 4 == 0 and <= 192, batch * Cr words fit a
-    // slot; OCCD_SE_FUSED=0 / occd_se_gate_set_fused(0) keep the two launches (A/B, and the reference of the bit-identity test)
+    // slot; opt-in (OCCD_SE_FUSED=1 / occd_se_gate_set_fused(1)): see g_se_fused for the measurement that kept two launches the default
     if (g_se_fused.load() != 0 && C <= 256 * kWPre && (Cr & 3) == 0 && Cr <= 16 * kEPre && (long)batch * Cr <= kSeWords &&
         (reinterpret_cast<uintptr_t>(w_expand) & 15) == 0) {
         SeSlot* slot = se_slot();
@@ -582,7 +587,8 @@ extern "C" int occd_se_gate(const float* pool_part, const float* w_reduce, const
         const int nexp = (C + 63) / 64;
         const size_t lds = ((size_t)((C + 3) & ~3) + Cr) * sizeof(float);
         hipLaunchKernelGGL(se_fused_kernel, dim3((unsigned)(nexp > Cr ? nexp : Cr), (unsigned)batch), dim3(256), lds, st, pool_part,
-                           w_reduce, b_reduce, w_expand, b_expand, gate, slot, C, Cr, nblk, (float)(1.0 / (double)S), tpc, nexp);
+                           w_reduce, b_reduce, w_expand, b_expand, gate, r_scratch, slot, C, Cr, nblk, (float)(1.0 / (double)S), tpc,
+                           nexp);
         return occd::check_launch();
     }
     hipLaunchKernelGGL(se_reduce_kernel, dim3((unsigned)Cr, (unsigned)batch), dim3(256), (size_t)C * sizeof(float), st,

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 12   # 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 13   # 13: occd_gemm_args.bias_n / stride_bias_n (column bias: CRP relation-logit convolutions on K16), occd_gemm_f32x3_splitk (K21), occd_se_gate_set_fused; 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -105,7 +105,7 @@ class GemmArgs(Structure):
         [(n, c_int32) for n in ("M", "N", "K", "batch")] + \
         [(n, c_int64) for n in ("lda", "ldb", "ldc", "stride_a", "stride_b", "stride_c")] + \
         [("act", c_int32), ("slope", c_float), ("tile_hint", c_int32), ("pre", c_int32), ("res", c_void_p), ("scale_k", c_void_p),
-         ("act_a", c_int32)]
+         ("act_a", c_int32), ("bias_n", c_void_p), ("stride_bias_n", c_int64)]
 
 
 class WinoArgs(Structure):
@@ -599,7 +599,7 @@ def gemm_x3_supported(a, b):
 
 
 def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_bf16=False, res=None, k_scale=None,
-            sigmoid_a=False):
+            sigmoid_a=False, bias_n=None):
     """K16 (occd_gemm_f32x3): out[i] = act(a[i] @ (b[i] * k_scale[i][:, None]) + bias[:, None]) + res[i] in float32-level
     accuracy on the bf16 matrix pipe (k_scale: (batch, K), the squeeze-excite gate of a project convolution; res: laid out
     like out, the block's skip connection).
@@ -658,6 +658,11 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
         if pa or plain_bf16:
             raise RuntimeError("gemm_x3: sigmoid_a takes a float32 tensor A and the split arithmetic")
         q.act_a = 1
+    if bias_n is not None:                                   # one value per COLUMN: (N,) shared or (batch, N)
+        if bias_n.dtype != torch.float32 or not bias_n.is_cuda or not bias_n.is_contiguous() or \
+                tuple(bias_n.shape) not in ((N,), (batch, N)):
+            raise RuntimeError("gemm_x3: bias_n must be (N,) or (batch, N) contiguous floats")
+        q.bias_n, q.stride_bias_n = bias_n.data_ptr(), (N if bias_n.dim() == 2 else 0)
     if _PROFILING:
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")

@@ -3,7 +3,8 @@
 Eval-mode dataflow on the HIP kernels (N = voxels at this level, M = mega voxels = N/8):
   x_agg   = ASPP(x)                                              6 x K2 (3x3x3, dilated)
   mega    = mega_context(x_agg)          (M rows x 2C)           K2, stride 2
-  logit_r = context_prior_logits[r](x_agg)   (N rows x M)        K2 1x1x1  -> P_logits[:, r]
+  logit_r = context_prior_logits[r](x_agg)   (N rows x M)        K16 (round 6): the R 1x1x1 convolutions of an image as ONE
+                                                                 batched launch (column bias)  -> P_logits[:, r]
   ctx_r   = sigmoid(logit_r) @ mega          (N rows x 2C)       K16 (round 5): the R products of an image as ONE
                                                                  batched launch, sigmoid applied while A is staged
   x       = resize([x | ctx_0 .. ctx_{R-1}])                     ctx_r written straight into its
@@ -20,6 +21,10 @@ import os
 
 # the relation products sigmoid(P_logits) @ mega as one batched K16 launch (OCCDEPTH_CRP_K16=0: four K2 launches, A/B)
 CRP_PRODUCTS_K16 = os.environ.get("OCCDEPTH_CRP_K16", "1") == "1"
+# round 6: the R relation-logit 1x1x1 convolutions (reference :54-62) as ONE batched K16 launch per image -- rows = voxels, the
+# weights transposed + split once (GemmPacked role "b"), the convolution bias as K16's column bias (ABI 13); four generic K2
+# launches at 38 TF/s before (OCCDEPTH_CRP_LOGITS_K16=0 restores them)
+CRP_LOGITS_K16 = os.environ.get("OCCDEPTH_CRP_LOGITS_K16", "1") == "1"
 
 
 class CPMegaVoxels(nn.Module):
@@ -75,7 +80,20 @@ class CPMegaVoxels(nn.Module):
         mega = Vox.empty(B, mega_plan.out_dims(x_agg.dims), mega_plan.cout, dev)   # (B, X/2, Y/2, Z/2, 2C): rows = mega voxels
         lgs = [Vox(logits[r * B:(r + 1) * B], M) for r in range(R)]
         # mega_context (64 workgroups) and the R relation-logit convolutions all read x_agg and nothing else
-        first = [lambda: mega_plan(x_agg, out=mega)] + [(lambda r=r: pl["logits"][r](x_agg, out=lgs[r])) for r in range(R)]
+        if (x.buf.is_cuda and CRP_LOGITS_K16 and hip.GEMM_X3 and C % 8 == 0 and x_agg.coff == 0 and x_agg.cs % 4 == 0
+                and M % 4 == 0 and x_agg.buf.dtype == torch.float32):
+            wb, bias_n = self._logit_operands()
+            if m_cs != M:
+                logits.zero_()                                  # (the K2 form wrote the pad columns as zeros)
+
+            def logit_gemm():
+                for b in range(B):
+                    a_op = x_agg.buf[b].reshape(N, x_agg.cs)[:, :C]                      # rows = voxels, k = channels
+                    out = torch.as_strided(logits, (R, N, M), (B * N * m_cs, m_cs, 1), b * N * m_cs)
+                    hip.gemm_x3(a_op, wb, out=out, bias_n=bias_n)
+            first = [lambda: mega_plan(x_agg, out=mega), logit_gemm]
+        else:
+            first = [lambda: mega_plan(x_agg, out=mega)] + [(lambda r=r: pl["logits"][r](x_agg, out=lgs[r])) for r in range(R)]
         if x.buf.is_cuda:
             run_parallel(first)
         else:
@@ -114,6 +132,21 @@ class CPMegaVoxels(nn.Module):
         y = self.resize[1].forward_vox(y)
         p_logits = logits.view(R, B, N, m_cs)[..., :M].permute(1, 0, 3, 2)
         return {"P_logits": p_logits, "x": y}
+
+    def _logit_operands(self):
+        """(GemmPacked role-"b" image of the R transposed 1x1x1 weights (R, C, M), column bias (R, M)), cached until a weight
+        or bias changes."""
+        from ..fused import _stamp
+        convs = [seq[0] for seq in self.context_prior_logits]
+        key = _stamp(*convs)
+        hit = self.__dict__.get("_logit_ops")
+        if hit is None or hit[0] != key:
+            w = torch.stack([c.weight.detach().float().reshape(c.out_channels, c.in_channels).t().contiguous() for c in convs])
+            bias = torch.stack([c.bias.detach().float() if c.bias is not None else
+                                torch.zeros(c.out_channels, device=w.device) for c in convs]).contiguous()
+            hit = (key, hip.GemmPacked(w, "b"), bias)
+            self.__dict__["_logit_ops"] = hit
+        return hit[1], hit[2]
 
     def _forward_autograd(self, inp):
         bs = inp.shape[0]

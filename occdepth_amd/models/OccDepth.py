@@ -551,7 +551,11 @@ class OccDepth(_Base):
     # ---------------------------------------------------------------- Lightning hooks
     def _log(self, key, value):
         self.logged[key] = value.detach()
-        self.log(key, value.detach(), on_epoch=True, sync_dist=True)
+        # inside the fast training step (its capture, its warm-up steps on a snapshot, its eager fall-back) the Trainer's
+        # logger is fed AFTER the step from `self.logged` (_fast_training_step): a logger call inside a capture would be
+        # baked into the graph -- or synchronise the host, which a capture forbids
+        if not self.__dict__.get("_in_fast_step", False):
+            self.log(key, value.detach(), on_epoch=True, sync_dist=True)
 
     def step(self, batch, step_type, metric):
         """Loss assembly of occdepth/models/OccDepth.py:378-533.  Same terms, same switches, same log keys; the

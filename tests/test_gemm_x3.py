@@ -404,7 +404,7 @@ def test_gemm_x3_splitk_plan_and_argument_checks(hip):
     for M, N, K, batch in ((384, 468, 2304, 2), (640, 468, 3840, 2), (224, 1848, 1344, 2), (160, 1848, 960, 2), (40, 37, 256, 3)):
         per, nz, rr, ws = hip.gemm_x3_splitk_plan(M, N, K, batch)
         k16 = (K + 15) // 16
-        assert 1 <= per <= 26 or nz == 1, (per, nz)
+        assert 1 <= per <= 52, (per, nz)                          # a chunk never exceeds the LDS (52 steps x 16 k x 192 B = 160 KB)
         assert (nz - 1) * per < k16 <= nz * per and rr >= 1 and ws == batch * nz * M * ((N + 31) // 32 * 32)
     w = torch.randn(64, 256, device=DEV)
     pa = hip.GemmPacked(w, "a")
@@ -416,3 +416,36 @@ def test_gemm_x3_splitk_plan_and_argument_checks(hip):
         hip.gemm_x3_splitk(w, b)                                   # float32 left operand: K16's business
     with pytest.raises(RuntimeError):
         hip.gemm_x3_splitk(pa, b, k_scale=torch.ones(2, 255, device=DEV))
+
+
+@pytest.mark.parametrize("packed_b", [False, True])
+@pytest.mark.parametrize("shape", [(4, 4096, 512, 256), (3, 70, 133, 104), (None, 40, 7, 8), (2, 300, 64, 1024)])
+def test_gemm_x3_column_bias(hip, shape, packed_b):
+    """occd_gemm_args.bias_n (ABI 13): one bias value per COLUMN, added ahead of the activation -- rows-times-weights products
+    (rows = voxels, columns = output channels): the CRP's relation-logit convolutions as one batched launch with the left
+    operand shared over the relations (first shape: config 2's R = 4, N = 4096 voxels, M = 512, C = 256)."""
+    batch, M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)                                   # shared over the batch
+    b = torch.randn(*((K, N) if batch is None else (batch, K, N)), generator=g) / K ** 0.5
+    bn = torch.randn(*((N,) if batch is None else (batch, N)), generator=g)
+    ref = torch.matmul(a.double(), b.double()) + (bn.double() if batch is None else bn.double().unsqueeze(1))
+    xb = hip.GemmPacked(b.to(DEV), "b") if packed_b else b.to(DEV)
+    got = hip.gemm_x3(a.to(DEV), xb, bias_n=bn.to(DEV)).cpu().double()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    # with the row bias and an activation on top; a column bias shared over the batch
+    rb = torch.randn(M, generator=g)
+    shared = bn if batch is None else bn[0].contiguous()
+    ref2 = F_leaky(torch.matmul(a.double(), b.double()) + shared.double() + rb.double().view(-1, 1))
+    got2 = hip.gemm_x3(a.to(DEV), xb, bias=rb.to(DEV), bias_n=shared.to(DEV), act="leaky").cpu().double()
+    assert float((got2 - ref2).abs().max() / ref2.abs().max()) < 2e-6
+    with pytest.raises(RuntimeError):
+        hip.gemm_x3(a.to(DEV), xb, bias_n=bn.to(DEV)[..., :-1].contiguous())
+    if not packed_b:
+        with pytest.raises(RuntimeError):                               # the wave-specialised kernel has no column bias
+            hip.gemm_x3(a.to(DEV), xb, bias_n=bn.to(DEV), tile_hint=6)
+
+
+def F_leaky(t, slope=0.01):
+    return torch.where(t > 0, t, t * slope)

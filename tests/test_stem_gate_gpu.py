@@ -159,6 +159,18 @@ def test_se_gate_one_launch_equals_two_launches_and_float64(hip, case):
     assert n1 == n2 == 40                                              # (one profiler scope per call in both forms)
     for i, (a, b) in enumerate(zip(fused, plain)):
         assert torch.equal(a, b), (case, i, float((a - b).abs().max()))
+    # the squeezed activations r = swish(Wr mean + br), which the TRAINING backward reads (occd_se_bwd), come out of both forms
+    rs = {}
+    for mode in (1, 0):
+        old = lib.occd_se_gate_set_fused(mode)
+        r = torch.full((batch, Cr), float("nan"), device=DEV)
+        gate = torch.empty((batch, C), device=DEV)
+        hip._check(lib.occd_se_gate(parts[7].data_ptr(), wr.data_ptr(), br.data_ptr(), we.data_ptr(), be.data_ptr(), r.data_ptr(),
+                                    gate.data_ptr(), batch, C, Cr, nblk, S, None), "occd_se_gate")
+        torch.cuda.synchronize()
+        lib.occd_se_gate_set_fused(old)
+        rs[mode] = r
+    assert torch.equal(rs[1], rs[0]) and bool(torch.isfinite(rs[1]).all())
     mean = parts[7].double().cpu().view(batch, C, nblk).sum(-1) / S
     r = mean @ wr.double().cpu().t() + br.double().cpu()
     r = r * torch.sigmoid(r)
