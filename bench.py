@@ -653,7 +653,9 @@ def roofline_2d(rows, frames):
                 e.update({"bound": "mfma", "algorithmic_tflops": round(tf, 1), "peak": FP32_MFMA_PEAK_TFLOPS,
                           "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "pipe": "fp32 (v_mfma_f32_32x32x2_f32)"})
         out[name] = e
-    out["launches_per_frame_all_kinds"] = round(sum(v["launches"] for v in rows.values()) / frames, 1)
+    # (profiler scopes = operators: a squeeze-excite gate or a K21 product is ONE scope of two kernel launches; the kernel-launch
+    #  count of a forward is in profiles/r06_steady_state_kernel_stats.csv)
+    out["profiled_operators_per_frame"] = round(sum(v["launches"] for v in rows.values()) / frames, 1)
     return out
 
 

@@ -503,7 +503,13 @@ __device__ __forceinline__ int to_sgpr(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <bool SKIP>
+// COOP (round 6): the four waves of a workgroup share their source rows.  Output rows oy0 .. oy0 + 3 at vertical tap ky touch
+// at most FOUR consecutive low-resolution rows (base(ky) .. base(ky) + 3 for any upsampling ratio >= 2: rh <= 0.5), and the
+// non-COOP form loads EIGHT (every wave its own y0 / y1 pair): 216 instead of 108 row-segment loads per workgroup through the
+// L1 / texture path, which -- not HBM (1.7 TB/s, traffic = algorithmic) -- is what bounds the kernel.  Here wave r loads row
+// base(ky) + r of the three taps of every ky RAW into LDS (27 loads per lane instead of 54), and the vertical interpolation
+// moves to the read side (four LDS reads per tap and output instead of two).
+template <bool SKIP, bool COOP = false>
 __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
                                                             int h, int w, int H, int W, float rh, float rw, long zcs,
                                                             long zbs, const UpSkipP sk) {
@@ -567,6 +573,26 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
             o0[ky] = (unsigned)(y0 * w) * 4u;
             o1[ky] = (unsigned)(y1 * w) * 4u;
         }
+        if (COOP) {
+            // this wave's share of the group's source rows: row base(ky) + r (clamped) of the three taps of every ky
+            unsigned oc[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int ryf = min(max(oy0 + ky - 1, 0), H - 1);
+                const int base = to_sgpr((int)(rh * ryf));
+                oc[ky] = (unsigned)(min(base + r, h - 1) * w) * 4u;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const unsigned s0 = (unsigned)t * tap_bytes + oc[t / 3];
+                st.a0[t][0] = ldz(vA, s0);
+                st.a0[t][1] = ldz(vB, s0);
+            }
+            if (third) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) st.a0[t][2] = ldz(vC, (unsigned)t * tap_bytes + oc[t / 3]);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const unsigned s0 = (unsigned)t * tap_bytes + o0[t / 3], s1 = (unsigned)t * tap_bytes + o1[t / 3];
@@ -581,6 +607,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
                 st.a0[t][2] = ldz(vC, (unsigned)t * tap_bytes + o0[t / 3]);
                 st.a1[t][2] = ldz(vC, (unsigned)t * tap_bytes + o1[t / 3]);
             }
+        }
         }
         if (SKIP) {
             // skip tile: rows oy0 - 1 .. oy0 + 4, columns X0 - 1 .. X0 + 256 of every skip channel, zero outside the image
@@ -607,6 +634,12 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
         for (int t = 0; t < 9; ++t) {
             const float ly = st.ly[t / 3], ok = st.ok[t / 3];
             float* row = L + (t * 4 + r) * kUpNC + lane;
+            if (COOP) {                                        // raw source row base(ky) + r; interpolated by the readers
+                row[0] = st.a0[t][0];
+                row[64] = st.a0[t][1];
+                row[128] = st.a0[t][2];
+                continue;
+            }
             row[0] = ok * ((1.f - ly) * st.a0[t][0] + ly * st.a1[t][0]);
             row[64] = ok * ((1.f - ly) * st.a0[t][1] + ly * st.a1[t][1]);
             row[128] = ok * ((1.f - ly) * st.a0[t][2] + ly * st.a1[t][2]);   // (columns >= nc: never read)
@@ -656,6 +689,40 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
     const int oy = oy0 + r;
     if (ox0 >= W || oy >= H) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (COOP) {
+        // vertical part of this output row per ky: rows y0 / y1 relative to the group's base(ky) (the same arithmetic as the
+        // loader's), weights (1 - ly, ly) * ok
+        int ra[3], rb[3];
+        float wa[3], wb[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ry = oy + ky - 1;
+            const bool ok = (unsigned)ry < (unsigned)H;
+            const float sy = rh * (ok ? ry : 0);
+            const int y0 = (int)sy;
+            const int y1 = y0 + (y0 < h - 1);
+            const float ly = sy - y0;
+            const int base = (int)(rh * min(max(oy0 + ky - 1, 0), H - 1));
+            ra[ky] = min(max(min(y0, h - 1) - base, 0), 3);
+            rb[ky] = min(max(min(y1, h - 1) - base, 0), 3);
+            // (rows base + r are clamped to h - 1 by the loader: relative index of a clamped row = its distance, capped at 3)
+            wa[ky] = ok ? 1.f - ly : 0.f;
+            wb[ky] = ok ? ly : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            const float* rowa = L + (t * 4 + ra[ky]) * kUpNC;
+            const float* rowb = L + (t * 4 + rb[ky]) * kUpNC;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = i + kx;
+                const float v0 = wa[ky] * rowa[x0[j]] + wb[ky] * rowb[x0[j]];
+                const float v1 = wa[ky] * rowa[x1[j]] + wb[ky] * rowb[x1[j]];
+                acc[i] += cm[j] * ((1.f - lx[j]) * v0 + lx[j] * v1);
+            }
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const float* row = L + (t * 4 + r) * kUpNC;
@@ -665,6 +732,7 @@ __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restr
             const int j = i + kx;
             acc[i] += cm[j] * ((1.f - lx[j]) * row[x0[j]] + lx[j] * row[x1[j]]);
         }
+    }
     }
     if (SKIP) {
         const int lc = ox0 - X0;                              // tile column of output ox0 - 1 is lc (tile starts at X0 - 1)
@@ -1112,7 +1180,13 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
     occd::ProfScope prof("upconv_gather_nchw", (hipStream_t)stream, 2.0 * 36 * batch * Cout * (double)H * W,
                          4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
-    if (staged)
+    // COOP: shared source rows (needs an upsampling ratio >= 2 so that four output rows see four source rows per ky);
+    // OCCD_UPCONV_COOP=0 keeps one row pair per wave (A/B)
+    static const bool coop_on = occd::env_flag("OCCD_UPCONV_COOP", true);
+    if (staged && coop_on && rh <= 0.5f)
+        hipLaunchKernelGGL((upconv_gather_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
+                           rh, rw, zcs, zbs, UpSkipP{});
+    else if (staged)
         hipLaunchKernelGGL(upconv_gather_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh,
                            rw, zcs, zbs, UpSkipP{});
     else
@@ -1139,8 +1213,13 @@ extern "C" int occd_upconv_gather_skip_nchw(const float* z, const float* skip, c
     occd::ProfScope prof("upconv_gather_skip_nchw", (hipStream_t)stream, 2.0 * (36 + 9.0 * Cs) * batch * Cout * (double)H * W,
                          4.0 * batch * (Cout * (9.0 * h * w + (double)H * W) + (double)Cs * H * W));
     UpSkipP sk{skip, wskip, shift, Cs, slope};
-    hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw,
-                       zcs, zbs, sk);
+    static const bool coop_on = occd::env_flag("OCCD_UPCONV_COOP", true);
+    if (coop_on && rh <= 0.5f)
+        hipLaunchKernelGGL((upconv_gather_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
+                           rh, rw, zcs, zbs, sk);
+    else
+        hipLaunchKernelGGL(upconv_gather_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W, rh, rw,
+                           zcs, zbs, sk);
     return occd::check_launch();
 }
 

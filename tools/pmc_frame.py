@@ -12,6 +12,8 @@ import sys
 from collections import defaultdict
 
 FAMILIES = [("conv3d_c32_slide_x3_kernel", "K2s3 head conv 32->32 3x3x3 (3x bf16 split)"), ("conv3d_c32_slide_kernel", "K2s head conv 32->32 3x3x3"),
+            ("gemm_x3_panel_splitk_kernel", "K21 split-K panel GEMM (project convolutions of the 1/16, 1/32 stages; round 6)"),
+            ("splitk_reduce_kernel", "K21 second launch (sum of the K chunks + shift + skip)"),
             ("gemm_x3_panel_kernel", "K16p panel-stationary GEMM (3x bf16 split, pre-split weights; late round 5)"), ("gemm_x3_pack", "K16 weight pre-split (once per weight)"), ("gemm_x3", "K16 fp32 GEMM (3x bf16 split)"), ("conv3d_igemm_kernel", "K2 generic 3-D igemm"), ("conv3d_bf16_kernel", "K2b 3-D conv (3x bf16 split: small volumes, transposed-conv phases)"), ("bneck_a_kernel", "K14 bottleneck A (conv1 + conv_z)"),
             ("bneck_b_kernel", "K14 bottleneck B (conv_y + conv_x + conv5)"),
             ("wino3x3_kernel", "K10 fused Winograd 3x3"), ("pw_gemm_splitk_kernel", "K11s split-K pointwise GEMM"),
