@@ -509,6 +509,11 @@ __device__ __forceinline__ int to_sgpr(int v) {
 // L1 / texture path, which -- not HBM (1.7 TB/s, traffic = algorithmic) -- is what bounds the kernel.  Here wave r loads row
 // base(ky) + r of the three taps of every ky RAW into LDS (27 loads per lane instead of 54), and the vertical interpolation
 // moves to the read side (four LDS reads per tap and output instead of two).
+// MEASURED AND NOT ADOPTED (same box, four alternating bench runs): K12 family 1.040 / 1.039 ms per frame with COOP against
+// 0.970 / 0.971 without (116 / 132 VGPRs against 106 / 95: one wave per SIMD fewer), frame 17.89 / 17.91 against 17.84 / 17.84 ms
+// -- halving the loads through L1 does not help, so the load path is not what bounds the kernel either; what is left is the
+// latency of one dependent load -> barrier -> compute -> store chain per workgroup at 4 workgroups per CU.  Opt-in:
+// OCCD_UPCONV_COOP=1 (bit-identical results: tests/test_winograd2d.py runs both).
 template <bool SKIP, bool COOP = false>
 __global__ void __launch_bounds__(256) upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout,
                                                             int h, int w, int H, int W, float rh, float rw, long zcs,
@@ -1181,8 +1186,8 @@ extern "C" int occd_upconv_gather_nchw(const float* z, float* out, int32_t batch
                          4.0 * batch * Cout * (9.0 * h * w + (double)H * W));
     // the staged kernel holds the low-resolution columns under 258 output columns in rows of kUpNC floats
     // COOP: shared source rows (needs an upsampling ratio >= 2 so that four output rows see four source rows per ky);
-    // OCCD_UPCONV_COOP=0 keeps one row pair per wave (A/B)
-    static const bool coop_on = occd::env_flag("OCCD_UPCONV_COOP", true);
+    // opt-in (OCCD_UPCONV_COOP=1): measured slower, see the kernel
+    static const bool coop_on = occd::env_flag("OCCD_UPCONV_COOP", false);
     if (staged && coop_on && rh <= 0.5f)
         hipLaunchKernelGGL((upconv_gather_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
                            rh, rw, zcs, zbs, UpSkipP{});
@@ -1213,7 +1218,7 @@ extern "C" int occd_upconv_gather_skip_nchw(const float* z, const float* skip, c
     occd::ProfScope prof("upconv_gather_skip_nchw", (hipStream_t)stream, 2.0 * (36 + 9.0 * Cs) * batch * Cout * (double)H * W,
                          4.0 * batch * (Cout * (9.0 * h * w + (double)H * W) + (double)Cs * H * W));
     UpSkipP sk{skip, wskip, shift, Cs, slope};
-    static const bool coop_on = occd::env_flag("OCCD_UPCONV_COOP", true);
+    static const bool coop_on = occd::env_flag("OCCD_UPCONV_COOP", false);
     if (coop_on && rh <= 0.5f)
         hipLaunchKernelGGL((upconv_gather_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, z, out, Cout, h, w, H, W,
                            rh, rw, zcs, zbs, sk);

@@ -329,3 +329,21 @@ def test_merged_head_algebra_cpu():
         got = dec._conv2_merged(f, head)
     assert got.shape == ref.shape == (2, 64, 7, 9)
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_upconv_gather_shared_source_rows_variant_in_child_process():
+    """K12's COOP form (round 6: the four waves of a workgroup share their source rows; measured slower and therefore opt-in,
+    OCCD_UPCONV_COOP=1 -- the switch is read once per process) must stay correct: the upconv tests of this file again, in a
+    child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("OCCD_UPCONV_COOP") == "1":
+        pytest.skip("already inside the child")
+    env = dict(os.environ, OCCD_UPCONV_COOP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "upconv and not child",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
+    assert r.returncode == 0 and " passed" in tail, tail
