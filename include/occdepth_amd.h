@@ -421,6 +421,11 @@ int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip, float* ou
  * gather: gx (B, h, w, C) from gout (B, H, W, gout_cs) rows (its first C channels), the exact transpose of the forward.    */
 int occd_upsample_bilinear_cat_nhwc(const float* x, const float* skip, float* out, int32_t batch, int32_t C, int32_t Cskip,
                                     int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
+/* Round 6: the same with output rows of out_cs >= C + Cskip floats, pad lanes written as zeros -- rows of ceil8(channels)
+ * floats are consumed in place by the convolution kernels (the 163-channel concat of the full-resolution decoder level in
+ * rows of 168: no strided copy into padded rows in front of the level's first convolution).                              */
+int occd_upsample_bilinear_cat_nhwc_rows(const float* x, const float* skip, float* out, int32_t batch, int32_t C, int32_t Cskip,
+                                         int32_t h, int32_t w, int32_t H, int32_t W, int32_t out_cs, void* stream);
 int occd_upsample_bilinear_nhwc_bwd(const float* gout, float* gx, int32_t batch, int32_t C, int32_t gout_cs, int32_t h,
                                     int32_t w, int32_t H, int32_t W, void* stream);
 

@@ -75,8 +75,11 @@ def _padded_rows(x):
     # the neighbour's DATA.  A view is taken in place only when its base IS the padded row buffer -- (B, X, Y, Z, cs) dense,
     # what hip.ssc_loss_grad allocates and fills, pads included -- not a wider (B, cs, X, Y, Z) tensor.
     base = x._base
-    if base is not None and not (base.dim() == 5 and tuple(base.shape) == (B, X, Y, Z, cs) and base.is_contiguous()):
-        return None
+    while base is not None and base._base is not None:      # (detach() of an autograd Function's output names that output, not its root)
+        base = base._base
+    if base is not None and not (base.is_contiguous() and base.shape[-1] == cs and base.numel() == B * X * Y * Z * cs
+                                 and base.dim() in (4, 5) and base.shape[0] == B):
+        return None                 # ((B, X, Y, Z, cs) rows, or the (B, H, W, cs) rows of a 2-D level seen as an X = 1 volume)
     return torch.as_strided(x, (B, X, Y, Z, cs), (X * Y * Z * cs, Y * Z * cs, Z * cs, cs, 1))
 
 
@@ -96,16 +99,16 @@ def _conv(x, w, bias, cout, kernel, out, **kw):
     return hip.conv3d(x, hip.pack_weights(w), bias, cout, kernel, out, **kw)
 
 
-def _conv_view(x, w, n_out, n_in, s_out, s_in, tap_ofs, kernel, out, **kw):
+def _conv_view(x, w, n_out, n_in, s_out, s_in, tap_ofs, kernel, out, bias=None, **kw):
     """Forward-kernel launch whose operator is a VIEW of the dense weight `w` (hip.pack_weights_gather): no permute /
-    index_select / contiguous temporaries."""
+    index_select / contiguous temporaries.  bias: per-output-channel floats padded to a multiple of 32, or None."""
     if BF16_MFMA:
-        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16=True), None, n_out,
+        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16=True), bias, n_out,
                                kernel, out, **kw)
     if _x3_head(x, n_out, kernel, out, kw):
-        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16="x3"), None, n_out,
+        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16="x3"), bias, n_out,
                                kernel, out, split3=True, **kw)
-    return hip.conv3d(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel), None, n_out, kernel, out, **kw)
+    return hip.conv3d(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel), bias, n_out, kernel, out, **kw)
 
 
 def _wgrad(x, gy, cin, cout, K, stride, dilation, padding):
@@ -142,8 +145,10 @@ def _axis_phases(K, s, p, d):
     return out
 
 
-def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
-    """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz)."""
+def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation, bias=None):
+    """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz).
+    bias (cin floats, or None): added to every output position -- the forward of a ConvTranspose3d with a bias; it rides in the
+    phase launches' epilogues (every position belongs to exactly one phase), a separate pass only when a phase has no tap."""
     cout, cin = w.shape[:2]
     K = tuple(w.shape[2:])
     wd = w.detach()
@@ -151,8 +156,16 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
     ntap = K[0] * K[1] * K[2]
     out = Vox.empty(gy.batch, in_dims, cin, gy.buf.device, dtype=gy.buf.dtype)
     axes = [_axis_phases(K[a], stride[a], padding[a], dilation[a]) for a in range(3)]
-    if any(not taps for ax in axes for _, taps, _, _ in ax) or out.cs != cin:
-        out.buf.zero_()                                                    # empty phases / channel pad
+    empty = any(not taps for ax in axes for _, taps, _, _ in ax)
+    if empty:
+        out.buf.zero_()                                                    # empty phases: positions no launch writes
+    bias_pad = None
+    if bias is not None and not empty:
+        bias_pad = torch.zeros(hip.round_up(cin, 32), device=gy.buf.device)
+        bias_pad[:cin] = bias.detach().float()
+    # (the channel pad needs no memset: every forward kernel writes the pad lanes of the rows it stores as zeros -- asserted by
+    #  tests/test_hip_vs_aten.py, test_bf16_conv.py and test_conv_grad.py -- and the phases together store every row; the
+    #  memsets here and in the two Functions below were 1.1 GB per config-2 step)
     for (rx, tx, dx_, px), (ry, ty, dy_, py), (rz, tz, dz_, pz) in itertools.product(*axes):
         if not (tx and ty and tz):
             continue
@@ -162,8 +175,10 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
         # the transposed operator of this phase, W'[ci][co][a, b, c] = w[co][ci][tx[a], ty[b], tz[c]], packed straight
         # from w (one launch; the permute + 3 index_select + contiguous chain was 5 launches per phase)
         ofs = [(a * K[1] + b_) * K[2] + c for a in tx for b_ in ty for c in tz]
-        _conv_view(gy, wd, cin, cout, ntap, cin * ntap, ofs, (len(tx), len(ty), len(tz)), out, dilation=(dx_, dy_, dz_),
-                   padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
+        _conv_view(gy, wd, cin, cout, ntap, cin * ntap, ofs, (len(tx), len(ty), len(tz)), out, bias=bias_pad,
+                   dilation=(dx_, dy_, dz_), padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
+    if bias is not None and empty:
+        out.buf[..., out.coff:out.coff + cin] += bias.detach().to(out.buf.dtype)
     return out
 
 
@@ -187,8 +202,6 @@ class _Conv3dFn(torch.autograd.Function):
             cout, cin = w.shape[:2]
             K = tuple(w.shape[2:])
             out = Vox.empty(xv.batch, _out_dims(xv.dims, K, stride, padding, dilation), cout, x.device, dtype=xv.buf.dtype)
-            if out.cs != cout:
-                out.buf.zero_()
             bias = None
             if b is not None:
                 bias = torch.zeros(hip.round_up(cout, 32), device=x.device)
@@ -228,10 +241,9 @@ class _ConvTranspose3dFn(torch.autograd.Function):
             K = tuple(w.shape[2:])
             dims = tuple((n - 1) * s - 2 * p + d * (k - 1) + op + 1
                          for n, k, s, p, d, op in zip(xv.dims, K, stride, padding, dilation, output_padding))
-            out = conv3d_dgrad(xv, w.detach().float(), dims, stride, padding, dilation)
+            # (the bias in the phase launches' epilogues: `y + b` as a separate pass was 0.8 GB per step at the full-resolution level)
+            out = conv3d_dgrad(xv, w.detach().float(), dims, stride, padding, dilation, bias=b)
             y = out.ncdhw()
-            if b is not None:
-                y = y + b.detach().to(y.dtype).view(1, -1, 1, 1, 1)
         ctx.save_for_backward(xv.buf, w)
         ctx.geom = (xv.C, xv.coff, stride, padding, dilation, b is not None)
         return y
@@ -248,8 +260,6 @@ class _ConvTranspose3dFn(torch.autograd.Function):
             dx = dw = db = None
             if ctx.needs_input_grad[0]:                     # the convolution (weight w: "cout" = cin of the transpose)
                 o = Vox.empty(xv.batch, xv.dims, cin, gy.device, dtype=gyv.buf.dtype)
-                if o.cs != cin:
-                    o.buf.zero_()
                 _conv(gyv, w.detach().float(), None, cin, K, o, stride=stride, dilation=dilation,
                       padding=padding, out_pos=xv.dims, cin=cout)
                 dx = o.ncdhw()

@@ -1055,17 +1055,20 @@ extern "C" int occd_dwconv2d_pool_nchw(const float* x, const float* w, const flo
 //          channel counts are not multiples of 4: 163 = 160 + 3 at the full-resolution level).
 __global__ void __launch_bounds__(256) upsample_cat_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ skip,
                                                                 float* __restrict__ out, int C, int Cs, int h, int w, int H,
-                                                                int W, float rh, float rw, long total) {
+                                                                int W, float rh, float rw, long total, int ct) {
+    // ct: floats per output row (>= C + Cs; the pad lanes are written as zeros -- round 6: rows of ceil8(C + Cs) floats are what
+    // the convolution kernels take in place, 163 channels in rows of 168 at the full-resolution level)
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int ct = C + Cs;
     const int c = (int)(i % ct);
     long t = i / ct;
     const int ox = (int)(t % W); t /= W;
     const int oy = (int)(t % H);
     const int b = (int)(t / H);
     float v;
-    if (c >= C) {
+    if (c >= C + Cs) {
+        v = 0.f;
+    } else if (c >= C) {
         v = skip[(((size_t)b * H + oy) * W + ox) * Cs + (c - C)];
     } else {
         const float sy = rh * oy;
@@ -1139,17 +1142,28 @@ extern "C" int occd_upsample_bilinear_cat_nchw(const float* x, const float* skip
     return occd::check_launch();
 }
 
+extern "C" int occd_upsample_bilinear_cat_nhwc_rows(const float* x, const float* skip, float* out, int32_t batch, int32_t C,
+                                                    int32_t Cskip, int32_t h, int32_t w, int32_t H, int32_t W, int32_t out_cs,
+                                                    void* stream);
 extern "C" int occd_upsample_bilinear_cat_nhwc(const float* x, const float* skip, float* out, int32_t batch, int32_t C,
                                                int32_t Cskip, int32_t h, int32_t w, int32_t H, int32_t W, void* stream) {
-    if (!x || !out || batch <= 0 || C <= 0 || Cskip < 0 || (Cskip > 0 && !skip) || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+    return occd_upsample_bilinear_cat_nhwc_rows(x, skip, out, batch, C, Cskip, h, w, H, W, C + Cskip, stream);
+}
+
+// the same with output rows of out_cs >= C + Cskip floats (pad lanes zeroed)
+extern "C" int occd_upsample_bilinear_cat_nhwc_rows(const float* x, const float* skip, float* out, int32_t batch, int32_t C,
+                                                    int32_t Cskip, int32_t h, int32_t w, int32_t H, int32_t W, int32_t out_cs,
+                                                    void* stream) {
+    if (!x || !out || batch <= 0 || C <= 0 || Cskip < 0 || (Cskip > 0 && !skip) || h <= 0 || w <= 0 || H <= 0 || W <= 0 ||
+        out_cs < C + Cskip)
         return OCCD_EINVAL;
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const long total = (long)batch * H * W * (C + Cskip);
+    const long total = (long)batch * H * W * out_cs;
     occd::ProfScope prof("upsample_cat_nhwc", (hipStream_t)stream, 0.0,
                          4.0 * batch * ((double)C * h * w + 2.0 * Cskip * H * W + (double)C * H * W));
     hipLaunchKernelGGL(upsample_cat_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       skip, out, C, Cskip, h, w, H, W, rh, rw, total);
+                       skip, out, C, Cskip, h, w, H, W, rh, rw, total, (int)out_cs);
     return occd::check_launch();
 }
 

@@ -200,6 +200,7 @@ EXPORTS = {
                                          c_int32, c_void_p]),
     "occd_conv3d_bf16_fwd": (c_int32, [POINTER(Conv3dArgs), c_int32, c_void_p]),
     "occd_upsample_bilinear_cat_nhwc": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "occd_upsample_bilinear_cat_nhwc_rows": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p]),
     "occd_upsample_bilinear_nhwc_bwd": (c_int32, [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
     "occd_pack_weights_gather": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64,
                                            c_void_p, c_void_p]),
@@ -1626,22 +1627,29 @@ class _UpCatClFn(torch.autograd.Function):
         Cs, H, W = skip.shape[1], skip.shape[2], skip.shape[3]
         xr = x.detach().float().permute(0, 2, 3, 1).contiguous()
         sr = skip.detach().float().permute(0, 2, 3, 1).contiguous()
-        out = torch.empty((B, H, W, C + Cs), device=x.device, dtype=torch.float32)
-        _check(load().occd_upsample_bilinear_cat_nhwc(_f32(xr, "x"), _f32(sr, "skip"), _f32(out, "out"), B, C, Cs, h, w, H, W,
-                                                      _stream()), "occd_upsample_bilinear_cat_nhwc")
+        # rows of ceil8(C + Cs) floats, pads zeroed by the kernel: the level's first convolution takes them in place
+        # (autograd3d._padded_rows) -- a dense (B, H, W, 163) result cost a 1.2 GB strided copy into padded rows per step
+        cs = round_up(C + Cs, 8)
+        out = torch.empty((B, H, W, cs), device=x.device, dtype=torch.float32)
+        _check(load().occd_upsample_bilinear_cat_nhwc_rows(_f32(xr, "x"), _f32(sr, "skip"), _f32(out, "out"), B, C, Cs, h, w, H, W,
+                                                           cs, _stream()), "occd_upsample_bilinear_cat_nhwc_rows")
         ctx.geom = (B, C, Cs, h, w, H, W)
-        return out.permute(0, 3, 1, 2)
+        return out[..., :C + Cs].permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g):
         B, C, Cs, h, w, H, W = ctx.geom
         gr = g.float().permute(0, 2, 3, 1)
-        if not gr.is_contiguous():
+        # dense rows, or rows on a pitch (the data gradient of the level's first convolution comes back as (B, H, W, ceil8(C +
+        # Cs)) rows: a .contiguous() here was a 1.2 GB copy per step) -- the kernel takes the pitch
+        gcs = gr.stride(2)
+        if not (gr.stride(3) == 1 and gcs >= C + Cs and gr.stride(1) == W * gcs and (B == 1 or gr.stride(0) == H * W * gcs)):
             gr = gr.contiguous()
+            gcs = C + Cs
         gx = gs = None
         if ctx.needs_input_grad[0]:
             gxr = torch.empty((B, h, w, C), device=g.device, dtype=torch.float32)
-            _check(load().occd_upsample_bilinear_nhwc_bwd(_f32(gr, "gout"), _f32(gxr, "gx"), B, C, C + Cs, h, w, H, W,
+            _check(load().occd_upsample_bilinear_nhwc_bwd(gr.data_ptr(), _f32(gxr, "gx"), B, C, gcs, h, w, H, W,
                                                           _stream()), "occd_upsample_bilinear_nhwc_bwd")
             gx = gxr.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:

@@ -252,3 +252,34 @@ def test_head_conv_forward_and_dgrad_take_k2s3_in_fp32_training_mode(d, hip_lib)
     for got, ref, what in ((y, yr, "y"), (x.grad, xr.grad, "dx"), (conv.weight.grad, wr.grad, "dw")):
         err = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
         assert err < 2e-5, (d, what, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("name", ["classes", "wide", "nyu_p5_s2", "nyu_p5_s2x", "nyu_20_5", "nyu_head", "k3_s2_p0"])
+def test_forward_and_data_gradient_write_their_own_zero_pads_gpu(name, bf16, hip_lib):
+    """Round 6: `_Conv3dFn.forward`, `conv3d_dgrad` and the transposed convolution's backward no longer memset their padded output
+    rows (1.1 GB per config-2 training step) -- every row a launch stores carries zero pad lanes, and the sub-pixel phases of a
+    strided data gradient store every row between them.  Checked on buffers the allocator hands back full of NaN."""
+    from occdepth_amd import hip
+    cin, cout, k, s, p, d, dims, bias = CONV_CASES[name]
+    x, w, b = conv_tensors(name)
+    old = ag.set_bf16_mfma(bf16)
+    try:
+        for _ in range(2):                                         # (the caching allocator recycles these blocks for the outputs)
+            junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(4)]
+            del junk
+        y = ag._Conv3dFn.apply(x.cuda(), w.cuda(), b.cuda() if b is not None else None, s, p, d)
+        rows = y._base if y._base is not None else y
+        assert rows.shape[-1] == hip.round_up(cout, 8) and bool(torch.isfinite(rows).all())
+        if rows.shape[-1] > cout:
+            assert float(rows[..., cout:].abs().max()) == 0.0
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(4)]
+        del junk
+        dx = ag.conv3d_dgrad(ag._to_vox(gy), w.cuda(), tuple(dims), s, p, d)
+        assert bool(torch.isfinite(dx.buf).all())
+        if dx.cs > cin:
+            assert float(dx.buf[..., cin:].abs().max()) == 0.0
+    finally:
+        ag.set_bf16_mfma(old)
