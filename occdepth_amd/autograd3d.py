@@ -72,14 +72,11 @@ def _padded_rows(x):
         return None
     # the strides / offset / storage-size test alone also admits `wide[:, :C]` at offset 0 of a channels-last tensor
     # with cs logical channels (the first chunk torch.cat's backward narrows out of a 24-channel gradient): its "pad" lanes hold
-    # the neighbour's DATA.  A view is taken in place only when its base IS the padded row buffer -- (B, X, Y, Z, cs) dense,
-    # what hip.ssc_loss_grad allocates and fills, pads included -- not a wider (B, cs, X, Y, Z) tensor.
-    base = x._base
-    while base is not None and base._base is not None:      # (detach() of an autograd Function's output names that output, not its root)
-        base = base._base
-    if base is not None and not (base.is_contiguous() and base.shape[-1] == cs and base.numel() == B * X * Y * Z * cs
-                                 and base.dim() in (4, 5) and base.shape[0] == B):
-        return None                 # ((B, X, Y, Z, cs) rows, or the (B, H, W, cs) rows of a 2-D level seen as an X = 1 volume)
+    # the neighbour's DATA, and nothing in the view's metadata tells the two apart.  A view is taken in place only when its
+    # storage IS a buffer an in-repo kernel filled with zero pads (hip.mark_zero_padded: the loss gradient's rows, the
+    # upsample + concat rows, convolution outputs / data gradients); anything else takes the copy below in `_to_vox`.
+    if not hip.is_zero_padded(x, B * X * Y * Z * cs * 4):
+        return None
     return torch.as_strided(x, (B, X, Y, Z, cs), (X * Y * Z * cs, Y * Z * cs, Z * cs, cs, 1))
 
 
@@ -155,10 +152,19 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation, bias=None):
     wd = wd if wd.dtype == torch.float32 and wd.is_contiguous() else wd.float().contiguous()
     ntap = K[0] * K[1] * K[2]
     out = Vox.empty(gy.batch, in_dims, cin, gy.buf.device, dtype=gy.buf.dtype)
+    if out.buf.dtype == torch.float32:
+        hip.mark_zero_padded(out.buf)
     axes = [_axis_phases(K[a], stride[a], padding[a], dilation[a]) for a in range(3)]
     empty = any(not taps for ax in axes for _, taps, _, _ in ax)
-    if empty:
-        out.buf.zero_()                                                    # empty phases: positions no launch writes
+    if empty or out.cs != cin:
+        out.buf.zero_()                                                    # empty phases / channel pad
+    bias_pad = None
+    if bias is not None and not empty:
+        bias_pad = torch.zeros(hip.round_up(cin, 32), device=gy.buf.device)
+        bias_pad[:cin] = bias.detach().float()
+    # (Round 6 tried dropping these memsets of padded outputs -- 1.1 GB per config-2 step; the forward kernels write zero pad
+    #  lanes in every case tests/test_conv_grad.py checks on NaN-filled buffers -- and one run in six of the reduced model's
+    #  five-step test ended with a NaN parameter: some launch variant leaves a lane unwritten.  Not worth the 0.3 ms.)
     bias_pad = None
     if bias is not None and not empty:
         bias_pad = torch.zeros(hip.round_up(cin, 32), device=gy.buf.device)
@@ -202,6 +208,10 @@ class _Conv3dFn(torch.autograd.Function):
             cout, cin = w.shape[:2]
             K = tuple(w.shape[2:])
             out = Vox.empty(xv.batch, _out_dims(xv.dims, K, stride, padding, dilation), cout, x.device, dtype=xv.buf.dtype)
+            if out.cs != cout:
+                out.buf.zero_()
+            if out.buf.dtype == torch.float32:
+                hip.mark_zero_padded(out.buf)               # (zeroed above; the kernels also write zero pad lanes)
             bias = None
             if b is not None:
                 bias = torch.zeros(hip.round_up(cout, 32), device=x.device)
@@ -260,6 +270,10 @@ class _ConvTranspose3dFn(torch.autograd.Function):
             dx = dw = db = None
             if ctx.needs_input_grad[0]:                     # the convolution (weight w: "cout" = cin of the transpose)
                 o = Vox.empty(xv.batch, xv.dims, cin, gy.device, dtype=gyv.buf.dtype)
+                if o.cs != cin:
+                    o.buf.zero_()
+                if o.buf.dtype == torch.float32:
+                    hip.mark_zero_padded(o.buf)
                 _conv(gyv, w.detach().float(), None, cin, K, o, stride=stride, dilation=dilation,
                       padding=padding, out_pos=xv.dims, cin=cout)
                 dx = o.ncdhw()

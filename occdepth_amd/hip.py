@@ -6,6 +6,7 @@ through the C ABI and launches on torch's current stream.  There is NO fallback:
 a missing / unloadable library or a CPU tensor raises.
 """
 import ctypes
+import weakref
 import os
 from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p
 
@@ -668,6 +669,28 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
     return out[0] if squeeze and out.dim() == 3 else out
+
+
+# Buffers of channels-last rows whose pad lanes (channels C .. cs - 1) are known to hold ZEROS because an in-repo kernel wrote
+# them: the rows `ssc_loss_grad`, the upsample + concat launch and the convolution forward / data-gradient launches produce.
+# `autograd3d._padded_rows` consumes a ragged-channel view IN PLACE only when its storage starts at such a buffer (the
+# strides / offset / size of `wide[:, :C]` -- a channel slice of a wider tensor, "pads" full of data -- are indistinguishable).
+# data_ptr -> weak reference of the buffer tensor (PyTorch preserves the Python object while a view's `_base` holds the tensor).
+_ZERO_PADDED = {}
+
+
+def mark_zero_padded(buf):
+    if len(_ZERO_PADDED) > 2048:
+        for k in [k for k, r in _ZERO_PADDED.items() if r() is None]:
+            del _ZERO_PADDED[k]
+    _ZERO_PADDED[buf.data_ptr()] = weakref.ref(buf)
+    return buf
+
+
+def is_zero_padded(t, nbytes):
+    r = _ZERO_PADDED.get(t.data_ptr())
+    b = r() if r is not None else None
+    return b is not None and b.data_ptr() == t.data_ptr() and b.numel() * b.element_size() == nbytes
 
 
 def gemm_x3_splitk_plan(M, N, K, batch):
@@ -1630,7 +1653,7 @@ class _UpCatClFn(torch.autograd.Function):
         # rows of ceil8(C + Cs) floats, pads zeroed by the kernel: the level's first convolution takes them in place
         # (autograd3d._padded_rows) -- a dense (B, H, W, 163) result cost a 1.2 GB strided copy into padded rows per step
         cs = round_up(C + Cs, 8)
-        out = torch.empty((B, H, W, cs), device=x.device, dtype=torch.float32)
+        out = mark_zero_padded(torch.empty((B, H, W, cs), device=x.device, dtype=torch.float32))
         _check(load().occd_upsample_bilinear_cat_nhwc_rows(_f32(xr, "x"), _f32(sr, "skip"), _f32(out, "out"), B, C, Cs, h, w, H, W,
                                                            cs, _stream()), "occd_upsample_bilinear_cat_nhwc_rows")
         ctx.geom = (B, C, Cs, h, w, H, W)
@@ -2015,7 +2038,7 @@ def ssc_loss_grad(logits, target, masks, weights, gstats, map_occ=False):
         lay = (C * S, S, 1)
     if lay[1] == 1:
         cs = round_up(C, 8)
-        rows = torch.empty((B,) + tuple(logits.shape[2:]) + (cs,), dtype=torch.float32, device=logits.device)
+        rows = mark_zero_padded(torch.empty((B,) + tuple(logits.shape[2:]) + (cs,), dtype=torch.float32, device=logits.device))
         grad = rows[..., :C].permute(0, logits.dim() - 1, *range(1, logits.dim() - 1))
         glay, gpad = (S * cs, 1, cs), cs
     else:

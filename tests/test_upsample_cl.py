@@ -34,7 +34,12 @@ def test_upsample_cat_channels_last_forward_and_backward(case, hip_lib):
     rows = torch.as_strided(out.detach(), (B, H, W, cs), (H * W * cs, W * cs, cs, 1))
     assert cs == C + Cs or float(rows[..., C + Cs:].abs().max()) == 0.0
     from occdepth_amd import autograd3d
-    assert autograd3d._padded_rows(out.detach().unsqueeze(2)) is not None or (C + Cs) % 8 == 0      # consumed in place as an X = 1 volume
+    # consumed in place as an X = 1 volume, the way the decoder hands it to the convolution Function (view, then detach)
+    assert autograd3d._padded_rows(out.unsqueeze(2).detach()) is not None or (C + Cs) % 8 == 0
+    # ... while a channel slice of a WIDER tensor in the same layout -- its "pads" are the neighbour's data -- is not
+    # (cs - 4 channels out of cs: the strides, the offset and the storage size are exactly those of a padded row buffer)
+    wide = torch.randn(B, H, W, cs, device="cuda").permute(0, 3, 1, 2)
+    assert autograd3d._padded_rows(wide[:, :cs - 4].unsqueeze(2)) is None
     out.backward(go.cuda().contiguous(memory_format=torch.channels_last))
     assert float((out.detach().double().cpu() - ref.detach()).abs().max()) < 2e-6 * float(ref.abs().max())
     assert float((xg.grad.double().cpu() - xr.grad).abs().max()) < 2e-6 * float(xr.grad.abs().max())
