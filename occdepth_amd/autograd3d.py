@@ -72,10 +72,10 @@ def _padded_rows(x):
         return None
     # the strides / offset / storage-size test alone also admits `wide[:, :C]` at offset 0 of a channels-last tensor
     # with cs logical channels (the first chunk torch.cat's backward narrows out of a 24-channel gradient): its "pad" lanes hold
-    # the neighbour's DATA, and nothing in the view's metadata tells the two apart.  A view is taken in place only when its
-    # storage IS a buffer an in-repo kernel filled with zero pads (hip.mark_zero_padded: the loss gradient's rows, the
-    # upsample + concat rows, convolution outputs / data gradients); anything else takes the copy below in `_to_vox`.
-    if not hip.is_zero_padded(x, B * X * Y * Z * cs * 4):
+    # the neighbour's DATA.  A view is taken in place only when its base IS the padded row buffer -- (B, X, Y, Z, cs) dense,
+    # what hip.ssc_loss_grad allocates and fills, pads included -- not a wider (B, cs, X, Y, Z) tensor.
+    base = x._base
+    if base is not None and not (base.dim() == 5 and tuple(base.shape) == (B, X, Y, Z, cs) and base.is_contiguous()):
         return None
     return torch.as_strided(x, (B, X, Y, Z, cs), (X * Y * Z * cs, Y * Z * cs, Z * cs, cs, 1))
 
@@ -96,16 +96,16 @@ def _conv(x, w, bias, cout, kernel, out, **kw):
     return hip.conv3d(x, hip.pack_weights(w), bias, cout, kernel, out, **kw)
 
 
-def _conv_view(x, w, n_out, n_in, s_out, s_in, tap_ofs, kernel, out, bias=None, **kw):
+def _conv_view(x, w, n_out, n_in, s_out, s_in, tap_ofs, kernel, out, **kw):
     """Forward-kernel launch whose operator is a VIEW of the dense weight `w` (hip.pack_weights_gather): no permute /
-    index_select / contiguous temporaries.  bias: per-output-channel floats padded to a multiple of 32, or None."""
+    index_select / contiguous temporaries."""
     if BF16_MFMA:
-        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16=True), bias, n_out,
+        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16=True), None, n_out,
                                kernel, out, **kw)
     if _x3_head(x, n_out, kernel, out, kw):
-        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16="x3"), bias, n_out,
+        return hip.conv3d_bf16(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel, bf16="x3"), None, n_out,
                                kernel, out, split3=True, **kw)
-    return hip.conv3d(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel), bias, n_out, kernel, out, **kw)
+    return hip.conv3d(x, hip.pack_weights_gather(w, n_out, n_in, s_out, s_in, tap_ofs, kernel), None, n_out, kernel, out, **kw)
 
 
 def _wgrad(x, gy, cin, cout, K, stride, dilation, padding):
@@ -142,36 +142,17 @@ def _axis_phases(K, s, p, d):
     return out
 
 
-def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation, bias=None):
-    """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz).
-    bias (cin floats, or None): added to every output position -- the forward of a ConvTranspose3d with a bias; it rides in the
-    phase launches' epilogues (every position belongs to exactly one phase), a separate pass only when a phase has no tap."""
+def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation):
+    """dL/dx (Vox, (B, in_dims, cin)) of y = conv3d(x, w) given gy = dL/dy (Vox).  w: (cout, cin, kx, ky, kz)."""
     cout, cin = w.shape[:2]
     K = tuple(w.shape[2:])
     wd = w.detach()
     wd = wd if wd.dtype == torch.float32 and wd.is_contiguous() else wd.float().contiguous()
     ntap = K[0] * K[1] * K[2]
     out = Vox.empty(gy.batch, in_dims, cin, gy.buf.device, dtype=gy.buf.dtype)
-    if out.buf.dtype == torch.float32:
-        hip.mark_zero_padded(out.buf)
     axes = [_axis_phases(K[a], stride[a], padding[a], dilation[a]) for a in range(3)]
-    empty = any(not taps for ax in axes for _, taps, _, _ in ax)
-    if empty or out.cs != cin:
+    if any(not taps for ax in axes for _, taps, _, _ in ax) or out.cs != cin:
         out.buf.zero_()                                                    # empty phases / channel pad
-    bias_pad = None
-    if bias is not None and not empty:
-        bias_pad = torch.zeros(hip.round_up(cin, 32), device=gy.buf.device)
-        bias_pad[:cin] = bias.detach().float()
-    # (Round 6 tried dropping these memsets of padded outputs -- 1.1 GB per config-2 step; the forward kernels write zero pad
-    #  lanes in every case tests/test_conv_grad.py checks on NaN-filled buffers -- and one run in six of the reduced model's
-    #  five-step test ended with a NaN parameter: some launch variant leaves a lane unwritten.  Not worth the 0.3 ms.)
-    bias_pad = None
-    if bias is not None and not empty:
-        bias_pad = torch.zeros(hip.round_up(cin, 32), device=gy.buf.device)
-        bias_pad[:cin] = bias.detach().float()
-    # (the channel pad needs no memset: every forward kernel writes the pad lanes of the rows it stores as zeros -- asserted by
-    #  tests/test_hip_vs_aten.py, test_bf16_conv.py and test_conv_grad.py -- and the phases together store every row; the
-    #  memsets here and in the two Functions below were 1.1 GB per config-2 step)
     for (rx, tx, dx_, px), (ry, ty, dy_, py), (rz, tz, dz_, pz) in itertools.product(*axes):
         if not (tx and ty and tz):
             continue
@@ -181,10 +162,8 @@ def conv3d_dgrad(gy, w, in_dims, stride, padding, dilation, bias=None):
         # the transposed operator of this phase, W'[ci][co][a, b, c] = w[co][ci][tx[a], ty[b], tz[c]], packed straight
         # from w (one launch; the permute + 3 index_select + contiguous chain was 5 launches per phase)
         ofs = [(a * K[1] + b_) * K[2] + c for a in tx for b_ in ty for c in tz]
-        _conv_view(gy, wd, cin, cout, ntap, cin * ntap, ofs, (len(tx), len(ty), len(tz)), out, bias=bias_pad,
-                   dilation=(dx_, dy_, dz_), padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
-    if bias is not None and empty:
-        out.buf[..., out.coff:out.coff + cin] += bias.detach().to(out.buf.dtype)
+        _conv_view(gy, wd, cin, cout, ntap, cin * ntap, ofs, (len(tx), len(ty), len(tz)), out, dilation=(dx_, dy_, dz_),
+                   padding=(px, py, pz), out_pos=n_pos, o_stride=tuple(stride), o_off=(rx, ry, rz), cin=cout)
     return out
 
 
@@ -210,8 +189,6 @@ class _Conv3dFn(torch.autograd.Function):
             out = Vox.empty(xv.batch, _out_dims(xv.dims, K, stride, padding, dilation), cout, x.device, dtype=xv.buf.dtype)
             if out.cs != cout:
                 out.buf.zero_()
-            if out.buf.dtype == torch.float32:
-                hip.mark_zero_padded(out.buf)               # (zeroed above; the kernels also write zero pad lanes)
             bias = None
             if b is not None:
                 bias = torch.zeros(hip.round_up(cout, 32), device=x.device)
@@ -251,9 +228,10 @@ class _ConvTranspose3dFn(torch.autograd.Function):
             K = tuple(w.shape[2:])
             dims = tuple((n - 1) * s - 2 * p + d * (k - 1) + op + 1
                          for n, k, s, p, d, op in zip(xv.dims, K, stride, padding, dilation, output_padding))
-            # (the bias in the phase launches' epilogues: `y + b` as a separate pass was 0.8 GB per step at the full-resolution level)
-            out = conv3d_dgrad(xv, w.detach().float(), dims, stride, padding, dilation, bias=b)
+            out = conv3d_dgrad(xv, w.detach().float(), dims, stride, padding, dilation)
             y = out.ncdhw()
+            if b is not None:
+                y = y + b.detach().to(y.dtype).view(1, -1, 1, 1, 1)
         ctx.save_for_backward(xv.buf, w)
         ctx.geom = (xv.C, xv.coff, stride, padding, dilation, b is not None)
         return y
@@ -272,8 +250,6 @@ class _ConvTranspose3dFn(torch.autograd.Function):
                 o = Vox.empty(xv.batch, xv.dims, cin, gy.device, dtype=gyv.buf.dtype)
                 if o.cs != cin:
                     o.buf.zero_()
-                if o.buf.dtype == torch.float32:
-                    hip.mark_zero_padded(o.buf)
                 _conv(gyv, w.detach().float(), None, cin, K, o, stride=stride, dilation=dilation,
                       padding=padding, out_pos=xv.dims, cin=cout)
                 dx = o.ncdhw()

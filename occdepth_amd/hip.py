@@ -6,7 +6,6 @@ through the C ABI and launches on torch's current stream.  There is NO fallback:
 a missing / unloadable library or a CPU tensor raises.
 """
 import ctypes
-import weakref
 import os
 from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int32, c_int64, c_uint8, c_void_p
 
@@ -669,28 +668,6 @@ def gemm_x3(a, b, bias=None, act=None, slope=0.01, out=None, tile_hint=0, plain_
         set_tag("%dx%dx%d b%d" % (M, N, K, batch))
     _check(load().occd_gemm_f32x3(ctypes.byref(q), _stream()), "occd_gemm_f32x3")
     return out[0] if squeeze and out.dim() == 3 else out
-
-
-# Buffers of channels-last rows whose pad lanes (channels C .. cs - 1) are known to hold ZEROS because an in-repo kernel wrote
-# them: the rows `ssc_loss_grad`, the upsample + concat launch and the convolution forward / data-gradient launches produce.
-# `autograd3d._padded_rows` consumes a ragged-channel view IN PLACE only when its storage starts at such a buffer (the
-# strides / offset / size of `wide[:, :C]` -- a channel slice of a wider tensor, "pads" full of data -- are indistinguishable).
-# data_ptr -> weak reference of the buffer tensor (PyTorch preserves the Python object while a view's `_base` holds the tensor).
-_ZERO_PADDED = {}
-
-
-def mark_zero_padded(buf):
-    if len(_ZERO_PADDED) > 2048:
-        for k in [k for k, r in _ZERO_PADDED.items() if r() is None]:
-            del _ZERO_PADDED[k]
-    _ZERO_PADDED[buf.data_ptr()] = weakref.ref(buf)
-    return buf
-
-
-def is_zero_padded(t, nbytes):
-    r = _ZERO_PADDED.get(t.data_ptr())
-    b = r() if r is not None else None
-    return b is not None and b.data_ptr() == t.data_ptr() and b.numel() * b.element_size() == nbytes
 
 
 def gemm_x3_splitk_plan(M, N, K, batch):
@@ -1650,29 +1627,22 @@ class _UpCatClFn(torch.autograd.Function):
         Cs, H, W = skip.shape[1], skip.shape[2], skip.shape[3]
         xr = x.detach().float().permute(0, 2, 3, 1).contiguous()
         sr = skip.detach().float().permute(0, 2, 3, 1).contiguous()
-        # rows of ceil8(C + Cs) floats, pads zeroed by the kernel: the level's first convolution takes them in place
-        # (autograd3d._padded_rows) -- a dense (B, H, W, 163) result cost a 1.2 GB strided copy into padded rows per step
-        cs = round_up(C + Cs, 8)
-        out = mark_zero_padded(torch.empty((B, H, W, cs), device=x.device, dtype=torch.float32))
-        _check(load().occd_upsample_bilinear_cat_nhwc_rows(_f32(xr, "x"), _f32(sr, "skip"), _f32(out, "out"), B, C, Cs, h, w, H, W,
-                                                           cs, _stream()), "occd_upsample_bilinear_cat_nhwc_rows")
+        out = torch.empty((B, H, W, C + Cs), device=x.device, dtype=torch.float32)
+        _check(load().occd_upsample_bilinear_cat_nhwc(_f32(xr, "x"), _f32(sr, "skip"), _f32(out, "out"), B, C, Cs, h, w, H, W,
+                                                      _stream()), "occd_upsample_bilinear_cat_nhwc")
         ctx.geom = (B, C, Cs, h, w, H, W)
-        return out[..., :C + Cs].permute(0, 3, 1, 2)
+        return out.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, g):
         B, C, Cs, h, w, H, W = ctx.geom
         gr = g.float().permute(0, 2, 3, 1)
-        # dense rows, or rows on a pitch (the data gradient of the level's first convolution comes back as (B, H, W, ceil8(C +
-        # Cs)) rows: a .contiguous() here was a 1.2 GB copy per step) -- the kernel takes the pitch
-        gcs = gr.stride(2)
-        if not (gr.stride(3) == 1 and gcs >= C + Cs and gr.stride(1) == W * gcs and (B == 1 or gr.stride(0) == H * W * gcs)):
+        if not gr.is_contiguous():
             gr = gr.contiguous()
-            gcs = C + Cs
         gx = gs = None
         if ctx.needs_input_grad[0]:
             gxr = torch.empty((B, h, w, C), device=g.device, dtype=torch.float32)
-            _check(load().occd_upsample_bilinear_nhwc_bwd(gr.data_ptr(), _f32(gxr, "gx"), B, C, gcs, h, w, H, W,
+            _check(load().occd_upsample_bilinear_nhwc_bwd(_f32(gr, "gout"), _f32(gxr, "gx"), B, C, C + Cs, h, w, H, W,
                                                           _stream()), "occd_upsample_bilinear_nhwc_bwd")
             gx = gxr.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
@@ -2038,7 +2008,7 @@ def ssc_loss_grad(logits, target, masks, weights, gstats, map_occ=False):
         lay = (C * S, S, 1)
     if lay[1] == 1:
         cs = round_up(C, 8)
-        rows = mark_zero_padded(torch.empty((B,) + tuple(logits.shape[2:]) + (cs,), dtype=torch.float32, device=logits.device))
+        rows = torch.empty((B,) + tuple(logits.shape[2:]) + (cs,), dtype=torch.float32, device=logits.device)
         grad = rows[..., :C].permute(0, logits.dim() - 1, *range(1, logits.dim() - 1))
         glay, gpad = (S * cs, 1, cs), cs
     else:

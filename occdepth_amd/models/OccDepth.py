@@ -577,10 +577,8 @@ class OccDepth(_Base):
         use_fp = self.fp_loss and step_type != "test"
         masks = dists = None
         if use_fp:
-            fm, fd = list(batch["frustums_masks"]), list(batch["frustums_class_dists"])
-            # (one frame per GPU -- the reference's batch -- needs no stacking copy: 268 MB of masks per step at config 2)
-            masks = (fm[0].unsqueeze(0) if len(fm) == 1 else torch.stack(fm)).to(dev)
-            dists = (fd[0].unsqueeze(0) if len(fd) == 1 else torch.stack(fd)).float().to(dev)
+            masks = torch.stack(list(batch["frustums_masks"])).to(dev)
+            dists = torch.stack(list(batch["frustums_class_dists"])).float().to(dev)
         terms = ssc_loss.ssc_losses(ssc_pred, target, self._on_device("class_weights", dev), masks, dists,
                                     ce=self.CE_ssc_loss, sem_scal=self.sem_scal_loss, geo_scal=self.geo_scal_loss)
         if self.CE_ssc_loss:

@@ -73,11 +73,9 @@ class _DilatedBranches(nn.Module):
         for i, (c1, b1, c2, b2) in enumerate(zip(self.conv1, self.bn1, self.conv2, self.bn2)):
             t = c2(bn_act(b1, c1(x), "relu"))
             if i < last:
-                # (the block input rides in the FIRST branch's fused pass: `y + x` as a separate pass over the full-resolution
-                #  head tensor was 0.8 GB per step; the sum is the reference's up to the order of its float32 additions)
-                y = bn_act(b2, t, res=x if y is None else y)
+                y = bn_act(b2, t, res=y)
             else:
-                y = bn_act(b2, t, "relu", res=x if y is None else y, res_first=True)
+                y = bn_act(b2, t, "relu", res=x if y is None else y + x, res_first=True)
         return y
 
 

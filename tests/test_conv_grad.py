@@ -285,28 +285,3 @@ def test_forward_and_data_gradient_write_their_own_zero_pads_gpu(name, bf16, hip
     finally:
         ag.set_bf16_mfma(old)
 
-
-def test_padded_rows_only_from_buffers_marked_as_zero_padded():
-    """`_padded_rows` used to accept ANY float32 view with the strides / offset / storage size of a padded row
-    buffer -- also `wide[:, :C]`, a channel slice of a wider channels-last tensor whose "pads" are the neighbour's data.  Now the
-    storage must be a buffer an in-repo kernel filled (hip.mark_zero_padded); views, detached aliases and X = 1 volumes of a 2-D
-    level qualify, an unmarked look-alike does not, and the mark dies with the buffer."""
-    import gc
-    from occdepth_amd import hip
-
-    def produce():
-        rows = hip.mark_zero_padded(torch.zeros(2, 3, 4, 5, 24))
-        return rows[..., :20].permute(0, 4, 1, 2, 3)
-    g = produce()
-    gc.collect()
-    assert ag._padded_rows(g) is not None and ag._padded_rows(g.detach()) is not None
-    assert tuple(ag._padded_rows(g).shape) == (2, 3, 4, 5, 24)
-    look_alike = torch.randn(2, 3, 4, 5, 24).permute(0, 4, 1, 2, 3)[:, :20]
-    assert look_alike.stride() == g.stride() and ag._padded_rows(look_alike) is None
-    flat = hip.mark_zero_padded(torch.zeros(2, 7, 9, 168))                       # a 2-D level: (B, H, W, cs) rows
-    assert ag._padded_rows(flat[..., :163].permute(0, 3, 1, 2).unsqueeze(2).detach()) is not None
-    assert ag._padded_rows(g[:, :12]) is None                                    # a slice of a marked buffer: other strides
-    ptr = g.data_ptr()
-    del g
-    gc.collect()
-    assert hip._ZERO_PADDED[ptr]() is None
