@@ -203,7 +203,39 @@ class OccDepth(_Base):
         self._drop_graphs()
         return super().load_state_dict(*a, **k)
 
-    def _net_rgb_graphed(self, x):
+    # Round 6 experiment (OCCDEPTH_DEPTHNET_OVERLAP=1): FLoSP-Depth's DepthNet (seven 3x3 convolutions + gate + softmax on the 1/8
+    # map: ~0.45 ms of 120-workgroup launches) only needs the 1/8 feature, which the decoder has after its second level; started
+    # on a side stream there, it runs beside the 1/4, 1/2 and 1/1 levels (~5 ms of chip-filling launches) instead of after them.
+    # Captured into the whole-forward hipGraph as a parallel branch (fork = the decoder's callback, join = in front of the lift).
+    depthnet_overlap = os.environ.get("OCCDEPTH_DEPTHNET_OVERLAP", "0") == "1"
+
+    def _depthnet_hook(self, batch, img, bs, n_views):
+        """The decoder callback that launches `_depth_volume` early, or None when the conditions of the fused eval lift (the only
+        consumer of a deferred frustum) do not hold."""
+        if not (self.depthnet_overlap and self.trans_2d_to_3d == "flosp_depth" and self.dataset == "kitti" and img.is_cuda
+                and not needs_autograd(self)):
+            return None
+        if self._lift_calibration(batch, img, "projected_pix_{}".format(self.project_scale)) is None:
+            return None
+        layer = "1_{}".format(self.flosp_depth_conf["downsample_factor"])
+        want = int(self.flosp_depth_conf["downsample_factor"])
+
+        def hook(s, feat):
+            if s != want:
+                return
+            cur = torch.cuda.current_stream(feat.device)
+            side = self.__dict__.get("_depth_stream")
+            if side is None or side.device != feat.device:
+                side = self.__dict__["_depth_stream"] = torch.cuda.Stream(device=feat.device)
+            side.wait_stream(cur)                              # fork: everything up to the 1/8 feature head
+            feat.record_stream(side)
+            with torch.cuda.stream(side):
+                views = feat.reshape(bs, n_views, *feat.shape[1:])
+                x_rgb = [{layer: views[:, i]} for i in range(n_views)]
+                self.__dict__["_early_depth"] = self._depth_volume(batch, x_rgb, None, defer_sample=True)
+        return hook
+
+    def _net_rgb_graphed(self, x, on_scale=None):
         """The 2-D network is ~1200 launches of mostly 5-40 us kernels: with `graph_2d` (opt-in, eval only) it is
         captured once per input shape into a hipGraph and replayed, so the host never gates the GPU there.  The 3-D
         stack stays outside (its launches are few, long, and individually timed by bench.py).  A captured graph holds
@@ -211,7 +243,8 @@ class OccDepth(_Base):
         every entry therefore carries a stamp of the network's tensors and is re-captured when it no longer matches
         (train(), load_state_dict() and device / dtype moves drop the cache outright)."""
         if not self.graph_2d or not x.is_cuda or torch.cuda.is_current_stream_capturing():
-            return self.net_rgb(x)                          # (inside the whole-forward capture the network is part of it)
+            # (inside the whole-forward capture the network is part of it)
+            return self.net_rgb(x) if on_scale is None else self.net_rgb(x, on_scale=on_scale)
         key = (tuple(x.shape), x.device)
         stamp = self._net_rgb_stamp()
         entry = self._graphs.get(key)
@@ -248,7 +281,9 @@ class OccDepth(_Base):
         if not needs_autograd(self) and self.batch_views and n_views > 1:
             # eval: BN uses running stats, so the views can share one batched pass (opt-in: a different
             # conv batch size changes backend algorithm choice and hence fp32 round-off)
-            both = self._net_rgb_graphed(img.reshape(bs * n_views, *img.shape[2:]))
+            self.__dict__.pop("_early_depth", None)
+            both = self._net_rgb_graphed(img.reshape(bs * n_views, *img.shape[2:]),
+                                         on_scale=self._depthnet_hook(batch, img, bs, n_views))
             x_rgb = [{k: v.reshape(bs, n_views, *v.shape[1:])[:, i] for k, v in both.items()}
                      for i in range(n_views)]
         elif self.training and self.batch_views_train and n_views > 1 and not self.share_2d_backbone_gradient:
@@ -352,7 +387,12 @@ class OccDepth(_Base):
             if cam is not None:
                 frustum = None
                 if self.trans_2d_to_3d == "flosp_depth":
-                    frustum, depth_pred = self._depth_volume(batch, x_rgb, vox_origin, defer_sample=True)
+                    early = self.__dict__.pop("_early_depth", None)
+                    if early is not None:                       # launched beside the decoder's fine levels: join here
+                        torch.cuda.current_stream(img.device).wait_stream(self.__dict__["_depth_stream"])
+                        frustum, depth_pred = early
+                    else:
+                        frustum, depth_pred = self._depth_volume(batch, x_rgb, vox_origin, defer_sample=True)
                 feats = [[x_rgb[v]["1_" + str(s)] for v in range(len(x_rgb))] for s in scales]
                 H, W = img.shape[-2:]
                 vox = lift_scales_proj(feats, scales, cam[0], cam[1], self._kitti_origin(batch), 0.2 * self.project_scale, (W, H),

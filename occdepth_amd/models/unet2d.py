@@ -251,7 +251,9 @@ class DecoderBN(nn.Module):
             return hip.matmul(w2d, fp.view(B, C, H * W), bias=self.conv2.bias.detach().float().contiguous()).view(B, -1, H, W)
         return F.conv2d(f, hit[1], self.conv2.bias, self.conv2.stride, pad)
 
-    def forward(self, features, merged_head=None):
+    def forward(self, features, merged_head=None, on_scale=None):
+        """on_scale(s, feature): optional callback right after the 1/s feature head has been launched (the caller may start work
+        that only needs that scale -- FLoSP-Depth's DepthNet on the 1/8 feature -- while the finer levels are still running)."""
         taps = {16: features[8], 8: features[6], 4: features[5], 2: features[4], 1: features[0]}
         cl_train = _ag.BF16_MFMA and features[0].is_cuda and needs_autograd(self)
         if merged_head is not None:
@@ -280,6 +282,8 @@ class DecoderBN(nn.Module):
                 res[f"1_{s}"] = _ag.conv2d_cl(x, head.weight, head.bias)       # pixel rows: what the lift gathers from
             else:
                 res[f"1_{s}"] = head(x)
+            if on_scale is not None:
+                on_scale(s, res[f"1_{s}"])
         return res
 
 
