@@ -312,9 +312,6 @@ __device__ __forceinline__ float softplus_f(float x) {       // log(1 + e^x), st
     return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
 }
 
-// Sign bit of a statistics word: "a non-finite value went into this sum" (the sums themselves stay far below 2^63).  ADVICE r5:
-// the fixed-point cast of Inf / NaN is undefined where the reference's loss propagates NaN.
-constexpr u64 kNonFiniteFlag = 1ull << 63;
 constexpr int kRelWalk = 16;     // elements of the walk axis per thread
 
 template <bool GRAD>
@@ -329,7 +326,6 @@ __global__ void __launch_bounds__(256) relation_bce_kernel(const RelP q) {
     const int il = lb * 256 + threadIdx.x;
     const int w0 = wb * kRelWalk, w1 = min(w0 + kRelWalk, n_walk);
     u64 cnt = 0, sp = 0, sn = 0;
-    bool bad = false;
     if (il < n_lane) {
         const long ls_lane = q.lane_is_n ? q.l_n : q.l_m, ls_walk = q.lane_is_n ? q.l_m : q.l_n;
         const long ys_lane = q.lane_is_n ? q.M : 1, ys_walk = q.lane_is_n ? 1 : q.M;     // labels (N, M): element (n, m) at n M + m
@@ -350,11 +346,7 @@ __global__ void __launch_bounds__(256) relation_bce_kernel(const RelP q) {
                 q.grad[lbase + (size_t)w * ls_walk] = y ? -cp * (1.f - sig) : cn * sig;
             } else {
                 const float v = softplus_f(y ? -x : x);
-                // a non-finite logit has no fixed-point image (the cast is undefined): the reference's loss is NaN / Inf then --
-                // flag it (sign bit of the relation's Spos word, below) and keep the sums defined; the host maps the flag to NaN
-                const bool fin = fabsf(v) <= 3.0e38f;
-                bad |= !fin;
-                const u64 f = fin ? (u64)((double)v * kQ24 + 0.5) : 0;
+                const u64 f = (u64)((double)v * kQ24 + 0.5);
                 if (y) { sp += f; cnt += 1; } else { sn += f; }
             }
         }
@@ -374,7 +366,6 @@ __global__ void __launch_bounds__(256) relation_bce_kernel(const RelP q) {
         }
         __syncthreads();
         if (threadIdx.x < 3 && sh[threadIdx.x]) atomicAdd(&q.stats[r * 3 + threadIdx.x], sh[threadIdx.x]);
-        if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&q.stats[r * 3 + 1], kNonFiniteFlag);
     }
 }
 
@@ -440,7 +431,6 @@ __global__ void __launch_bounds__(256) depth_bce_kernel(const DepthP q) {
     const long cells = (long)q.Bn * q.h * q.w;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     u64 loss = 0, cnt = 0;
-    bool bad = false;
     if (i < cells) {
         const int x = (int)(i % q.w);
         const long t = i / q.w;
@@ -462,13 +452,9 @@ __global__ void __launch_bounds__(256) depth_bce_kernel(const DepthP q) {
             for (int d = 0; d < q.D; ++d) {
                 const float pv = p[(size_t)d * hw];
                 // -(t log p + (1 - t) log(1 - p)), both logs clamped at -100 (F.binary_cross_entropy)
-                // (fmaxf returns the other operand for a NaN: a NaN probability must stay NaN like torch.clamp keeps it)
-                const float lg = d == kb ? logf(pv) : log1pf(-pv);
-                acc -= lg == lg ? fmaxf(lg, -100.f) : lg;
+                acc -= fmaxf(d == kb ? logf(pv) : log1pf(-pv), -100.f);
             }
-            const bool fin = fabsf(acc) <= 3.0e38f;        // (NaN probabilities: see relation_bce_kernel)
-            bad = !fin;
-            loss = fin ? (u64)((double)acc * kQ24 + 0.5) : 0;
+            loss = (u64)((double)acc * kQ24 + 0.5);
             cnt = 1;
         }
     }
@@ -484,7 +470,6 @@ __global__ void __launch_bounds__(256) depth_bce_kernel(const DepthP q) {
         }
         __syncthreads();
         if (threadIdx.x < 2 && sh[threadIdx.x]) atomicAdd(&q.stats[threadIdx.x], sh[threadIdx.x]);
-        if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&q.stats[0], kNonFiniteFlag);
     }
 }
 

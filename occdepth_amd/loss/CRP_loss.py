@@ -23,16 +23,12 @@ class _RelationBCE(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, logits, labels):
         B, R, M, N = logits.shape
-        raw = hip.relation_bce_stats(logits, labels)                     # (R, 3) int64: #pos, Spos, Sneg (Q24)
-        # sign bit of Spos = "a non-finite logit entered this relation's sums" (csrc/loss.hip): the reference's loss is NaN
-        # then; the bit is masked out of the sum and turned into a NaN factor (tensor ops: no host synchronisation)
-        poison = torch.where((raw[:, 1] < 0).any(), float("nan"), 1.0)
-        st = (raw & 0x7FFFFFFFFFFFFFFF).double()
+        st = hip.relation_bce_stats(logits, labels).double()             # (R, 3): #pos, Spos, Sneg (Q24)
         total = float(B * M * N)
         cnt_pos = st[:, 0]
         pos_weight = (total - cnt_pos) / cnt_pos                         # (inf / nan without positives, like the reference)
         ctx.save_for_backward(logits, labels, pos_weight)
-        return ((pos_weight * st[:, 1] + st[:, 2]).sum() / (hip.REL_Q24 * R * total) * poison).float()
+        return ((pos_weight * st[:, 1] + st[:, 2]).sum() / (hip.REL_Q24 * R * total)).float()
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")

@@ -35,13 +35,11 @@ class _DepthBCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prob, gt, cell, d_off, d_step):
-        raw = hip.depth_bce_stats(prob, gt, cell, d_off, d_step)        # int64 [sum of the cells' BCE (Q24), #measured cells]
-        poison = torch.where(raw[0] < 0, float("nan"), 1.0)                # sign bit: a non-finite probability (csrc/loss.hip)
-        st = (raw & 0x7FFFFFFFFFFFFFFF).double()
+        st = hip.depth_bce_stats(prob, gt, cell, d_off, d_step).double()
         measured = st[1].clamp(min=1.0)
         ctx.save_for_backward(prob, gt, measured)
         ctx.geom = (cell, d_off, d_step)
-        return (st[0] / (hip.REL_Q24 * measured) * poison).float()
+        return (st[0] / (hip.REL_Q24 * measured)).float()
 
     @staticmethod
     def backward(ctx, g):
