@@ -540,6 +540,15 @@ int occd_se_gate(const float* pool_part, const float* w_reduce, const float* b_r
  * in the environment) selects the one-launch kernel; returns the previous setting.                                       */
 int32_t occd_se_gate_set_fused(int32_t on);
 
+/* Round 6 (ABI 14): captured-graph hygiene.  `graph` is a hipGraph_t that stream capture produced and that has NOT been
+ * instantiated yet (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every MEMSET node is replaced by a KERNEL node
+ * with the same destination, value, extent and edges: on ROCm 7.2 / gfx950 a captured hipMemsetAsync fills with its value on
+ * the first launch of the instantiated graph only and with a stale pattern afterwards (tools/probe_graph_memset.py), which
+ * leaves ATen's multi-block reductions -- they zero their semaphores that way -- without output on replays.  No reference
+ * counterpart (scripts/train.py:176-206 launches the step eagerly).  Returns the number of nodes replaced (>= 0) or a
+ * negative OCCD_E* code; element sizes 1 / 2 / 4, flat and pitched extents.                                              */
+int occd_graph_replace_memsets(void* graph);
+
 /* K11: pointwise (1x1) convolution on NCHW maps as a GEMM on the fp32 matrix pipe with the
  * EfficientNet / decoder epilogue fused -- replaces conv1x1 + BatchNorm2d (eval) + Swish (+ squeeze-excite gate on the
  * input, + MBConv skip add) of the geffnet blocks behind occdepth/models/unet2d.py:175-190, the `resize_output_1_s`

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv3d_igemm.hip", "conv3d_c32p.hip", "lift.hip", "nchw2d.hip", "loss.hip", "conv3d_wgrad.hip", "conv3d_bf16.hip", "bn.hip", "bneck3d.hip", "rows_gemm.hip", "gemm_x3.hip", "wino2d.hip", "wino_conv2d.hip", "pw_gemm.hip", "se2d.hip", "ipc_allreduce.hip", "prof.cpp"]
+SOURCES = ["conv3d_igemm.hip", "conv3d_c32p.hip", "lift.hip", "nchw2d.hip", "loss.hip", "conv3d_wgrad.hip", "conv3d_bf16.hip", "bn.hip", "bneck3d.hip", "rows_gemm.hip", "gemm_x3.hip", "wino2d.hip", "wino_conv2d.hip", "pw_gemm.hip", "se2d.hip", "ipc_allreduce.hip", "graph_fix.hip", "prof.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "occdepth_amd.h")]
 LIB = os.path.join(HERE, "libocc_hip.so")
 ARCH = "gfx950"

@@ -121,7 +121,7 @@ extern "C" int occd_prof_report(occd_prof_row* rows, int32_t max_rows) {
     return n;
 }
 
-extern "C" int occd_abi_version(void) { return 13; }
+extern "C" int occd_abi_version(void) { return 14; }
 
 extern "C" const char* occd_strerror(int code) {
     switch (code) {

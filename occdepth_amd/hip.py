@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libocc_hip.so")
 MAX_VIEWS = 4
 MAX_SCALES = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_RELU_PRE = 0, 1, 2, 3
-ABI_VERSION = 13   # 13: occd_gemm_args.bias_n / stride_bias_n (column bias: CRP relation-logit convolutions on K16), occd_gemm_f32x3_splitk (K21), occd_se_gate_set_fused; 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
+ABI_VERSION = 14   # 14: occd_graph_replace_memsets (captured memset nodes -> fill kernels); 13: occd_gemm_args.bias_n / stride_bias_n (column bias: CRP relation-logit convolutions on K16), occd_gemm_f32x3_splitk (K21), occd_se_gate_set_fused; 11: occd_gemm_args.act_a (sigmoid on A: CRP products on K16), peer-memory exchanges (occd_ipc_*, occd_bn_*_small_xchg), occd_stem_conv3x3_nchw, occd_depthnet_gate, occd_plane_reduce / occd_se_bwd; 10: strided (channels-last) ssc loss / confusion passes, occd_relation_bce_*, occd_depth_bce_*, occd_flosp_sample_bwd (N1 kernels); 9: occd_gemm_args.res / scale_k (project convolutions on K16), occd_conv3d_fwd_phases; 8: occd_gemm_f32x3 (K16, row-major float32 GEMM with the 3-way bf16 split), K2s3 behind occd_conv3d_bf16_fwd dtype 2; 7: occd_lift_proj_fwd (fused projection + frustum sample + lift), occd_pack_weights_bf16x3 + split mode of occd_conv3d_bf16_fwd; 6: K2b / K8b bf16-MFMA convolution forward + weight gradient, BN kernels; 5: K11s split-K hints, occd_upconv_gather_nchw (K12); 4: K11 pointwise GEMM, SE gate, depthwise pool/backward, softmax, lift backward + xcd_mode/feat_bstride; 3: K10
 
 _c_float_p = POINTER(c_float)
 
@@ -267,6 +267,7 @@ EXPORTS = {
                                               POINTER(c_int32), POINTER(c_int64)]),
     "occd_gemm_f32x3_splitk": (c_int32, [POINTER(GemmArgs), c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
     "occd_se_gate_set_fused": (c_int32, [c_int32]),
+    "occd_graph_replace_memsets": (c_int32, [c_void_p]),
     "occd_prof_set_tag": (c_int32, [c_char_p]),
     "occd_prof_report": (c_int32, [POINTER(ProfRow), c_int32]),
 }

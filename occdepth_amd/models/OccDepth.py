@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..fused import needs_autograd
+from ..train_graph import new_graph, seal_graph
 from .SFA import SFA, lift_scales, lift_scales_proj
 from .flosp_depth import flosp_depth_conf_map
 from .flosp_depth.flosp_depth import FlospDepth
@@ -259,9 +260,10 @@ class OccDepth(_Base):
                     for _ in range(2):                         # warm-up: lazy initialisation, weight caches, MIOpen solvers
                         self.net_rgb(static_in)
                 torch.cuda.current_stream(x.device).wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
+                graph = new_graph()
                 with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                     static_out = self.net_rgb(static_in)
+                seal_graph(graph)
                 entry = (graph, static_in, static_out, stamp)
             except (RuntimeError, torch.AcceleratorError) as e:   # capture is an optimisation, never a requirement
                 import warnings
@@ -538,9 +540,10 @@ class OccDepth(_Base):
                         self._forward_impl(static, allow_graph_2d=False)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
-                graph = torch.cuda.CUDAGraph()
+                graph = new_graph()
                 with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                     static_out = self._forward_impl(static, allow_graph_2d=False)
+                seal_graph(graph)
                 entry = (graph, static, static_out, stamp)
             except (RuntimeError, torch.AcceleratorError) as e:   # capture is an optimisation, never a requirement
                 import warnings

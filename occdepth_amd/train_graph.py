@@ -25,12 +25,39 @@ capturing (or re-capturing) trains nothing -- the reference's eager Lightning lo
 Reference: scripts/train.py:176-206 drives the same step through PyTorch-Lightning, eagerly.
 """
 import contextlib
+import os
 
 import torch
 
 # hipStreamCaptureModeThreadLocal: only the capturing thread's calls are checked, so a process group's watchdog thread
 # (event queries) cannot invalidate -- or abort -- a capture running beside it (N > 1 ranks, OCCDEPTH_FORCE_DIST=1)
 CAPTURE_MODE = "thread_local"
+
+
+# ROCm 7.2 / gfx950: a hipMemsetAsync captured into a hipGraph fills with its value on the FIRST launch of the instantiated
+# graph only; later launches fill with a stale pattern (tools/probe_graph_memset.py, csrc/graph_fix.hip).  ATen's multi-block
+# reductions zero their semaphores with such a node, so a `sum` over many rows -- a convolution's bias gradient -- can come
+# back unwritten on replays: the intermittent NaN of the captured step.  Every graph of this package is therefore captured
+# with `keep_graph=True`, has its memset nodes rewritten as fill kernels (`occd_graph_replace_memsets`) and is instantiated
+# afterwards.  OCCDEPTH_GRAPH_FIX_MEMSETS=0 keeps the captured nodes (A/B, debugging).
+FIX_MEMSETS = os.environ.get("OCCDEPTH_GRAPH_FIX_MEMSETS", "1").lower() not in ("0", "", "off", "false")
+
+
+def new_graph():
+    """A CUDAGraph object whose hipGraph_t stays editable until `seal_graph`."""
+    return torch.cuda.CUDAGraph(keep_graph=True) if FIX_MEMSETS else torch.cuda.CUDAGraph()
+
+
+def seal_graph(graph):
+    """After the capture: memset nodes -> kernel nodes, then instantiate.  Returns the number of nodes rewritten."""
+    if not FIX_MEMSETS:
+        return 0
+    from . import hip
+    n = hip.load().occd_graph_replace_memsets(graph.raw_cuda_graph())
+    if n < 0:
+        raise RuntimeError(f"occd_graph_replace_memsets failed ({n})")
+    graph.instantiate()
+    return n
 
 
 def make_capturable(opt):
@@ -98,6 +125,7 @@ class GraphedTrainStep:
         self.loss = None
         self.warmup = warmup
         self.error = None
+        self.memsets_replaced = 0
 
     def _eager(self):
         if self.buckets is not None:
@@ -135,13 +163,14 @@ class GraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
+        graph = new_graph()
         if self.buckets is None:
             self.opt.zero_grad(set_to_none=True)            # gradients are (re)allocated inside the graph's pool
         ok = True
         try:
             with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 self.loss = self._eager()
+            self.memsets_replaced = seal_graph(graph)
         except (RuntimeError, torch.AcceleratorError) as e:
             self.error = repr(e)
             ok = False

@@ -302,6 +302,10 @@ def test_whole_step_hipgraph_matches_eager_gpu(hip_lib):
         if mode == "graph":
             before = {k: v.detach().clone() for k, v in m.state_dict().items()}
             assert gs.capture(), gs.error
+            # ATen's multi-block reductions (bias gradients) bring hipMemsetAsync nodes into the capture; they are rewritten
+            # as fill kernels before instantiation (csrc/graph_fix.hip: the cause of this test's former intermittent NaN)
+            print("memset nodes rewritten:", gs.memsets_replaced)
+            assert gs.memsets_replaced >= 1 or not train_graph.FIX_MEMSETS
             after = m.state_dict()
             assert all(torch.equal(before[k], after[k]) for k in before), "capture must not train"
             assert m.cur_batch == 0 and m.train_metrics.count == 1e-8
