@@ -10,6 +10,7 @@
 // tests/test_train_step.py::test_whole_step_hipgraph_matches_eager_gpu (about 1 in 12 fresh processes after any change of
 // the step's allocation pattern), and the K5 statistics memset of round 4.  Kernel nodes replay
 // correctly, so the node is replaced by a fill KERNEL with the same destination, value and edges before instantiation.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -69,6 +70,9 @@ extern "C" int occd_graph_replace_memsets(void* graph_handle) {
         hipKernelNodeParams kp = {};
         unsigned char* dst = static_cast<unsigned char*>(p.dst);
         unsigned value = p.value, esz = p.elementSize, pat;
+        // debugging only (tools/probe_train_graph_memset.py): OCCD_DBG_MEMSET_XOR=<n> perturbs every fill value the way the
+        // runtime's stale pattern does, to show WHAT a captured step loses when its memset nodes misfire
+        if (const char* e = getenv("OCCD_DBG_MEMSET_XOR")) value ^= (unsigned)strtoul(e, nullptr, 0);
         size_t width = p.width, height = p.height ? p.height : 1, pitch = p.pitch, bytes;
         void* args1[3];
         void* args2[6];
