@@ -120,15 +120,22 @@ def test_unrewritten_memset_node_behaviour_is_recorded(hip_lib, capsys):
     """Informative: what a plain captured memset does on replays on this stack (the reason for the rewrite).  Never fails on
     the stack's behaviour -- a fixed runtime simply reports zero bad replays."""
     rt = _hiprt()
-    bad = 0
-    for s in (4, 12, 64):
-        b = torch.empty(s + 300, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        _capture_fill(rt, g, b, 0, 0, s)
-        for r in range(3):
-            b.fill_(0xEE)
-            g.replay()
-            bad += int(not bool((b[:s] == 0).all()))
+    bad, total, seen = 0, 0, set()
+    for v in (0, 0x5A):
+        for s in (4, 12, 64):
+            b = torch.empty(s + 300, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            _capture_fill(rt, g, b, 0, v, s)
+            for r in range(3):
+                b.fill_(0xEE)
+                g.replay()
+                total += 1
+                if not bool((b[:s] == v).all()):
+                    bad += 1
+                    seen.add(bytes(b[:min(s, 16)].cpu().tolist()).hex())
     with capsys.disabled():
-        print(f"\n[plain hipGraph memset nodes: {bad} of 9 replays filled with a wrong pattern]")
+        # (process-dependent: tools/probe_graph_memset2.py, a bare interpreter, sees 90 of 90 lone memset nodes fill with a
+        # stale pattern from the second launch on -- 0 of 90 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 --, this pytest process
+        # usually none: the replayed AQL packet's pattern argument points at recycled host memory)
+        print(f"\n[plain hipGraph memset nodes: {bad} of {total} replays filled with a wrong pattern {sorted(seen)[:4]}]")
